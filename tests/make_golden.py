@@ -1,0 +1,280 @@
+"""
+Golden-vector generator (build container only).
+
+Imports the REAL reference from /root/reference (read-only, never copied), runs its training step
+(`train.train`) / eval forward / test.py-style rollout on tiny seeded configurations, records the RNG tape
+(torch.randint, torch.randperm, Normal.rsample draws) and dumps inputs + expected outputs as small .npz
+fixtures under tests/golden/.  The fixtures are data only; the oracle (oracle/srvp_oracle.py) and the HIP path
+are both checked against them.  /root/reference does not exist on the GPU box, so this script is never run there.
+
+    python tests/make_golden.py            # regenerate every fixture
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, 'golden')
+REF = '/root/reference'
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    # configargparse is not installed: argparse subclass with `.add` (args.py:16,43)
+    if 'configargparse' not in sys.modules:
+        m = types.ModuleType('configargparse')
+
+        class ArgumentParser(argparse.ArgumentParser):
+            def add(self, *a, **k):
+                return self.add_argument(*a, **k)
+        m.ArgumentParser = ArgumentParser
+        m.ArgumentDefaultsHelpFormatter = argparse.ArgumentDefaultsHelpFormatter
+        sys.modules['configargparse'] = m
+        # argument groups need .add too
+        argparse._ArgumentGroup.add = argparse._ArgumentGroup.add_argument
+        argparse._MutuallyExclusiveGroup.add = argparse._MutuallyExclusiveGroup.add_argument
+    if 'torchvision' not in sys.modules:
+        tv = types.ModuleType('torchvision')
+        tvd = types.ModuleType('torchvision.datasets')
+        tv.datasets = tvd
+        sys.modules['torchvision'] = tv
+        sys.modules['torchvision.datasets'] = tvd
+    import module.srvp as srvp
+    import train as ref_train
+    import helper
+    return srvp, ref_train, helper
+
+
+class Tape:
+    """Records the reference's random draws in call order."""
+
+    def __init__(self):
+        self.randint, self.randperm, self.normal = [], [], []
+        self._orig = {}
+
+    def __enter__(self):
+        import torch.distributions.normal as tdn
+        self._orig = dict(randint=torch.randint, randperm=torch.randperm, sn=tdn._standard_normal)
+        tape = self
+
+        def randint(*a, **k):
+            r = tape._orig['randint'](*a, **k)
+            tape.randint.append(r.clone())
+            return r
+
+        def randperm(*a, **k):
+            r = tape._orig['randperm'](*a, **k)
+            tape.randperm.append(r.clone())
+            return r
+
+        def sn(shape, dtype, device):
+            r = tape._orig['sn'](shape, dtype, device)
+            tape.normal.append(r.clone())
+            return r
+        torch.randint, torch.randperm, tdn._standard_normal = randint, randperm, sn
+        return self
+
+    def __exit__(self, *exc):
+        import torch.distributions.normal as tdn
+        torch.randint, torch.randperm, tdn._standard_normal = self._orig['randint'], self._orig['randperm'], self._orig['sn']
+
+
+def tape_arrays(tape, cfg, training):
+    out = {}
+    if training:
+        if cfg['skipco']:
+            out['tape.t_skip'] = tape.randint[0].numpy()
+        out['tape.t_w'] = torch.stack([p[:cfg['nt_inf']] for p in tape.randperm], 1).numpy()
+    out['tape.eps_y0'] = tape.normal[0].numpy()
+    if len(tape.normal) > 1:
+        out['tape.eps_z'] = torch.stack(tape.normal[1:]).numpy()
+    return out
+
+
+OUT_NAMES = ['x_', 'y', 'z', 'w', 'q_y_0_params', 'q_z_params', 'p_z_params', 'res']
+
+# name: constructor args (reference positional order), T, B, n_euler, hyper-parameters
+TINY = {}
+for archi, nc in (('dcgan', 1), ('vgg', 3)):
+    for skipco in (False, True):
+        for n_euler in (1, 2):
+            TINY[f'tiny_{archi}_nc{nc}_skip{int(skipco)}_e{n_euler}'] = dict(
+                ctor=(64, nc, 4, 8, 3, 3, skipco, 2, 8, 3, 16, 4, archi), T=4, B=3, n_euler=n_euler,
+                hp=dict(obs_scale=0.2 if archi == 'vgg' else 1.0, beta_y=1.0, beta_z=2.0 if archi == 'dcgan' else 1.0,
+                        l2_res=1.0), res_gain=1.41 if archi == 'dcgan' else 1.2, lr=3e-4)
+# cross cases (channel count vs archi) and a wider/odd-dimension case
+TINY['tiny_dcgan_nc3_skip1_e2'] = dict(ctor=(64, 3, 4, 8, 3, 3, True, 2, 8, 3, 16, 4, 'dcgan'), T=4, B=3, n_euler=2,
+                                       hp=dict(obs_scale=0.71, beta_y=1.0, beta_z=1.0, l2_res=1.0), res_gain=1.41, lr=3e-4)
+TINY['tiny_vgg_nc1_skip1_e2'] = dict(ctor=(64, 1, 4, 8, 3, 3, True, 3, 8, 3, 16, 4, 'vgg'), T=5, B=2, n_euler=2,
+                                     hp=dict(obs_scale=0.2, beta_y=1.0, beta_z=1.0, l2_res=1.0), res_gain=1.2, lr=3e-4)
+TINY['small_vgg_nc3_skip1_e2'] = dict(ctor=(64, 3, 8, 16, 5, 7, True, 2, 24, 3, 40, 4, 'vgg'), T=3, B=2, n_euler=2,
+                                      hp=dict(obs_scale=0.2, beta_y=1.0, beta_z=1.0, l2_res=1.0), res_gain=1.2, lr=3e-4)
+TINY['small_dcgan_nc1_skip0_e1'] = dict(ctor=(64, 1, 8, 16, 5, 7, False, 3, 24, 2, 40, 3, 'dcgan'), T=4, B=2, n_euler=1,
+                                        hp=dict(obs_scale=1.0, beta_y=1.0, beta_z=2.0, l2_res=1.0), res_gain=1.41, lr=3e-4)
+
+
+def synth_video(T, B, C, seed):
+    """Seeded smooth-ish synthetic frames in [0,1] (moving blobs) -- pure numpy, no dataset needed."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:64, 0:64].astype(np.float32)
+    x = np.zeros((T, B, C, 64, 64), np.float32)
+    for b in range(B):
+        for c in range(C):
+            p = rng.uniform(12, 52, 2)
+            v = rng.uniform(-4, 4, 2)
+            s = rng.uniform(3, 8)
+            for t in range(T):
+                q = p + v * t
+                x[t, b, c] = np.exp(-((yy - q[0]) ** 2 + (xx - q[1]) ** 2) / (2 * s * s))
+    x += rng.uniform(0, 0.05, x.shape).astype(np.float32)
+    return np.clip(x, 0, 1)
+
+
+def gen_one(name, spec, srvp, ref_train, helper):
+    torch.set_num_threads(1)
+    ctor, T, B, n_euler, hp = spec['ctor'], spec['T'], spec['B'], spec['n_euler'], spec['hp']
+    cfg_keys = ['nx', 'nc', 'nf', 'nhx', 'ny', 'nz', 'skipco', 'nt_inf', 'nh_inf', 'nlayers_inf', 'nh_res',
+                'nlayers_res', 'archi']
+    cfg = dict(zip(cfg_keys, ctor))
+    torch.manual_seed(1)
+    model = srvp.StochasticLatentResidualVideoPredictor(*ctor)
+    model.init(res_gain=spec['res_gain'])
+    # perturb BN affine / running stats so eval-mode and bias paths are non-trivial
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if k.endswith('running_mean'):
+                v.copy_(0.1 * torch.randn(v.shape, generator=g))
+            elif k.endswith('running_var'):
+                v.copy_(1 + 0.3 * torch.rand(v.shape, generator=g))
+            elif k.endswith('.1.bias') or k.endswith('upconv.1.bias') or k.endswith('last_conv.1.bias'):
+                v.copy_(0.05 * torch.randn(v.shape, generator=g))
+    x = torch.from_numpy(synth_video(T, B, cfg['nc'], seed=123))
+    out = {}
+    out['x'] = x.numpy()
+    for k, v in model.state_dict().items():
+        out['sd0.' + k] = v.detach().numpy().copy()
+
+    # ---------------- train step through the reference's own train.train (train.py:49-129) ----------------
+    opt = helper.DotDict(dict(n_euler_steps=n_euler, torch_amp=False, apex_amp=False, **hp))
+    optimizer = torch.optim.Adam(model.parameters(), lr=spec['lr'])
+    model.train()
+    grads = {}
+    orig_step = optimizer.step
+
+    def step_and_capture(*a, **k):
+        for kk, p in model.named_parameters():
+            grads[kk] = p.grad.detach().clone()
+        return orig_step(*a, **k)
+    optimizer.step = step_and_capture
+    fwd_outs = {}
+
+    def forward_fn(xx, nt, dt):
+        o = model(xx, nt, dt=dt)
+        for n_, v in zip(OUT_NAMES, o):
+            fwd_outs[n_] = v.detach().clone()
+        return o
+    with Tape() as tape:
+        loss, nll, kl_y_0, kl_z = ref_train.train(forward_fn, optimizer, None, x, torch.device('cpu'), opt)
+    out.update(tape_arrays(tape, cfg, True))
+    for n_, v in fwd_outs.items():
+        out['train.' + n_] = v.numpy()
+    out['train.scalars'] = np.array([loss, nll, kl_y_0, kl_z], np.float64)
+    out['train.l2_res'] = np.array(torch.norm(fwd_outs['res'], p=2, dim=2).sum().item(), np.float64)
+    for k, v in grads.items():
+        out['grad.' + k] = v.numpy()
+    for k, v in model.state_dict().items():
+        out['sd1.' + k] = v.detach().numpy().copy()
+
+    # ---------------- eval forward with prediction beyond the data (train.py:165-173) ----------------
+    model.eval()
+    nt_cond = max(cfg['nt_inf'], T - 1)
+    nt_pred = T + 2
+    with torch.no_grad(), Tape() as tape:
+        o = model(x[:nt_cond], nt_pred, dt=1 / n_euler)
+    ev = tape_arrays(tape, cfg, False)
+    out.update({k.replace('tape.', 'eval.tape.'): v for k, v in ev.items()})
+    out['eval.nt_cond'] = np.array(nt_cond)
+    out['eval.nt'] = np.array(nt_pred)
+    for n_, v in zip(OUT_NAMES, o):
+        if v is not None:
+            out['eval.' + n_] = v.numpy()
+
+    # ---------------- test.py-style rollout (test.py:235-246) ----------------
+    nt_gen = 6
+    with torch.no_grad(), Tape() as tape:
+        skip = model.encode(x[:nt_cond])[1] if cfg['skipco'] else None
+        x_rec, y, _, w, _, _, _, _ = model(x[:nt_cond], nt_cond, dt=1 / n_euler)
+        n_fwd = len(tape.normal)
+        y_os = model.generate(y[-1], [], nt_gen - nt_cond + 1 + 2, 1 / n_euler)[0]
+        y2 = y_os[1:].contiguous()
+        x_pred = model.decode(w, y2, skip).clamp(0, 1)
+    out['roll.eps_y0'] = tape.normal[0].numpy()
+    out['roll.eps_z_fwd'] = torch.stack(tape.normal[1:n_fwd]).numpy()
+    out['roll.eps_z_gen'] = torch.stack(tape.normal[n_fwd:]).numpy()
+    out['roll.x_rec'] = x_rec.numpy()
+    out['roll.y_gen'] = y_os.numpy()
+    out['roll.x_pred'] = x_pred.numpy()
+
+    meta = dict(ctor=list(ctor), T=T, B=B, n_euler=n_euler, hp=hp, res_gain=spec['res_gain'], lr=spec['lr'])
+    out['meta'] = np.array(repr(meta))
+    np.savez_compressed(os.path.join(GOLDEN, name + '.npz'), **out)
+    return loss
+
+
+def gen_known_answers():
+    """Small known-answer vectors produced by the reference's utils / schedule code."""
+    import math
+    import module.utils as rutils
+    import torch.distributions as distrib
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    raw = torch.randn(4, 10, generator=g) * 3
+    raw[0, 5] = 25.0   # softplus threshold branch
+    raw[1, 6] = -30.0
+    raw2 = torch.randn(4, 10, generator=g)
+    q = rutils.make_normal_from_raw_params(raw)
+    p = rutils.make_normal_from_raw_params(raw2)
+    out['ka.raw_q'], out['ka.raw_p'] = raw.numpy(), raw2.numpy()
+    out['ka.q_scale'] = q.scale.numpy()
+    out['ka.kl_qp'] = distrib.kl_divergence(q, p).numpy()
+    out['ka.kl_q0'] = distrib.kl_divergence(q, distrib.Normal(0, 1)).numpy()
+    loc = torch.rand(3, 7, generator=g)
+    data = torch.rand(3, 7, generator=g)
+    for s in (1.0, 0.2, 0.71):
+        out[f'ka.nll_{s}'] = rutils.neg_logprob(loc, data, scale=s).numpy()
+    out['ka.nll_loc'], out['ka.nll_data'] = loc.numpy(), data.numpy()
+    # Euler grid exactly as srvp.py:377-402 walks it
+    for n in (1, 2, 4):
+        for nt in (12, 15, 16, 20, 53):
+            dt = 1 / n
+            rows, t_data = [], 0
+            for t in np.linspace(dt, nt - 1, n * (nt - 1)):
+                prev = t_data
+                t_data = int(math.ceil(t))
+                rows.append((t_data, int(t_data != prev), int(float(t).is_integer())))
+            out[f'ka.euler_n{n}_nt{nt}'] = np.array(rows, np.int64)
+    # LR schedule (train.py:292-293)
+    n_iter = 1000
+    out['ka.lr_lambda'] = np.array([max(0, (n_iter - i) / n_iter) for i in range(0, 1200, 100)])
+    np.savez_compressed(os.path.join(GOLDEN, 'known_answers.npz'), **out)
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    srvp, ref_train, helper = import_reference()
+    for name, spec in TINY.items():
+        loss = gen_one(name, spec, srvp, ref_train, helper)
+        print(f'{name}: loss {loss:.6f}')
+    gen_known_answers()
+    print('done')
+
+
+if __name__ == '__main__':
+    main()
