@@ -1,0 +1,249 @@
+/*
+ * srvp_hip.h -- C ABI of libsrvp_hip.so, the MI355X (gfx950 / CDNA4) kernel library behind the SRVP
+ * training / rollout hot path.
+ *
+ * The reference (edouardelasalles/srvp) has no FFI layer: its hot path is PyTorch modules calling cuDNN/cuBLAS
+ * implicitly.  Each entry point below replaces the implicit device op(s) behind the cited reference lines
+ * (paths relative to the reference root).  Conventions:
+ *   - extern "C", plain pointers and sizes, no torch types; every call returns 0 on success or a non-zero
+ *     code with a message available from srvp_last_error(); no exception crosses the ABI.
+ *   - the caller owns every buffer (device pointers); the library allocates nothing.
+ *   - every launch is asynchronous on the hipStream_t passed as `stream` (void*), no host sync inside.
+ *   - activations are NHWC bfloat16 with an optional 1-pixel zero border ("padded" tensors);
+ *     channel counts are padded to a multiple of 32 by the caller (zero weights / zero gamma,beta).
+ */
+#ifndef SRVP_HIP_H
+#define SRVP_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRVP_MAX_TAPS 16
+
+#define SRVP_ACT_NONE 0
+#define SRVP_ACT_LRELU 1    /* LeakyReLU(0.2), module/utils.py:41 */
+#define SRVP_ACT_TANH 2
+#define SRVP_ACT_RELU 3
+#define SRVP_ACT_SIGMOID 4
+
+int srvp_version(void);
+const char* srvp_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tap-table implicit-GEMM convolution on MFMA (bf16 operands, fp32 accumulate).
+ * Replaces nn.Conv2d / nn.ConvTranspose2d forward (module/conv.py:174-179,200-223,299-304,330-353) and, with
+ * transposed packed weights and the gradient as input, their data-gradient.
+ *   out[n, oy*so+ooy, ox*so+oox, j] = sum_t sum_c in_t[n, oy, ox, c] * W[t][j][c]
+ *   in_t[n, oy, ox, c] = src{0|1}[n', (oy*si+dy[t]) (>>1 after +1 if ups), (ox*si+dx[t]) (...), c]
+ * src0 supplies channels [0,C0), src1 (optional: the skip connection of conv.py:270, selected per sample through
+ * map1[n], module/srvp.py:185-190,222-223) channels [C0, C0+C1).  dy/dx are in padded coordinates of the source.
+ * Optional epilogue: per-column sum / sum-of-squares (fp64 atomics) for BatchNorm batch statistics
+ * (conv.py:104); column j contributes to stats[j % stat_mod] and stats[stat_mod + j % stat_mod].
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* src0; const void* src1; const int32_t* map1;
+    int32_t C0, C1;
+    int32_t H0p, W0p, H1p, W1p;   /* physical (padded) spatial dims of each source */
+    int32_t ups0, ups1;           /* nearest x2 upsample folded into the gather (conv.py:331-349) */
+    int32_t si;                   /* input stride */
+    int32_t ntaps; int32_t dy[SRVP_MAX_TAPS]; int32_t dx[SRVP_MAX_TAPS];
+    const void* wt;               /* bf16 [ntaps][Cout][C0+C1] */
+    int32_t Cout;
+    int32_t N, OH, OW;            /* output (sub-)grid */
+    void* dst; int32_t DHp, DWp, so, ooy, oox, Cdst, cdst_off;
+    double* stats; int32_t stat_mod;
+} srvp_conv_desc;
+int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
+
+/* Weight gradient of the same tap-table convolution (autograd of the modules above):
+ *   dW[t][j][c] += sum_{n,oy,ox} dout[n, oy*so+ooy[t], ox*so+oox[t], j] * in_t[n, oy, ox, c]     (fp32 atomics)
+ */
+typedef struct {
+    const void* src0; const void* src1; const int32_t* map1;
+    int32_t C0, C1;
+    int32_t H0p, W0p, H1p, W1p;
+    int32_t ups0, ups1;
+    int32_t si;
+    int32_t ntaps; int32_t dy[SRVP_MAX_TAPS]; int32_t dx[SRVP_MAX_TAPS];
+    const void* dout; int32_t DHp, DWp, so; int32_t ooy[SRVP_MAX_TAPS]; int32_t oox[SRVP_MAX_TAPS];
+    int32_t Cout;                 /* channels of dout (its physical channel count) */
+    int32_t N, OH, OW;
+    float* dw;                    /* fp32 [ntaps][Cout][C0+C1], accumulated into */
+    int32_t splitk;
+} srvp_wgrad_desc;
+int srvp_wgrad_mfma(const srvp_wgrad_desc* d, void* stream);
+/* 1: fragments through ds_read_b64_tr_b16 (default), 0: 16-bit LDS reads (conservative fallback) */
+int srvp_wgrad_set_tr(int on);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm2d (training / eval) + activation, split around the grid-wide reduction (conv.py:103-106).
+ * ------------------------------------------------------------------------------------------------ */
+/* stats(double [2][C]) -> scale, shift, mean, invstd (fp32 [C]); updates running stats (momentum 0.1, unbiased
+ * variance) and num_batches_tracked when running_mean != NULL.  C_real <= C: padded channels get scale=shift=0. */
+int srvp_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                     float* scale, float* shift, float* mean, float* invstd,
+                     int C, int C_real, float eps, float momentum, void* stream);
+/* eval mode: scale/shift from running statistics */
+int srvp_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        float* scale, float* shift, int C, int C_real, float eps, void* stream);
+/* act = f(scale*raw + shift) -> bf16 padded tensor (+ optional 2x2 max-pooled copy, conv.py:204-222;
+ * + optional fp32 unpadded copy used for the encoder output hx). */
+int srvp_bn_act(const void* raw, const float* scale, const float* shift, int act,
+                int N, int H, int W, int C,
+                void* dst, int dst_border, void* dst_pool, int pool_border, float* dst_f32, void* stream);
+
+/* backward of activation+BN.  dA comes from one or two places:
+ *   main: tensor `da` with channel stride da_cstride / offset da_coff, mode 0 = same resolution,
+ *         mode 1 = gradient of the nearest-x2-upsampled tensor (sum the 2x2 block),
+ *         mode 2 = gradient of the 2x2-max-pooled tensor (routed to the arg-max pixel, first-max tie rule);
+ *   extra: optional second same-resolution gradient `da2` (skip-connection gradient), bf16 [N][H][W][C].
+ * pass 1 accumulates red[0][c] = sum g, red[1][c] = sum g*xhat (fp64 atomics), g = dA * f'(scale*raw+shift). */
+typedef struct {
+    const void* raw; const void* act; int32_t act_border;   /* act: padded activated tensor (mode 2 only) */
+    const float* scale; const float* shift; const float* mean; const float* invstd; int32_t act_kind;
+    const void* da; int32_t da_mode, da_cstride, da_coff, da_border; int32_t da_is_f32;
+    const void* da2; const int32_t* da2_idx;                /* da2: compact [B][H][W][C]; da2_idx[n] = row or -1 */
+    int32_t N, H, W, C;
+} srvp_bnbwd_desc;
+int srvp_bn_bwd_reduce(const srvp_bnbwd_desc* d, double* red, void* stream);
+/* red -> dgamma, dbeta (accumulated into fp32 grads when non-NULL) and the per-channel coefficients used by apply */
+int srvp_bn_bwd_finalize(const double* red, double count, const float* scale, const float* mean, const float* invstd,
+                         float* dgamma, float* dbeta, float* coef, int C, int C_real, int has_bn, void* stream);
+/* pass 2: draw = scale*(g - mean_g - xhat*mean_gx) -> bf16 tensor with border `dst_border` */
+int srvp_bn_bwd_apply(const srvp_bnbwd_desc* d, const float* coef, void* draw, int dst_border, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small-channel layers (first encoder conv, last decoder conv; conv.py:174,200,304,353), direct fp32 VALU
+ * kernels on the reference's own (T*B, C, 64, 64) fp32 frame layout -- these layers are HBM-bound.
+ * ------------------------------------------------------------------------------------------------ */
+/* x fp32 NCHW [N][Cin<=4][H][W] -> raw bf16 NHWC [N][OH][OW][Cout]; w fp32 [Cout_real][Cin][k][k] (OIHW) */
+int srvp_conv_in_fwd(const float* x, const float* w, void* raw, double* stats,
+                     int N, int Cin, int H, int W, int Cout, int Cout_real, int k, int s, int p, void* stream);
+/* dW[Cout_real][Cin][k][k] += sum draw * x   (draw: bf16 padded(border 1) [N][OH+2][OW+2][Cout]) */
+int srvp_conv_in_wgrad(const float* x, const void* draw, float* dw,
+                       int N, int Cin, int H, int W, int Cout, int Cout_real, int k, int s, int p, void* stream);
+/* last decoder layer: transposed convolution (IOHW fp32 weights [Cin_real][Cout<=4][k][k]) of one or two bf16
+ * NHWC tensors with a 1-pixel zero border (second = skip connection, DCGAN conv.py:304 with --skipco), then sigmoid
+ * (conv.py:273-274):  x_ fp32 NCHW [N][Cout][OH][OW]. */
+typedef struct {
+    const void* src0; const void* src1; const int32_t* map1;
+    int32_t C0, C1, C0_real, C1_real;       /* padded / real channel counts of each source */
+    int32_t N, H, W, Cout, k, s, p, apply_sigmoid;
+} srvp_convout_desc;
+int srvp_convT_out_fwd(const srvp_convout_desc* d, const float* w, float* x_out, void* stream);
+/* given dx_ (fp32 NCHW) and x_: dpre = dx_*x_*(1-x_) (if sigmoid); dact bf16 [N][H][W][C0+C1] (unpadded) and
+ * dw (+=, IOHW fp32); either output may be NULL */
+int srvp_convT_out_bwd(const srvp_convout_desc* d, const float* w, const float* x_out, const float* dx_out,
+                       void* dact, float* dw, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight packing between the reference state-dict layouts (OIHW conv / IOHW convT, fp32) and tap-major bf16.
+ * ------------------------------------------------------------------------------------------------ */
+/* packed bf16 [ntaps][J][K]: packed[t][j][k] = w[ jr*sj + kr*sk + tap_off[t] ], 0 for padding.  Each of the J / K
+ * axes is one or two zero-padded segments (two when the layer input is the concat of two padded tensors):
+ * index i < X0 maps to real i (if < X0r), index X0 + i maps to real X0r + i (if i < X1r). */
+typedef struct {
+    int32_t ntaps; int32_t tap_off[SRVP_MAX_TAPS];
+    int32_t J, K;
+    int32_t J0, J0r, J1r;
+    int32_t K0, K0r, K1r;
+    int64_t sj, sk;
+} srvp_pack_desc;
+int srvp_pack_weight(const float* src, void* dst, const srvp_pack_desc* d, void* stream);
+/* fp32 gradient: w_grad[ jr*sj + kr*sk + tap_off[t] ] += packed_grad[t][j][k]  (inverse mapping, for dW) */
+int srvp_unpack_wgrad(const float* src, float* dst, const srvp_pack_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Latent path: Linear / MLP / LSTM / residual Euler rollout (module/mlp.py, module/srvp.py:229-413), fp32.
+ * ------------------------------------------------------------------------------------------------ */
+/* C[M][N] (+)= act( A[M][K] (strides as,ak) * B[K][N] (strides bk,bn) + bias[N] ), fp32, generic strides */
+int srvp_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs,
+                  const float* bias, float* C, int64_t c_rs, int M, int N, int K, int act, int accumulate,
+                  void* stream);
+/* out = a*x + b*y (y may be NULL) */
+int srvp_axpby_f32(float* out, float a, const float* x, float b, const float* y, int64_t n, void* stream);
+/* column sums: out[n] (+)= sum_m A[m][n] */
+int srvp_colsum_f32(const float* A, int64_t a_rs, float* out, int M, int N, int accumulate, void* stream);
+/* elementwise helpers on fp32 rows */
+int srvp_act_bwd_f32(const float* pre_or_out, const float* dy, float* dx, int64_t n, int act, int from_output,
+                     void* stream);
+
+/* LSTM (nn.LSTM(nhx, nh, 1), srvp.py:132,366): gates_x = x W_ih^T + b (precomputed by srvp_gemm_f32),
+ * recurrent part here.  Saves gate activations for backward.  Layout: [T][B][4*nh], gate order i,f,g,o. */
+int srvp_lstm_fwd(const float* gates_x, const float* w_hh, float* h_out, float* c_out, float* gates_act,
+                  int T, int B, int nh, void* stream);
+/* scratch: 2*B*nh floats */
+int srvp_lstm_bwd(const float* dh_out, const float* w_hh, const float* c_out, const float* gates_act,
+                  float* dgates, float* scratch, int T, int B, int nh, void* stream);
+
+/* Residual Euler rollout (srvp.py:300-323,370-405) for the MLP `dynamics` and the prior MLP `p_z` (nl linear layers,
+ * ReLU between; weights [out][in] row-major exactly as in the state dict).  Step i (0-based) belongs to frame slot
+ * f = i / n_euler (frame index f+1); the first sub-step of a frame evaluates p_z on the current state and draws z from
+ * the posterior parameters while f+1 < n_data_frames, from the prior afterwards (srvp.py:383-393). F = #frame slots. */
+typedef struct {
+    int32_t B, ny, nz, nh, nl;
+    int32_t nsteps, n_euler, n_data_frames;
+    float dt;
+    const float* dyn_w[8]; const float* dyn_b[8];
+    const float* pz_w[8]; const float* pz_b[8];
+    const float* y0;                       /* [B][ny] */
+    const float* q_z_params;               /* [F][B][2nz] (entries used only for posterior frames) or NULL */
+    const float* eps_z;                    /* [F][B][nz] */
+    float* y_all;                          /* [nsteps+1][B][ny] every state incl. y0 */
+    float* z;                              /* [F][B][nz] */
+    float* p_z_params;                     /* [F][B][2nz] */
+    float* res;                            /* [nsteps][B][ny] */
+    float* inp_all;                        /* [nsteps][B][ny+nz] dynamics inputs (saved for the weight gradient) */
+    float* hid_dyn;                        /* [nl-1][nsteps][B][nh] post-ReLU hidden activations, or NULL (inference) */
+    float* hid_pz;                         /* [nl-1][F][B][nh] or NULL */
+    float* scratch_hid;                    /* [nl-1][B][nh], used when hid_* is NULL */
+    float* scratch_out;                    /* [B][max(ny, 2nz)] */
+} srvp_rollout_desc;
+int srvp_rollout_fwd(const srvp_rollout_desc* d, void* stream);
+typedef struct {
+    srvp_rollout_desc f;
+    const float* d_y_all;                  /* [nsteps+1][B][ny] gradient wrt every stored state (zeros where unused) */
+    const float* d_z;                      /* [F][B][nz] or NULL */
+    const float* d_pz;                     /* [F][B][2nz] direct gradient wrt the prior parameters (KL) or NULL */
+    const float* d_res;                    /* [nsteps][B][ny] or NULL */
+    float* d_y0;                           /* [B][ny] */
+    float* d_qz;                           /* [F][B][2nz] gradient wrt the posterior parameters through the samples */
+    float* dhid_dyn;                       /* [nl][nsteps][B][max(nh,ny)] per-layer pre-activation deltas */
+    float* dhid_pz;                        /* [nl][F][B][max(nh,2nz)] */
+    float* work;                           /* 3*B*ny + B*(ny+nz) + B*nz floats */
+} srvp_rollout_bwd_desc;
+int srvp_rollout_bwd(const srvp_rollout_bwd_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ELBO terms (train.py:90-106) and Adam (train.py:289; torch.optim.Adam defaults)
+ * ------------------------------------------------------------------------------------------------ */
+/* nll = sum (x-x_)^2/(2 s^2) + log s + .5 log 2pi ; optionally d_x_ = gscale*(x_-x)/s^2.  out: double[1] += */
+int srvp_nll(const float* x_, const float* x, float* d_x_, int64_t n, float scale, float gscale, double* out,
+             void* stream);
+/* KL( N(q) || N(p) ) summed (p == NULL -> N(0,1)); raw params [rows][2d]; grads scaled by gscale. out: double[1] += */
+int srvp_kl(const float* q, const float* p, float* dq, float* dp, int64_t rows, int d, float gscale, double* out,
+            void* stream);
+/* sum over rows of ||res_row||_2 ; d_res = gscale * res/||res|| (0 at 0).  out: double[1] += */
+int srvp_l2rows(const float* res, float* d_res, int64_t rows, int d, float gscale, double* out, void* stream);
+/* rsample: out = loc + eps*(softplus(raw)+1e-8) ; backward: dparams += [dout, dout*eps*sigmoid(raw)] */
+int srvp_rsample_fwd(const float* params, const float* eps, float* out, int64_t rows, int d, void* stream);
+int srvp_rsample_bwd(const float* params, const float* eps, const float* dout, float* dparams, int64_t rows, int d,
+                     int accumulate, void* stream);
+/* fused Adam over one flat fp32 buffer; step_size = lr/(1-b1^t), bc2_sqrt = sqrt(1-b2^t) */
+int srvp_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+              int step, float grad_scale, void* stream);
+
+/* misc */
+int srvp_fill_f64(double* p, int64_t n, double v, void* stream);
+int srvp_cast_f32_bf16(const float* src, void* dst, int64_t rows, int cols, int dst_cols, void* stream);
+/* dsel[b][hw][c] = sum_t dcat[t*B+b][hw][coff+c]  (gradient of the skip expand over time, srvp.py:222-223; the
+ * gather of srvp.py:187 is undone by srvp_bn_bwd_* through da2_idx) */
+int srvp_skip_grad_reduce(const void* dcat, int cstride, int coff, int C, int HW, int T, int B, void* dsel, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

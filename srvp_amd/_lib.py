@@ -1,0 +1,177 @@
+"""
+ctypes binding of libsrvp_hip.so (C ABI declared in include/srvp_hip.h).
+
+The library is the product's only compute path: there is no Python / CPU fallback.  If it is missing, loading
+fails loudly with instructions to build it (`python -c "import __graft_entry__ as g; g.build()"`).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsrvp_hip.so')
+MAX_TAPS = 16
+
+ACT_NONE, ACT_LRELU, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3, 4
+
+c_i32, c_i64, c_f32, c_f64, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
+TAPS = c_i32 * MAX_TAPS
+P8 = c_vp * 8
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('src0', c_vp), ('src1', c_vp), ('map1', c_vp),
+                ('C0', c_i32), ('C1', c_i32),
+                ('H0p', c_i32), ('W0p', c_i32), ('H1p', c_i32), ('W1p', c_i32),
+                ('ups0', c_i32), ('ups1', c_i32), ('si', c_i32),
+                ('ntaps', c_i32), ('dy', TAPS), ('dx', TAPS),
+                ('wt', c_vp), ('Cout', c_i32),
+                ('N', c_i32), ('OH', c_i32), ('OW', c_i32),
+                ('dst', c_vp), ('DHp', c_i32), ('DWp', c_i32), ('so', c_i32), ('ooy', c_i32), ('oox', c_i32),
+                ('Cdst', c_i32), ('cdst_off', c_i32),
+                ('stats', c_vp), ('stat_mod', c_i32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [('src0', c_vp), ('src1', c_vp), ('map1', c_vp),
+                ('C0', c_i32), ('C1', c_i32),
+                ('H0p', c_i32), ('W0p', c_i32), ('H1p', c_i32), ('W1p', c_i32),
+                ('ups0', c_i32), ('ups1', c_i32), ('si', c_i32),
+                ('ntaps', c_i32), ('dy', TAPS), ('dx', TAPS),
+                ('dout', c_vp), ('DHp', c_i32), ('DWp', c_i32), ('so', c_i32), ('ooy', TAPS), ('oox', TAPS),
+                ('Cout', c_i32), ('N', c_i32), ('OH', c_i32), ('OW', c_i32),
+                ('dw', c_vp), ('splitk', c_i32)]
+
+
+class BnBwdDesc(C.Structure):
+    _fields_ = [('raw', c_vp), ('act', c_vp), ('act_border', c_i32),
+                ('scale', c_vp), ('shift', c_vp), ('mean', c_vp), ('invstd', c_vp), ('act_kind', c_i32),
+                ('da', c_vp), ('da_mode', c_i32), ('da_cstride', c_i32), ('da_coff', c_i32), ('da_border', c_i32),
+                ('da_is_f32', c_i32),
+                ('da2', c_vp), ('da2_idx', c_vp),
+                ('N', c_i32), ('H', c_i32), ('W', c_i32), ('C', c_i32)]
+
+
+class ConvOutDesc(C.Structure):
+    _fields_ = [('src0', c_vp), ('src1', c_vp), ('map1', c_vp),
+                ('C0', c_i32), ('C1', c_i32), ('C0_real', c_i32), ('C1_real', c_i32),
+                ('N', c_i32), ('H', c_i32), ('W', c_i32), ('Cout', c_i32), ('k', c_i32), ('s', c_i32), ('p', c_i32),
+                ('apply_sigmoid', c_i32)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [('ntaps', c_i32), ('tap_off', TAPS), ('J', c_i32), ('K', c_i32),
+                ('J0', c_i32), ('J0r', c_i32), ('J1r', c_i32), ('K0', c_i32), ('K0r', c_i32), ('K1r', c_i32),
+                ('sj', c_i64), ('sk', c_i64)]
+
+
+class RolloutDesc(C.Structure):
+    _fields_ = [('B', c_i32), ('ny', c_i32), ('nz', c_i32), ('nh', c_i32), ('nl', c_i32),
+                ('nsteps', c_i32), ('n_euler', c_i32), ('n_data_frames', c_i32), ('dt', c_f32),
+                ('dyn_w', P8), ('dyn_b', P8), ('pz_w', P8), ('pz_b', P8),
+                ('y0', c_vp), ('q_z_params', c_vp), ('eps_z', c_vp),
+                ('y_all', c_vp), ('z', c_vp), ('p_z_params', c_vp), ('res', c_vp),
+                ('inp_all', c_vp), ('hid_dyn', c_vp), ('hid_pz', c_vp), ('scratch_hid', c_vp), ('scratch_out', c_vp)]
+
+
+class RolloutBwdDesc(C.Structure):
+    _fields_ = [('f', RolloutDesc),
+                ('d_y_all', c_vp), ('d_z', c_vp), ('d_pz', c_vp), ('d_res', c_vp),
+                ('d_y0', c_vp), ('d_qz', c_vp), ('dhid_dyn', c_vp), ('dhid_pz', c_vp), ('work', c_vp)]
+
+
+_SIGS = {
+    'srvp_version': ([], c_i32),
+    'srvp_conv_mfma': ([C.POINTER(ConvDesc), c_vp], c_i32),
+    'srvp_wgrad_mfma': ([C.POINTER(WgradDesc), c_vp], c_i32),
+    'srvp_wgrad_set_tr': ([c_i32], c_i32),
+    'srvp_bn_finalize': ([c_vp, c_f64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_vp], c_i32),
+    'srvp_bn_eval_coeffs': ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp], c_i32),
+    'srvp_bn_act': ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp], c_i32),
+    'srvp_bn_bwd_reduce': ([C.POINTER(BnBwdDesc), c_vp, c_vp], c_i32),
+    'srvp_bn_bwd_finalize': ([c_vp, c_f64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
+    'srvp_bn_bwd_apply': ([C.POINTER(BnBwdDesc), c_vp, c_vp, c_i32, c_vp], c_i32),
+    'srvp_conv_in_fwd': ([c_vp, c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp], c_i32),
+    'srvp_conv_in_wgrad': ([c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp], c_i32),
+    'srvp_convT_out_fwd': ([C.POINTER(ConvOutDesc), c_vp, c_vp, c_vp], c_i32),
+    'srvp_convT_out_bwd': ([C.POINTER(ConvOutDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
+    'srvp_pack_weight': ([c_vp, c_vp, C.POINTER(PackDesc), c_vp], c_i32),
+    'srvp_unpack_wgrad': ([c_vp, c_vp, C.POINTER(PackDesc), c_vp], c_i32),
+    'srvp_gemm_f32': ([c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
+    'srvp_axpby_f32': ([c_vp, c_f32, c_vp, c_f32, c_vp, c_i64, c_vp], c_i32),
+    'srvp_colsum_f32': ([c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
+    'srvp_act_bwd_f32': ([c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp], c_i32),
+    'srvp_lstm_fwd': ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
+    'srvp_lstm_bwd': ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
+    'srvp_rollout_fwd': ([C.POINTER(RolloutDesc), c_vp], c_i32),
+    'srvp_rollout_bwd': ([C.POINTER(RolloutBwdDesc), c_vp], c_i32),
+    'srvp_nll': ([c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_vp, c_vp], c_i32),
+    'srvp_kl': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp], c_i32),
+    'srvp_l2rows': ([c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp], c_i32),
+    'srvp_rsample_fwd': ([c_vp, c_vp, c_vp, c_i64, c_i32, c_vp], c_i32),
+    'srvp_rsample_bwd': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp], c_i32),
+    'srvp_adam': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_vp], c_i32),
+    'srvp_fill_f64': ([c_vp, c_i64, c_f64, c_vp], c_i32),
+    'srvp_cast_f32_bf16': ([c_vp, c_vp, c_i64, c_i32, c_i32, c_vp], c_i32),
+    'srvp_skip_grad_reduce': ([c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp], c_i32),
+}
+
+_lib = None
+
+
+class SrvpHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libsrvp_hip.so (once).  Raises if it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SrvpHipError(
+            f'{LIB_PATH} not found: the HIP kernel library is the only compute path of srvp_amd. Build it with '
+            '`make -C srvp_amd/csrc` (or `python -c "import __graft_entry__ as g; g.build()"`).')
+    lib = C.CDLL(LIB_PATH)
+    lib.srvp_last_error.restype = C.c_char_p
+    lib.srvp_last_error.argtypes = []
+    for name, (args, res) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return ['srvp_last_error'] + list(_SIGS)
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().srvp_last_error().decode()
+        raise SrvpHipError(f'{what} failed (code {rc}): {msg}')
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    fn = getattr(load(), name)
+    check(fn(*args), name)
+
+
+def taps(vals):
+    a = TAPS()
+    for i, v in enumerate(vals):
+        a[i] = int(v)
+    return a

@@ -1,0 +1,539 @@
+"""
+HIP launch plans for the convolutional encoder / decoder (reference module/conv.py:129-154, 249-275 and their
+autograd backward), built from the layer tables in arch.py.
+
+Data layout: every activation is an NHWC bfloat16 tensor with channels padded to a multiple of 32 and a 1-pixel
+zero border physically present (class Feat), so the MFMA convolutions gather without bounds checks; MaxPool /
+nearest-Upsample / skip-concat / the per-sample skip gather never materialise a tensor -- they are index arithmetic
+inside the consuming kernel.  BatchNorm is split around its grid-wide reduction: statistics in the conv epilogue,
+`bn_finalize`, then `bn_act` writes the activated tensor.  All compute is in libsrvp_hip.so (see _lib.py); torch is
+used for allocation and streams only.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+CP = 32                      # channel padding granule
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+ACT = {'none': L.ACT_NONE, 'leaky_relu': L.ACT_LRELU, 'tanh': L.ACT_TANH, 'relu': L.ACT_RELU, 'sigmoid': L.ACT_SIGMOID}
+# transposed conv 4x4 s2 p1 (and data-gradient of conv 4x4 s2 p1): output parity -> [(kernel index, padded input offset)]
+PHASE = {0: [(1, 1), (3, 0)], 1: [(0, 2), (2, 1)]}
+
+
+def cpad(c):
+    return (c + CP - 1) // CP * CP
+
+
+class Feat:
+    """NHWC bf16 tensor [N][H+2b][W+2b][C] with zero border b; Cr = number of real channels."""
+
+    def __init__(self, N, H, W, Cr, device, b=1, C=None):
+        self.N, self.H, self.W, self.Cr, self.b = N, H, W, Cr, b
+        self.C = cpad(Cr) if C is None else C
+        self.t = torch.zeros(N, H + 2 * b, W + 2 * b, self.C, dtype=torch.bfloat16, device=device)
+
+    @property
+    def Hp(self):
+        return self.H + 2 * self.b
+
+    @property
+    def Wp(self):
+        return self.W + 2 * self.b
+
+    def interior(self):
+        b = self.b
+        return self.t[:, b:b + self.H, b:b + self.W, :self.Cr]
+
+    def to_nchw(self):
+        return self.interior().permute(0, 3, 1, 2).float().contiguous()
+
+    def load_nchw(self, x):
+        self.interior().copy_(x.permute(0, 2, 3, 1))
+
+
+def _pack_desc(taps_off, J, K, Jsegs, Ksegs, sj, sk):
+    d = L.PackDesc()
+    d.ntaps = len(taps_off)
+    d.tap_off = L.taps(taps_off)
+    d.J, d.K = J, K
+    d.J0, d.J0r, d.J1r = Jsegs
+    d.K0, d.K0r, d.K1r = Ksegs
+    d.sj, d.sk = sj, sk
+    return d
+
+
+class Block:
+    """One conv block (conv -> [BN] -> act) of the encoder or decoder: buffers + launch descriptors."""
+
+    def __init__(self, spec, role, srcs, ups, N, device, training, skip_map=None):
+        """
+        role: 'in' (fp32 frames in), 'mfma', 'out' (fp32 frames out)
+        srcs: list of source Feat (1 or 2) -- for role 'in' empty;  ups: nearest-x2 applied to srcs[0] by the gather
+        """
+        self.spec, self.role, self.srcs, self.ups, self.N, self.dev = spec, role, srcs, ups, N, device
+        self.training = training
+        self.skip_map = skip_map                      # int32 [N] image index into srcs[1]
+        k, s, p = spec['k'], spec['s'], spec['p']
+        self.k, self.s, self.p = k, s, p
+        self.kind = spec['kind']
+        self.cout_r = spec['cout']
+        self.cout = cpad(self.cout_r) if role != 'out' else self.cout_r
+        self.has_bn = spec['bnkey'] is not None
+        self.act = ACT[spec['act']]
+        if role == 'in':
+            self.cin_r = [spec['cin']]
+            self.Hin = self.Win = 64
+        else:
+            self.cin_r = [f.Cr for f in srcs]
+            assert sum(self.cin_r) == spec['cin'], (self.cin_r, spec['cin'])
+            f0 = srcs[0]
+            self.Hin, self.Win = (f0.H * 2, f0.W * 2) if ups else (f0.H, f0.W)
+        if self.kind == 'conv':
+            self.OH = (self.Hin + 2 * p - k) // s + 1
+            self.OW = (self.Win + 2 * p - k) // s + 1
+        else:
+            self.OH = (self.Hin - 1) * s - 2 * p + k
+            self.OW = (self.Win - 1) * s - 2 * p + k
+        # geometry class of the MFMA layers
+        if role == 'mfma':
+            if self.kind == 'conv' and self.OH == 1 and p == 0:
+                self.geom = 'full'                    # k x k conv covering the whole k x k input -> 1x1 (encoder last_conv)
+            elif self.kind == 'conv' and s == 1:
+                self.geom = 'same'                    # 3x3 s1 p1
+            elif self.kind == 'conv' and s == 2:
+                self.geom = 'down'                    # 4x4 s2 p1
+            elif self.kind == 'convT' and s == 2:
+                self.geom = 'up'                      # transposed 4x4 s2 p1
+            elif self.kind == 'convT' and self.Hin == 1:
+                self.geom = 'expand'                  # transposed k x k on a 1x1 input (decoder first_upconv)
+            else:
+                raise NotImplementedError(spec)
+            assert not (self.geom in ('full', 'expand') and len(srcs) != 1)
+        self.ctot = sum(f.C for f in srcs) if srcs else 0
+        if role != 'out':
+            self.raw = torch.empty(N, self.OH, self.OW, self.cout, dtype=torch.bfloat16, device=device)
+            C_ = self.cout
+            self.coef = torch.zeros(4, C_, dtype=torch.float32, device=device)      # scale, shift, mean, invstd
+            if not self.has_bn:
+                self.coef[0, :self.cout_r] = 1.0
+            if self.has_bn and training:
+                self.stats = torch.zeros(2, C_, dtype=torch.float64, device=device)
+        self.out = None           # Feat (activated), set by the net
+        self.pool = None          # pooled Feat
+        self.out_f32 = None       # fp32 [N][C] (encoder output)
+        if role == 'mfma':
+            self._alloc_weights()
+        if training and role != 'in':
+            # gradient wrt the (virtual, concatenated) input of this block: [N][Hin][Win][ctot] bf16, unpadded
+            self.dcat = torch.empty(N, self.Hin, self.Win, self.ctot, dtype=torch.bfloat16, device=device)
+        if training and role != 'out':
+            self.draw_b = 0 if (role == 'mfma' and self.geom in ('full', 'expand')) else 1
+            bd = self.draw_b
+            self.draw = torch.zeros(N, self.OH + 2 * bd, self.OW + 2 * bd, self.cout, dtype=torch.bfloat16, device=device)
+            self.red = torch.zeros(2, self.cout, dtype=torch.float64, device=device)
+            self.bcoef = torch.zeros(3, self.cout, dtype=torch.float32, device=device)
+        if training and role == 'mfma':
+            ntaps = self.k * self.k
+            self.dw = torch.zeros(ntaps, self.cout, self.ctot, dtype=torch.float32, device=device)
+
+    # ------------------------------------------------------------------ weights
+    def _alloc_weights(self):
+        k, kk = self.k, self.k * self.k
+        dev = self.dev
+        co_p, co_r = self.cout, self.cout_r
+        ci_r = sum(self.cin_r)
+        c0p = self.srcs[0].C
+        c0r = self.cin_r[0]
+        c1r = self.cin_r[1] if len(self.cin_r) > 1 else 0
+        isegs = (c0p, c0r, c1r)
+        osegs = (co_p, co_r, 0)
+        nat = list(range(kk))
+        if self.kind == 'conv':
+            sj_f, sk_f = ci_r * kk, kk               # OIHW: j = co, k = ci
+        else:
+            sj_f, sk_f = kk, co_r * kk               # IOHW: j = co, k = ci
+        if self.geom == 'up':
+            order_f = [kh * k + kw for py in (0, 1) for px in (0, 1) for kh, _ in PHASE[py] for kw, _ in PHASE[px]]
+        else:
+            order_f = nat
+        if self.geom == 'down':
+            order_d = [kh * k + kw for py in (0, 1) for px in (0, 1) for kh, _ in PHASE[py] for kw, _ in PHASE[px]]
+        else:
+            order_d = nat
+        self.pf = _pack_desc(order_f, co_p, self.ctot, osegs, isegs, sj_f, sk_f)
+        self.pd = _pack_desc(order_d, self.ctot, co_p, isegs, osegs, sk_f, sj_f)
+        self.pu = _pack_desc(nat, co_p, self.ctot, osegs, isegs, sj_f, sk_f)
+        self.wt_f = torch.empty(kk, co_p, self.ctot, dtype=torch.bfloat16, device=dev)
+        self.wt_d = torch.empty(kk, self.ctot, co_p, dtype=torch.bfloat16, device=dev) if self.training else None
+
+    def pack(self, w, st):
+        L.call('srvp_pack_weight', L.ptr(w), L.ptr(self.wt_f), C.byref(self.pf), st)
+        if self.wt_d is not None:
+            L.call('srvp_pack_weight', L.ptr(w), L.ptr(self.wt_d), C.byref(self.pd), st)
+
+    # ------------------------------------------------------------------ descriptors
+    def _src_fields(self, d):
+        f0 = self.srcs[0]
+        d.src0, d.C0, d.H0p, d.W0p, d.ups0 = L.ptr(f0.t), f0.C, f0.Hp, f0.Wp, 1 if self.ups else 0
+        if len(self.srcs) > 1:
+            f1 = self.srcs[1]
+            d.src1, d.C1, d.H1p, d.W1p, d.ups1 = L.ptr(f1.t), f1.C, f1.Hp, f1.Wp, 0
+            d.map1 = L.ptr(self.skip_map)
+        else:
+            d.src1, d.C1, d.H1p, d.W1p, d.ups1, d.map1 = None, 0, 1, 1, 0, None
+
+    def _set_taps(self, d, taps):
+        d.ntaps = len(taps)
+        d.dy = L.taps([t[0] for t in taps])
+        d.dx = L.taps([t[1] for t in taps])
+
+    def fwd_descs(self):
+        """List of ConvDesc for the forward convolution (4 for the transposed stride-2 phases, else 1)."""
+        k, N = self.k, self.N
+        out = []
+        use_stats = self.has_bn and self.training
+        b_in = self.srcs[0].b
+        if self.geom in ('same', 'down', 'full'):
+            d = L.ConvDesc()
+            self._src_fields(d)
+            off = b_in - self.p
+            self._set_taps(d, [(kh + off, kw + off) for kh in range(k) for kw in range(k)])
+            d.si, d.wt, d.Cout = self.s, L.ptr(self.wt_f), self.cout
+            d.N, d.OH, d.OW = N, self.OH, self.OW
+            d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox, d.Cdst, d.cdst_off = L.ptr(self.raw), self.OH, self.OW, 1, 0, 0, self.cout, 0
+            d.stats, d.stat_mod = (L.ptr(self.stats) if use_stats else None), self.cout
+            out.append(d)
+        elif self.geom == 'up':
+            assert b_in == 1
+            for ph, (py, px) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+                d = L.ConvDesc()
+                self._src_fields(d)
+                self._set_taps(d, [(dy, dx) for _, dy in PHASE[py] for _, dx in PHASE[px]])
+                d.si, d.Cout = 1, self.cout
+                d.wt = L.ptr(self.wt_f) + ph * 4 * self.cout * self.ctot * 2
+                d.N, d.OH, d.OW = N, self.Hin, self.Win
+                d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox, d.Cdst, d.cdst_off = L.ptr(self.raw), self.OH, self.OW, 2, py, px, self.cout, 0
+                d.stats, d.stat_mod = (L.ptr(self.stats) if use_stats else None), self.cout
+                out.append(d)
+        elif self.geom == 'expand':
+            d = L.ConvDesc()
+            self._src_fields(d)
+            self._set_taps(d, [(b_in, b_in)])
+            d.si, d.wt, d.Cout = 1, L.ptr(self.wt_f), k * k * self.cout
+            d.N, d.OH, d.OW = N, 1, 1
+            d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox, d.Cdst, d.cdst_off = L.ptr(self.raw), 1, 1, 1, 0, 0, k * k * self.cout, 0
+            d.stats, d.stat_mod = (L.ptr(self.stats) if use_stats else None), self.cout
+            out.append(d)
+        return out
+
+    def dgrad_descs(self):
+        """ConvDesc list computing dcat = gradient wrt the block input from draw."""
+        k, N, bd = self.k, self.N, self.draw_b
+        out = []
+
+        def base():
+            d = L.ConvDesc()
+            d.src0, d.C0, d.ups0 = L.ptr(self.draw), self.cout, 0
+            d.src1, d.C1, d.H1p, d.W1p, d.ups1, d.map1 = None, 0, 1, 1, 0, None
+            d.H0p, d.W0p = self.OH + 2 * bd, self.OW + 2 * bd
+            d.Cout = self.ctot
+            d.stats, d.stat_mod = None, 1
+            d.Cdst, d.cdst_off = self.ctot, 0
+            return d
+        if self.geom == 'same':
+            d = base()
+            # dIn[i] = sum_kh dOut[i + p - kh]  -> padded coordinate i + p - kh + bd
+            self._set_taps(d, [(self.p - kh + bd, self.p - kw + bd) for kh in range(k) for kw in range(k)])
+            d.si, d.wt = 1, L.ptr(self.wt_d)
+            d.N, d.OH, d.OW = N, self.Hin, self.Win
+            d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox = L.ptr(self.dcat), self.Hin, self.Win, 1, 0, 0
+            out.append(d)
+        elif self.geom == 'down':
+            for ph, (py, px) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+                d = base()
+                self._set_taps(d, [(dy, dx) for _, dy in PHASE[py] for _, dx in PHASE[px]])
+                d.si = 1
+                d.wt = L.ptr(self.wt_d) + ph * 4 * self.ctot * self.cout * 2
+                d.N, d.OH, d.OW = N, self.OH, self.OW
+                d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox = L.ptr(self.dcat), self.Hin, self.Win, 2, py, px
+                out.append(d)
+        elif self.geom == 'up':
+            d = base()
+            # dIn[ih] = sum_kh dOut[2 ih - 1 + kh] -> padded 2 ih + kh (bd = 1)
+            self._set_taps(d, [(kh, kw) for kh in range(k) for kw in range(k)])
+            d.si, d.wt = 2, L.ptr(self.wt_d)
+            d.N, d.OH, d.OW = N, self.Hin, self.Win
+            d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox = L.ptr(self.dcat), self.Hin, self.Win, 1, 0, 0
+            out.append(d)
+        elif self.geom == 'full':
+            d = base()                                 # GEMM: [N][cout] x [cout][(kh,kw,ci)]
+            self._set_taps(d, [(0, 0)])
+            d.H0p, d.W0p = 1, 1
+            d.si, d.wt, d.Cout = 1, L.ptr(self.wt_d), k * k * self.ctot
+            d.N, d.OH, d.OW = N, 1, 1
+            d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox, d.Cdst = L.ptr(self.dcat), 1, 1, 1, 0, 0, k * k * self.ctot
+            out.append(d)
+        elif self.geom == 'expand':
+            d = base()                                 # k x k conv of draw [N][k][k][cout] -> [N][1][1][cin]
+            self._set_taps(d, [(kh, kw) for kh in range(k) for kw in range(k)])
+            d.H0p, d.W0p = k, k
+            d.si, d.wt = 1, L.ptr(self.wt_d)
+            d.N, d.OH, d.OW = N, 1, 1
+            d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox = L.ptr(self.dcat), 1, 1, 1, 0, 0
+            out.append(d)
+        return out
+
+    def wgrad_desc(self):
+        k, N, bd = self.k, self.N, self.draw_b
+        d = L.WgradDesc()
+        self._src_fields(d)
+        b_in = self.srcs[0].b
+        nat = [(kh, kw) for kh in range(k) for kw in range(k)]
+        d.ntaps = k * k
+        d.dout, d.Cout = L.ptr(self.draw), self.cout
+        d.DHp, d.DWp = self.OH + 2 * bd, self.OW + 2 * bd
+        if self.geom in ('same', 'down', 'full'):
+            off = b_in - self.p
+            d.dy, d.dx = L.taps([kh + off for kh, _ in nat]), L.taps([kw + off for _, kw in nat])
+            d.si, d.so = self.s, 1
+            d.ooy, d.oox = L.taps([bd] * (k * k)), L.taps([bd] * (k * k))
+            d.N, d.OH, d.OW = N, self.OH, self.OW
+        elif self.geom == 'up':
+            d.dy, d.dx = L.taps([b_in] * (k * k)), L.taps([b_in] * (k * k))
+            d.si, d.so = 1, 2
+            d.ooy, d.oox = L.taps([kh - self.p + bd for kh, _ in nat]), L.taps([kw - self.p + bd for _, kw in nat])
+            d.N, d.OH, d.OW = N, self.Hin, self.Win
+        elif self.geom == 'expand':
+            d.dy, d.dx = L.taps([b_in] * (k * k)), L.taps([b_in] * (k * k))
+            d.si, d.so = 1, 1
+            d.ooy, d.oox = L.taps([kh for kh, _ in nat]), L.taps([kw for _, kw in nat])
+            d.N, d.OH, d.OW = N, 1, 1
+        d.dw = L.ptr(self.dw)
+        # split-K: enough workgroups to fill the chip, but no more than one per 4 pixel chunks
+        M = d.N * d.OH * d.OW
+        bj = 128 if self.cout % 128 == 0 else (64 if self.cout % 64 == 0 else 32)
+        c0, c1 = d.C0, d.C1
+        bc = 32
+        for cand in (128, 64):
+            if c0 % cand == 0 and (c1 == 0 or c1 % cand == 0):
+                bc = cand
+                break
+        tiles = (self.cout // bj) * (self.ctot // bc) * k * k
+        chunks = (M + 31) // 32
+        d.splitk = int(max(1, min((1024 + tiles - 1) // tiles, chunks // 4 if chunks >= 4 else 1)))
+        return d
+
+
+class ConvNetBase:
+    """Shared launch helpers."""
+
+    def _bn_forward(self, blk, params, st, sync):
+        N, C_ = blk.N, blk.cout
+        scale, shift, mean, invstd = (blk.coef[i] for i in range(4))
+        if blk.has_bn:
+            bk = blk.spec['bnkey']
+            g, b = params[bk + '.weight'], params[bk + '.bias']
+            rm, rv, nbt = params[bk + '.running_mean'], params[bk + '.running_var'], params.get(bk + '.num_batches_tracked')
+            if blk.training:
+                count = float(N * blk.OH * blk.OW)
+                if sync is not None:
+                    count = sync.allreduce_stats(blk.stats, count)
+                L.call('srvp_bn_finalize', L.ptr(blk.stats), count, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(nbt),
+                       L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), C_, blk.cout_r, BN_EPS, BN_MOMENTUM, st)
+                blk.count = count
+            else:
+                L.call('srvp_bn_eval_coeffs', L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(scale), L.ptr(shift), C_,
+                       blk.cout_r, BN_EPS, st)
+        out, pool = blk.out, blk.pool
+        L.call('srvp_bn_act', L.ptr(blk.raw), L.ptr(scale), L.ptr(shift), blk.act, N, blk.OH, blk.OW, C_,
+               L.ptr(out.t) if out is not None else None, out.b if out is not None else 0,
+               L.ptr(pool.t) if pool is not None else None, pool.b if pool is not None else 0,
+               L.ptr(blk.out_f32), st)
+
+    def _block_forward(self, blk, params, st, sync, x=None):
+        if blk.has_bn and blk.training:
+            blk.stats.zero_()
+        if blk.role == 'in':
+            w = params[blk.spec['key'] + '.weight']
+            L.call('srvp_conv_in_fwd', L.ptr(x), L.ptr(w), L.ptr(blk.raw),
+                   L.ptr(blk.stats) if (blk.has_bn and blk.training) else None,
+                   blk.N, blk.cin_r[0], 64, 64, blk.cout, blk.cout_r, blk.k, blk.s, blk.p, st)
+        else:
+            for d in blk._fwd:
+                L.call('srvp_conv_mfma', C.byref(d), st)
+        self._bn_forward(blk, params, st, sync)
+
+    def _bn_backward(self, blk, params, grads, da, st, sync):
+        """da: dict(t, mode, cstride, coff, border, f32, da2, da2_idx).  Produces blk.draw (and BN param grads)."""
+        d = L.BnBwdDesc()
+        d.raw = L.ptr(blk.raw)
+        d.act, d.act_border = (L.ptr(blk.out.t), blk.out.b) if blk.out is not None else (None, 0)
+        d.scale, d.shift, d.mean, d.invstd = (L.ptr(blk.coef[i]) for i in range(4))
+        d.act_kind = blk.act
+        d.da, d.da_mode, d.da_cstride, d.da_coff, d.da_border = L.ptr(da['t']), da['mode'], da['cstride'], da['coff'], da['border']
+        d.da_is_f32 = 1 if da.get('f32') else 0
+        d.da2, d.da2_idx = L.ptr(da.get('da2')), L.ptr(da.get('da2_idx'))
+        d.N, d.H, d.W, d.C = blk.N, blk.OH, blk.OW, blk.cout
+        if blk.has_bn:
+            blk.red.zero_()
+            L.call('srvp_bn_bwd_reduce', C.byref(d), L.ptr(blk.red), st)
+            count = float(blk.N * blk.OH * blk.OW)
+            if sync is not None:
+                count = sync.allreduce_stats(blk.red, count)
+            bk = blk.spec['bnkey']
+            L.call('srvp_bn_bwd_finalize', L.ptr(blk.red), count, L.ptr(blk.coef[0]), L.ptr(blk.coef[2]), L.ptr(blk.coef[3]),
+                   L.ptr(grads[bk + '.weight']), L.ptr(grads[bk + '.bias']), L.ptr(blk.bcoef), blk.cout, blk.cout_r, 1, st)
+        else:
+            L.call('srvp_bn_bwd_finalize', None, 1.0, None, None, None, None, None, L.ptr(blk.bcoef), blk.cout, blk.cout_r, 0, st)
+        L.call('srvp_bn_bwd_apply', C.byref(d), L.ptr(blk.bcoef), L.ptr(blk.draw), blk.draw_b, st)
+
+    def _mfma_backward(self, blk, grads, st, need_dgrad=True):
+        blk.dw.zero_()
+        L.call('srvp_wgrad_mfma', C.byref(blk._wg), st)
+        L.call('srvp_unpack_wgrad', L.ptr(blk.dw), L.ptr(grads[blk.spec['key'] + '.weight']), C.byref(blk.pu), st)
+        if need_dgrad:
+            for d in blk._dg:
+                L.call('srvp_conv_mfma', C.byref(d), st)
+
+    def pack_weights(self, params, st):
+        for blk in self.blocks:
+            if blk.role == 'mfma':
+                blk.pack(params[blk.spec['key'] + '.weight'], st)
+
+
+class EncoderNet(ConvNetBase):
+    """conv.py:129-154 on N = T*B frames: x fp32 (N, C, 64, 64) -> hx fp32 (N, nh) and the stage outputs (skips)."""
+
+    def __init__(self, specs, N, device, training):
+        self.N, self.dev, self.training = N, device, training
+        self.blocks = []
+        cur = None
+        for i, sp in enumerate(specs):
+            role = 'in' if i == 0 else 'mfma'
+            blk = Block(sp, role, [] if role == 'in' else [cur], False, N, device, training)
+            last = i == len(specs) - 1
+            nxt_pool = (not last) and specs[i + 1]['pre'] == 'pool'
+            if last:
+                blk.out_f32 = torch.empty(N, blk.cout, dtype=torch.float32, device=device)
+                cur = None
+            else:
+                need_full = (sp['skip_out'] is not None) or not nxt_pool or training
+                blk.out = Feat(N, blk.OH, blk.OW, blk.cout_r, device) if need_full else None
+                if nxt_pool:
+                    blk.pool = Feat(N, blk.OH // 2, blk.OW // 2, blk.cout_r, device)
+                    cur = blk.pool
+                else:
+                    cur = blk.out
+            self.blocks.append(blk)
+        for blk in self.blocks:
+            if blk.role == 'mfma':
+                blk._fwd = blk.fwd_descs()
+                if training:
+                    blk._dg = blk.dgrad_descs()
+                    blk._wg = blk.wgrad_desc()
+        # keyed by the decoder's skip index (deepest first, conv.py:153): encoder stage s feeds decoder block 3 - s
+        self.skips = {3 - sp['skip_out']: b.out for sp, b in zip(specs, self.blocks) if sp['skip_out'] is not None}
+        self.nh_r = specs[-1]['cout']
+
+    def forward(self, x, params, st, sync=None):
+        for blk in self.blocks:
+            self._block_forward(blk, params, st, sync, x=x)
+        return self.blocks[-1].out_f32[:, :self.nh_r]
+
+    def backward(self, x, d_hx, skip_grads, params, grads, st, sync=None):
+        """
+        d_hx: fp32 [N][nh_padded] gradient of the encoder output; skip_grads: {stage: (dsel bf16 [B][H][W][C], idx int32 [N])}
+        """
+        nb = len(self.blocks)
+        da = dict(t=d_hx, mode=0, cstride=d_hx.shape[1], coff=0, border=0, f32=True)
+        for i in range(nb - 1, -1, -1):
+            blk = self.blocks[i]
+            sk = blk.spec['skip_out']
+            if sk is not None and skip_grads and (3 - sk) in skip_grads:
+                da['da2'], da['da2_idx'] = skip_grads[3 - sk]
+            self._bn_backward(blk, params, grads, da, st, sync)
+            if blk.role == 'in':
+                w = blk.spec['key'] + '.weight'
+                L.call('srvp_conv_in_wgrad', L.ptr(x), L.ptr(blk.draw), L.ptr(grads[w]), blk.N, blk.cin_r[0], 64, 64,
+                       blk.cout, blk.cout_r, blk.k, blk.s, blk.p, st)
+            else:
+                self._mfma_backward(blk, grads, st)
+                pooled = blk.spec['pre'] == 'pool'
+                da = dict(t=blk.dcat, mode=2 if pooled else 0, cstride=blk.ctot, coff=0, border=0)
+
+
+class DecoderNet(ConvNetBase):
+    """conv.py:249-275 on N = nt*B latent rows: z (N, nz) -> x_ fp32 (N, C, 64, 64); skips come from an EncoderNet."""
+
+    def __init__(self, specs, N, device, training, skip_feats=None, skip_map=None):
+        self.N, self.dev, self.training = N, device, training
+        self.blocks = []
+        z_r = specs[0]['cin']
+        self.z = Feat(N, 1, 1, z_r, device, b=0)
+        cur, ups = self.z, False
+        for i, sp in enumerate(specs):
+            last = i == len(specs) - 1
+            srcs = [cur]
+            if sp['cat'] is not None:
+                srcs.append(skip_feats[sp['cat']])
+            blk = Block(sp, 'out' if last else 'mfma', srcs, ups, N, device, training,
+                        skip_map=skip_map if sp['cat'] is not None else None)
+            if not last:
+                blk.out = Feat(N, blk.OH, blk.OW, blk.cout_r, device)
+                cur, ups = blk.out, sp['post_up']
+            self.blocks.append(blk)
+        for blk in self.blocks:
+            if blk.role == 'mfma':
+                blk._fwd = blk.fwd_descs()
+                if training:
+                    blk._dg = blk.dgrad_descs()
+                    blk._wg = blk.wgrad_desc()
+        ob = self.blocks[-1]
+        self.nc = ob.cout_r
+        d = L.ConvOutDesc()
+        f0 = ob.srcs[0]
+        assert not ob.ups
+        d.src0, d.C0, d.C0_real = L.ptr(f0.t), f0.C, f0.Cr
+        if len(ob.srcs) > 1:
+            f1 = ob.srcs[1]
+            d.src1, d.C1, d.C1_real, d.map1 = L.ptr(f1.t), f1.C, f1.Cr, L.ptr(skip_map)
+        else:
+            d.src1, d.C1, d.C1_real, d.map1 = None, 0, 0, None
+        d.N, d.H, d.W, d.Cout, d.k, d.s, d.p, d.apply_sigmoid = N, f0.H, f0.W, ob.cout_r, ob.k, ob.s, ob.p, 1
+        self.out_desc = d
+        self.x_out = torch.empty(N, ob.cout_r, ob.OH, ob.OW, dtype=torch.float32, device=device)
+
+    def forward(self, z_f32, params, st, sync=None):
+        """z_f32: fp32 [N][nz_real]"""
+        L.call('srvp_cast_f32_bf16', L.ptr(z_f32), L.ptr(self.z.t), self.N, z_f32.shape[1], self.z.C, st)
+        for blk in self.blocks[:-1]:
+            self._block_forward(blk, params, st, sync)
+        ob = self.blocks[-1]
+        L.call('srvp_convT_out_fwd', C.byref(self.out_desc), L.ptr(params[ob.spec['key'] + '.weight']), L.ptr(self.x_out), st)
+        return self.x_out
+
+    def backward(self, d_x, params, grads, st, sync=None):
+        """d_x: fp32 (N, C, 64, 64).  Returns dz bf16 [N][nz_padded]; skip gradients are left in the blocks' dcat."""
+        ob = self.blocks[-1]
+        wkey = ob.spec['key'] + '.weight'
+        L.call('srvp_convT_out_bwd', C.byref(self.out_desc), L.ptr(params[wkey]), L.ptr(self.x_out), L.ptr(d_x),
+               L.ptr(ob.dcat), L.ptr(grads[wkey]), st)
+        nxt = ob
+        for i in range(len(self.blocks) - 2, -1, -1):
+            blk = self.blocks[i]
+            da = dict(t=nxt.dcat, mode=1 if blk.spec['post_up'] else 0, cstride=nxt.ctot, coff=0, border=0)
+            self._bn_backward(blk, params, grads, da, st, sync)
+            self._mfma_backward(blk, grads, st)
+            nxt = blk
+        return self.blocks[0].dcat.view(self.N, -1)
+
+    def skip_grad_sources(self):
+        """{stage: (dcat tensor, cstride, coff, C, H*W)} for the blocks that consumed a skip connection."""
+        out = {}
+        for blk in self.blocks:
+            if blk.spec['cat'] is not None:
+                f1 = blk.srcs[1]
+                out[blk.spec['cat']] = (blk.dcat, blk.ctot, blk.srcs[0].C, f1.C, f1.H * f1.W)
+        return out

@@ -1,0 +1,358 @@
+// BatchNorm2d (training / eval) + activation around the MFMA convolutions, forward and backward.
+// HBM-bound elementwise / reduction kernels: 16-byte (8 x bf16) accesses, one channel group per thread so that the
+// per-channel coefficients live in registers, fp64 atomics for the grid-wide per-channel reductions.
+//
+// Replaces nn.BatchNorm2d + LeakyReLU/Tanh (+ MaxPool2d) as placed by reference module/conv.py:81-107,204-222 and
+// their autograd backward; running-statistics semantics as torch (momentum 0.1, unbiased running_var, eps 1e-5).
+#include "common.h"
+#include "../../include/srvp_hip.h"
+
+namespace {
+
+__global__ void bn_finalize_kernel(const double* stats, double count, const float* gamma, const float* beta,
+                                   float* rmean, float* rvar, long long* nbt, float* scale, float* shift, float* mean,
+                                   float* invstd, int C, int C_real, float eps, float momentum) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    if (c >= C_real) { scale[c] = 0.f; shift[c] = 0.f; mean[c] = 0.f; invstd[c] = 0.f; return; }
+    double m = stats[c] / count;
+    double var = stats[C + c] / count - m * m;
+    if (var < 0.) var = 0.;
+    double is = 1.0 / sqrt(var + (double)eps);
+    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    mean[c] = (float)m; invstd[c] = (float)is;
+    scale[c] = (float)(g * is);
+    shift[c] = (float)(b - m * g * is);
+    if (rmean) {
+        double unb = count > 1. ? var * count / (count - 1.) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                                      float* scale, float* shift, int C, int C_real, float eps) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (c >= C_real) { scale[c] = 0.f; shift[c] = 0.f; return; }
+    if (!gamma) { scale[c] = 1.f; shift[c] = 0.f; return; }     // block without BatchNorm
+    float is = 1.f / sqrtf(rvar[c] + eps);
+    scale[c] = gamma[c] * is;
+    shift[c] = beta[c] - rmean[c] * gamma[c] * is;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward: act = f(scale*raw + shift)
+// ---------------------------------------------------------------------------------------------------------
+template <bool POOL>
+__global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ raw, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, int act, int N, int H, int W, int C,
+                                                     bf16_t* __restrict__ dst, int db, bf16_t* __restrict__ dpool, int pb,
+                                                     float* __restrict__ dst_f32) {
+    const int CG = C / 8;
+    const int OH = POOL ? H / 2 : H, OW = POOL ? W / 2 : W;
+    const long long total = (long long)N * OH * OW * CG;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
+        int cg = (int)(it % CG);
+        long long p = it / CG;
+        int x = (int)(p % OW); p /= OW;
+        int y = (int)(p % OH);
+        int n = (int)(p / OH);
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = scale[cg * 8 + e]; sh[e] = shift[cg * 8 + e]; }
+        float mx[8];
+        constexpr int R = POOL ? 2 : 1;
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                int yy = y * R + i, xx = x * R + j;
+                size_t off = (((size_t)n * H + yy) * W + xx) * C + cg * 8;
+                u32x4_t v = *reinterpret_cast<const u32x4_t*>(raw + off);
+                float f[8];
+                unpack8(v, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = act_fwd(f[e] * sc[e] + sh[e], act);
+                u32x4_t o = pack8(f);
+                if (dst) {
+                    size_t doff = (((size_t)n * (H + 2 * db) + yy + db) * (W + 2 * db) + xx + db) * C + cg * 8;
+                    *reinterpret_cast<u32x4_t*>(dst + doff) = o;
+                }
+                if (dst_f32) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dst_f32[off + e] = f[e];
+                }
+                if (POOL) {
+                    // pooled values are taken from the bf16-rounded activations (what the consumer of `dst` sees)
+                    float fr[8];
+                    unpack8(o, fr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) mx[e] = (i == 0 && j == 0) ? fr[e] : fmaxf(mx[e], fr[e]);
+                }
+            }
+        if (POOL) {
+            size_t poff = (((size_t)n * (OH + 2 * pb) + y + pb) * (OW + 2 * pb) + x + pb) * C + cg * 8;
+            *reinterpret_cast<u32x4_t*>(dpool + poff) = pack8(mx);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------------
+struct BnBwdK {
+    const bf16_t* raw; const bf16_t* act; int act_border;
+    const float* scale; const float* shift; const float* mean; const float* invstd; int act_kind;
+    const void* da; int da_mode, da_cstride, da_coff, da_border, da_is_f32;
+    const bf16_t* da2; const int* da2_idx;
+    int N, H, W, C;
+};
+
+// g[8] = dA * f'(pre) for pixel (n,y,x), channel group cg; also returns raw values
+__device__ __forceinline__ void bn_bwd_g(const BnBwdK& a, int n, int y, int x, int cg, const float* sc, const float* sh,
+                                         float* g, float* rawf) {
+    const int C = a.C, H = a.H, W = a.W;
+    size_t roff = (((size_t)n * H + y) * W + x) * C + cg * 8;
+    unpack8(*reinterpret_cast<const u32x4_t*>(a.raw + roff), rawf);
+    float d[8];
+    const int db = a.da_border, cs = a.da_cstride, co = a.da_coff + cg * 8;
+    if (a.da_is_f32) {
+        const float* da = (const float*)a.da;
+        size_t off = (((size_t)n * (H + 2 * db) + y + db) * (W + 2 * db) + x + db) * cs + co;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] = da[off + e];
+    } else {
+        const bf16_t* da = (const bf16_t*)a.da;
+        if (a.da_mode == 0) {
+            size_t off = (((size_t)n * (H + 2 * db) + y + db) * (W + 2 * db) + x + db) * cs + co;
+            unpack8(*reinterpret_cast<const u32x4_t*>(da + off), d);
+        } else if (a.da_mode == 1) {
+            const int H2 = 2 * H, W2 = 2 * W;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    size_t off = (((size_t)n * (H2 + 2 * db) + 2 * y + i + db) * (W2 + 2 * db) + 2 * x + j + db) * cs + co;
+                    float t[8];
+                    unpack8(*reinterpret_cast<const u32x4_t*>(da + off), t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d[e] += t[e];
+                }
+        } else {
+            const int Hh = H / 2, Wh = W / 2;
+            size_t off = (((size_t)n * (Hh + 2 * db) + (y >> 1) + db) * (Wh + 2 * db) + (x >> 1) + db) * cs + co;
+            float t[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(da + off), t);
+            // arg-max routing with torch's first-max tie rule (scan order (0,0),(0,1),(1,0),(1,1) of the window)
+            const int ab = a.act_border;
+            const int y0 = y & ~1, x0 = x & ~1;
+            const int me = (y & 1) * 2 + (x & 1);
+            float w4[4][8];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    size_t aoff = (((size_t)n * (H + 2 * ab) + y0 + i + ab) * (W + 2 * ab) + x0 + j + ab) * C + cg * 8;
+                    unpack8(*reinterpret_cast<const u32x4_t*>(a.act + aoff), w4[i * 2 + j]);
+                }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int best = 0; float bv = w4[0][e];
+#pragma unroll
+                for (int q = 1; q < 4; ++q) if (w4[q][e] > bv) { bv = w4[q][e]; best = q; }
+                d[e] = (best == me) ? t[e] : 0.f;
+            }
+        }
+    }
+    if (a.da2) {
+        int idx = a.da2_idx ? a.da2_idx[n] : n;
+        if (idx >= 0) {
+            size_t off = (((size_t)idx * H + y) * W + x) * C + cg * 8;
+            float t[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(a.da2 + off), t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] += t[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = d[e] * act_bwd(rawf[e] * sc[e] + sh[e], a.act_kind);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdK a, double* red) {
+    const int CG = a.C / 8;
+    const int PPB = blockDim.x / CG;             // pixels handled in parallel by one workgroup
+    const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+    __shared__ float sred[256][17];
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    if (pl < PPB) {
+        float sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = a.scale[cg * 8 + e]; sh[e] = a.shift[cg * 8 + e];
+            mu[e] = a.mean ? a.mean[cg * 8 + e] : 0.f; is[e] = a.invstd ? a.invstd[cg * 8 + e] : 0.f;
+        }
+        const long long P = (long long)a.N * a.H * a.W;
+        for (long long p = (long long)blockIdx.x * PPB + pl; p < P; p += (long long)gridDim.x * PPB) {
+            int x = (int)(p % a.W); long long q = p / a.W;
+            int y = (int)(q % a.H); int n = (int)(q / a.H);
+            float g[8], rawf[8];
+            bn_bwd_g(a, n, y, x, cg, sc, sh, g, rawf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s1[e] += g[e]; s2[e] += g[e] * (rawf[e] - mu[e]) * is[e]; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sred[threadIdx.x][e] = s1[e]; sred[threadIdx.x][8 + e] = s2[e]; }
+    __syncthreads();
+    // thread t < CG*16 sums column (cg = t / 16, k = t % 16) over the PPB pixel lanes
+    for (int t = threadIdx.x; t < CG * 16; t += blockDim.x) {
+        int c = t / 16, k = t % 16;
+        double s = 0.;
+        for (int l = 0; l < PPB; ++l) s += sred[l * CG + c][k];
+        int ch = c * 8 + (k & 7);
+        atomicAdd(red + (k >> 3) * a.C + ch, s);
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* red, double count, const float* scale, const float* mean,
+                                       const float* invstd, float* dgamma, float* dbeta, float* coef, int C, int C_real,
+                                       int has_bn) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (c >= C_real) { coef[c] = 0.f; coef[C + c] = 0.f; coef[2 * C + c] = 0.f; return; }
+    if (!has_bn) { coef[c] = 1.f; coef[C + c] = 0.f; coef[2 * C + c] = 0.f; return; }
+    double sg = red[c], sgx = red[C + c];
+    if (dgamma) dgamma[c] += (float)sgx;
+    if (dbeta) dbeta[c] += (float)sg;
+    double mg = sg / count, mgx = sgx / count;
+    double k1 = scale[c];
+    double k3 = -k1 * mgx * invstd[c];
+    double k2 = -k1 * mg - k3 * mean[c];
+    coef[c] = (float)k1; coef[C + c] = (float)k2; coef[2 * C + c] = (float)k3;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK a, const float* __restrict__ coef,
+                                                           bf16_t* __restrict__ draw, int db) {
+    const int CG = a.C / 8;
+    const int PPB = blockDim.x / CG;
+    const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+    if (pl >= PPB) return;
+    float sc[8], sh[8], k1[8], k2[8], k3[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = a.scale[cg * 8 + e]; sh[e] = a.shift[cg * 8 + e];
+        k1[e] = coef[cg * 8 + e]; k2[e] = coef[a.C + cg * 8 + e]; k3[e] = coef[2 * a.C + cg * 8 + e];
+    }
+    const long long P = (long long)a.N * a.H * a.W;
+    for (long long p = (long long)blockIdx.x * PPB + pl; p < P; p += (long long)gridDim.x * PPB) {
+        int x = (int)(p % a.W); long long q = p / a.W;
+        int y = (int)(q % a.H); int n = (int)(q / a.H);
+        float g[8], rawf[8], o[8];
+        bn_bwd_g(a, n, y, x, cg, sc, sh, g, rawf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = k1[e] * g[e] + k2[e] + k3[e] * rawf[e];
+        size_t off = (((size_t)n * (a.H + 2 * db) + y + db) * (a.W + 2 * db) + x + db) * a.C + cg * 8;
+        *reinterpret_cast<u32x4_t*>(draw + off) = pack8(o);
+    }
+}
+
+int fill_k(const srvp_bnbwd_desc* d, BnBwdK& k) {
+    SRVP_REQUIRE(d && d->raw && d->scale && d->shift && d->da, "srvp_bn_bwd: null pointer");
+    SRVP_REQUIRE(d->C % 8 == 0 && d->C / 8 <= 256, "srvp_bn_bwd: C=%d unsupported", d->C);
+    SRVP_REQUIRE(d->da_mode != 2 || d->act, "srvp_bn_bwd: pooled mode needs the activated tensor");
+    SRVP_REQUIRE(d->da_mode != 2 || (d->H % 2 == 0 && d->W % 2 == 0), "srvp_bn_bwd: pooled mode needs even H, W");
+    k.raw = (const bf16_t*)d->raw; k.act = (const bf16_t*)d->act; k.act_border = d->act_border;
+    k.scale = d->scale; k.shift = d->shift; k.mean = d->mean; k.invstd = d->invstd; k.act_kind = d->act_kind;
+    k.da = d->da; k.da_mode = d->da_mode; k.da_cstride = d->da_cstride; k.da_coff = d->da_coff;
+    k.da_border = d->da_border; k.da_is_f32 = d->da_is_f32; k.da2 = (const bf16_t*)d->da2; k.da2_idx = d->da2_idx;
+    k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C;
+    return SRVP_OK;
+}
+
+inline unsigned grid_for(long long work_items, int per_block) {
+    long long b = (work_items + per_block - 1) / per_block;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int srvp_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift,
+                                float* mean, float* invstd, int C, int C_real, float eps, float momentum, void* stream) {
+    SRVP_REQUIRE(stats && scale && shift && mean && invstd && C > 0, "srvp_bn_finalize: bad args");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, count, gamma,
+                       beta, running_mean, running_var, (long long*)nbt, scale, shift, mean, invstd, C, C_real, eps, momentum);
+    SRVP_CHECK_LAUNCH("srvp_bn_finalize");
+    return SRVP_OK;
+}
+
+extern "C" int srvp_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                   const float* running_var, float* scale, float* shift, int C, int C_real, float eps,
+                                   void* stream) {
+    SRVP_REQUIRE(scale && shift && C > 0, "srvp_bn_eval_coeffs: bad args");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, scale, shift, C, C_real, eps);
+    SRVP_CHECK_LAUNCH("srvp_bn_eval_coeffs");
+    return SRVP_OK;
+}
+
+extern "C" int srvp_bn_act(const void* raw, const float* scale, const float* shift, int act, int N, int H, int W, int C,
+                           void* dst, int dst_border, void* dst_pool, int pool_border, float* dst_f32, void* stream) {
+    SRVP_REQUIRE(raw && scale && shift && C % 8 == 0, "srvp_bn_act: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (dst_pool) {
+        SRVP_REQUIRE(H % 2 == 0 && W % 2 == 0, "srvp_bn_act: pooling needs even H, W");
+        long long total = (long long)N * (H / 2) * (W / 2) * (C / 8);
+        hipLaunchKernelGGL(bn_act_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)raw, scale, shift,
+                           act, N, H, W, C, (bf16_t*)dst, dst_border, (bf16_t*)dst_pool, pool_border, dst_f32);
+    } else {
+        long long total = (long long)N * H * W * (C / 8);
+        hipLaunchKernelGGL(bn_act_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)raw, scale, shift,
+                           act, N, H, W, C, (bf16_t*)dst, dst_border, (bf16_t*)nullptr, 0, dst_f32);
+    }
+    SRVP_CHECK_LAUNCH("srvp_bn_act");
+    return SRVP_OK;
+}
+
+extern "C" int srvp_bn_bwd_reduce(const srvp_bnbwd_desc* d, double* red, void* stream) {
+    BnBwdK k;
+    int rc = fill_k(d, k);
+    if (rc) return rc;
+    SRVP_REQUIRE(red, "srvp_bn_bwd_reduce: null red");
+    const int CG = k.C / 8, PPB = 256 / CG;
+    long long P = (long long)k.N * k.H * k.W;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for(P, PPB * 8)), dim3(256), 0, (hipStream_t)stream, k, red);
+    SRVP_CHECK_LAUNCH("srvp_bn_bwd_reduce");
+    return SRVP_OK;
+}
+
+extern "C" int srvp_bn_bwd_finalize(const double* red, double count, const float* scale, const float* mean,
+                                    const float* invstd, float* dgamma, float* dbeta, float* coef, int C, int C_real,
+                                    int has_bn, void* stream) {
+    SRVP_REQUIRE(coef && C > 0 && (!has_bn || (red && scale && mean && invstd)), "srvp_bn_bwd_finalize: bad args");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, red, count, scale,
+                       mean, invstd, dgamma, dbeta, coef, C, C_real, has_bn);
+    SRVP_CHECK_LAUNCH("srvp_bn_bwd_finalize");
+    return SRVP_OK;
+}
+
+extern "C" int srvp_bn_bwd_apply(const srvp_bnbwd_desc* d, const float* coef, void* draw, int dst_border, void* stream) {
+    BnBwdK k;
+    int rc = fill_k(d, k);
+    if (rc) return rc;
+    SRVP_REQUIRE(coef && draw, "srvp_bn_bwd_apply: null pointer");
+    const int CG = k.C / 8, PPB = 256 / CG;
+    long long P = (long long)k.N * k.H * k.W;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(P, PPB * 4)), dim3(256), 0, (hipStream_t)stream, k, coef,
+                       (bf16_t*)draw, dst_border);
+    SRVP_CHECK_LAUNCH("srvp_bn_bwd_apply");
+    return SRVP_OK;
+}

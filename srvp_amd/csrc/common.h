@@ -1,0 +1,96 @@
+// Common device helpers for the SRVP gfx950 (MI355X / CDNA4) kernels.
+// Everything here is written for wave64 + MFMA; there is no other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef unsigned short bf16_t;   // raw bfloat16 bits
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+#define SRVP_OK 0
+#define SRVP_ERR_ARG 1
+#define SRVP_ERR_LAUNCH 2
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even (same as torch's float->bfloat16); NaN kept quiet
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ void unpack8(const u32x4_t& v, float* f) {
+    f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
+    f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
+}
+__device__ __forceinline__ u32x4_t pack8(const float* f) {
+    u32x4_t v;
+    v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]); v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+    return v;
+}
+
+// activation ids shared with the host side (srvp_hip.h)
+#define ACT_NONE 0
+#define ACT_LRELU 1   // LeakyReLU(0.2)  (reference utils.py:41)
+#define ACT_TANH 2
+#define ACT_RELU 3
+#define ACT_SIGMOID 4
+#define LRELU_SLOPE 0.2f
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    switch (act) {
+        case ACT_LRELU: return v > 0.f ? v : LRELU_SLOPE * v;
+        case ACT_TANH: return tanhf(v);
+        case ACT_RELU: return v > 0.f ? v : 0.f;
+        case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+// derivative given the pre-activation value v (and for tanh/sigmoid recomputed output)
+__device__ __forceinline__ float act_bwd(float v, int act) {
+    switch (act) {
+        case ACT_LRELU: return v > 0.f ? 1.f : LRELU_SLOPE;
+        case ACT_TANH: { float t = tanhf(v); return 1.f - t * t; }
+        case ACT_RELU: return v > 0.f ? 1.f : 0.f;
+        case ACT_SIGMOID: { float s = 1.f / (1.f + __expf(-v)); return s * (1.f - s); }
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- error reporting across the C ABI (no exceptions cross it) ----
+void srvp_set_error(const char* fmt, ...);
+#define SRVP_CHECK_LAUNCH(name)                                                         \
+    do {                                                                                \
+        hipError_t e__ = hipGetLastError();                                             \
+        if (e__ != hipSuccess) {                                                        \
+            srvp_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+            return SRVP_ERR_LAUNCH;                                                     \
+        }                                                                               \
+    } while (0)
+#define SRVP_REQUIRE(cond, ...)                                                         \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            srvp_set_error(__VA_ARGS__);                                                \
+            return SRVP_ERR_ARG;                                                        \
+        }                                                                               \
+    } while (0)

@@ -1,0 +1,480 @@
+// Latent path of SRVP in fp32: Linear / MLP building block (generic strided GEMM with fused bias, activation and
+// ReLU-mask epilogues), LSTM recurrence, the residual Euler rollout with its prior network, and their backward
+// passes.  <0.1 % of the model FLOPs but a long serial chain: the C entry points sequence the whole
+// chain on the stream with no host synchronisation.
+//
+// Replaces: module/mlp.py:21-90, nn.LSTM (module/srvp.py:132,366), q_z / p_z / dynamics and the Euler loop
+// (srvp.py:280-323, 370-405), utils.rsample_normal (module/utils.py:115-134), and their autograd backward.
+#include "common.h"
+#include "../../include/srvp_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// C[M][N] (+)= epi( A[M][K] * B[K][N] + bias ),  generic element strides.  64x64 tile, 256 threads, 4x4 micro-tile.
+// epi: activation, then optional multiply by (mask > 0) (ReLU derivative taken from the saved post-ReLU activation).
+// ---------------------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const float* A; long long a_rs, a_cs;
+    const float* B; long long b_rs, b_cs;
+    const float* bias; float* C; long long c_rs;
+    const float* mask; long long mask_rs;
+    int M, N, K, act, accumulate;
+    float alpha;
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+    constexpr int BK = 16;
+    constexpr int TM = BM / 16, TN = BN / 16;
+    __shared__ float As[BK][BM + 4];
+    __shared__ float Bs[BK][BN + 4];
+    const int tid = threadIdx.x;
+    const int tx = tid % 16, ty = tid / 16;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    float acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = 0.f;
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        for (int q = tid; q < BM * BK; q += 256) {
+            int kk, mm;
+            if (g.a_cs == 1) { kk = q % BK; mm = q / BK; } else { mm = q % BM; kk = q / BM; }
+            int m = m0 + mm, k = k0 + kk;
+            As[kk][mm] = (m < g.M && k < g.K) ? g.A[m * g.a_rs + k * g.a_cs] : 0.f;
+        }
+        for (int q = tid; q < BN * BK; q += 256) {
+            int kk, nn;
+            if (g.b_rs == 1) { kk = q % BK; nn = q / BK; } else { nn = q % BN; kk = q / BN; }
+            int n = n0 + nn, k = k0 + kk;
+            Bs[kk][nn] = (n < g.N && k < g.K) ? g.B[k * g.b_rs + n * g.b_cs] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[kk][ty + 16 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[kk][tx + 16 * j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] += a[i] * b[j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int m = m0 + ty + 16 * i;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int n = n0 + tx + 16 * j;
+            if (n >= g.N) continue;
+            float v = acc[i][j] * g.alpha;
+            if (g.bias) v += g.bias[n];
+            v = act_fwd(v, g.act);
+            if (g.mask) v = g.mask[m * g.mask_rs + n] > 0.f ? v : 0.f;
+            float* c = g.C + m * g.c_rs + n;
+            *c = g.accumulate ? *c + v : v;
+        }
+    }
+}
+
+int gemm(hipStream_t st, const float* A, long long a_rs, long long a_cs, const float* B, long long b_rs, long long b_cs,
+         const float* bias, float* C, long long c_rs, int M, int N, int K, int act, int accumulate,
+         const float* mask = nullptr, long long mask_rs = 0, float alpha = 1.f) {
+    if (M <= 0 || N <= 0) return SRVP_OK;
+    GemmArgs g{A, a_rs, a_cs, B, b_rs, b_cs, bias, C, c_rs, mask, mask_rs, M, N, K, act, accumulate, alpha};
+    if ((long long)M * N <= 64 * 1024) {
+        dim3 grid((N + 31) / 32, (M + 31) / 32);
+        hipLaunchKernelGGL((gemm_f32_kernel<32, 32>), grid, dim3(256), 0, st, g);
+    } else {
+        dim3 grid((N + 63) / 64, (M + 63) / 64);
+        hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), grid, dim3(256), 0, st, g);
+    }
+    SRVP_CHECK_LAUNCH("srvp_gemm_f32");
+    return SRVP_OK;
+}
+
+__global__ void colsum_kernel(const float* A, long long a_rs, float* out, int M, int N, int accumulate) {
+    // one workgroup per 64 columns; 4 waves stride over rows
+    __shared__ float part[4][64];
+    int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    int w = threadIdx.x >> 6;
+    float s = 0.f;
+    if (n < N)
+        for (int m = w; m < M; m += 4) s += A[m * a_rs + n];
+    part[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && n < N) {
+        float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        out[n] = accumulate ? out[n] + t : t;
+    }
+}
+
+__global__ void act_bwd_kernel(const float* v, const float* dy, float* dx, long long n, int act, int from_output) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float d;
+    if (from_output) {
+        float o = v[i];
+        switch (act) {
+            case ACT_RELU: d = o > 0.f ? 1.f : 0.f; break;
+            case ACT_TANH: d = 1.f - o * o; break;
+            case ACT_SIGMOID: d = o * (1.f - o); break;
+            case ACT_LRELU: d = o > 0.f ? 1.f : LRELU_SLOPE; break;
+            default: d = 1.f;
+        }
+    } else {
+        d = act_bwd(v[i], act);
+    }
+    dx[i] = dy[i] * d;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// rsample (utils.py:108-112,132-133): out = loc + eps * (softplus(raw) + 1e-8), softplus threshold 20
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__global__ void rsample_fwd_kernel(const float* params, const float* eps, float* out, long long rows, int d) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * d) return;
+    long long r = i / d; int c = (int)(i - r * d);
+    const float* p = params + r * 2 * d;
+    out[i] = p[c] + eps[i] * (softplus_f(p[d + c]) + 1e-8f);
+}
+// dparams[r][c] (+)= dout ; dparams[r][d+c] (+)= dout * eps * softplus'(raw)
+__global__ void rsample_bwd_kernel(const float* params, const float* eps, const float* dout, float* dparams, long long rows,
+                                   int d, int accumulate, long long dp_rs) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * d) return;
+    long long r = i / d; int c = (int)(i - r * d);
+    float raw = params[r * 2 * d + d + c];
+    float ds = raw > 20.f ? 1.f : sigmoid_f(raw);
+    float g = dout[i];
+    float* o = dparams + r * dp_rs;
+    if (accumulate) { o[c] += g; o[d + c] += g * eps[i] * ds; }
+    else { o[c] = g; o[d + c] = g * eps[i] * ds; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// small row helpers for the rollout
+// ---------------------------------------------------------------------------------------------------------
+// inp[b] = [y[b] (ny), z[b] (nz)]
+__global__ void concat_yz_kernel(const float* y, const float* z, float* inp, int B, int ny, int nz) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int w = ny + nz;
+    if (i >= B * w) return;
+    int b = i / w, c = i - b * w;
+    inp[i] = c < ny ? y[b * ny + c] : z[b * nz + c - ny];
+}
+// res = dt*out ; y_next = y + res
+__global__ void euler_update_kernel(const float* y, const float* out, float dt, float* res, float* y_next, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r = dt * out[i];
+    res[i] = r;
+    y_next[i] = y[i] + r;
+}
+// backward seed of one Euler step: dy = d_y_all[i+1] + carry ; dout = dt * (d_res + dy)
+__global__ void euler_bwd_seed_kernel(const float* d_y_next, const float* carry, const float* d_res, float dt, float* dy,
+                                      float* dout, int B, int ny, int dout_rs) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * ny) return;
+    int b = i / ny, c = i - b * ny;
+    float v = (d_y_next ? d_y_next[i] : 0.f) + carry[i];
+    dy[i] = v;
+    dout[(size_t)b * dout_rs + c] = dt * ((d_res ? d_res[i] : 0.f) + v);
+}
+// dst[b][c] (row stride rs) = src[b][c] (compact, width w) or 0
+__global__ void rows_copy_kernel(float* dst, int rs, const float* src, int B, int w) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * w) return;
+    int b = i / w, c = i - b * w;
+    dst[(size_t)b * rs + c] = src ? src[i] : 0.f;
+}
+// carry = dy + dinp[:, :ny] ; dz_acc (+)= dinp[:, ny:]
+__global__ void euler_bwd_split_kernel(const float* dy, const float* dinp, float* carry, float* dz_acc, int B, int ny, int nz,
+                                       int first_of_frame_in_reverse) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int w = ny + nz;
+    if (i >= B * w) return;
+    int b = i / w, c = i - b * w;
+    if (c < ny) carry[b * ny + c] = dy[b * ny + c] + dinp[i];
+    else {
+        float* o = dz_acc + b * nz + c - ny;
+        *o = first_of_frame_in_reverse ? dinp[i] : *o + dinp[i];
+    }
+}
+__global__ void add_inplace_kernel(float* a, const float* b, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] += b[i];
+}
+__global__ void add3_kernel(float* out, const float* a, const float* b, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (a ? a[i] : 0.f) + (b ? b[i] : 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LSTM pointwise
+// ---------------------------------------------------------------------------------------------------------
+// gates: [B][4nh] pre-activation (i,f,g,o) -> activations in place; c = f*c_prev + i*g ; h = o*tanh(c)
+__global__ void lstm_cell_fwd_kernel(float* gates, const float* c_prev, float* c, float* h, int B, int nh) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * nh) return;
+    int b = i / nh, j = i - b * nh;
+    float* g = gates + (size_t)b * 4 * nh;
+    float ig = sigmoid_f(g[j]), fg = sigmoid_f(g[nh + j]), gg = tanhf(g[2 * nh + j]), og = sigmoid_f(g[3 * nh + j]);
+    float cp = c_prev ? c_prev[i] : 0.f;
+    float cc = fg * cp + ig * gg;
+    g[j] = ig; g[nh + j] = fg; g[2 * nh + j] = gg; g[3 * nh + j] = og;
+    c[i] = cc;
+    h[i] = og * tanhf(cc);
+}
+// dh = dh_out + dh_carry ; produces dgates (pre-activation grads) and dc_carry (in place)
+__global__ void lstm_cell_bwd_kernel(const float* dh_out, const float* dh_carry, float* dc_carry, const float* gates_act,
+                                     const float* c, const float* c_prev, float* dgates, int B, int nh, int has_carry) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * nh) return;
+    int b = i / nh, j = i - b * nh;
+    const float* g = gates_act + (size_t)b * 4 * nh;
+    float ig = g[j], fg = g[nh + j], gg = g[2 * nh + j], og = g[3 * nh + j];
+    float dh = (dh_out ? dh_out[i] : 0.f) + (has_carry ? dh_carry[i] : 0.f);
+    float tc = tanhf(c[i]);
+    float dc = (has_carry ? dc_carry[i] : 0.f) + dh * og * (1.f - tc * tc);
+    float cp = c_prev ? c_prev[i] : 0.f;
+    float* d = dgates + (size_t)b * 4 * nh;
+    d[j] = dc * gg * ig * (1.f - ig);
+    d[nh + j] = dc * cp * fg * (1.f - fg);
+    d[2 * nh + j] = dc * ig * (1.f - gg * gg);
+    d[3 * nh + j] = dh * tc * og * (1.f - og);
+    dc_carry[i] = dc * fg;
+}
+
+__global__ void axpby_kernel(float* out, float a, const float* x, float b, const float* y, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+
+inline dim3 g1(long long n) { return dim3((unsigned)((n + 255) / 256)); }
+
+// y = MLP(x): saves post-ReLU hidden activations hid + l*hid_ls (l = 0..nl-2), each [B][nh]
+int mlp_fwd(hipStream_t st, const float* const* W, const float* const* b, int nl, int nin, int nh, int nout, const float* x,
+            int B, float* hid, size_t hid_ls, float* out) {
+    const float* cur = x;
+    int cin = nin;
+    for (int l = 0; l < nl; ++l) {
+        const bool last = l == nl - 1;
+        int cout = last ? nout : nh;
+        float* dst = last ? out : hid + (size_t)l * hid_ls;
+        int rc = gemm(st, cur, cin, 1, W[l], 1, cin, b[l], dst, cout, B, cout, cin, last ? ACT_NONE : ACT_RELU, 0);
+        if (rc) return rc;
+        cur = dst; cin = cout;
+    }
+    return SRVP_OK;
+}
+// deltas + l*del_ls (l = 0..nl-1): gradient wrt the pre-activation output of layer l, rows [B][dw]; slot nl-1 must
+// already hold the output gradient.  dx (optional) = gradient wrt the MLP input ([B][nin] compact).
+int mlp_bwd(hipStream_t st, const float* const* W, int nl, int nin, int nh, int nout, int B, const float* hid, size_t hid_ls,
+            float* deltas, size_t del_ls, int dw, float* dx) {
+    for (int l = nl - 1; l >= 1; --l) {
+        int cout = l == nl - 1 ? nout : nh;
+        // delta_{l-1} = (delta_l W_l) * relu'(h_{l-1})
+        int rc = gemm(st, deltas + (size_t)l * del_ls, dw, 1, W[l], nh, 1, nullptr, deltas + (size_t)(l - 1) * del_ls, dw, B, nh,
+                      cout, ACT_NONE, 0, hid + (size_t)(l - 1) * hid_ls, nh);
+        if (rc) return rc;
+    }
+    if (dx) {
+        int cout0 = nl == 1 ? nout : nh;
+        return gemm(st, deltas, dw, 1, W[0], nin, 1, nullptr, dx, nin, B, nin, cout0, ACT_NONE, 0);
+    }
+    return SRVP_OK;
+}
+
+}  // namespace
+
+extern "C" int srvp_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs,
+                             const float* bias, float* C, int64_t c_rs, int M, int N, int K, int act, int accumulate,
+                             void* stream) {
+    SRVP_REQUIRE(A && B && C, "srvp_gemm_f32: null pointer");
+    return gemm((hipStream_t)stream, A, a_rs, a_cs, B, b_rs, b_cs, bias, C, c_rs, M, N, K, act, accumulate);
+}
+
+extern "C" int srvp_axpby_f32(float* out, float a, const float* x, float b, const float* y, int64_t n, void* stream) {
+    SRVP_REQUIRE(out && x, "srvp_axpby_f32: null pointer");
+    if (n <= 0) return SRVP_OK;
+    hipLaunchKernelGGL(axpby_kernel, g1(n), dim3(256), 0, (hipStream_t)stream, out, a, x, b, y, (long long)n);
+    SRVP_CHECK_LAUNCH("srvp_axpby_f32");
+    return SRVP_OK;
+}
+
+extern "C" int srvp_colsum_f32(const float* A, int64_t a_rs, float* out, int M, int N, int accumulate, void* stream) {
+    SRVP_REQUIRE(A && out, "srvp_colsum_f32: null pointer");
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, A, (long long)a_rs, out, M, N, accumulate);
+    SRVP_CHECK_LAUNCH("srvp_colsum_f32");
+    return SRVP_OK;
+}
+
+extern "C" int srvp_act_bwd_f32(const float* v, const float* dy, float* dx, int64_t n, int act, int from_output, void* stream) {
+    if (n <= 0) return SRVP_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, g1(n), dim3(256), 0, (hipStream_t)stream, v, dy, dx, (long long)n, act, from_output);
+    SRVP_CHECK_LAUNCH("srvp_act_bwd_f32");
+    return SRVP_OK;
+}
+
+extern "C" int srvp_rsample_fwd(const float* params, const float* eps, float* out, int64_t rows, int d, void* stream) {
+    if (rows * d <= 0) return SRVP_OK;
+    hipLaunchKernelGGL(rsample_fwd_kernel, g1(rows * d), dim3(256), 0, (hipStream_t)stream, params, eps, out, (long long)rows, d);
+    SRVP_CHECK_LAUNCH("srvp_rsample_fwd");
+    return SRVP_OK;
+}
+extern "C" int srvp_rsample_bwd(const float* params, const float* eps, const float* dout, float* dparams, int64_t rows, int d,
+                                int accumulate, void* stream) {
+    if (rows * d <= 0) return SRVP_OK;
+    hipLaunchKernelGGL(rsample_bwd_kernel, g1(rows * d), dim3(256), 0, (hipStream_t)stream, params, eps, dout, dparams,
+                       (long long)rows, d, accumulate, (long long)2 * d);
+    SRVP_CHECK_LAUNCH("srvp_rsample_bwd");
+    return SRVP_OK;
+}
+
+extern "C" int srvp_lstm_fwd(const float* gates_x, const float* w_hh, float* h_out, float* c_out, float* gates_act, int T, int B,
+                             int nh, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SRVP_REQUIRE(gates_x && w_hh && h_out && c_out && gates_act, "srvp_lstm_fwd: null pointer");
+    const size_t gs = (size_t)B * 4 * nh, hs = (size_t)B * nh;
+    hipError_t e = hipMemcpyAsync(gates_act, gates_x, sizeof(float) * gs * T, hipMemcpyDeviceToDevice, st);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_lstm_fwd: copy failed: %s", hipGetErrorString(e));
+    for (int t = 0; t < T; ++t) {
+        float* g = gates_act + gs * t;
+        if (t > 0) {
+            int rc = gemm(st, h_out + hs * (t - 1), nh, 1, w_hh, 1, nh, nullptr, g, 4 * nh, B, 4 * nh, nh, ACT_NONE, 1);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(lstm_cell_fwd_kernel, g1((long long)hs), dim3(256), 0, st, g, t > 0 ? c_out + hs * (t - 1) : nullptr,
+                           c_out + hs * t, h_out + hs * t, B, nh);
+    }
+    SRVP_CHECK_LAUNCH("srvp_lstm_fwd");
+    return SRVP_OK;
+}
+
+// dgates [T][B][4nh]; scratch (2*B*nh floats: dh_carry, dc_carry) is taken from the tail of dgates' allocation by
+// the caller: pass `scratch` explicitly.
+extern "C" int srvp_lstm_bwd(const float* dh_out, const float* w_hh, const float* c_out, const float* gates_act, float* dgates,
+                             float* scratch, int T, int B, int nh, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SRVP_REQUIRE(dh_out && w_hh && c_out && gates_act && dgates && scratch, "srvp_lstm_bwd: null pointer");
+    const size_t gs = (size_t)B * 4 * nh, hs = (size_t)B * nh;
+    float* dh_carry = scratch;
+    float* dc_carry = scratch + hs;
+    for (int t = T - 1; t >= 0; --t) {
+        const int has_carry = t < T - 1;
+        hipLaunchKernelGGL(lstm_cell_bwd_kernel, g1((long long)hs), dim3(256), 0, st, dh_out + hs * t, dh_carry, dc_carry,
+                           gates_act + gs * t, c_out + hs * t, t > 0 ? c_out + hs * (t - 1) : nullptr, dgates + gs * t, B, nh,
+                           has_carry);
+        if (t > 0) {
+            // dh_carry = dgates[t] * W_hh      ([B][4nh] x [4nh][nh])
+            int rc = gemm(st, dgates + gs * t, 4 * nh, 1, w_hh, nh, 1, nullptr, dh_carry, nh, B, nh, 4 * nh, ACT_NONE, 0);
+            if (rc) return rc;
+        }
+    }
+    SRVP_CHECK_LAUNCH("srvp_lstm_bwd");
+    return SRVP_OK;
+}
+
+extern "C" int srvp_rollout_fwd(const srvp_rollout_desc* d, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SRVP_REQUIRE(d && d->y0 && d->y_all && d->res && d->z && d->p_z_params && d->eps_z && d->inp_all && d->scratch_out,
+                 "srvp_rollout_fwd: null pointer");
+    SRVP_REQUIRE(d->nl >= 2 && d->nl <= 8 && d->n_euler >= 1, "srvp_rollout_fwd: nl=%d n_euler=%d", d->nl, d->n_euler);
+    SRVP_REQUIRE((d->hid_dyn && d->hid_pz) || d->scratch_hid, "srvp_rollout_fwd: no hidden-activation storage");
+    const int B = d->B, ny = d->ny, nz = d->nz, nh = d->nh, nl = d->nl;
+    const size_t ys = (size_t)B * ny, zs = (size_t)B * nz, hl = (size_t)B * nh;
+    const int nin = ny + nz;
+    const int F = (d->nsteps + d->n_euler - 1) / d->n_euler;
+    hipError_t e = hipMemcpyAsync(d->y_all, d->y0, sizeof(float) * ys, hipMemcpyDeviceToDevice, st);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd: copy failed");
+    for (int i = 0; i < d->nsteps; ++i) {
+        const int f = i / d->n_euler;             // 0-based frame slot (frame index f+1)
+        const float* y_prev = d->y_all + ys * i;
+        if (i % d->n_euler == 0) {
+            float* pz = d->p_z_params + (size_t)f * B * 2 * nz;
+            float* hid = d->hid_pz ? d->hid_pz + (size_t)f * hl : d->scratch_hid;
+            size_t ls = d->hid_pz ? (size_t)F * hl : hl;
+            int rc = mlp_fwd(st, d->pz_w, d->pz_b, nl, ny, nh, 2 * nz, y_prev, B, hid, ls, pz);
+            if (rc) return rc;
+            const bool posterior = (f + 1) < d->n_data_frames;
+            const float* params = posterior ? d->q_z_params + (size_t)f * B * 2 * nz : pz;
+            hipLaunchKernelGGL(rsample_fwd_kernel, g1((long long)zs), dim3(256), 0, st, params, d->eps_z + zs * f, d->z + zs * f,
+                               (long long)B, nz);
+        }
+        float* inp = d->inp_all + (size_t)i * B * nin;
+        hipLaunchKernelGGL(concat_yz_kernel, g1((long long)B * nin), dim3(256), 0, st, y_prev, d->z + zs * f, inp, B, ny, nz);
+        float* hid = d->hid_dyn ? d->hid_dyn + (size_t)i * hl : d->scratch_hid;
+        size_t ls = d->hid_dyn ? (size_t)d->nsteps * hl : hl;
+        int rc = mlp_fwd(st, d->dyn_w, d->dyn_b, nl, nin, nh, ny, inp, B, hid, ls, d->scratch_out);
+        if (rc) return rc;
+        hipLaunchKernelGGL(euler_update_kernel, g1((long long)ys), dim3(256), 0, st, y_prev, d->scratch_out, d->dt, d->res + ys * i,
+                           d->y_all + ys * (i + 1), (int)ys);
+    }
+    SRVP_CHECK_LAUNCH("srvp_rollout_fwd");
+    return SRVP_OK;
+}
+
+extern "C" int srvp_rollout_bwd(const srvp_rollout_bwd_desc* d, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SRVP_REQUIRE(d, "srvp_rollout_bwd: null descriptor");
+    const srvp_rollout_desc& f = d->f;
+    SRVP_REQUIRE(d->d_y_all && d->d_y0 && d->dhid_dyn && d->dhid_pz && d->work && f.hid_dyn && f.hid_pz && d->d_qz,
+                 "srvp_rollout_bwd: null pointer");
+    const int B = f.B, ny = f.ny, nz = f.nz, nh = f.nh, nl = f.nl, nin = ny + nz;
+    const size_t ys = (size_t)B * ny, zs = (size_t)B * nz, hl = (size_t)B * nh;
+    const int F = (f.nsteps + f.n_euler - 1) / f.n_euler;
+    const int dwd = nh > ny ? nh : ny;             // delta row width (dynamics)
+    const int dwp = nh > 2 * nz ? nh : 2 * nz;     // delta row width (p_z)
+    const size_t dls_d = (size_t)f.nsteps * B * dwd, dls_p = (size_t)F * B * dwp;
+    // work: carry[ys] | dy[ys] | dinp[B*nin] | dz_acc[zs] | dypz[ys]
+    float* carry = d->work;
+    float* dy = carry + ys;
+    float* dinp = dy + ys;
+    float* dz_acc = dinp + (size_t)B * nin;
+    float* dypz = dz_acc + zs;
+    hipError_t e = hipMemsetAsync(carry, 0, sizeof(float) * ys, st);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_bwd: memset failed");
+    for (int i = f.nsteps - 1; i >= 0; --i) {
+        const int fr = i / f.n_euler;
+        const bool last_sub = (i % f.n_euler) == f.n_euler - 1 || i == f.nsteps - 1;   // first visited sub-step of the frame
+        const bool first_sub = (i % f.n_euler) == 0;
+        float* deltas = d->dhid_dyn + (size_t)i * B * dwd;             // layer l at + l*dls_d
+        hipLaunchKernelGGL(euler_bwd_seed_kernel, g1((long long)ys), dim3(256), 0, st, d->d_y_all + ys * (i + 1), carry,
+                           d->d_res ? d->d_res + ys * i : nullptr, f.dt, dy, deltas + (size_t)(nl - 1) * dls_d, B, ny, dwd);
+        int rc = mlp_bwd(st, f.dyn_w, nl, nin, nh, ny, B, f.hid_dyn + (size_t)i * hl, (size_t)f.nsteps * hl, deltas, dls_d, dwd, dinp);
+        if (rc) return rc;
+        hipLaunchKernelGGL(euler_bwd_split_kernel, g1((long long)B * nin), dim3(256), 0, st, dy, dinp, carry, dz_acc, B, ny, nz,
+                           last_sub ? 1 : 0);
+        if (first_sub) {
+            // gradient wrt z of this frame is complete
+            if (d->d_z) hipLaunchKernelGGL(add_inplace_kernel, g1((long long)zs), dim3(256), 0, st, dz_acc, d->d_z + zs * fr, (int)zs);
+            const bool posterior = (fr + 1) < f.n_data_frames;
+            float* pdel = d->dhid_pz + (size_t)fr * B * dwp;
+            float* pout = pdel + (size_t)(nl - 1) * dls_p;
+            hipLaunchKernelGGL(rows_copy_kernel, g1((long long)B * 2 * nz), dim3(256), 0, st, pout, dwp,
+                               d->d_pz ? d->d_pz + (size_t)fr * B * 2 * nz : (const float*)nullptr, B, 2 * nz);
+            if (posterior)
+                hipLaunchKernelGGL(rsample_bwd_kernel, g1((long long)zs), dim3(256), 0, st, f.q_z_params + (size_t)fr * B * 2 * nz,
+                                   f.eps_z + zs * fr, dz_acc, d->d_qz + (size_t)fr * B * 2 * nz, (long long)B, nz, 0, (long long)2 * nz);
+            else
+                hipLaunchKernelGGL(rsample_bwd_kernel, g1((long long)zs), dim3(256), 0, st, f.p_z_params + (size_t)fr * B * 2 * nz,
+                                   f.eps_z + zs * fr, dz_acc, pout, (long long)B, nz, 1, (long long)dwp);
+            rc = mlp_bwd(st, f.pz_w, nl, ny, nh, 2 * nz, B, f.hid_pz + (size_t)fr * hl, (size_t)F * hl, pdel, dls_p, dwp, dypz);
+            if (rc) return rc;
+            hipLaunchKernelGGL(add_inplace_kernel, g1((long long)ys), dim3(256), 0, st, carry, dypz, (int)ys);
+        }
+    }
+    hipLaunchKernelGGL(add3_kernel, g1((long long)ys), dim3(256), 0, st, d->d_y0, d->d_y_all, carry, (int)ys);
+    SRVP_CHECK_LAUNCH("srvp_rollout_bwd");
+    return SRVP_OK;
+}

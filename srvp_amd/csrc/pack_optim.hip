@@ -1,0 +1,287 @@
+// Weight packing (state-dict fp32 OIHW / IOHW <-> tap-major padded bf16), skip-gradient reduction, the ELBO terms
+// and the fused Adam update.
+//
+// Replaces: the reference's torch.distributions / reductions in train.py:90-106 (NLL, KL(q(y0)||N(0,1)), KL(q(z)||p(z)),
+// sum of residual norms) with their gradients, and torch.optim.Adam (train.py:289) as one elementwise launch over a
+// flat parameter buffer.
+#include "common.h"
+#include "../../include/srvp_hip.h"
+
+namespace {
+
+struct PackArgs {
+    int ntaps; int tap_off[SRVP_MAX_TAPS];
+    int J, K;                 // padded sizes of the packed [t][J][K] tensor
+    int J0, J0r, J1r;         // J axis = segment 0 (padded J0, real J0r) followed by segment 1 (real J1r)
+    int K0, K0r, K1r;
+    long long sj, sk;         // element strides of the real j / k index in the fp32 tensor
+};
+
+__device__ __forceinline__ int real_index(int i, int seg0_pad, int seg0_real, int seg1_real) {
+    if (i < seg0_pad) return i < seg0_real ? i : -1;
+    int i1 = i - seg0_pad;
+    return i1 < seg1_real ? seg0_real + i1 : -1;
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, const PackArgs a) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)a.ntaps * a.J * a.K;
+    if (i >= total) return;
+    int k = (int)(i % a.K); long long q = i / a.K;
+    int j = (int)(q % a.J); int t = (int)(q / a.J);
+    int jr = real_index(j, a.J0, a.J0r, a.J1r), kr = real_index(k, a.K0, a.K0r, a.K1r);
+    float v = 0.f;
+    if (jr >= 0 && kr >= 0) {
+        int off = 0;
+#pragma unroll
+        for (int u = 0; u < SRVP_MAX_TAPS; ++u) if (u == t) off = a.tap_off[u];
+        v = src[jr * a.sj + kr * a.sk + off];
+    }
+    dst[i] = f2bf(v);
+}
+
+__global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst, const PackArgs a) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)a.ntaps * a.J * a.K;
+    if (i >= total) return;
+    int k = (int)(i % a.K); long long q = i / a.K;
+    int j = (int)(q % a.J); int t = (int)(q / a.J);
+    int jr = real_index(j, a.J0, a.J0r, a.J1r), kr = real_index(k, a.K0, a.K0r, a.K1r);
+    if (jr < 0 || kr < 0) return;
+    int off = 0;
+#pragma unroll
+    for (int u = 0; u < SRVP_MAX_TAPS; ++u) if (u == t) off = a.tap_off[u];
+    dst[jr * a.sj + kr * a.sk + off] += src[i];     // every (t,j,k) maps to a distinct element: no atomics needed
+}
+
+int fill_pack(const srvp_pack_desc* d, PackArgs& a) {
+    SRVP_REQUIRE(d && d->ntaps >= 1 && d->ntaps <= SRVP_MAX_TAPS, "srvp_pack: ntaps");
+    a.ntaps = d->ntaps;
+    for (int t = 0; t < SRVP_MAX_TAPS; ++t) a.tap_off[t] = t < d->ntaps ? d->tap_off[t] : 0;
+    a.J = d->J; a.K = d->K; a.J0 = d->J0; a.J0r = d->J0r; a.J1r = d->J1r; a.K0 = d->K0; a.K0r = d->K0r; a.K1r = d->K1r;
+    a.sj = d->sj; a.sk = d->sk;
+    return SRVP_OK;
+}
+
+// dsel[b][hw][c] = sum_t dcat[(t*B+b)][hw][coff + c]
+__global__ void skip_grad_reduce_kernel(const bf16_t* __restrict__ dcat, int cstride, int coff, int C, int HW, int T, int B,
+                                        bf16_t* __restrict__ dsel) {
+    const int CG = C / 8;
+    long long total = (long long)B * HW * CG;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int cg = (int)(i % CG); long long q = i / CG;
+        int hw = (int)(q % HW); int b = (int)(q / HW);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int t = 0; t < T; ++t) {
+            size_t off = (((size_t)(t * B + b)) * HW + hw) * cstride + coff + cg * 8;
+            float f[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(dcat + off), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += f[e];
+        }
+        *reinterpret_cast<u32x4_t*>(dsel + ((size_t)b * HW + hw) * C + cg * 8) = pack8(acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ELBO terms
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_sum_to(double v, double* out) {
+    __shared__ double part[4];
+    v = wave_sum_d(v);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += part[w];
+        atomicAdd(out, s);
+    }
+}
+
+__global__ __launch_bounds__(256) void nll_kernel(const float* __restrict__ xr, const float* __restrict__ x, float* __restrict__ dxr,
+                                                  long long n, float inv2s2, float logc, float gcoef, double* out) {
+    double acc = 0.;
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+        if (i + 4 <= n) {
+            f32x4_t a = *reinterpret_cast<const f32x4_t*>(xr + i), b = *reinterpret_cast<const f32x4_t*>(x + i);
+            f32x4_t d = a - b;
+            acc += (double)((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * inv2s2 + 4.0 * logc;
+            if (dxr) *reinterpret_cast<f32x4_t*>(dxr + i) = d * gcoef;
+        } else {
+            for (long long j = i; j < n; ++j) {
+                float d = xr[j] - x[j];
+                acc += (double)(d * d) * inv2s2 + logc;
+                if (dxr) dxr[j] = d * gcoef;
+            }
+        }
+    }
+    block_sum_to(acc, out);
+}
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// KL(N(ql,qs) || N(pl,ps)) = 0.5*(r + ((ql-pl)/ps)^2 - 1 - log r), r = (qs/ps)^2 ; s = softplus(raw)+1e-8
+__global__ __launch_bounds__(256) void kl_kernel(const float* __restrict__ q, const float* __restrict__ p, float* dq, float* dp,
+                                                 long long rows, int d, float gscale, double* out) {
+    double acc = 0.;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rows * d; i += (long long)gridDim.x * blockDim.x) {
+        long long r = i / d; int c = (int)(i - r * d);
+        float ql = q[r * 2 * d + c], qraw = q[r * 2 * d + d + c];
+        float qs = softplus_f(qraw) + 1e-8f;
+        float pl = 0.f, ps = 1.f, praw = 0.f;
+        if (p) { pl = p[r * 2 * d + c]; praw = p[r * 2 * d + d + c]; ps = softplus_f(praw) + 1e-8f; }
+        float ratio = qs / ps;
+        float r2 = ratio * ratio;
+        float t = (ql - pl) / ps;
+        acc += 0.5 * ((double)r2 + (double)t * t - 1.0 - (double)logf(r2));
+        if (dq) {
+            float dql = t / ps;
+            float dqs = qs / (ps * ps) - 1.f / qs;
+            float dsq = qraw > 20.f ? 1.f : sigmoid_f(qraw);
+            dq[r * 2 * d + c] = gscale * dql;
+            dq[r * 2 * d + d + c] = gscale * dqs * dsq;
+        }
+        if (dp && p) {
+            float dpl = -t / ps;
+            float dps = -(qs * qs) / (ps * ps * ps) - t * t / ps + 1.f / ps;
+            float dsp = praw > 20.f ? 1.f : sigmoid_f(praw);
+            dp[r * 2 * d + c] = gscale * dpl;
+            dp[r * 2 * d + d + c] = gscale * dps * dsp;
+        }
+    }
+    block_sum_to(acc, out);
+}
+
+// one wave per row: ||row||_2
+__global__ __launch_bounds__(256) void l2rows_kernel(const float* __restrict__ res, float* dres, long long rows, int d, float gscale,
+                                                     double* out) {
+    const int lane = threadIdx.x & 63;
+    double acc = 0.;
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * 4) {
+        float s = 0.f;
+        for (int c = lane; c < d; c += 64) { float v = res[r * d + c]; s += v * v; }
+        s = wave_sum(s);
+        float nrm = sqrtf(s);
+        if (lane == 0) acc += nrm;
+        if (dres) {
+            float inv = nrm > 0.f ? gscale / nrm : 0.f;
+            for (int c = lane; c < d; c += 64) dres[r * d + c] = res[r * d + c] * inv;
+        }
+    }
+    block_sum_to(acc, out);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n, float step_size, float beta1, float beta2,
+                                                   float eps, float inv_bc2_sqrt, float grad_scale) {
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+        if (i + 4 <= n) {
+            f32x4_t gv = *reinterpret_cast<const f32x4_t*>(g + i) * grad_scale;
+            f32x4_t mv = *reinterpret_cast<f32x4_t*>(m + i), vv = *reinterpret_cast<f32x4_t*>(v + i);
+            f32x4_t pv = *reinterpret_cast<f32x4_t*>(p + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mv[e] = beta1 * mv[e] + (1.f - beta1) * gv[e];
+                vv[e] = beta2 * vv[e] + (1.f - beta2) * gv[e] * gv[e];
+                float denom = sqrtf(vv[e]) * inv_bc2_sqrt + eps;
+                pv[e] -= step_size * (mv[e] / denom);
+            }
+            *reinterpret_cast<f32x4_t*>(m + i) = mv; *reinterpret_cast<f32x4_t*>(v + i) = vv;
+            *reinterpret_cast<f32x4_t*>(p + i) = pv;
+        } else {
+            for (long long j = i; j < n; ++j) {
+                float gj = g[j] * grad_scale;
+                float mj = beta1 * m[j] + (1.f - beta1) * gj;
+                float vj = beta2 * v[j] + (1.f - beta2) * gj * gj;
+                m[j] = mj; v[j] = vj;
+                p[j] -= step_size * (mj / (sqrtf(vj) * inv_bc2_sqrt + eps));
+            }
+        }
+    }
+}
+
+inline unsigned capped_grid(long long items, int per_block, int cap) {
+    long long b = (items + per_block - 1) / per_block;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int srvp_pack_weight(const float* src, void* dst, const srvp_pack_desc* d, void* stream) {
+    PackArgs a;
+    int rc = fill_pack(d, a);
+    if (rc) return rc;
+    SRVP_REQUIRE(src && dst, "srvp_pack_weight: null pointer");
+    long long total = (long long)a.ntaps * a.J * a.K;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       (bf16_t*)dst, a);
+    SRVP_CHECK_LAUNCH("srvp_pack_weight");
+    return SRVP_OK;
+}
+
+extern "C" int srvp_unpack_wgrad(const float* src, float* dst, const srvp_pack_desc* d, void* stream) {
+    PackArgs a;
+    int rc = fill_pack(d, a);
+    if (rc) return rc;
+    SRVP_REQUIRE(src && dst, "srvp_unpack_wgrad: null pointer");
+    long long total = (long long)a.ntaps * a.J * a.K;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, a);
+    SRVP_CHECK_LAUNCH("srvp_unpack_wgrad");
+    return SRVP_OK;
+}
+
+extern "C" int srvp_skip_grad_reduce(const void* dcat, int cstride, int coff, int C, int HW, int T, int B, void* dsel,
+                                     void* stream) {
+    SRVP_REQUIRE(dcat && dsel && C % 8 == 0 && coff % 8 == 0 && cstride % 8 == 0, "srvp_skip_grad_reduce: bad args");
+    long long total = (long long)B * HW * (C / 8);
+    hipLaunchKernelGGL(skip_grad_reduce_kernel, dim3(capped_grid(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dcat, cstride, coff, C, HW, T, B, (bf16_t*)dsel);
+    SRVP_CHECK_LAUNCH("srvp_skip_grad_reduce");
+    return SRVP_OK;
+}
+
+extern "C" int srvp_nll(const float* x_, const float* x, float* d_x_, int64_t n, float scale, float gscale, double* out,
+                        void* stream) {
+    SRVP_REQUIRE(x_ && x && out && scale > 0.f, "srvp_nll: bad args");
+    const float inv2s2 = 1.f / (2.f * scale * scale);
+    const float logc = logf(scale) + 0.91893853320467274f;
+    hipLaunchKernelGGL(nll_kernel, dim3(capped_grid(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, x_, x, d_x_, (long long)n,
+                       inv2s2, logc, gscale / (scale * scale), out);
+    SRVP_CHECK_LAUNCH("srvp_nll");
+    return SRVP_OK;
+}
+
+extern "C" int srvp_kl(const float* q, const float* p, float* dq, float* dp, int64_t rows, int d, float gscale, double* out,
+                       void* stream) {
+    SRVP_REQUIRE(q && out, "srvp_kl: bad args");
+    if (rows * d <= 0) return SRVP_OK;
+    hipLaunchKernelGGL(kl_kernel, dim3(capped_grid(rows * d, 256, 1024)), dim3(256), 0, (hipStream_t)stream, q, p, dq, dp,
+                       (long long)rows, d, gscale, out);
+    SRVP_CHECK_LAUNCH("srvp_kl");
+    return SRVP_OK;
+}
+
+extern "C" int srvp_l2rows(const float* res, float* d_res, int64_t rows, int d, float gscale, double* out, void* stream) {
+    SRVP_REQUIRE(res && out, "srvp_l2rows: bad args");
+    if (rows <= 0) return SRVP_OK;
+    hipLaunchKernelGGL(l2rows_kernel, dim3(capped_grid(rows, 4, 1024)), dim3(256), 0, (hipStream_t)stream, res, d_res,
+                       (long long)rows, d, gscale, out);
+    SRVP_CHECK_LAUNCH("srvp_l2rows");
+    return SRVP_OK;
+}
+
+extern "C" int srvp_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                         int step, float grad_scale, void* stream) {
+    SRVP_REQUIRE(p && g && m && v && step >= 1, "srvp_adam: bad args");
+    if (n <= 0) return SRVP_OK;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(capped_grid(n, 1024, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n,
+                       (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale);
+    SRVP_CHECK_LAUNCH("srvp_adam");
+    return SRVP_OK;
+}

@@ -1,0 +1,43 @@
+// Error plumbing + small utility kernels of libsrvp_hip.so.
+#include "common.h"
+#include "../../include/srvp_hip.h"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+void srvp_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* srvp_last_error(void) { return g_err; }
+extern "C" int srvp_version(void) { return 1; }
+
+namespace {
+__global__ void fill_f64_kernel(double* p, long long n, double v) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void cast_f32_bf16_kernel(const float* src, bf16_t* dst, long long rows, int cols, int dst_cols) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * dst_cols) return;
+    long long r = i / dst_cols;
+    int c = (int)(i - r * dst_cols);
+    dst[i] = c < cols ? f2bf(src[r * cols + c]) : (bf16_t)0;
+}
+}  // namespace
+
+extern "C" int srvp_fill_f64(double* p, int64_t n, double v, void* stream) {
+    if (n <= 0) return SRVP_OK;
+    hipLaunchKernelGGL(fill_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, (long long)n, v);
+    SRVP_CHECK_LAUNCH("srvp_fill_f64");
+    return SRVP_OK;
+}
+extern "C" int srvp_cast_f32_bf16(const float* src, void* dst, int64_t rows, int cols, int dst_cols, void* stream) {
+    long long n = (long long)rows * dst_cols;
+    if (n <= 0) return SRVP_OK;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       (bf16_t*)dst, (long long)rows, cols, dst_cols);
+    SRVP_CHECK_LAUNCH("srvp_cast_f32_bf16");
+    return SRVP_OK;
+}

@@ -1,0 +1,256 @@
+// Weight gradient of the tap-table convolution on the CDNA4 matrix cores.
+//
+//   dW[t][j][c] += sum_p dout_t[p][j] * in_t[p][c]          p = (n, oy, ox)
+//
+// A "TN" GEMM: the reduction index (pixels) is the slow index of both NHWC operands, so each K step stages a
+// [BP pixels][channels] tile of both operands in LDS and the MFMA fragments (8 consecutive pixels of one channel)
+// are read through the gfx950 LDS transpose-read ds_read_b64_tr_b16 (USE_TR) or, as a conservative fallback,
+// eight 16-bit LDS reads.  Split-K over pixel chunks, fp32 atomic accumulation into the tap-major gradient.
+//
+// Replaces the implicit weight-gradient kernels behind autograd for nn.Conv2d / nn.ConvTranspose2d
+// (reference module/conv.py:174-179, 200-223, 299-304, 330-353; train.py:109-119 backward).
+#include "common.h"
+#include "../../include/srvp_hip.h"
+
+namespace {
+
+struct WgradK {
+    const bf16_t* src0; const bf16_t* src1; const int* map1;
+    int C0, C1, H0p, W0p, H1p, W1p, ups0, ups1, si, ntaps;
+    unsigned long long dy_bits, dx_bits, ooy_bits, oox_bits;
+    const bf16_t* dout; int DHp, DWp, so, Cout;
+    int N, OH, OW;
+    float* dw; int splitk;
+};
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+// ds_read_b64_tr_b16: every lane supplies the address of 4 contiguous bf16; within each 16-lane group the 16x4
+// element block is transposed so that lane s receives element (s&3) of lanes 4j+(s>>2), j = 0..3.
+__device__ __forceinline__ s16x4_t lds_tr_read(const bf16_t* p) {
+    typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)p);
+}
+
+template <int BJ, int BC, int WJ, int WC, bool USE_TR>
+__global__ __launch_bounds__(WJ * WC * 64) void wgrad_mfma_kernel(const WgradK a) {
+    constexpr int NT = WJ * WC * 64;
+    constexpr int BP = 32;                       // pixels per K step
+    constexpr int LDX = BJ + 32;                 // row stride (elements): +64 B keeps the 4 rows of a tr-read on distinct banks
+    constexpr int LDY = BC + 32;
+    constexpr int XCH = BJ / 8, YCH = BC / 8;    // 16-byte chunks per pixel row
+    constexpr int X_LD = (BP * XCH + NT - 1) / NT, Y_LD = (BP * YCH + NT - 1) / NT;
+    constexpr int TJ = BJ / WJ / 32, TC = BC / WC / 32;
+    __shared__ __attribute__((aligned(16))) bf16_t Xs[2][BP][LDX];
+    __shared__ __attribute__((aligned(16))) bf16_t Ys[2][BP][LDY];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wj = wid / WC, wc = wid % WC;
+    const int Ctot = a.C0 + a.C1;
+    const int tj_n = a.Cout / BJ, tc_n = Ctot / BC;
+    int b = blockIdx.x;
+    const int tc = b % tc_n; b /= tc_n;
+    const int tj = b % tj_n; b /= tj_n;
+    const int t = b % a.ntaps; b /= a.ntaps;
+    const int split = b;
+    const int j0 = tj * BJ, c0 = tc * BC;
+    const long long M = (long long)a.N * a.OH * a.OW;
+    const long long nchunks = (M + BP - 1) / BP;
+    const long long per = (nchunks + a.splitk - 1) / a.splitk;
+    const long long ch_beg = (long long)split * per;
+    long long ch_end = ch_beg + per; if (ch_end > nchunks) ch_end = nchunks;
+    if (ch_beg >= ch_end) return;
+
+    // source selection for this channel tile (a tile never straddles the two sources)
+    const bool second = c0 >= a.C0;
+    const bf16_t* src = second ? a.src1 : a.src0;
+    const int C = second ? a.C1 : a.C0, Hp = second ? a.H1p : a.H0p, Wp = second ? a.W1p : a.W0p;
+    const int ups = second ? a.ups1 : a.ups0;
+    const int cs = second ? c0 - a.C0 : c0;
+    const int dy = (int)((a.dy_bits >> (4 * t)) & 15), dx = (int)((a.dx_bits >> (4 * t)) & 15);
+    const int ooy = (int)((a.ooy_bits >> (4 * t)) & 15), oox = (int)((a.oox_bits >> (4 * t)) & 15);
+    const int hw = a.OH * a.OW;
+
+    u32x4_t rx[X_LD], ry[Y_LD];
+    auto load_step = [&](long long chunk) {
+#pragma unroll
+        for (int i = 0; i < X_LD; ++i) {
+            int q = tid + i * NT;
+            int row = q / XCH, ch = q % XCH;
+            long long m = chunk * BP + row;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (q < BP * XCH && m < M) {
+                int n = (int)(m / hw); int r = (int)(m - (long long)n * hw);
+                int oy = r / a.OW, ox = r - oy * a.OW;
+                size_t off = (((size_t)n * a.DHp + oy * a.so + ooy) * a.DWp + ox * a.so + oox) * a.Cout + j0 + ch * 8;
+                v = *reinterpret_cast<const u32x4_t*>(a.dout + off);
+            }
+            rx[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < Y_LD; ++i) {
+            int q = tid + i * NT;
+            int row = q / YCH, ch = q % YCH;
+            long long m = chunk * BP + row;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (q < BP * YCH && m < M) {
+                int n = (int)(m / hw); int r = (int)(m - (long long)n * hw);
+                int oy = r / a.OW, ox = r - oy * a.OW;
+                int vy = oy * a.si + dy, vx = ox * a.si + dx;
+                if (ups) { vy = (vy + 1) >> 1; vx = (vx + 1) >> 1; }
+                if (second && a.map1) n = a.map1[n];
+                size_t off = (((size_t)n * Hp + vy) * Wp + vx) * C + cs + ch * 8;
+                v = *reinterpret_cast<const u32x4_t*>(src + off);
+            }
+            ry[i] = v;
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < X_LD; ++i) {
+            int q = tid + i * NT;
+            if (q < BP * XCH) *reinterpret_cast<u32x4_t*>(&Xs[buf][q / XCH][(q % XCH) * 8]) = rx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < Y_LD; ++i) {
+            int q = tid + i * NT;
+            if (q < BP * YCH) *reinterpret_cast<u32x4_t*>(&Ys[buf][q / YCH][(q % YCH) * 8]) = ry[i];
+        }
+    };
+
+    f32x16_t acc[TJ][TC];
+#pragma unroll
+    for (int i = 0; i < TJ; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_step(ch_beg);
+    store_step(0);
+    __syncthreads();
+    const int lrow = lane & 31, lk = (lane >> 5) * 8;
+    // tr-read addressing: 16-lane group g reads the [4 pixels][16 channels] block; lane s supplies the address of
+    // pixel (s>>2), channels (s&3)*4..+3 and receives channel s, pixels 0..3.
+    const int g = lane >> 4, sl = lane & 15;
+    const int tr_col = (g & 1) * 16 + (sl & 3) * 4, tr_row = (g >> 1) * 8 + (sl >> 2);
+    int it = 0;
+    for (long long chunk = ch_beg; chunk < ch_end; ++chunk, ++it) {
+        const int buf = it & 1;
+        if (chunk + 1 < ch_end) load_step(chunk + 1);
+#pragma unroll
+        for (int kk = 0; kk < BP / 16; ++kk) {
+            bf16x8_t xf[TJ], yf[TC];
+            if constexpr (USE_TR) {
+#pragma unroll
+                for (int i = 0; i < TJ; ++i) {
+                    const bf16_t* p = &Xs[buf][kk * 16 + tr_row][wj * (TJ * 32) + i * 32 + tr_col];
+                    s16x4_t lo = lds_tr_read(p), hi = lds_tr_read(p + 4 * LDX);
+                    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+                    s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    xf[i] = __builtin_bit_cast(bf16x8_t, v);
+                }
+#pragma unroll
+                for (int j = 0; j < TC; ++j) {
+                    const bf16_t* p = &Ys[buf][kk * 16 + tr_row][wc * (TC * 32) + j * 32 + tr_col];
+                    s16x4_t lo = lds_tr_read(p), hi = lds_tr_read(p + 4 * LDY);
+                    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+                    s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    yf[j] = __builtin_bit_cast(bf16x8_t, v);
+                }
+            } else {
+                typedef short s16x8_t __attribute__((ext_vector_type(8)));
+#pragma unroll
+                for (int i = 0; i < TJ; ++i) {
+                    s16x8_t v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (short)Xs[buf][kk * 16 + lk + e][wj * (TJ * 32) + i * 32 + lrow];
+                    xf[i] = __builtin_bit_cast(bf16x8_t, v);
+                }
+#pragma unroll
+                for (int j = 0; j < TC; ++j) {
+                    s16x8_t v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (short)Ys[buf][kk * 16 + lk + e][wc * (TC * 32) + j * 32 + lrow];
+                    yf[j] = __builtin_bit_cast(bf16x8_t, v);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TJ; ++i)
+#pragma unroll
+                for (int j = 0; j < TC; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[i], yf[j], acc[i][j], 0, 0, 0);
+        }
+        if (chunk + 1 < ch_end) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    const int lcol = lane & 31, lhalf = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TJ; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int jj = j0 + wj * (TJ * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                int cc = c0 + wc * (TC * 32) + j * 32 + lcol;
+                atomicAdd(a.dw + ((size_t)t * a.Cout + jj) * Ctot + cc, acc[i][j][r]);
+            }
+}
+
+template <int BJ, int BC, int WJ, int WC>
+int launch(const WgradK& k, hipStream_t st, bool use_tr) {
+    long long blocks = (long long)(k.Cout / BJ) * ((k.C0 + k.C1) / BC) * k.ntaps * k.splitk;
+    SRVP_REQUIRE(blocks > 0 && blocks < (1ll << 31), "srvp_wgrad_mfma: bad grid");
+    if (use_tr)
+        hipLaunchKernelGGL((wgrad_mfma_kernel<BJ, BC, WJ, WC, true>), dim3((unsigned)blocks), dim3(WJ * WC * 64), 0, st, k);
+    else
+        hipLaunchKernelGGL((wgrad_mfma_kernel<BJ, BC, WJ, WC, false>), dim3((unsigned)blocks), dim3(WJ * WC * 64), 0, st, k);
+    SRVP_CHECK_LAUNCH("srvp_wgrad_mfma");
+    return SRVP_OK;
+}
+
+int g_use_tr = -1;
+
+}  // namespace
+
+extern "C" int srvp_wgrad_set_tr(int on) { g_use_tr = on; return SRVP_OK; }
+
+extern "C" int srvp_wgrad_mfma(const srvp_wgrad_desc* d, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SRVP_REQUIRE(d && d->src0 && d->dout && d->dw, "srvp_wgrad_mfma: null pointer");
+    SRVP_REQUIRE(d->C0 % 32 == 0 && d->C1 % 32 == 0 && d->Cout % 32 == 0 && d->C0 > 0,
+                 "srvp_wgrad_mfma: channel counts must be padded to 32");
+    SRVP_REQUIRE(d->ntaps >= 1 && d->ntaps <= SRVP_MAX_TAPS && d->splitk >= 1, "srvp_wgrad_mfma: ntaps/splitk");
+    if (g_use_tr < 0) {
+        const char* e = getenv("SRVP_WGRAD_TR");
+        g_use_tr = (e && e[0] == '0') ? 0 : 1;
+    }
+    WgradK k;
+    k.src0 = (const bf16_t*)d->src0; k.src1 = (const bf16_t*)d->src1; k.map1 = d->map1;
+    k.C0 = d->C0; k.C1 = d->C1; k.H0p = d->H0p; k.W0p = d->W0p; k.H1p = d->H1p; k.W1p = d->W1p;
+    k.ups0 = d->ups0; k.ups1 = d->ups1; k.si = d->si; k.ntaps = d->ntaps;
+    k.dy_bits = k.dx_bits = k.ooy_bits = k.oox_bits = 0;
+    for (int t = 0; t < d->ntaps; ++t) {
+        SRVP_REQUIRE(d->dy[t] >= 0 && d->dy[t] < 16 && d->dx[t] >= 0 && d->dx[t] < 16 && d->ooy[t] >= 0 && d->ooy[t] < 16 &&
+                         d->oox[t] >= 0 && d->oox[t] < 16, "srvp_wgrad_mfma: tap offset out of [0,15]");
+        k.dy_bits |= (unsigned long long)d->dy[t] << (4 * t); k.dx_bits |= (unsigned long long)d->dx[t] << (4 * t);
+        k.ooy_bits |= (unsigned long long)d->ooy[t] << (4 * t); k.oox_bits |= (unsigned long long)d->oox[t] << (4 * t);
+    }
+    k.dout = (const bf16_t*)d->dout; k.DHp = d->DHp; k.DWp = d->DWp; k.so = d->so; k.Cout = d->Cout;
+    k.N = d->N; k.OH = d->OH; k.OW = d->OW; k.dw = d->dw; k.splitk = d->splitk;
+    const bool tr = g_use_tr != 0;
+    // channel tile of the input operand must not straddle the two sources
+    auto divides = [&](int bc) { return d->C0 % bc == 0 && (d->C1 == 0 || d->C1 % bc == 0); };
+    const int bj = d->Cout % 128 == 0 ? 128 : (d->Cout % 64 == 0 ? 64 : 32);
+    const int bc = divides(128) ? 128 : (divides(64) ? 64 : 32);
+    if (bj == 128 && bc == 128) return launch<128, 128, 2, 2>(k, st, tr);
+    if (bj == 128 && bc == 64) return launch<128, 64, 2, 2>(k, st, tr);
+    if (bj == 128 && bc == 32) return launch<128, 32, 4, 1>(k, st, tr);
+    if (bj == 64 && bc == 128) return launch<64, 128, 2, 2>(k, st, tr);
+    if (bj == 64 && bc == 64) return launch<64, 64, 2, 2>(k, st, tr);
+    if (bj == 64 && bc == 32) return launch<64, 32, 2, 1>(k, st, tr);
+    if (bj == 32 && bc == 128) return launch<32, 128, 1, 4>(k, st, tr);
+    if (bj == 32 && bc == 64) return launch<32, 64, 1, 2>(k, st, tr);
+    return launch<32, 32, 1, 1>(k, st, tr);
+}

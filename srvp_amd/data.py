@@ -1,0 +1,52 @@
+"""
+Input side of the hot path.  The reference's dataset readers / generators (data/*.py) are out of scope for this
+round; what the training loop needs is the batch contract of data/base.py:54-84 --
+float32 (T, B, C, H, W) in [0, 1], time-major -- which `SyntheticVideos` produces from seeded procedural blobs.
+"""
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+
+class SyntheticVideos(Dataset):
+    def __init__(self, n, seq_len, nc, nx=64, seed=0):
+        self.n, self.seq_len, self.nc, self.nx, self.seed = n, seq_len, nc, nx, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        rng = np.random.RandomState(self.seed * 1000003 + i)
+        yy, xx = np.mgrid[0:self.nx, 0:self.nx].astype(np.float32)
+        v = np.zeros((self.seq_len, self.nc, self.nx, self.nx), np.float32)
+        for c in range(self.nc):
+            p, d, s = rng.uniform(12, 52, 2), rng.uniform(-3, 3, 2), rng.uniform(3, 7)
+            for t in range(self.seq_len):
+                q = p + d * t
+                v[t, c] = np.exp(-((yy - q[0]) ** 2 + (xx - q[1]) ** 2) / (2 * s * s))
+        return torch.from_numpy(np.clip(v, 0, 1))
+
+
+def collate_fn(videos):
+    """(B x (T, C, H, W)) -> (T, B, C, H, W) float32, the layout of reference data/base.py:76-84."""
+    return torch.stack(videos, 1)
+
+
+def make_loaders(opt, local_rank):
+    if opt.dataset != 'synthetic':
+        raise NotImplementedError(
+            f"dataset '{opt.dataset}': the reference's dataset readers are outside the hot path rebuilt here "
+            "(SURVEY.md §8f-2); use --dataset synthetic or feed (T, B, C, 64, 64) batches to srvp_amd.train.train")
+    sampler = None
+    trainset = SyntheticVideos(4096, opt.seq_len, opt.nc, opt.nx, seed=opt.seed + local_rank)
+    if opt.n_gpu > 1:
+        sampler = torch.utils.data.distributed.DistributedSampler(trainset)
+    train_loader = DataLoader(trainset, batch_size=opt.batch_size, collate_fn=collate_fn, sampler=sampler,
+                              shuffle=sampler is None, drop_last=True, num_workers=opt.n_workers, pin_memory=True)
+    val_loader = None
+    if local_rank == 0:
+        valset = SyntheticVideos(max(opt.batch_size_test * opt.n_iter_test, 1), opt.seq_len_test or opt.seq_len, opt.nc,
+                                 opt.nx, seed=opt.seed + 7919)
+        val_loader = DataLoader(valset, batch_size=opt.batch_size_test, collate_fn=collate_fn, shuffle=True, drop_last=True,
+                                num_workers=0)
+    return train_loader, val_loader, sampler

@@ -1,0 +1,266 @@
+"""
+Latent path of SRVP on the HIP library: content variable w, initial state y_0, posterior LSTM + q_z, prior p_z and the
+residual Euler rollout, forward and backward (reference module/srvp.py:229-413, module/mlp.py, module/utils.py).
+fp32 throughout; every GEMM / recurrence / sampling step is a libsrvp_hip.so kernel, torch only allocates, views and
+gathers rows.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _gemm(st, A, a_rs, a_cs, B, b_rs, b_cs, bias, Cm, c_rs, M, N, K, act=L.ACT_NONE, acc=0):
+    L.call('srvp_gemm_f32', L.ptr(A), a_rs, a_cs, L.ptr(B), b_rs, b_cs, L.ptr(bias), L.ptr(Cm), c_rs, M, N, K, act, acc, st)
+
+
+def linear_fwd(st, x, w, b, out, act=L.ACT_NONE):
+    """out[M][N] = act(x[M][K] w[N][K]^T + b)"""
+    M, K = x.shape
+    N = w.shape[0]
+    _gemm(st, x, K, 1, w, 1, K, b, out, N, M, N, K, act)
+    return out
+
+
+def linear_bwd(st, x, w, dy, gw, gb, dx=None, dx_acc=0):
+    """dy: [M][N] (contiguous).  gw += dy^T x ; gb += colsum(dy) ; dx (+)= dy w"""
+    M, K = x.shape
+    N = w.shape[0]
+    _gemm(st, dy, 1, N, x, K, 1, None, gw, K, N, K, M, acc=1)
+    if gb is not None:
+        L.call('srvp_colsum_f32', L.ptr(dy), N, L.ptr(gb), M, N, 1, st)
+    if dx is not None:
+        _gemm(st, dy, N, 1, w, K, 1, None, dx, K, M, K, N, acc=dx_acc)
+
+
+def axpby(st, out, a, x, b=0.0, y=None):
+    L.call('srvp_axpby_f32', L.ptr(out), float(a), L.ptr(x), float(b), L.ptr(y), out.numel(), st)
+
+
+def mlp_keys(prefix, n):
+    return [f'{prefix}.module.{i}.{0 if i == 0 else 1}' for i in range(n)]
+
+
+class LatentNet:
+    """Buffers + launch sequence for one (T, B, nt, n_euler) problem size."""
+
+    def __init__(self, cfg, T, B, nt, n_euler, device, training):
+        self.cfg, self.T, self.B, self.nt, self.ne, self.dev, self.training = cfg, T, B, nt, n_euler, device, training
+        f32 = dict(dtype=torch.float32, device=device)
+        nhx, nh, ny, nz, nhr = cfg['nhx'], cfg['nh_inf'], cfg['ny'], cfg['nz'], cfg['nh_res']
+        self.nl_inf, self.nl_res, self.nt_inf = cfg['nlayers_inf'], cfg['nlayers_res'], cfg['nt_inf']
+        S = n_euler * (nt - 1)
+        F = nt - 1
+        self.S, self.F = S, F
+        ti = self.nt_inf
+        z = lambda *s: torch.zeros(*s, **f32)
+        # content variable
+        self.h_sel = z(ti * B, nhx)
+        self.proj = z(ti * B, nh)
+        self.hsum = z(B, nh)
+        self.w = z(B, nh)
+        # y_0
+        self.qy_in = z(B, ti * nhx)
+        self.qy_hid = [z(B, nh) for _ in range(self.nl_inf - 1)]
+        self.q_y0 = z(B, 2 * ny)
+        self.y0 = z(B, ny)
+        # LSTM / q_z
+        if T > 0:
+            self.lstm_bias = z(4 * nh)
+            self.gates_x = z(T * B, 4 * nh)
+            self.gates_act = z(T * B, 4 * nh)
+            self.hz = z(T * B, nh)
+            self.cz = z(T * B, nh)
+        self.q_z = z(max(F, 1), B, 2 * nz)
+        # rollout
+        self.y_all = z(S + 1, B, ny)
+        self.z = z(max(F, 1), B, nz)
+        self.p_z = z(max(F, 1), B, 2 * nz)
+        self.res = z(max(S, 1), B, ny)
+        self.inp_all = z(max(S, 1), B, ny + nz)
+        self.scratch_out = z(B, max(ny, 2 * nz))
+        nlr = self.nl_res
+        if training:
+            self.hid_dyn = z(nlr - 1, max(S, 1), B, nhr)
+            self.hid_pz = z(nlr - 1, max(F, 1), B, nhr)
+            self.scratch_hid = None
+            dwd, dwp = max(nhr, ny), max(nhr, 2 * nz)
+            self.dwd, self.dwp = dwd, dwp
+            self.dhid_dyn = z(nlr, max(S, 1), B, dwd)
+            self.dhid_pz = z(nlr, max(F, 1), B, dwp)
+            self.work = z(3 * B * ny + B * (ny + nz) + B * nz)
+            self.d_y_all = z(S + 1, B, ny)
+            self.d_y0 = z(B, ny)
+            self.d_qz_samp = z(max(F, 1), B, 2 * nz)
+            self.d_qy0_tot = z(B, 2 * ny)
+            self.d_qz_tot = z(max(F, 1), B, 2 * nz)
+            self.d_hz = z(max(T, 1) * B, nh)
+            self.dgates = z(max(T, 1) * B, 4 * nh)
+            self.lstm_scratch = z(2 * B * nh)
+            self.d_hx = z(max(T, 1) * B, nhx)
+            self.d_qy_hid = [z(B, nh) for _ in range(self.nl_inf - 1)]
+            self.d_qy_in = z(B, ti * nhx)
+            self.d_wpre = z(B, nh)
+            self.d_hsum = z(B, nh)
+            self.d_proj = z(ti * B, nh)
+            self.d_hsel = z(ti * B, nhx)
+        else:
+            self.hid_dyn = self.hid_pz = None
+            self.scratch_hid = z(nlr - 1, B, nhr)
+
+    # ------------------------------------------------------------------------------------------------
+    def _rollout_desc(self, params, n_data, eps_z, y0, nsteps=None):
+        cfg = self.cfg
+        d = L.RolloutDesc()
+        d.B, d.ny, d.nz, d.nh, d.nl = self.B, cfg['ny'], cfg['nz'], cfg['nh_res'], self.nl_res
+        d.nsteps, d.n_euler, d.n_data_frames, d.dt = self.S, self.ne, n_data, 1.0 / self.ne
+        for i, k in enumerate(mlp_keys('dynamics', self.nl_res)):
+            d.dyn_w[i], d.dyn_b[i] = L.ptr(params[k + '.weight']), L.ptr(params[k + '.bias'])
+        for i, k in enumerate(mlp_keys('p_z', self.nl_res)):
+            d.pz_w[i], d.pz_b[i] = L.ptr(params[k + '.weight']), L.ptr(params[k + '.bias'])
+        d.y0, d.q_z_params, d.eps_z = L.ptr(y0), L.ptr(self.q_z), L.ptr(eps_z)
+        d.y_all, d.z, d.p_z_params, d.res = L.ptr(self.y_all), L.ptr(self.z), L.ptr(self.p_z), L.ptr(self.res)
+        d.inp_all, d.hid_dyn, d.hid_pz = L.ptr(self.inp_all), L.ptr(self.hid_dyn), L.ptr(self.hid_pz)
+        d.scratch_hid, d.scratch_out = L.ptr(self.scratch_hid), L.ptr(self.scratch_out)
+        return d
+
+    def infer_w(self, hx, params, t_w, st):
+        """srvp.py:229-256.  hx: (T, B, nhx) fp32 contiguous; t_w: (nt_inf, B) long (train) or None (last nt_inf frames)."""
+        B, ti = self.B, self.nt_inf
+        T = hx.shape[0]
+        if t_w is not None:
+            rows = (t_w.reshape(-1) * B + torch.arange(B, device=hx.device).repeat(ti)).to(torch.long)
+        else:
+            rows = torch.arange((T - ti) * B, T * B, device=hx.device)
+        self.w_rows = rows
+        torch.index_select(hx.view(T * B, -1), 0, rows, out=self.h_sel)
+        linear_fwd(st, self.h_sel, params['w_proj.0.weight'], params['w_proj.0.bias'], self.proj, L.ACT_RELU)
+        pv = self.proj.view(ti, B, -1)
+        axpby(st, self.hsum, 1.0, pv[0], 1.0 if ti > 1 else 0.0, pv[1] if ti > 1 else None)
+        for i in range(2, ti):
+            axpby(st, self.hsum, 1.0, self.hsum, 1.0, pv[i])
+        linear_fwd(st, self.hsum, params['w_inf.0.weight'], params['w_inf.0.bias'], self.w, L.ACT_TANH)
+        return self.w
+
+    def infer_y(self, hx_first, params, eps_y0, st):
+        """srvp.py:258-278.  hx_first: (nt_inf, B, nhx)."""
+        B = self.B
+        self.qy_in.view(B, self.nt_inf, -1).copy_(hx_first.permute(1, 0, 2))
+        keys = mlp_keys('q_y', self.nl_inf)
+        cur = self.qy_in
+        for i, k in enumerate(keys):
+            last = i == len(keys) - 1
+            dst = self.q_y0 if last else self.qy_hid[i]
+            linear_fwd(st, cur, params[k + '.weight'], params[k + '.bias'], dst, L.ACT_NONE if last else L.ACT_RELU)
+            cur = dst
+        L.call('srvp_rsample_fwd', L.ptr(self.q_y0), L.ptr(eps_y0), L.ptr(self.y0), B, self.cfg['ny'], st)
+        return self.y0, self.q_y0
+
+    def posterior(self, hx, params, st):
+        """LSTM over the frame encodings + q_z (srvp.py:366,387,296): fills q_z[f] for frames f+1 < T."""
+        T, B = hx.shape[0], self.B
+        nh, nz = self.cfg['nh_inf'], self.cfg['nz']
+        axpby(st, self.lstm_bias, 1.0, params['inf_z.bias_ih_l0'], 1.0, params['inf_z.bias_hh_l0'])
+        linear_fwd(st, hx.view(T * B, -1), params['inf_z.weight_ih_l0'], self.lstm_bias, self.gates_x[:T * B])
+        L.call('srvp_lstm_fwd', L.ptr(self.gates_x), L.ptr(params['inf_z.weight_hh_l0']), L.ptr(self.hz), L.ptr(self.cz),
+               L.ptr(self.gates_act), T, B, nh, st)
+        if T > 1:
+            nq = min(T - 1, self.F)
+            linear_fwd(st, self.hz[B:(nq + 1) * B], params['q_z.weight'], params['q_z.bias'], self.q_z.view(-1, 2 * nz)[:nq * B])
+
+    def generate(self, y0, n_data, params, eps_z, st):
+        """srvp.py:325-413 (remove_intermediate=True); the LSTM/q_z part must have run if n_data > 1."""
+        if self.S > 0:
+            self._rd = self._rollout_desc(params, n_data, eps_z, y0)
+            L.call('srvp_rollout_fwd', C.byref(self._rd), st)
+        else:
+            self.y_all[0].copy_(y0)
+        y = self.y_all[::self.ne]
+        nq = max(min(n_data, self.nt) - 1, 0)
+        return y, self.z[:self.F], (self.q_z[:nq] if nq > 0 else None), self.p_z[:self.F], self.res[:self.S]
+
+    # ------------------------------------------------------------------------------------------------
+    def backward(self, hx, params, grads, eps_y0, eps_z, d_y, d_w, d_qy0, d_qz, d_pz, d_res, d_z, st):
+        """
+        Gradients wrt the latent-path outputs -> parameter gradients (accumulated into `grads`) and d_hx (T*B, nhx).
+        Any d_* may be None.  Training forward (n_data = T = nt) must have run.
+        """
+        cfg, B, T, ne, S, F = self.cfg, self.B, self.T, self.ne, self.S, self.F
+        ny, nz, nh, nhr, nhx = cfg['ny'], cfg['nz'], cfg['nh_inf'], cfg['nh_res'], cfg['nhx']
+        nlr = self.nl_res
+        self.d_hx.zero_()
+        # ---- rollout
+        self.d_y_all.zero_()
+        if d_y is not None:
+            self.d_y_all[::ne].copy_(d_y)
+        bd = L.RolloutBwdDesc()
+        bd.f = self._rd
+        bd.d_y_all, bd.d_z, bd.d_pz, bd.d_res = L.ptr(self.d_y_all), L.ptr(d_z), L.ptr(d_pz), L.ptr(d_res)
+        bd.d_y0, bd.d_qz, bd.dhid_dyn, bd.dhid_pz, bd.work = (L.ptr(self.d_y0), L.ptr(self.d_qz_samp), L.ptr(self.dhid_dyn),
+                                                               L.ptr(self.dhid_pz), L.ptr(self.work))
+        self.d_qz_samp.zero_()
+        L.call('srvp_rollout_bwd', C.byref(bd), st)
+        # weight gradients of dynamics / p_z: one GEMM per layer over all (step, sample) rows
+        for name, nrow, width, dh, hid, inp, nin, nout in (
+                ('dynamics', S * B, self.dwd, self.dhid_dyn, self.hid_dyn, self.inp_all.view(S * B, -1), ny + nz, ny),
+                ('p_z', F * B, self.dwp, self.dhid_pz, self.hid_pz, None, ny, 2 * nz)):
+            keys = mlp_keys(name, nlr)
+            for l, k in enumerate(keys):
+                cout = nout if l == nlr - 1 else nhr
+                delta = dh[l].view(nrow, width)
+                if l == 0:
+                    a_prev = inp if inp is not None else None
+                    cin = nin
+                else:
+                    a_prev, cin = hid[l - 1].view(nrow, nhr), nhr
+                if a_prev is None:
+                    # p_z input = state at the start of every frame: y_all[f*ne]
+                    a_prev = self.y_all[0:S:ne].reshape(nrow, ny)
+                _gemm(st, delta, 1, width, a_prev, cin, 1, None, grads[k + '.weight'], cin, cout, cin, nrow, acc=1)
+                L.call('srvp_colsum_f32', L.ptr(delta), width, L.ptr(grads[k + '.bias']), nrow, cout, 1, st)
+        # ---- q_z + LSTM
+        nq = T - 1
+        if nq > 0:
+            axpby(st, self.d_qz_tot[:nq], 1.0, self.d_qz_samp[:nq], 1.0 if d_qz is not None else 0.0, d_qz)
+            dq = self.d_qz_tot[:nq].view(nq * B, 2 * nz)
+            self.d_hz[:B].zero_()
+            linear_bwd(st, self.hz[B:T * B], params['q_z.weight'], dq, grads['q_z.weight'], grads['q_z.bias'],
+                       dx=self.d_hz[B:T * B])
+            L.call('srvp_lstm_bwd', L.ptr(self.d_hz), L.ptr(params['inf_z.weight_hh_l0']), L.ptr(self.cz), L.ptr(self.gates_act),
+                   L.ptr(self.dgates), L.ptr(self.lstm_scratch), T, B, nh, st)
+            dg = self.dgates[:T * B]
+            # W_hh: sum_t dgates[t]^T h_{t-1}
+            _gemm(st, dg[B:], 1, 4 * nh, self.hz[:(T - 1) * B], nh, 1, None, grads['inf_z.weight_hh_l0'], nh, 4 * nh, nh,
+                  (T - 1) * B, acc=1)
+            linear_bwd(st, hx.view(T * B, nhx), params['inf_z.weight_ih_l0'], dg, grads['inf_z.weight_ih_l0'],
+                       grads['inf_z.bias_ih_l0'], dx=self.d_hx, dx_acc=1)
+            L.call('srvp_colsum_f32', L.ptr(dg), 4 * nh, L.ptr(grads['inf_z.bias_hh_l0']), T * B, 4 * nh, 1, st)
+        # ---- y_0
+        L.call('srvp_rsample_bwd', L.ptr(self.q_y0), L.ptr(eps_y0), L.ptr(self.d_y0), L.ptr(self.d_qy0_tot), B, ny, 0, st)
+        if d_qy0 is not None:
+            axpby(st, self.d_qy0_tot, 1.0, self.d_qy0_tot, 1.0, d_qy0)
+        keys = mlp_keys('q_y', self.nl_inf)
+        dcur = self.d_qy0_tot
+        for i in range(len(keys) - 1, -1, -1):
+            x_in = self.qy_in if i == 0 else self.qy_hid[i - 1]
+            dx = self.d_qy_in if i == 0 else self.d_qy_hid[i - 1]
+            linear_bwd(st, x_in, params[keys[i] + '.weight'], dcur, grads[keys[i] + '.weight'], grads[keys[i] + '.bias'], dx=dx)
+            if i > 0:
+                L.call('srvp_act_bwd_f32', L.ptr(self.qy_hid[i - 1]), L.ptr(dx), L.ptr(dx), dx.numel(), L.ACT_RELU, 1, st)
+            dcur = dx
+        ti = self.nt_inf
+        self.d_hx.view(T, B, nhx)[:ti] += self.d_qy_in.view(B, ti, nhx).permute(1, 0, 2)
+        # ---- w
+        if d_w is not None:
+            L.call('srvp_act_bwd_f32', L.ptr(self.w), L.ptr(d_w), L.ptr(self.d_wpre), d_w.numel(), L.ACT_TANH, 1, st)
+            linear_bwd(st, self.hsum, params['w_inf.0.weight'], self.d_wpre, grads['w_inf.0.weight'], grads['w_inf.0.bias'],
+                       dx=self.d_hsum)
+            dp = self.d_proj.view(ti, B, nh)
+            for i in range(ti):
+                L.call('srvp_act_bwd_f32', L.ptr(self.proj.view(ti, B, nh)[i]), L.ptr(self.d_hsum), L.ptr(dp[i]), B * nh,
+                       L.ACT_RELU, 1, st)
+            linear_bwd(st, self.h_sel, params['w_proj.0.weight'], self.d_proj, grads['w_proj.0.weight'], grads['w_proj.0.bias'],
+                       dx=self.d_hsel)
+            self.d_hx.index_add_(0, self.w_rows, self.d_hsel)
+        return self.d_hx

@@ -1,0 +1,467 @@
+"""
+StochasticLatentResidualVideoPredictor -- MI355X-native drop-in for the reference class of the same name
+(reference module/srvp.py:29-470): same constructor signature, public attributes, method names / shapes and
+state-dict keys, with all arithmetic in hand-written HIP kernels (libsrvp_hip.so).
+
+The nn.Conv2d / nn.BatchNorm2d / nn.Linear / nn.LSTM objects built here are *parameter containers only*: they
+reproduce the reference's module hierarchy (hence its state-dict keys, its default-initialisation RNG order and
+compatibility with `SyncBatchNorm.convert_sync_batchnorm`), but their forward methods are never called.
+
+Differences from the reference, all documented in DESIGN.md:
+  * random draws can be supplied explicitly (`tape=`) so that results are reproducible against the CPU oracle;
+    by default they are drawn in the reference's order (CPU generator for indices, device generator for normals);
+  * `forward` is differentiable through one fused autograd node; the granular methods (`encode`, `infer_*`,
+    `generate`, `decode`) run the same kernels without recording a graph (inference / test.py call pattern);
+  * the Euler schedule is the integer one (identical to the reference for n_euler in {1, 2, 4, ...}).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import arch
+from .convnet import EncoderNet, DecoderNet, cpad
+from .latent import LatentNet
+
+
+def _set_module(root, path, module):
+    """Places `module` at dotted `path` under `root`, creating nn.Sequential / nn.ModuleList containers like the
+    reference hierarchy (integer path elements index containers)."""
+    parts = path.split('.')
+    cur = root
+    for i, p in enumerate(parts[:-1]):
+        nxt = getattr(cur, p, None) if not p.isdigit() else (cur._modules.get(p))
+        if nxt is None:
+            nxt = nn.Module()
+            cur.add_module(p, nxt)
+        cur = nxt
+    cur.add_module(parts[-1], module)
+
+
+class _Holder(nn.Module):
+    """Generic container (stands for nn.Sequential / nn.ModuleList levels of the reference)."""
+
+
+def _build_convnet(root, blocks):
+    for b in blocks:
+        if b['kind'] == 'conv':
+            m = nn.Conv2d(b['cin'], b['cout'], b['k'], b['s'], b['p'], bias=False)
+        else:
+            m = nn.ConvTranspose2d(b['cin'], b['cout'], b['k'], b['s'], b['p'], bias=False)
+        _set_module(root, b['key'], m)
+        if b['bnkey'] is not None:
+            _set_module(root, b['bnkey'], nn.BatchNorm2d(b['cout']))
+
+
+def _mlp(n_inp, n_hid, n_out, n_layers):
+    """Same parameter layout as reference module/mlp.py:47-90: module.0.0, module.1.1, module.2.1, ..."""
+    root = _Holder()
+    seq = _Holder()
+    root.add_module('module', seq)
+    for il in range(n_layers):
+        blk = _Holder()
+        lin = nn.Linear(n_inp if il == 0 else n_hid, n_out if il == n_layers - 1 else n_hid)
+        blk.add_module('0' if il == 0 else '1', lin)
+        seq.add_module(str(il), blk)
+    return root
+
+
+class _SrvpForward(torch.autograd.Function):
+    """One autograd node for the whole training forward (srvp.py:415-470): backward runs the HIP backward chain and
+    writes parameter gradients straight into the model's flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, model, x, nt, n_euler, tape, *params):
+        outs = model._forward_impl(x, nt, n_euler, tape, training=True)
+        ctx.model = model
+        ctx.mark_non_differentiable(outs[2])      # z is a sample: gradient flows through q_z / p_z params
+        return outs
+
+    @staticmethod
+    def backward(ctx, d_x, d_y, d_z, d_w, d_qy0, d_qz, d_pz, d_res):
+        ctx.model._backward_impl(d_x, d_y, d_w, d_qy0, d_qz, d_pz, d_res)
+        return (None,) * (5 + len(list(ctx.model.parameters())))
+
+
+class StochasticLatentResidualVideoPredictor(nn.Module):
+    def __init__(self, nx, nc, nf, nhx, ny, nz, skipco, nt_inf, nh_inf, nlayers_inf, nh_res, nlayers_res, archi):
+        super().__init__()
+        assert nx == 64, 'the encoder / decoder families are 64x64 architectures (reference conv.py:45-48)'
+        self.nx, self.nc, self.ny, self.nz, self.skipco = nx, nc, ny, nz, skipco
+        self.nt_inf, self.nh_inf, self.nlayers_inf = nt_inf, nh_inf, nlayers_inf
+        self.nh_res, self.nlayers_res, self.nhx = nh_res, nlayers_res, nhx
+        self.nf, self.archi = nf, archi
+        self._enc_blocks = arch.encoder_blocks(archi, nc, nhx, nf)
+        self._dec_blocks = arch.decoder_blocks(archi, nc, nh_inf + ny, nf, skipco)
+        # module construction order = reference order (srvp.py:124-137), so that default initialisation consumes the
+        # global RNG identically
+        self.encoder = _Holder()
+        self.decoder = _Holder()
+        _build_convnet(self, self._enc_blocks)
+        _build_convnet(self, self._dec_blocks)
+        self.w_proj = _Holder()
+        self.w_proj.add_module('0', nn.Linear(nhx, nh_inf))
+        self.w_inf = _Holder()
+        self.w_inf.add_module('0', nn.Linear(nh_inf, nh_inf))
+        self.q_y = _mlp(nhx * nt_inf, nh_inf, ny * 2, nlayers_inf)
+        self.inf_z = nn.LSTM(nhx, nh_inf, 1)
+        self.q_z = nn.Linear(nh_inf, nz * 2)
+        self.p_z = _mlp(ny, nh_res, nz * 2, nlayers_res)
+        self.dynamics = _mlp(ny + nz, nh_res, ny, nlayers_res)
+        self._plans = {}
+        self._flat = None
+        self._pack_version = None
+        self.sync = None            # set by srvp_amd.distributed for multi-GPU (SyncBN statistics + gradient all-reduce)
+        self.last_tape = None
+
+    # ------------------------------------------------------------------------------------------------ init
+    def init(self, res_gain=1.41):
+        """srvp.py:139-154 / utils.py:51-85: N(0, 0.02) conv weights, N(1, 0.02) BN weights (zero bias) for the encoder and
+        decoder; orthogonal(res_gain) weights and zero bias for `dynamics`."""
+        for root in (self.encoder, self.decoder):
+            for m in root.modules():
+                if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d, nn.Linear)):
+                    nn.init.normal_(m.weight.data, 0.0, 0.02)
+                    if getattr(m, 'bias', None) is not None:
+                        nn.init.constant_(m.bias.data, 0.0)
+                elif isinstance(m, nn.BatchNorm2d):
+                    nn.init.normal_(m.weight.data, 1.0, 0.02)
+                    nn.init.constant_(m.bias.data, 0.0)
+        for m in self.dynamics.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.orthogonal_(m.weight.data, gain=res_gain)
+                nn.init.constant_(m.bias.data, 0.0)
+
+    # ------------------------------------------------------------------------------------------------ plumbing
+    def _cfg(self):
+        return dict(nx=self.nx, nc=self.nc, nf=self.nf, nhx=self.nhx, ny=self.ny, nz=self.nz, skipco=self.skipco,
+                    nt_inf=self.nt_inf, nh_inf=self.nh_inf, nlayers_inf=self.nlayers_inf, nh_res=self.nh_res,
+                    nlayers_res=self.nlayers_res, archi=self.archi)
+
+    def _device(self):
+        return next(self.parameters()).device
+
+    def _require_gpu(self):
+        dev = self._device()
+        if dev.type != 'cuda':
+            raise L.SrvpHipError('srvp_amd runs on an MI355X only: move the model to the GPU (model.to("cuda")); '
+                                 'there is no CPU compute path')
+        L.load()
+        return dev
+
+    def flatten_parameters_(self):
+        """Re-homes every parameter (and its gradient) into one flat fp32 buffer: one fused Adam launch and one
+        contiguous all-reduce payload.  Parameter objects (and hence optimizers / state dicts) are unchanged."""
+        ps = list(self.parameters())
+        dev = ps[0].device
+        if self._flat is not None and self._flat[0].device == dev and all(
+                p.data_ptr() == v.data_ptr() for p, v in zip(ps, self._flat[2])):
+            return
+        n = sum(p.numel() for p in ps)
+        n_al = (n + 3) // 4 * 4
+        flat_p = torch.zeros(n_al, dtype=torch.float32, device=dev)
+        flat_g = torch.zeros(n_al, dtype=torch.float32, device=dev)
+        views, gviews, off = [], [], 0
+        for p in ps:
+            v = flat_p[off:off + p.numel()].view_as(p)
+            v.copy_(p.data)
+            p.data = v
+            g = flat_g[off:off + p.numel()].view_as(p)
+            if p.grad is not None:
+                g.copy_(p.grad)
+            p.grad = g
+            views.append(v)
+            gviews.append(g)
+            off += p.numel()
+        self._flat = (flat_p, flat_g, views, gviews)
+        self._pack_version = None
+
+    def _named_tensors(self):
+        d = dict(self.named_parameters())
+        d.update(dict(self.named_buffers()))
+        return d
+
+    def _grads(self):
+        """name -> gradient view inside the flat gradient buffer (re-attached if an optimizer set .grad to None)."""
+        self.flatten_parameters_()
+        _, flat_g, _, gviews = self._flat
+        fresh = False
+        for p, g in zip(self.parameters(), gviews):
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                fresh = True
+                break
+        if fresh:
+            flat_g.zero_()
+            for p, g in zip(self.parameters(), gviews):
+                p.grad = g
+        return {k: p.grad for k, p in self.named_parameters()}
+
+    def _plan(self, T, B, nt, n_euler, training):
+        key = (T, B, nt, n_euler, training, str(self._device()))
+        pl = self._plans.get(key)
+        if pl is None:
+            dev = self._device()
+            enc = EncoderNet(self._enc_blocks, T * B, dev, training) if T > 0 else None
+            skip_map = torch.zeros(nt * B, dtype=torch.int32, device=dev) if self.skipco else None
+            dec = DecoderNet(self._dec_blocks, nt * B, dev, training, enc.skips if (self.skipco and enc) else None, skip_map)
+            lat = LatentNet(self._cfg(), T, B, nt, n_euler, dev, training)
+            pl = dict(enc=enc, dec=dec, lat=lat, skip_map=skip_map)
+            # keep at most two training plans alive (they own all activation memory)
+            if training:
+                for k in [k for k in self._plans if isinstance(k[0], int) and k[4]]:
+                    del self._plans[k]
+            self._plans[key] = pl
+            self._pack_version = None
+        return pl
+
+    def _pack(self, pl, params, st):
+        ver = (id(pl), tuple(p._version for p in self.parameters()))
+        if ver == self._pack_version:
+            return
+        if pl['enc'] is not None:
+            pl['enc'].pack_weights(params, st)
+        pl['dec'].pack_weights(params, st)
+        self._pack_version = ver
+
+    def _draw_tape(self, T, B, nt, training, dev):
+        """Random draws in the reference's order: CPU generator for the frame indices, device
+        generator for the normals."""
+        tape = {}
+        if training:
+            if self.skipco:
+                tape['t_skip'] = torch.randint(T, size=(B,))
+            tape['t_w'] = torch.stack([torch.randperm(T)[:self.nt_inf] for _ in range(B)], 1)
+        tape['eps_y0'] = torch.randn(B, self.ny, device=dev)
+        tape['eps_z'] = torch.randn(max(nt - 1, 1), B, self.nz, device=dev)
+        return tape
+
+    # ------------------------------------------------------------------------------------------------ core
+    def _forward_impl(self, x, nt, n_euler, tape, training):
+        dev = self._require_gpu()
+        T, B = x.shape[0], x.shape[1]
+        if training:
+            assert nt == T, 'training mode requires observations for every generated frame (srvp.py:391)'
+            self.flatten_parameters_()
+        st = L.stream()
+        pl = self._plan(T, B, nt, n_euler, training)
+        params = self._named_tensors()
+        self._pack(pl, params, st)
+        if tape is None:
+            tape = self._draw_tape(T, B, nt, training, dev)
+        tape = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in tape.items()}
+        self.last_tape = tape
+        enc, dec, lat = pl['enc'], pl['dec'], pl['lat']
+        x = x.contiguous().float()
+        hx = enc.forward(x.view(T * B, *x.shape[2:]), params, st, self.sync if training else None)
+        hx = hx.contiguous().view(T, B, self.nhx)
+        if self.skipco:
+            ar = torch.arange(B, device=dev, dtype=torch.int32)
+            if training:
+                sel = tape['t_skip'].to(torch.int32) * B + ar
+            else:
+                sel = (T - 1) * B + ar
+            pl['skip_map'].copy_(sel.repeat(nt))
+            pl['skip_sel'] = sel
+        w = lat.infer_w(hx, params, tape.get('t_w') if training else None, st)
+        y0, q_y0 = lat.infer_y(hx[:self.nt_inf], params, tape['eps_y0'], st)
+        lat.posterior(hx, params, st)
+        y, z, qz, pz, res = lat.generate(y0, T, params, tape['eps_z'], st)
+        z_in = torch.cat([w.repeat(nt, 1), y.reshape(nt * B, self.ny)], 1)
+        x_flat = dec.forward(z_in, params, st, self.sync if training else None)
+        x_ = x_flat.view(nt, B, *x_flat.shape[1:])
+        pl['hx'], pl['x'] = hx, x
+        self._last_plan = pl
+        return x_, y, z, w, q_y0, qz, pz, res
+
+    def _backward_impl(self, d_x, d_y, d_w, d_qy0, d_qz, d_pz, d_res):
+        pl = self._last_plan
+        enc, dec, lat = pl['enc'], pl['dec'], pl['lat']
+        st = L.stream()
+        params = self._named_tensors()
+        grads = self._grads()
+        tape = self.last_tape
+        T, B = lat.T, lat.B
+        nt = lat.nt
+        cz = lambda t: None if t is None else t.contiguous().float()
+        if d_x is None:
+            d_x = torch.zeros_like(dec.x_out)
+        dz = dec.backward(cz(d_x).view(nt * B, *dec.x_out.shape[1:]), params, grads, st, self.sync)
+        dzf = dz[:, :self.nh_inf + self.ny].float()
+        d_w_tot = dzf[:, :self.nh_inf].reshape(nt, B, self.nh_inf).sum(0)
+        if d_w is not None:
+            d_w_tot = d_w_tot + d_w
+        d_y_tot = dzf[:, self.nh_inf:].reshape(nt, B, self.ny)
+        if d_y is not None:
+            d_y_tot = d_y_tot + d_y
+        if self.sync is not None:
+            self.sync.grads_ready('decoder', self)
+        d_hx = lat.backward(pl['hx'], params, grads, tape['eps_y0'], tape['eps_z'], d_y_tot.contiguous(), d_w_tot.contiguous(),
+                            cz(d_qy0), cz(d_qz), cz(d_pz), cz(d_res), None, st)
+        skip_grads = None
+        if self.skipco:
+            skip_grads = {}
+            idx = torch.full((T * B,), -1, dtype=torch.int32, device=d_hx.device)
+            idx[pl['skip_sel'].long()] = torch.arange(B, dtype=torch.int32, device=d_hx.device)
+            for stage, (dcat, cstride, coff, Cc, HW) in dec.skip_grad_sources().items():
+                dsel = pl.setdefault(('dsel', stage), torch.empty(B, HW, Cc, dtype=torch.bfloat16, device=d_hx.device))
+                L.call('srvp_skip_grad_reduce', L.ptr(dcat), cstride, coff, Cc, HW, nt, B, L.ptr(dsel), st)
+                skip_grads[stage] = (dsel, idx)
+        nhp = cpad(self.nhx)
+        if nhp != self.nhx:
+            d_hx_p = torch.zeros(T * B, nhp, dtype=torch.float32, device=d_hx.device)
+            d_hx_p[:, :self.nhx] = d_hx
+        else:
+            d_hx_p = d_hx
+        enc.backward(pl['x'].view(T * B, *pl['x'].shape[2:]), d_hx_p, skip_grads, params, grads, st, self.sync)
+        if self.sync is not None:
+            self.sync.grads_ready('all', self)
+
+    # ------------------------------------------------------------------------------------------------ reference API
+    def forward(self, x, nt, dt, remove_intermediate=True, tape=None):
+        """srvp.py:415-470.  Returns (x_, y, z, w, q_y_0_params, q_z_params, p_z_params, res)."""
+        assert remove_intermediate, 'remove_intermediate=False is not supported by the fused rollout'
+        n_euler = int(round(1 / dt))
+        assert abs(n_euler * dt - 1) < 1e-6, 'dt must be the inverse of an integer (srvp.py:371)'
+        if self.training and torch.is_grad_enabled():
+            return _SrvpForward.apply(self, x, nt, n_euler, tape, *self.parameters())
+        with torch.no_grad():
+            return self._forward_impl(x, nt, n_euler, tape, training=self.training)
+
+    def _infer_plan(self, T, B, nt, n_euler=1):
+        return self._plan(T, B, nt, n_euler, False)
+
+    @torch.no_grad()
+    def encode(self, x, tape=None):
+        """srvp.py:156-193 -> (hx (T,B,nhx), skips: list of (B,C,H,W) deepest first, or None)."""
+        dev = self._require_gpu()
+        T, B = x.shape[0], x.shape[1]
+        training = self.training
+        pl = self._plan(T, B, T, 1, training)
+        st = L.stream()
+        params = self._named_tensors()
+        self._pack(pl, params, st)
+        enc = pl['enc']
+        hx = enc.forward(x.contiguous().float().view(T * B, *x.shape[2:]), params, st, self.sync if training else None)
+        hx = hx.contiguous().view(T, B, self.nhx).clone()
+        skips = None
+        if self.skipco:
+            if training:
+                t = tape['t_skip'] if tape is not None else torch.randint(T, size=(B,))
+                sel = t.to(dev).long() * B + torch.arange(B, device=dev)
+            else:
+                sel = (T - 1) * B + torch.arange(B, device=dev)
+            skips = []
+            for stage in sorted(enc.skips):
+                f = enc.skips[stage]
+                skips.append(f.interior()[sel].permute(0, 3, 1, 2).float().contiguous())
+        return hx, skips
+
+    @torch.no_grad()
+    def decode(self, w, y, skip):
+        """srvp.py:195-227: w (B, nh_inf), y (nt, B, ny), skip list (B, C, H, W) or None -> x_ (nt, B, C, 64, 64)."""
+        dev = self._require_gpu()
+        nt, B = y.shape[0], y.shape[1]
+        assert (skip is None) == (not self.skipco)
+        key = ('decode', nt, B, self.training, str(dev))
+        pl = self._plans.get(key)
+        if pl is None:
+            from .convnet import Feat
+            feats = None
+            skip_map = None
+            if self.skipco:
+                feats = {i: Feat(B, s.shape[2], s.shape[3], s.shape[1], dev) for i, s in enumerate(skip)}
+                skip_map = torch.arange(B, dtype=torch.int32, device=dev).repeat(nt)
+            dec = DecoderNet(self._dec_blocks, nt * B, dev, False, feats, skip_map)
+            pl = dict(dec=dec, feats=feats)
+            self._plans[key] = pl
+        st = L.stream()
+        params = self._named_tensors()
+        if self.training:
+            raise NotImplementedError('decode() in training mode: use forward() (fused autograd node)')
+        pl['dec'].pack_weights(params, st)
+        if self.skipco:
+            for i, s in enumerate(skip):
+                pl['feats'][i].load_nchw(s.to(dev))
+        z_in = torch.cat([w.repeat(nt, 1), y.reshape(nt * B, self.ny)], 1).float().contiguous()
+        x_flat = pl['dec'].forward(z_in, params, st, None)
+        return x_flat.view(nt, B, *x_flat.shape[1:]).clone()
+
+    @torch.no_grad()
+    def infer_w(self, hx, tape=None):
+        """srvp.py:229-256."""
+        self._require_gpu()
+        T, B = hx.shape[0], hx.shape[1]
+        lat = self._infer_plan(T, B, max(T, 2))['lat']
+        t_w = None
+        if self.training:
+            t_w = tape['t_w'] if tape is not None else torch.stack([torch.randperm(T)[:self.nt_inf] for _ in range(B)], 1)
+            t_w = t_w.to(hx.device)
+        return lat.infer_w(hx.contiguous().float(), self._named_tensors(), t_w, L.stream()).clone()
+
+    @torch.no_grad()
+    def infer_y(self, hx, eps=None):
+        """srvp.py:258-278 -> (y_0, q_y_0_params)."""
+        self._require_gpu()
+        B = hx.shape[1]
+        lat = self._infer_plan(hx.shape[0], B, max(hx.shape[0], 2))['lat']
+        if eps is None:
+            eps = torch.randn(B, self.ny, device=hx.device)
+        y0, q = lat.infer_y(hx.contiguous().float(), self._named_tensors(), eps.to(hx.device), L.stream())
+        return y0.clone(), q.clone()
+
+    @torch.no_grad()
+    def infer_z(self, hx, eps=None):
+        """srvp.py:280-298: hx here is the LSTM output for one frame (B, nh_inf) -> (z, q_z_params)."""
+        self._require_gpu()
+        from .latent import linear_fwd
+        st = L.stream()
+        B = hx.shape[0]
+        q = torch.empty(B, 2 * self.nz, dtype=torch.float32, device=hx.device)
+        linear_fwd(st, hx.contiguous().float(), self.q_z.weight, self.q_z.bias, q)
+        if eps is None:
+            eps = torch.randn(B, self.nz, device=hx.device)
+        z = torch.empty(B, self.nz, dtype=torch.float32, device=hx.device)
+        L.call('srvp_rsample_fwd', L.ptr(q), L.ptr(eps.contiguous()), L.ptr(z), B, self.nz, st)
+        return z, q
+
+    @torch.no_grad()
+    def _residual_step(self, y_t, z_tp1, dt):
+        """srvp.py:300-323."""
+        self._require_gpu()
+        from .latent import linear_fwd, mlp_keys
+        st = L.stream()
+        cur = torch.cat([y_t, z_tp1], 1).float().contiguous()
+        params = self._named_tensors()
+        keys = mlp_keys('dynamics', self.nlayers_res)
+        for i, k in enumerate(keys):
+            last = i == len(keys) - 1
+            out = torch.empty(cur.shape[0], params[k + '.weight'].shape[0], dtype=torch.float32, device=cur.device)
+            linear_fwd(st, cur, params[k + '.weight'], params[k + '.bias'], out, L.ACT_NONE if last else L.ACT_RELU)
+            cur = out
+        res = dt * cur
+        return y_t + res, res
+
+    @torch.no_grad()
+    def generate(self, y_0, hx, nt, dt, remove_intermediate=True, eps_z=None):
+        """srvp.py:325-413 -> (y, z, q_z_params, p_z_params, res); hx may be [] (pure prior rollout, test.py:244)."""
+        assert remove_intermediate
+        self._require_gpu()
+        n_euler = int(round(1 / dt))
+        B = y_0.shape[0]
+        T = len(hx)
+        assert not (self.training and nt > T), 'prior sampling is an inference-only path (srvp.py:391)'
+        key = ('gen', T, B, nt, n_euler, str(y_0.device))
+        lat = self._plans.get(key)
+        if lat is None:
+            lat = LatentNet(self._cfg(), T, B, nt, n_euler, y_0.device, False)
+            self._plans[key] = lat
+        st = L.stream()
+        params = self._named_tensors()
+        if eps_z is None:
+            eps_z = torch.randn(max(nt - 1, 1), B, self.nz, device=y_0.device)
+        if T > 0:
+            lat.posterior(hx.contiguous().float(), params, st)
+        y, z, qz, pz, res = lat.generate(y_0.contiguous().float(), T, params, eps_z.contiguous().float(), st)
+        cl = lambda t: None if t is None else t.clone()
+        return cl(y), (cl(z) if nt > 1 else None), cl(qz), (cl(pz) if nt > 1 else None), cl(res)

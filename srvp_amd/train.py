@@ -1,0 +1,214 @@
+"""
+Training driver mirroring the reference's train.py (same function names, arguments, CLI flags and outputs):
+`train(forward_fn, optimizer, scaler, batch, device, opt)` (reference train.py:49-129), `evaluate(...)`
+(train.py:132-189) and `main(opt)` (train.py:192-384).
+
+The optimisation step is the MI355X-native one: forward, ELBO terms with their gradients, backward and Adam are all
+HIP kernels (libsrvp_hip.so); the four logged scalars come back in ONE device->host copy per step instead of the
+reference's four `.item()` syncs (train.py:124-127).
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .model import StochasticLatentResidualVideoPredictor
+from .optim import FusedAdam
+
+
+def _unwrap(forward_fn):
+    m = getattr(forward_fn, 'module', forward_fn)
+    return m if isinstance(m, StochasticLatentResidualVideoPredictor) else None
+
+
+def elbo_terms_and_grads(model, x, outs, opt, want_grads=True):
+    """
+    train.py:90-106 on the device: returns a float64 tensor [nll, kl_y0, kl_z, l2_res] (sums, not yet /batch) and
+    the gradients of loss = (nll + beta_y kl_y0 + beta_z kl_z + l2_res * sum||res||) / batch wrt the forward outputs.
+    """
+    x_, y, z, w, q_y0, qz, pz, res = outs
+    B = x.shape[1]
+    dev = x.device
+    st = L.stream()
+    acc = torch.zeros(4, dtype=torch.float64, device=dev)
+    inv = 1.0 / B
+    bufs = model._last_plan.setdefault('elbo_bufs', {})
+
+    def buf(name, like):
+        if like is None or not want_grads:
+            return None
+        t = bufs.get(name)
+        if t is None or t.shape != like.shape:
+            t = torch.empty_like(like, dtype=torch.float32)
+            bufs[name] = t
+        return t
+    d_x, d_qy0, d_qz, d_pz, d_res = buf('d_x', x_), buf('d_qy0', q_y0), buf('d_qz', qz), buf('d_pz', pz), buf('d_res', res)
+    xc = x.contiguous().float()
+    L.call('srvp_nll', L.ptr(x_), L.ptr(xc), L.ptr(d_x), x_.numel(), float(opt.obs_scale), inv, L.ptr(acc[0:1]), st)
+    L.call('srvp_kl', L.ptr(q_y0), None, L.ptr(d_qy0), None, q_y0.shape[0], q_y0.shape[1] // 2, float(opt.beta_y) * inv,
+           L.ptr(acc[1:2]), st)
+    if qz is not None:
+        rows = qz.shape[0] * qz.shape[1]
+        L.call('srvp_kl', L.ptr(qz), L.ptr(pz), L.ptr(d_qz), L.ptr(d_pz), rows, qz.shape[2] // 2, float(opt.beta_z) * inv,
+               L.ptr(acc[2:3]), st)
+    l2 = float(opt.l2_res) if opt.l2_res is not None else 0.0
+    if l2 > 0:
+        L.call('srvp_l2rows', L.ptr(res), L.ptr(d_res), res.shape[0] * res.shape[1], res.shape[2], l2 * inv, L.ptr(acc[3:4]), st)
+    else:
+        d_res = None
+    return acc, (d_x, d_qy0, d_qz, d_pz, d_res)
+
+
+def fused_step(model, x, opt, tape=None):
+    """Forward + ELBO + backward entirely on the HIP path (no autograd graph).  Returns the float64 device tensor
+    [nll, kl_y0, kl_z, l2_res]."""
+    T = x.shape[0]
+    outs = model._forward_impl(x, T, opt.n_euler_steps, tape, training=True)
+    acc, (d_x, d_qy0, d_qz, d_pz, d_res) = elbo_terms_and_grads(model, x, outs, opt)
+    model._backward_impl(d_x, None, None, d_qy0, d_qz, d_pz, d_res)
+    return acc
+
+
+def train(forward_fn, optimizer, scaler, batch, device, opt):
+    """
+    One optimisation step (reference train.py:49-129): returns (loss, nll, kl_y_0, kl_z) as python floats, all
+    batch-averaged like the reference's logs.  `scaler` (torch.cuda.amp.GradScaler in the reference) is accepted for
+    signature compatibility and ignored: the bf16 kernels keep fp32 accumulation and need no loss scaling.
+    """
+    model = _unwrap(forward_fn)
+    if model is None:
+        raise TypeError('srvp_amd.train.train needs the srvp_amd StochasticLatentResidualVideoPredictor (or a wrapper '
+                        'exposing it as .module)')
+    optimizer.zero_grad()
+    x = batch.to(device, non_blocking=True)
+    n = x.shape[1]
+    acc = fused_step(model, x, opt)
+    optimizer.step()
+    nll, kl_y_0, kl_z, l2 = acc.cpu().tolist()          # the step's single host sync
+    loss = nll + opt.beta_y * kl_y_0 + opt.beta_z * kl_z
+    if opt.l2_res is not None and opt.l2_res > 0:
+        loss += opt.l2_res * l2
+    return loss / n, nll / n, kl_y_0 / n, kl_z / n
+
+
+def evaluate(forward_fn, val_loader, device, opt):
+    """Validation PSNR, best of n_samples_test predictions per video (reference train.py:132-189); returns -PSNR."""
+    inf_len = opt.nt_cond
+    assert val_loader is not None and opt.n_iter_test <= len(val_loader)
+    n, global_psnr = 0, 0.0
+    with torch.no_grad():
+        for j, batch in enumerate(val_loader):
+            if j >= opt.n_iter_test:
+                break
+            x = batch.to(device)
+            x_inf = x[:inf_len]
+            nt, n_b = x.shape[0], x.shape[1]
+            n += n_b
+            best_psnr, best_x = None, None
+            for _ in range(opt.n_samples_test):
+                x_s = forward_fn(x_inf, nt, dt=1 / opt.n_euler_steps)[0]
+                mse = torch.mean((x_s - x) ** 2, dim=[3, 4])              # (nt, B, C)
+                psnr = torch.mean(10 * torch.log10(1 / mse), dim=[0, 2])  # (B,)
+                if best_psnr is None:
+                    best_psnr, best_x = psnr, x_s.clone()
+                else:
+                    better = psnr > best_psnr
+                    best_psnr = torch.where(better, psnr, best_psnr)
+                    best_x[:, better] = x_s[:, better]
+            mse = torch.mean((best_x - x) ** 2, dim=[3, 4])
+            psnr = 10 * torch.log10(1 / mse)
+            global_psnr += psnr[inf_len:].mean().item() * n_b
+    return -global_psnr / n
+
+
+def main(opt):
+    """Trains SRVP and saves the resulting model (reference train.py:192-384); same flags (srvp_amd/args.py)."""
+    from . import data as sdata
+    from . import distributed as sdist
+    if opt.device is None:
+        raise SystemExit('srvp_amd trains on MI355X GPUs only: pass --device')
+    opt.n_gpu = len(opt.device)
+    local_rank = int(os.environ.get('LOCAL_RANK', opt.local_rank or 0))
+    opt.local_rank = local_rank
+    os.environ.setdefault('HIP_VISIBLE_DEVICES', str(opt.device[local_rank]))
+    device = torch.device('cuda:0')
+    torch.cuda.set_device(0)
+    sync = None
+    if opt.n_gpu > 1 or local_rank > 0:
+        sync = sdist.init_process_group()
+        assert opt.seed is not None
+        assert opt.batch_size % opt.n_gpu == 0
+        opt.batch_size = opt.batch_size // opt.n_gpu
+    if opt.seed is None:
+        opt.seed = random.randint(1, 10000)
+    print(f'Learning on {opt.n_gpu} GPU(s) (seed: {opt.seed})')
+    random.seed(opt.seed)
+    np.random.seed(opt.seed + local_rank)
+    torch.manual_seed(opt.seed)
+
+    print('Loading data...')
+    train_loader, val_loader, sampler = sdata.make_loaders(opt, local_rank)
+
+    print('Building model...')
+    model = StochasticLatentResidualVideoPredictor(opt.nx, opt.nc, opt.nf, opt.nhx, opt.ny, opt.nz, opt.skipco, opt.nt_inf,
+                                                   opt.nh_inf, opt.nlayers_inf, opt.nh_res, opt.nlayers_res, opt.archi)
+    model.init(res_gain=opt.res_gain)
+    model.to(device)
+    forward_fn = model
+    if sync is not None:
+        forward_fn = sdist.DataParallel(model, sync)
+
+    optimizer = FusedAdam(model, lr=opt.lr)
+    opt.n_iter = opt.lr_scheduling_burnin + opt.lr_scheduling_n_iter
+    n_sch = opt.lr_scheduling_n_iter
+    lr_scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda i: max(0, (n_sch - i) / n_sch))
+
+    assert opt.n_iter > 0
+    os.makedirs(opt.save_path, exist_ok=True)
+    itr, finished, status_code = 0, False, 0
+    val_metric = best_val_metric = None
+    try:
+        while not finished:
+            if sampler is not None:
+                sampler.set_epoch(opt.seed + itr)
+            for batch in train_loader:
+                if itr >= opt.n_iter:
+                    finished = True
+                    break
+                itr += 1
+                model.train()
+                loss, nll, kl_y_0, kl_z = train(forward_fn, optimizer, None, batch, device, opt)
+                if itr >= opt.lr_scheduling_burnin:
+                    lr_scheduler.step()
+                if local_rank == 0:
+                    if itr % opt.val_interval == 0 and val_loader is not None:
+                        model.eval()
+                        val_metric = evaluate(model, val_loader, device, opt)
+                        if best_val_metric is None or best_val_metric > val_metric:
+                            best_val_metric = val_metric
+                            torch.save(model.state_dict(), os.path.join(opt.save_path, 'model_best.pt'))
+                    if opt.chkpt_interval is not None and itr % opt.chkpt_interval == 0:
+                        torch.save(model.state_dict(), os.path.join(opt.save_path, f'model_{itr}.pt'))
+                    if itr % 50 == 0 or itr == 1:
+                        print(f'itr {itr}: loss {loss:.3f} nll {nll:.3f} kl_y_0 {kl_y_0:.4f} kl_z {kl_z:.4f} '
+                              f'val {val_metric} best {best_val_metric}', flush=True)
+    except KeyboardInterrupt:
+        status_code = 130
+    print('Saving...')
+    if local_rank == 0:
+        torch.save(model.state_dict(), os.path.join(opt.save_path, 'model.pt'))
+    print('Done')
+    return status_code
+
+
+if __name__ == '__main__':
+    from . import args as sargs
+    from .helper import DotDict
+    p = sargs.create_args()
+    opt = DotDict(vars(p.parse_args()))
+    if int(os.environ.get('LOCAL_RANK', opt.local_rank or 0)) != 0:
+        sys.stdout = open(os.devnull, 'w')
+    sys.exit(main(opt))

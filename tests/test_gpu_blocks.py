@@ -1,0 +1,294 @@
+"""
+GPU parity tests of the conv-block kernels at real layer widths (the golden fixtures only reach 32-channel tiles):
+srvp_conv_mfma (forward + data-gradient), srvp_wgrad_mfma (transpose-read and fallback paths), BatchNorm statistics,
+srvp_bn_act / srvp_bn_bwd_* incl. max-pool / upsample / skip-gradient routing, and the small-channel image layers.
+Reference: torch CPU fp32 ops on the same bf16-rounded operands (so only accumulation order and the final bf16
+rounding differ): tolerance = 2^-7 relative to the tensor's scale for bf16 outputs, 1e-3 for fp32 reductions.
+"""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def make_feat(N, H, W, Cr, dev, gen):
+    from srvp_amd.convnet import Feat
+    f = Feat(N, H, W, Cr, dev)
+    f.interior().copy_(torch.randn(N, H, W, Cr, generator=gen) * 0.5)
+    return f
+
+
+def feat_nchw(f):
+    return f.interior().permute(0, 3, 1, 2).float().cpu()
+
+
+CASES = [
+    # kind, k, s, p, c0r, c1r, ups, Hsrc, cout, N
+    ('conv', 3, 1, 1, 64, 0, False, 16, 128, 3),       # BN=128, BK=64
+    ('conv', 3, 1, 1, 64, 0, False, 32, 64, 2),        # BN=64
+    ('conv', 3, 1, 1, 128, 128, True, 8, 128, 3),      # upsample + skip concat (decoder stage entry)
+    ('conv', 3, 1, 1, 24, 24, True, 8, 40, 2),         # padded channels everywhere, BK=32
+    ('conv', 4, 2, 1, 64, 0, False, 16, 128, 2),       # DCGAN encoder stride 2
+    ('conv', 4, 1, 0, 64, 0, False, 4, 128, 5),        # encoder last_conv ("full")
+    ('convT', 4, 2, 1, 64, 64, False, 8, 64, 2),       # DCGAN decoder (4 phases) with skip
+    ('convT', 4, 1, 0, 50, 0, False, 1, 64, 6),        # decoder first_upconv ("expand"), odd K padded to 64
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[f'{c[0]}{c[1]}s{c[2]}_{c[4]}+{c[5]}_{"up" if c[6] else "id"}_{c[8]}' for c in CASES])
+@pytest.mark.parametrize('use_tr', [1, 0])
+def test_block_conv_fwd_bwd(case, use_tr):
+    from srvp_amd import _lib as L
+    from srvp_amd.convnet import Block, Feat
+    kind, k, s, p, c0r, c1r, ups, Hs, cout, N = case
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    if kind == 'convT' and Hs == 1:
+        f0 = Feat(N, 1, 1, c0r, dev, b=0)
+        f0.interior().copy_(torch.randn(N, 1, 1, c0r, generator=g))
+    else:
+        f0 = make_feat(N, Hs, Hs, c0r, dev, g)
+    srcs = [f0]
+    skip_map = None
+    Hin = Hs * 2 if ups else Hs
+    if c1r:
+        NB = 2                                           # skip tensor holds NB images, selected through the map
+        f1 = make_feat(NB * 2, Hin, Hin, c1r, dev, g)
+        srcs.append(f1)
+        skip_map = torch.tensor([(n % NB) * 2 + 1 for n in range(N)], dtype=torch.int32, device=dev)
+    spec = dict(kind=kind, key='w', bnkey='bn', cin=c0r + c1r, cout=cout, k=k, s=s, p=p, act='leaky_relu')
+    blk = Block(spec, 'mfma', srcs, ups, N, dev, True, skip_map=skip_map)
+    blk._fwd, blk._dg, blk._wg = blk.fwd_descs(), blk.dgrad_descs(), blk.wgrad_desc()
+    wshape = (cout, c0r + c1r, k, k) if kind == 'conv' else (c0r + c1r, cout, k, k)
+    w = (torch.randn(*wshape, generator=g) * 0.1).to(dev)
+    st = L.stream()
+    L.call('srvp_wgrad_set_tr', use_tr)
+    blk.pack(w, st)
+    blk.stats.zero_()
+    for d in blk._fwd:
+        L.call('srvp_conv_mfma', C.byref(d), st)
+    torch.cuda.synchronize()
+    # ---- reference forward
+    x0 = feat_nchw(f0)
+    if ups:
+        x0 = F.interpolate(x0, scale_factor=2, mode='nearest')
+    xin = x0
+    if c1r:
+        x1 = feat_nchw(f1)[skip_map.cpu().long()]
+        xin = torch.cat([x0, x1], 1)
+    xin = xin.clone().requires_grad_(True)
+    wr = bf(w.cpu()).clone().requires_grad_(True)
+    ref = F.conv2d(xin, wr, None, s, p) if kind == 'conv' else F.conv_transpose2d(xin, wr, None, s, p)
+    raw = blk.raw[..., :cout].permute(0, 3, 1, 2).float().cpu()
+    assert raw.shape == ref.shape
+    assert rel_err(raw, ref) < 2 ** -7, rel_err(raw, ref)
+    assert blk.raw[..., cout:].abs().max().item() == 0 if blk.cout > cout else True
+    s1 = ref.sum(dim=(0, 2, 3)).double()
+    s2 = (ref.double() ** 2).sum(dim=(0, 2, 3))
+    assert rel_err(blk.stats[0, :cout], s1) < 1e-3 * max(1.0, (s2.sqrt().max() / (s1.abs().max() + 1e-9)).item())
+    assert rel_err(blk.stats[1, :cout], s2) < 1e-3
+    # ---- backward
+    bd = blk.draw_b
+    dr = torch.randn(N, blk.OH, blk.OW, cout, generator=g) * 0.5
+    blk.draw.zero_()
+    blk.draw[:, bd:bd + blk.OH, bd:bd + blk.OW, :cout].copy_(dr)
+    dr_ref = blk.draw[:, bd:bd + blk.OH, bd:bd + blk.OW, :cout].permute(0, 3, 1, 2).float().cpu()
+    ref.backward(dr_ref)
+    grads = {'w.weight': torch.zeros_like(w)}
+    blk.dw.zero_()
+    L.call('srvp_wgrad_mfma', C.byref(blk._wg), st)
+    L.call('srvp_unpack_wgrad', L.ptr(blk.dw), L.ptr(grads['w.weight']), C.byref(blk.pu), st)
+    for d in blk._dg:
+        L.call('srvp_conv_mfma', C.byref(d), st)
+    torch.cuda.synchronize()
+    assert rel_err(grads['w.weight'], wr.grad) < 2e-3, rel_err(grads['w.weight'], wr.grad)
+    dcat = blk.dcat.float().cpu()                       # [N][Hin][Win][ctot]
+    c0p = f0.C
+    d0 = dcat[..., :c0r].permute(0, 3, 1, 2)
+    assert rel_err(d0, xin.grad[:, :c0r]) < 2 ** -7, rel_err(d0, xin.grad[:, :c0r])
+    if c1r:
+        d1 = dcat[..., c0p:c0p + c1r].permute(0, 3, 1, 2)
+        assert rel_err(d1, xin.grad[:, c0r:]) < 2 ** -7
+
+
+@pytest.mark.parametrize('mode', ['plain', 'ups', 'pool', 'skip'])
+@pytest.mark.parametrize('C_', [64, 40])
+def test_bn_act_fwd_bwd(mode, C_):
+    """bn_finalize + bn_act (+pool) forward and bn_bwd_{reduce,finalize,apply} against torch batch_norm autograd."""
+    from srvp_amd import _lib as L
+    from srvp_amd.convnet import Feat, cpad, BN_EPS, BN_MOMENTUM
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(3)
+    N, H = 4, 8
+    Cp = cpad(C_)
+    raw = torch.zeros(N, H, H, Cp, dtype=torch.bfloat16, device=dev)
+    raw[..., :C_] = (torch.randn(N, H, H, C_, generator=g) * 1.5 + 0.3)
+    rawf = raw[..., :C_].permute(0, 3, 1, 2).float().cpu().requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(C_, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(C_, generator=g)).to(dev)
+    rm, rv = torch.zeros(C_, device=dev), torch.ones(C_, device=dev)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    stats = torch.zeros(2, Cp, dtype=torch.float64, device=dev)
+    stats[0, :C_] = raw[..., :C_].double().sum(dim=(0, 1, 2))
+    stats[1, :C_] = (raw[..., :C_].double() ** 2).sum(dim=(0, 1, 2))
+    coef = torch.zeros(4, Cp, device=dev)
+    st = L.stream()
+    cnt = float(N * H * H)
+    L.call('srvp_bn_finalize', L.ptr(stats), cnt, L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(nbt),
+           L.ptr(coef[0]), L.ptr(coef[1]), L.ptr(coef[2]), L.ptr(coef[3]), Cp, C_, BN_EPS, BN_MOMENTUM, st)
+    out = Feat(N, H, H, C_, dev)
+    pool = Feat(N, H // 2, H // 2, C_, dev) if mode == 'pool' else None
+    L.call('srvp_bn_act', L.ptr(raw), L.ptr(coef[0]), L.ptr(coef[1]), L.ACT_LRELU, N, H, H, Cp, L.ptr(out.t), 1,
+           L.ptr(pool.t) if pool else None, 1, None, st)
+    torch.cuda.synchronize()
+    rm_ref, rv_ref = torch.zeros(C_), torch.ones(C_)
+    y = F.batch_norm(rawf, rm_ref, rv_ref, gamma.cpu(), beta.cpu(), True, BN_MOMENTUM, BN_EPS)
+    a = F.leaky_relu(y, 0.2)
+    assert rel_err(feat_nchw(out), a) < 2 ** -7
+    assert rel_err(rm, rm_ref) < 1e-4 and rel_err(rv, rv_ref) < 1e-4 and int(nbt) == 1
+    assert out.t[:, 0].abs().max().item() == 0 and out.t[:, :, 0].abs().max().item() == 0      # border stays zero
+    # ---- backward: build dA in the requested form
+    d = L.BnBwdDesc()
+    d.raw, d.act, d.act_border = L.ptr(raw), L.ptr(out.t), 1
+    d.scale, d.shift, d.mean, d.invstd, d.act_kind = L.ptr(coef[0]), L.ptr(coef[1]), L.ptr(coef[2]), L.ptr(coef[3]), L.ACT_LRELU
+    d.N, d.H, d.W, d.C = N, H, H, Cp
+    d.da_border, d.da_is_f32, d.da2, d.da2_idx = 0, 0, None, None
+    keep = []
+    if mode in ('plain', 'skip'):
+        da = torch.zeros(N, H, H, Cp + 32, dtype=torch.bfloat16, device=dev)         # channel slice of a wider tensor
+        da[..., 32:32 + C_] = torch.randn(N, H, H, C_, generator=g)
+        d.da, d.da_mode, d.da_cstride, d.da_coff = L.ptr(da), 0, Cp + 32, 32
+        da_ref = da[..., 32:32 + C_].permute(0, 3, 1, 2).float().cpu()
+        loss_in = a
+        if mode == 'skip':
+            da2 = torch.zeros(2, H, H, Cp, dtype=torch.bfloat16, device=dev)
+            da2[..., :C_] = torch.randn(2, H, H, C_, generator=g)
+            idx = torch.tensor([-1, 1, -1, 0], dtype=torch.int32, device=dev)
+            d.da2, d.da2_idx = L.ptr(da2), L.ptr(idx)
+            extra = torch.zeros_like(da_ref)
+            extra[1] = da2[1, ..., :C_].permute(2, 0, 1).float().cpu()
+            extra[3] = da2[0, ..., :C_].permute(2, 0, 1).float().cpu()
+            da_ref = da_ref + extra
+            keep += [da2, idx]
+        (loss_in * da_ref).sum().backward()
+    elif mode == 'ups':
+        da = torch.zeros(N, 2 * H, 2 * H, Cp, dtype=torch.bfloat16, device=dev)
+        da[..., :C_] = torch.randn(N, 2 * H, 2 * H, C_, generator=g)
+        d.da, d.da_mode, d.da_cstride, d.da_coff = L.ptr(da), 1, Cp, 0
+        up = F.interpolate(a, scale_factor=2, mode='nearest')
+        (up * da[..., :C_].permute(0, 3, 1, 2).float().cpu()).sum().backward()
+    else:
+        da = torch.zeros(N, H // 2, H // 2, Cp, dtype=torch.bfloat16, device=dev)
+        da[..., :C_] = torch.randn(N, H // 2, H // 2, C_, generator=g)
+        d.da, d.da_mode, d.da_cstride, d.da_coff = L.ptr(da), 2, Cp, 0
+        # pool on the bf16-rounded activations (what the kernel pooled), gradient routed by torch's own arg-max
+        a_b = bf(a)
+        pooled = F.max_pool2d(a_b + (a - a.detach()), 2, 2)
+        assert rel_err(feat_nchw(pool), pooled.detach()) < 1e-6
+        (pooled * da[..., :C_].permute(0, 3, 1, 2).float().cpu()).sum().backward()
+    red = torch.zeros(2, Cp, dtype=torch.float64, device=dev)
+    bcoef = torch.zeros(3, Cp, device=dev)
+    dgamma, dbeta = torch.zeros(C_, device=dev), torch.zeros(C_, device=dev)
+    draw = torch.zeros(N, H + 2, H + 2, Cp, dtype=torch.bfloat16, device=dev)
+    L.call('srvp_bn_bwd_reduce', C.byref(d), L.ptr(red), st)
+    L.call('srvp_bn_bwd_finalize', L.ptr(red), cnt, L.ptr(coef[0]), L.ptr(coef[2]), L.ptr(coef[3]), L.ptr(dgamma), L.ptr(dbeta),
+           L.ptr(bcoef), Cp, C_, 1, st)
+    L.call('srvp_bn_bwd_apply', C.byref(d), L.ptr(bcoef), L.ptr(draw), 1, st)
+    torch.cuda.synchronize()
+    got = draw[:, 1:-1, 1:-1, :C_].permute(0, 3, 1, 2).float().cpu()
+    assert rel_err(got, rawf.grad) < 2 ** -6, rel_err(got, rawf.grad)
+    assert draw[:, 0].abs().max().item() == 0
+    # parameter gradients via a second autograd pass on gamma/beta
+    gm, bt = gamma.cpu().clone().requires_grad_(True), beta.cpu().clone().requires_grad_(True)
+    y2 = F.batch_norm(rawf.detach(), None, None, gm, bt, True, BN_MOMENTUM, BN_EPS)
+    a2 = F.leaky_relu(y2, 0.2)
+    if mode in ('plain', 'skip'):
+        (a2 * da_ref).sum().backward()
+    elif mode == 'ups':
+        (F.interpolate(a2, scale_factor=2, mode='nearest') * da[..., :C_].permute(0, 3, 1, 2).float().cpu()).sum().backward()
+    else:
+        (F.max_pool2d(bf(a2) + (a2 - a2.detach()), 2, 2) * da[..., :C_].permute(0, 3, 1, 2).float().cpu()).sum().backward()
+    assert rel_err(dgamma, gm.grad) < 5e-3 and rel_err(dbeta, bt.grad) < 5e-3
+    del keep
+
+
+@pytest.mark.parametrize('nc,k,s,p', [(3, 3, 1, 1), (1, 4, 2, 1), (3, 4, 2, 1)])
+def test_image_side_layers(nc, k, s, p):
+    """First encoder conv (fp32 frames in) and last decoder transposed conv + sigmoid (fp32 frames out)."""
+    from srvp_amd import _lib as L
+    from srvp_amd.convnet import cpad
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(11)
+    N, cout_r = 3, 24
+    Cp = cpad(cout_r)
+    x = torch.rand(N, nc, 64, 64, generator=g)
+    w = torch.randn(cout_r, nc, k, k, generator=g) * 0.2
+    OH = (64 + 2 * p - k) // s + 1
+    raw = torch.zeros(N, OH, OH, Cp, dtype=torch.bfloat16, device=dev)
+    stats = torch.zeros(2, Cp, dtype=torch.float64, device=dev)
+    st = L.stream()
+    xd, wd = x.to(dev), w.to(dev)
+    L.call('srvp_conv_in_fwd', L.ptr(xd), L.ptr(wd), L.ptr(raw), L.ptr(stats), N, nc, 64, 64, Cp, cout_r, k, s, p, st)
+    torch.cuda.synchronize()
+    xr, wr = x.clone(), w.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, s, p)
+    assert rel_err(raw[..., :cout_r].permute(0, 3, 1, 2).float(), ref) < 2 ** -7
+    assert rel_err(stats[0, :cout_r], ref.sum(dim=(0, 2, 3))) < 2e-3
+    assert rel_err(stats[1, :cout_r], (ref ** 2).sum(dim=(0, 2, 3))) < 1e-3
+    draw = torch.zeros(N, OH + 2, OH + 2, Cp, dtype=torch.bfloat16, device=dev)
+    draw[:, 1:-1, 1:-1, :cout_r] = torch.randn(N, OH, OH, cout_r, generator=g)
+    dw = torch.zeros_like(wd)
+    L.call('srvp_conv_in_wgrad', L.ptr(xd), L.ptr(draw), L.ptr(dw), N, nc, 64, 64, Cp, cout_r, k, s, p, st)
+    torch.cuda.synchronize()
+    ref.backward(draw[:, 1:-1, 1:-1, :cout_r].permute(0, 3, 1, 2).float().cpu())
+    assert rel_err(dw, wr.grad) < 1e-3
+    # ---- last layer: ConvTranspose2d(cin -> nc) + sigmoid, input = [main, skip] bf16 padded tensors
+    from srvp_amd.convnet import Feat
+    Hin = 64 if s == 1 else 32
+    c0r, c1r = 24, (24 if s == 2 else 0)
+    f0 = make_feat(N, Hin, Hin, c0r, dev, g)
+    srcs = [f0]
+    d = L.ConvOutDesc()
+    d.src0, d.C0, d.C0_real = L.ptr(f0.t), f0.C, c0r
+    if c1r:
+        f1 = make_feat(2, Hin, Hin, c1r, dev, g)
+        mp = torch.tensor([1, 0, 1], dtype=torch.int32, device=dev)
+        d.src1, d.C1, d.C1_real, d.map1 = L.ptr(f1.t), f1.C, c1r, L.ptr(mp)
+        srcs.append(f1)
+    d.N, d.H, d.W, d.Cout, d.k, d.s, d.p, d.apply_sigmoid = N, Hin, Hin, nc, k, s, p, 1
+    wt = (torch.randn(c0r + c1r, nc, k, k, generator=g) * 0.2)
+    wtd = wt.to(dev)
+    xo = torch.zeros(N, nc, 64, 64, device=dev)
+    L.call('srvp_convT_out_fwd', C.byref(d), L.ptr(wtd), L.ptr(xo), st)
+    xin = feat_nchw(f0)
+    if c1r:
+        xin = torch.cat([xin, feat_nchw(f1)[mp.cpu().long()]], 1)
+    xin = xin.clone().requires_grad_(True)
+    wtr = wt.clone().requires_grad_(True)
+    ref = torch.sigmoid(F.conv_transpose2d(xin, wtr, None, s, p))
+    torch.cuda.synchronize()
+    assert (xo.cpu() - ref).abs().max().item() < 1e-4
+    dxo = torch.randn(N, nc, 64, 64, generator=g)
+    ref.backward(dxo)
+    ctot = f0.C + (srcs[1].C if c1r else 0)
+    dact = torch.zeros(N, Hin, Hin, ctot, dtype=torch.bfloat16, device=dev)
+    dwt = torch.zeros_like(wtd)
+    dxd = dxo.to(dev)
+    L.call('srvp_convT_out_bwd', C.byref(d), L.ptr(wtd), L.ptr(xo), L.ptr(dxd), L.ptr(dact), L.ptr(dwt), st)
+    torch.cuda.synchronize()
+    assert rel_err(dwt, wtr.grad) < 2e-3
+    assert rel_err(dact[..., :c0r].permute(0, 3, 1, 2).float(), xin.grad[:, :c0r]) < 2 ** -7
+    if c1r:
+        assert rel_err(dact[..., f0.C:f0.C + c1r].permute(0, 3, 1, 2).float(), xin.grad[:, c0r:]) < 2 ** -7

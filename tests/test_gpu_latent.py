@@ -1,0 +1,120 @@
+"""
+GPU parity of the fp32 latent path in isolation (content variable, y_0, LSTM + q_z, prior, residual Euler rollout and
+their backward) against the CPU oracle's autograd on the same frame encodings and noise tape.  fp32 on both sides:
+tolerance 1e-4 relative (accumulation order only).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-9)).item()
+
+
+@pytest.mark.parametrize('ne,T,B,dims', [(1, 4, 3, (8, 3, 3, 8, 16, 3, 4, 2)), (2, 5, 6, (128, 50, 50, 256, 512, 3, 4, 2)),
+                                          (2, 4, 5, (16, 5, 7, 24, 40, 2, 3, 3))])
+def test_latent_forward_backward(ne, T, B, dims):
+    import srvp_amd
+    from oracle import srvp_oracle as O
+    from srvp_amd import _lib as L
+    from srvp_amd.latent import LatentNet
+    nhx, ny, nz, nh_inf, nh_res, nl_inf, nl_res, nt_inf = dims
+    ctor = (64, 1, 4, nhx, ny, nz, False, nt_inf, nh_inf, nl_inf, nh_res, nl_res, 'dcgan')
+    torch.manual_seed(5)
+    model = srvp_amd.StochasticLatentResidualVideoPredictor(*ctor)
+    model.init(1.2)
+    cfg = O.make_cfg(*ctor)
+    g = torch.Generator().manual_seed(9)
+    hx = torch.tanh(torch.randn(T, B, nhx, generator=g))
+    tape = dict(t_w=torch.stack([torch.randperm(T, generator=g)[:nt_inf] for _ in range(B)], 1),
+                eps_y0=torch.randn(B, ny, generator=g), eps_z=torch.randn(T - 1, B, nz, generator=g))
+    # ---- oracle
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    lat_keys = [k for k in sd if not k.startswith(('encoder.', 'decoder.'))]
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in lat_keys}
+    work = dict(sd)
+    work.update(leaves)
+    hxr = hx.clone().requires_grad_(True)
+    w = O.infer_w(work, cfg, hxr, True, tape['t_w'])
+    y0, qy0 = O.infer_y(work, cfg, hxr[:nt_inf], tape['eps_y0'])
+    y, z, qz, pz, res = O.generate(work, cfg, y0, hxr, T, ne, tape['eps_z'], True)
+    cot = {n: torch.randn(t.shape, generator=g) for n, t in dict(y=y, w=w, qy0=qy0, qz=qz, pz=pz, res=res).items()}
+    total = (y * cot['y']).sum() + (w * cot['w']).sum() + (qy0 * cot['qy0']).sum() + (qz * cot['qz']).sum() + \
+        (pz * cot['pz']).sum() + (res * cot['res']).sum()
+    gl = torch.autograd.grad(total, [hxr] + [leaves[k] for k in lat_keys])
+    g_hx, g_par = gl[0], dict(zip(lat_keys, gl[1:]))
+    # ---- HIP
+    model = model.cuda()
+    model.flatten_parameters_()
+    grads = model._grads()
+    model._flat[1].zero_()
+    params = model._named_tensors()
+    st = L.stream()
+    lat = LatentNet(model._cfg(), T, B, T, ne, torch.device('cuda'), True)
+    hxg = hx.cuda()
+    tg = {k: v.cuda() for k, v in tape.items()}
+    w_g = lat.infer_w(hxg, params, tg['t_w'], st)
+    y0_g, qy0_g = lat.infer_y(hxg[:nt_inf], params, tg['eps_y0'], st)
+    lat.posterior(hxg, params, st)
+    y_g, z_g, qz_g, pz_g, res_g = lat.generate(y0_g, T, params, tg['eps_z'], st)
+    torch.cuda.synchronize()
+    for n, a, b in (('w', w_g, w), ('qy0', qy0_g, qy0), ('y', y_g, y), ('z', z_g, z), ('qz', qz_g, qz), ('pz', pz_g, pz),
+                    ('res', res_g, res)):
+        assert rel(a, b.detach()) < 1e-4, (n, rel(a, b.detach()))
+    c = {k: v.cuda().contiguous() for k, v in cot.items()}
+    d_hx = lat.backward(hxg, params, grads, tg['eps_y0'], tg['eps_z'], c['y'], c['w'], c['qy0'], c['qz'], c['pz'], c['res'],
+                        None, st)
+    torch.cuda.synchronize()
+    assert rel(d_hx.view(T, B, nhx), g_hx) < 2e-4, rel(d_hx.view(T, B, nhx), g_hx)
+    for k in lat_keys:
+        assert rel(grads[k], g_par[k]) < 5e-4, (k, rel(grads[k], g_par[k]))
+
+
+def test_elbo_and_adam_kernels():
+    """srvp_nll / srvp_kl / srvp_l2rows values + gradients and srvp_adam against the oracle formulas (train.py:90-106,289)."""
+    import srvp_amd
+    from oracle import srvp_oracle as O
+    from srvp_amd import _lib as L
+    g = torch.Generator().manual_seed(2)
+    dev = torch.device('cuda')
+    st = L.stream()
+    x_ = torch.rand(3, 2, 3, 64, 64, generator=g).requires_grad_(True)
+    x = torch.rand(3, 2, 3, 64, 64, generator=g)
+    q = (torch.randn(4, 6, 10, generator=g) * 2).requires_grad_(True)
+    p = torch.randn(4, 6, 10, generator=g).requires_grad_(True)
+    with torch.no_grad():
+        q[0, 0, 7] = 25.0
+    res = torch.randn(7, 6, 5, generator=g)
+    res[2, 3] = 0
+    res.requires_grad_(True)
+    nll = O.neg_logprob(x_, x, 0.2).sum()
+    klq = O.kl_normal(q, p).sum()
+    kl0 = O.kl_normal(q, None).sum()
+    l2 = torch.norm(res, p=2, dim=2).sum()
+    (0.5 * nll + 0.25 * klq + 2.0 * l2).backward()
+    acc = torch.zeros(4, dtype=torch.float64, device=dev)
+    xd, x_d, qd, pd, rd = x.to(dev), x_.detach().to(dev), q.detach().to(dev), p.detach().to(dev), res.detach().to(dev)
+    d_x, dq, dp, dr = torch.empty_like(x_d), torch.empty_like(qd), torch.empty_like(pd), torch.empty_like(rd)
+    L.call('srvp_nll', L.ptr(x_d), L.ptr(xd), L.ptr(d_x), x_d.numel(), 0.2, 0.5, L.ptr(acc[0:1]), st)
+    L.call('srvp_kl', L.ptr(qd), L.ptr(pd), L.ptr(dq), L.ptr(dp), 24, 5, 0.25, L.ptr(acc[1:2]), st)
+    L.call('srvp_kl', L.ptr(qd), None, None, None, 24, 5, 1.0, L.ptr(acc[2:3]), st)
+    L.call('srvp_l2rows', L.ptr(rd), L.ptr(dr), 42, 5, 2.0, L.ptr(acc[3:4]), st)
+    a = acc.cpu()
+    for got, ref in zip(a.tolist(), (nll.item(), klq.item(), kl0.item(), l2.item())):
+        assert abs(got - ref) < 1e-5 * abs(ref), (got, ref)
+    assert rel(d_x, x_.grad) < 1e-5 and rel(dq, q.grad) < 1e-4 and rel(dp, p.grad) < 1e-4 and rel(dr, res.grad) < 1e-5
+    # Adam: 3 steps against the oracle's update
+    n = 1003
+    p0 = torch.randn(n, generator=g)
+    sd = {'p': p0.clone()}
+    state = {}
+    pd_, m, v = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g)
+        O.adam_step(sd, {'p': gr}, state, 3e-4)
+        grd = gr.to(dev)
+        L.call('srvp_adam', L.ptr(pd_), L.ptr(grd), L.ptr(m), L.ptr(v), n, 3e-4, 0.9, 0.999, 1e-8, step, 1.0, st)
+    assert (pd_.cpu() - sd['p']).abs().max().item() < 1e-6

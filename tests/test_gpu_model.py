@@ -1,0 +1,186 @@
+"""
+GPU parity of the full hot path (model forward, ELBO, backward, Adam, eval prediction, rollout API) against
+(a) the golden fixtures generated from the real reference (tests/golden/*.npz) and (b) the CPU oracle at full layer
+width.  The HIP path computes convolutions with bf16 operands / fp32 accumulation (DESIGN.md "precision"), so the
+tolerances below are the bf16 ones, stated per quantity; the ELBO itself must match to 1e-4 relative at full width
+(BASELINE.json north_star) and 5e-4 on the tiny fixtures (whose 4..32-channel layers average less rounding noise).
+"""
+import json
+import os
+
+import pytest
+import torch
+
+from golden_util import Fixture, OUT_NAMES, fixture_names
+
+pytestmark = pytest.mark.gpu
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'parity_report.jsonl')
+
+
+def report(**kw):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, 'a') as f:
+        f.write(json.dumps(kw) + '\n')
+
+
+def max_abs(a, b):
+    return (a.double().cpu() - b.double().cpu()).abs().max().item()
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def build(fx, sd_key='sd0'):
+    import srvp_amd
+    m = srvp_amd.StochasticLatentResidualVideoPredictor(*fx.meta['ctor'])
+    missing = m.load_state_dict(fx.state(sd_key), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return m.cuda()
+
+
+def opt_of(fx):
+    import srvp_amd
+    return srvp_amd.DotDict(dict(n_euler_steps=fx.meta['n_euler'], **fx.meta['hp']))
+
+
+@pytest.mark.parametrize('name', fixture_names())
+def test_train_step_vs_reference_fixture(name):
+    from srvp_amd import FusedAdam
+    from srvp_amd.train import elbo_terms_and_grads
+    fx = Fixture(name)
+    model = build(fx)
+    model.train()
+    x = fx.t('x').cuda()
+    tape = fx.tape()
+    opt = opt_of(fx)
+    optim = FusedAdam(model, lr=fx.meta['lr'])
+    optim.zero_grad()
+    outs = model._forward_impl(x, x.shape[0], fx.meta['n_euler'], tape, training=True)
+    outs_c = [o.clone() if o is not None else None for o in outs]
+    acc, g = elbo_terms_and_grads(model, x, outs, opt)
+    model._backward_impl(g[0], None, None, g[1], g[2], g[3], g[4])
+    nll, kl_y0, kl_z, l2 = acc.cpu().tolist()
+    B = x.shape[1]
+    hp = fx.meta['hp']
+    loss = (nll + hp['beta_y'] * kl_y0 + hp['beta_z'] * kl_z + hp['l2_res'] * l2) / B
+    ref = fx.z['train.scalars']
+    errs = dict(loss=abs(loss - ref[0]) / abs(ref[0]), nll=abs(nll / B - ref[1]) / abs(ref[1]),
+                kl_y0=abs(kl_y0 / B - ref[2]) / max(abs(ref[2]), 1e-6), kl_z=abs(kl_z / B - ref[3]) / max(abs(ref[3]), 1e-6),
+                l2=abs(l2 - float(fx.z['train.l2_res'])) / abs(float(fx.z['train.l2_res'])))
+    out_err = {}
+    for n, o in zip(OUT_NAMES, outs_c):
+        r = fx.t('train.' + n)
+        out_err[n] = (max_abs(o, r), rel_l2(o, r))
+    gref = fx.group('grad.')
+    grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+    gerr = {k: rel_l2(grads[k], gref[k]) for k in gref}
+    worst = sorted(gerr.items(), key=lambda kv: -kv[1])[:5]
+    report(test='train_fixture', name=name, scalars=errs, outs=out_err, worst_grads=worst,
+           median_grad=sorted(gerr.values())[len(gerr) // 2])
+    assert errs['loss'] < 5e-4 and errs['nll'] < 5e-4, errs
+    assert errs['kl_y0'] < 2e-2 and errs['kl_z'] < 3e-2 and errs['l2'] < 2e-2, errs
+    assert out_err['x_'][0] < 3e-2, out_err
+    for n in ('y', 'z', 'w', 'q_y_0_params', 'q_z_params', 'p_z_params', 'res'):
+        assert out_err[n][1] < 3e-2, (n, out_err[n])
+    # gradients: bf16 backward; every tensor within 10 % relative L2, the typical one within 2 %
+    assert max(gerr.values()) < 0.10, worst
+    assert sorted(gerr.values())[len(gerr) // 2] < 0.02
+    # ---- Adam + BN running statistics (train.py:120; conv.py:104)
+    optim.step()
+    sd0, sd1 = fx.state('sd0'), fx.state('sd1')
+    lr = fx.meta['lr']
+    agree_all = []
+    for k, v in model.state_dict().items():
+        v = v.detach().cpu()
+        if k.endswith('num_batches_tracked'):
+            assert int(v) == int(sd1[k]), k
+        elif k.endswith(('running_mean', 'running_var')):
+            assert max_abs(v, sd1[k]) < 2e-3 + 2e-2 * sd1[k].abs().max().item(), k
+        else:
+            assert max_abs(v, sd1[k]) < 2.5 * lr, k
+            moved = (sd1[k] - sd0[k]).abs() > 0.5 * lr
+            if moved.any():
+                agree_all.append((((v - sd0[k]).sign() == (sd1[k] - sd0[k]).sign()) | ~moved).float().mean().item())
+    assert sum(agree_all) / len(agree_all) > 0.97, sum(agree_all) / len(agree_all)
+
+
+@pytest.mark.parametrize('name', fixture_names())
+def test_eval_prediction_and_rollout_vs_reference_fixture(name):
+    fx = Fixture(name)
+    model = build(fx, 'sd1')
+    model.eval()
+    x = fx.t('x').cuda()
+    ne = fx.meta['n_euler']
+    nt_cond, nt = int(fx.z['eval.nt_cond']), int(fx.z['eval.nt'])
+    tape = fx.tape('eval.tape.')
+    outs = model(x[:nt_cond], nt, dt=1 / ne, tape=tape)
+    errs = {}
+    for n, o in zip(OUT_NAMES, outs):
+        if o is None:
+            assert not fx.has('eval.' + n)
+            continue
+        r = fx.t('eval.' + n)
+        errs[n] = (max_abs(o, r), rel_l2(o, r))
+    report(test='eval_fixture', name=name, outs=errs)
+    assert errs['x_'][0] < 3e-2, errs
+    for n in errs:
+        if n != 'x_':
+            assert errs[n][1] < 3e-2, (n, errs[n])
+    # test.py:235-246 call pattern through the granular API
+    skip = model.encode(x[:nt_cond])[1] if model.skipco else None
+    tape2 = {'eps_y0': fx.t('roll.eps_y0'), 'eps_z': fx.t('roll.eps_z_fwd')}
+    x_rec, y, _, w, _, _, _, _ = model(x[:nt_cond], nt_cond, dt=1 / ne, tape=tape2)
+    x_rec, y, w = x_rec.clone(), y.clone(), w.clone()
+    eps_gen = fx.t('roll.eps_z_gen').cuda()
+    y_os = model.generate(y[-1], [], eps_gen.shape[0] + 1, 1 / ne, eps_z=eps_gen)[0]
+    x_pred = model.decode(w, y_os[1:].contiguous(), skip).clamp(0, 1)
+    e = dict(x_rec=max_abs(x_rec, fx.t('roll.x_rec')), y_gen=rel_l2(y_os, fx.t('roll.y_gen')),
+             x_pred=max_abs(x_pred, fx.t('roll.x_pred')))
+    report(test='rollout_fixture', name=name, errs=e)
+    assert e['x_rec'] < 3e-2 and e['x_pred'] < 3e-2 and e['y_gen'] < 3e-2, e
+
+
+@pytest.mark.parametrize('archi,nc,skipco,ne,B,T', [('vgg', 3, True, 2, 4, 4), ('dcgan', 1, False, 1, 8, 5), ('dcgan', 1, True, 2, 4, 4)])
+def test_full_width_vs_oracle(archi, nc, skipco, ne, B, T):
+    """Full layer widths (nf=64, nhx=128, nh_res=512): ELBO within 1e-4 relative of the CPU oracle (north_star)."""
+    import srvp_amd
+    from oracle import srvp_oracle as O
+    from srvp_amd.train import elbo_terms_and_grads
+    torch.manual_seed(1)
+    ny = nz = 50 if archi == 'vgg' else 20
+    nt_inf = 2
+    ctor = (64, nc, 64, 128, ny, nz, skipco, nt_inf, 256, 3, 512, 4, archi)
+    model = srvp_amd.StochasticLatentResidualVideoPredictor(*ctor)
+    model.init(1.2)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(123)
+    x = torch.rand(T, B, nc, 64, 64, generator=g)
+    tape = dict(t_w=torch.stack([torch.randperm(T, generator=g)[:nt_inf] for _ in range(B)], 1),
+                eps_y0=torch.randn(B, ny, generator=g), eps_z=torch.randn(T - 1, B, nz, generator=g))
+    if skipco:
+        tape['t_skip'] = torch.randint(T, (B,), generator=g)
+    hp = dict(obs_scale=0.2 if archi == 'vgg' else 1.0, beta_y=1.0, beta_z=1.0, l2_res=1.0)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    scal, outs_ref, grads_ref = O.train_step(sd, O.make_cfg(*ctor), x, ne, tape, hp)
+    model = model.cuda().train()
+    opt = srvp_amd.DotDict(dict(n_euler_steps=ne, **hp))
+    model.flatten_parameters_()
+    model._grads()
+    model._flat[1].zero_()
+    xg = x.cuda()
+    outs = model._forward_impl(xg, T, ne, tape, training=True)
+    x_ = outs[0].clone()
+    acc, gr = elbo_terms_and_grads(model, xg, outs, opt)
+    model._backward_impl(gr[0], None, None, gr[1], gr[2], gr[3], gr[4])
+    nll, kl_y0, kl_z, l2 = acc.cpu().tolist()
+    loss = (nll + kl_y0 + kl_z + l2) / B
+    e_loss = abs(loss - scal['loss']) / abs(scal['loss'])
+    gerr = {k: rel_l2(p.grad, grads_ref[k]) for k, p in model.named_parameters()}
+    worst = sorted(gerr.items(), key=lambda kv: -kv[1])[:6]
+    report(test='full_width', archi=archi, skipco=skipco, loss=loss, loss_ref=scal['loss'], e_loss=e_loss,
+           x_maxabs=max_abs(x_, outs_ref[0]), worst_grads=worst, median_grad=sorted(gerr.values())[len(gerr) // 2])
+    assert e_loss < 1e-4, (loss, scal['loss'])
+    assert max_abs(x_, outs_ref[0]) < 3e-2
+    assert max(gerr.values()) < 0.10, worst
