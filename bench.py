@@ -1,0 +1,202 @@
+"""
+Headline benchmark of the SRVP training hot path on MI355X (BASELINE.json metric):
+
+    training frames/sec (B x T) per node, BAIR VGG-64 (vgg + skipco, nc=3, seq_len=12, n_euler=2, batch 192 per GPU)
+
+One "step" = one full optimisation step of reference train.py:49-129 -- forward, ELBO, backward, Adam -- through the
+HIP kernels, on a synthetic (T, B, C, 64, 64) batch already resident in HBM.  `python bench.py --gpus N --steps K
+--warmup W` (for N > 1 launched by torch.distributed.run, one rank per GPU over RCCL); rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     : the dominant kernel class (srvp_conv_mfma: forward + data-gradient implicit GEMMs), its algorithmic
+                 FLOPs per step (2*MACs of the reference layer definitions) divided by its summed launch
+                 durations measured with HIP events on the launch stream during the timed steps; peak = dense bf16 MFMA.
+  cpu_baseline : the CPU oracle (port of the reference path, fixture-verified) timed on the host cores on a bounded
+                 sample of the same workload (reduced batch: frames/s is batch-independent on CPU; B=192 needs > 60 GB).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+CONFIGS = {
+    # name: (ctor args in the reference's positional order, T, hyper-parameters)  -- README.md:111-128 recipes
+    'bair': dict(ctor=(64, 3, 64, 128, 50, 50, True, 2, 256, 3, 512, 4, 'vgg'), T=12, n_euler=2, obs_scale=0.71, beta_z=1.0,
+                 res_gain=1.41, label='BAIR 64x64x3 vgg+skipco seq_len=12 n_euler=2'),
+    'kth': dict(ctor=(64, 1, 64, 128, 50, 50, True, 3, 256, 3, 512, 4, 'vgg'), T=20, n_euler=2, obs_scale=0.2, beta_z=1.0,
+                res_gain=1.2, label='KTH 64x64x1 vgg+skipco seq_len=20 n_euler=2'),
+    'smmnist': dict(ctor=(64, 1, 64, 128, 20, 20, False, 5, 256, 3, 512, 4, 'dcgan'), T=15, n_euler=1, obs_scale=1.0, beta_z=2.0,
+                    res_gain=1.41, label='SM-MNIST 64x64x1 dcgan seq_len=15'),
+}
+
+
+def conv_flops(model, N_enc, N_dec):
+    """Algorithmic FLOPs (2*MACs of the reference layer definitions) per step, split by kernel class."""
+    out = dict(fwd_mfma=0.0, dgrad_mfma=0.0, wgrad_mfma=0.0, fwd_all=0.0)
+    for blocks, N, enc in ((model._enc_blocks, N_enc, True), (model._dec_blocks, N_dec, False)):
+        h = 64 if enc else 1
+        for i, b in enumerate(blocks):
+            if enc and b.get('pre') == 'pool':
+                h //= 2
+            hin = h
+            if b['kind'] == 'conv':
+                ho = (hin + 2 * b['p'] - b['k']) // b['s'] + 1
+                macs = N * ho * ho * b['cout'] * b['cin'] * b['k'] ** 2
+            else:
+                ho = (hin - 1) * b['s'] - 2 * b['p'] + b['k']
+                macs = N * hin * hin * b['cout'] * b['cin'] * b['k'] ** 2
+            h = ho * (2 if (not enc and b.get('post_up')) else 1)
+            f = 2.0 * macs
+            out['fwd_all'] += f
+            image_side = (enc and i == 0) or ((not enc) and i == len(blocks) - 1)
+            if not image_side:
+                out['fwd_mfma'] += f
+                out['dgrad_mfma'] += f
+                out['wgrad_mfma'] += f
+    return out
+
+
+def cpu_baseline(cfg, seconds=20.0):
+    """Oracle train step (forward + ELBO + backward + Adam) on the host cores, reduced batch."""
+    from oracle import srvp_oracle as O
+    import srvp_amd
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(1)
+    m = srvp_amd.StochasticLatentResidualVideoPredictor(*cfg['ctor'])
+    m.init(cfg['res_gain'])
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    ocfg = O.make_cfg(*cfg['ctor'])
+    T, B = cfg['T'], 4
+    g = torch.Generator().manual_seed(123)
+    x = torch.rand(T, B, cfg['ctor'][1], 64, 64, generator=g)
+    hp = dict(obs_scale=cfg['obs_scale'], beta_y=1.0, beta_z=cfg['beta_z'], l2_res=1.0)
+    nt_inf, ny, nz = cfg['ctor'][7], cfg['ctor'][4], cfg['ctor'][5]
+
+    def tape():
+        t = dict(t_w=torch.stack([torch.randperm(T, generator=g)[:nt_inf] for _ in range(B)], 1),
+                 eps_y0=torch.randn(B, ny, generator=g), eps_z=torch.randn(T - 1, B, nz, generator=g))
+        if cfg['ctor'][6]:
+            t['t_skip'] = torch.randint(T, (B,), generator=g)
+        return t
+    adam = {}
+    O.train_step(sd, ocfg, x, cfg['n_euler'], tape(), hp, adam, 3e-4)      # warm-up
+    t0, n = time.time(), 0
+    while time.time() - t0 < seconds or n < 2:
+        O.train_step(sd, ocfg, x, cfg['n_euler'], tape(), hp, adam, 3e-4)
+        n += 1
+    dt = (time.time() - t0) / n
+    return dict(value=B * T / dt, unit='frames/s', cores=cores, kind='port',
+                sample=f'{n} oracle train steps (fwd+ELBO+bwd+Adam, fp32, torch {torch.__version__} CPU) of the same '
+                       f'architecture at B={B}, T={T} ({B * T} frames/step, {dt:.2f} s/step)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='bair', choices=list(CONFIGS))
+    ap.add_argument('--batch', type=int, default=192, help='per-GPU batch (weak scaling) unless --global-batch is given')
+    ap.add_argument('--global-batch', type=int, default=None, help='fixed global batch split over the ranks (strong scaling)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    import srvp_amd
+    from srvp_amd import _lib as L
+    from srvp_amd import distributed as sdist
+    from srvp_amd.train import train
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    sync = None
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        sync = sdist.init_process_group('nccl')
+
+    cfg = CONFIGS[args.config]
+    T = cfg['T']
+    B = args.batch if args.global_batch is None else args.global_batch // world
+    scaling = 'weak' if args.global_batch is None else 'strong'
+    torch.manual_seed(1)
+    model = srvp_amd.StochasticLatentResidualVideoPredictor(*cfg['ctor'])
+    model.init(res_gain=cfg['res_gain'])
+    model.to(dev).train()
+    fwd = sdist.DataParallel(model, sync) if sync is not None else model
+    optim = srvp_amd.FusedAdam(model, lr=3e-4)
+    opt = srvp_amd.DotDict(dict(n_euler_steps=cfg['n_euler'], obs_scale=cfg['obs_scale'], beta_y=1.0, beta_z=cfg['beta_z'], l2_res=1.0))
+    g = torch.Generator().manual_seed(123 + rank)
+    x = torch.rand(T, B, cfg['ctor'][1], 64, 64, generator=g).to(dev)          # synthetic batch, resident in HBM
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = train(fwd, optim, None, x, dev, opt)
+    if not args.no_kernel_timing:
+        L.PROFILE = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train(fwd, optim, None, x, dev, opt)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, L.PROFILE = L.PROFILE, None
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = tmax.item()
+    if rank != 0:
+        return
+    frames = B * T * world
+    ms_step = dt / args.steps * 1e3
+    fl = conv_flops(model, T * B, T * B)
+    line = {
+        'metric': 'training frames/sec (BxT) per node, BAIR VGG-64 seq_len=12' if args.config == 'bair' else f'training frames/sec ({cfg["label"]})',
+        'value': frames * args.steps / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': 'bf16',
+        'data': 'synthetic (uniform random frames, random-init weights)',
+        'config': {'workload': cfg['label'], 'per_gpu_batch': B, 'global_batch': B * world, 'seq_len': T,
+                   'parallelism': f'dp{world}', 'step': 'forward + ELBO + backward + Adam (reference train.py:49-129)'},
+        'loss': loss[0] if loss else None,
+        'model_flops_frac_of_bf16_peak': (3 * fl['fwd_all'] * world * args.steps / dt) / (PEAK_BF16_TFLOPS * 1e12 * world),
+    }
+    if prof:
+        per = {}
+        for name, evs in prof.items():
+            per[name] = sum(a.elapsed_time(b) for a, b in evs) / args.steps      # ms per step
+        tot = sum(per.values())
+        dom = 'srvp_conv_mfma'
+        ach = (fl['fwd_mfma'] + fl['dgrad_mfma']) / (per[dom] * 1e-3) / 1e12
+        line['roofline'] = {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (srvp_conv_mfma: forward + data-gradient implicit GEMMs)',
+                            'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
+                            'traffic': None, 'launches_per_step': len(prof[dom]) // args.steps, 'ms_per_step': per[dom]}
+        wg = fl['wgrad_mfma'] / (per['srvp_wgrad_mfma'] * 1e-3) / 1e12
+        line['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'wgrad_mfma_kernel', 'achieved': wg, 'peak': PEAK_BF16_TFLOPS,
+                                  'unit': 'TFLOP/s', 'frac': wg / PEAK_BF16_TFLOPS, 'ms_per_step': per['srvp_wgrad_mfma']}
+        line['kernel_ms_per_step'] = {k: round(v, 3) for k, v in sorted(per.items(), key=lambda kv: -kv[1])}
+        line['kernel_ms_total'] = round(tot, 3)
+    if world == 1 and not args.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline(cfg)
+    print(json.dumps(line))
+
+
+if __name__ == '__main__':
+    main()

@@ -165,9 +165,20 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+PROFILE = None      # set to a dict by bench.py: name -> list of (start_event, end_event) on the launch stream
+
+
 def call(name, *args):
     fn = getattr(load(), name)
+    if PROFILE is None:
+        check(fn(*args), name)
+        return
+    # torch.cuda.Event records on torch's current stream, which is the stream every launch is issued on (stream())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(fn(*args), name)
+    e1.record()
+    PROFILE.setdefault(name, []).append((e0, e1))
 
 
 def taps(vals):

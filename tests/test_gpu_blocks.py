@@ -194,7 +194,7 @@ def test_bn_act_fwd_bwd(mode, C_):
         da[..., :C_] = torch.randn(N, H // 2, H // 2, C_, generator=g)
         d.da, d.da_mode, d.da_cstride, d.da_coff = L.ptr(da), 2, Cp, 0
         # pool on the bf16-rounded activations (what the kernel pooled), gradient routed by torch's own arg-max
-        a_b = bf(a)
+        a_b = bf(a).detach()
         pooled = F.max_pool2d(a_b + (a - a.detach()), 2, 2)
         assert rel_err(feat_nchw(pool), pooled.detach()) < 1e-6
         (pooled * da[..., :C_].permute(0, 3, 1, 2).float().cpu()).sum().backward()
@@ -219,7 +219,7 @@ def test_bn_act_fwd_bwd(mode, C_):
     elif mode == 'ups':
         (F.interpolate(a2, scale_factor=2, mode='nearest') * da[..., :C_].permute(0, 3, 1, 2).float().cpu()).sum().backward()
     else:
-        (F.max_pool2d(bf(a2) + (a2 - a2.detach()), 2, 2) * da[..., :C_].permute(0, 3, 1, 2).float().cpu()).sum().backward()
+        (F.max_pool2d(bf(a2).detach() + (a2 - a2.detach()), 2, 2) * da[..., :C_].permute(0, 3, 1, 2).float().cpu()).sum().backward()
     assert rel_err(dgamma, gm.grad) < 5e-3 and rel_err(dbeta, bt.grad) < 5e-3
     del keep
 
