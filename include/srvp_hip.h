@@ -54,6 +54,9 @@ typedef struct {
     int32_t N, OH, OW;            /* output (sub-)grid */
     void* dst; int32_t DHp, DWp, so, ooy, oox, Cdst, cdst_off;
     double* stats; int32_t stat_mod;
+    /* image-side output layer (conv.py:304,353 + sigmoid :273-274): when out_f32 != NULL the first out_nc columns are
+     * written as fp32 into the (N, out_nc, DHp, DWp) frame tensor (optionally through a sigmoid) instead of `dst` */
+    float* out_f32; int32_t out_nc, out_sigmoid;
 } srvp_conv_desc;
 int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
 
@@ -125,19 +128,10 @@ int srvp_conv_in_fwd(const float* x, const float* w, void* raw, double* stats,
 /* dW[Cout_real][Cin][k][k] += sum draw * x   (draw: bf16 padded(border 1) [N][OH+2][OW+2][Cout]) */
 int srvp_conv_in_wgrad(const float* x, const void* draw, float* dw,
                        int N, int Cin, int H, int W, int Cout, int Cout_real, int k, int s, int p, void* stream);
-/* last decoder layer: transposed convolution (IOHW fp32 weights [Cin_real][Cout<=4][k][k]) of one or two bf16
- * NHWC tensors with a 1-pixel zero border (second = skip connection, DCGAN conv.py:304 with --skipco), then sigmoid
- * (conv.py:273-274):  x_ fp32 NCHW [N][Cout][OH][OW]. */
-typedef struct {
-    const void* src0; const void* src1; const int32_t* map1;
-    int32_t C0, C1, C0_real, C1_real;       /* padded / real channel counts of each source */
-    int32_t N, H, W, Cout, k, s, p, apply_sigmoid;
-} srvp_convout_desc;
-int srvp_convT_out_fwd(const srvp_convout_desc* d, const float* w, float* x_out, void* stream);
-/* given dx_ (fp32 NCHW) and x_: dpre = dx_*x_*(1-x_) (if sigmoid); dact bf16 [N][H][W][C0+C1] (unpadded) and
- * dw (+=, IOHW fp32); either output may be NULL */
-int srvp_convT_out_bwd(const srvp_convout_desc* d, const float* w, const float* x_out, const float* dx_out,
-                       void* dact, float* dw, void* stream);
+/* sigmoid backward of the last decoder layer (conv.py:273-274): dpre = dx_ * x_ * (1 - x_) from the fp32
+ * (N, nc, H, W) frame tensors into a bf16 NHWC tensor [N][H+2][W+2][C] (zero border, channels >= nc zero) */
+int srvp_out_dpre(const float* x_out, const float* dx_out, void* draw, int N, int nc, int H, int W, int C,
+                  int apply_sigmoid, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Weight packing between the reference state-dict layouts (OIHW conv / IOHW convT, fp32) and tap-major bf16.

@@ -30,7 +30,8 @@ class ConvDesc(C.Structure):
                 ('N', c_i32), ('OH', c_i32), ('OW', c_i32),
                 ('dst', c_vp), ('DHp', c_i32), ('DWp', c_i32), ('so', c_i32), ('ooy', c_i32), ('oox', c_i32),
                 ('Cdst', c_i32), ('cdst_off', c_i32),
-                ('stats', c_vp), ('stat_mod', c_i32)]
+                ('stats', c_vp), ('stat_mod', c_i32),
+                ('out_f32', c_vp), ('out_nc', c_i32), ('out_sigmoid', c_i32)]
 
 
 class WgradDesc(C.Structure):
@@ -51,13 +52,6 @@ class BnBwdDesc(C.Structure):
                 ('da_is_f32', c_i32),
                 ('da2', c_vp), ('da2_idx', c_vp),
                 ('N', c_i32), ('H', c_i32), ('W', c_i32), ('C', c_i32)]
-
-
-class ConvOutDesc(C.Structure):
-    _fields_ = [('src0', c_vp), ('src1', c_vp), ('map1', c_vp),
-                ('C0', c_i32), ('C1', c_i32), ('C0_real', c_i32), ('C1_real', c_i32),
-                ('N', c_i32), ('H', c_i32), ('W', c_i32), ('Cout', c_i32), ('k', c_i32), ('s', c_i32), ('p', c_i32),
-                ('apply_sigmoid', c_i32)]
 
 
 class PackDesc(C.Structure):
@@ -94,8 +88,7 @@ _SIGS = {
     'srvp_bn_bwd_apply': ([C.POINTER(BnBwdDesc), c_vp, c_vp, c_i32, c_vp], c_i32),
     'srvp_conv_in_fwd': ([c_vp, c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp], c_i32),
     'srvp_conv_in_wgrad': ([c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp], c_i32),
-    'srvp_convT_out_fwd': ([C.POINTER(ConvOutDesc), c_vp, c_vp, c_vp], c_i32),
-    'srvp_convT_out_bwd': ([C.POINTER(ConvOutDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
+    'srvp_out_dpre': ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_pack_weight': ([c_vp, c_vp, C.POINTER(PackDesc), c_vp], c_i32),
     'srvp_unpack_wgrad': ([c_vp, c_vp, C.POINTER(PackDesc), c_vp], c_i32),
     'srvp_gemm_f32': ([c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),

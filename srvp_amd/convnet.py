@@ -79,7 +79,7 @@ class Block:
         self.k, self.s, self.p = k, s, p
         self.kind = spec['kind']
         self.cout_r = spec['cout']
-        self.cout = cpad(self.cout_r) if role != 'out' else self.cout_r
+        self.cout = cpad(self.cout_r)
         self.has_bn = spec['bnkey'] is not None
         self.act = ACT[spec['act']]
         if role == 'in':
@@ -97,7 +97,7 @@ class Block:
             self.OH = (self.Hin - 1) * s - 2 * p + k
             self.OW = (self.Win - 1) * s - 2 * p + k
         # geometry class of the MFMA layers
-        if role == 'mfma':
+        if role in ('mfma', 'out'):
             if self.kind == 'conv' and self.OH == 1 and p == 0:
                 self.geom = 'full'                    # k x k conv covering the whole k x k input -> 1x1 (encoder last_conv)
             elif self.kind == 'conv' and s == 1:
@@ -108,6 +108,8 @@ class Block:
                 self.geom = 'up'                      # transposed 4x4 s2 p1
             elif self.kind == 'convT' and self.Hin == 1:
                 self.geom = 'expand'                  # transposed k x k on a 1x1 input (decoder first_upconv)
+            elif self.kind == 'convT' and s == 1:
+                self.geom = 'sameT'                   # transposed 3x3 s1 p1 (VGG decoder output layer)
             else:
                 raise NotImplementedError(spec)
             assert not (self.geom in ('full', 'expand') and len(srcs) != 1)
@@ -123,18 +125,22 @@ class Block:
         self.out = None           # Feat (activated), set by the net
         self.pool = None          # pooled Feat
         self.out_f32 = None       # fp32 [N][C] (encoder output)
-        if role == 'mfma':
+        if role == 'out':
+            # fp32 frames out: (N, C, 64, 64), the layout of reference module/srvp.py:226
+            self.x_out = torch.empty(N, self.cout_r, self.OH, self.OW, dtype=torch.float32, device=device)
+        if role in ('mfma', 'out'):
             self._alloc_weights()
         if training and role != 'in':
             # gradient wrt the (virtual, concatenated) input of this block: [N][Hin][Win][ctot] bf16, unpadded
             self.dcat = torch.empty(N, self.Hin, self.Win, self.ctot, dtype=torch.bfloat16, device=device)
-        if training and role != 'out':
+        if training:
             self.draw_b = 0 if (role == 'mfma' and self.geom in ('full', 'expand')) else 1
             bd = self.draw_b
             self.draw = torch.zeros(N, self.OH + 2 * bd, self.OW + 2 * bd, self.cout, dtype=torch.bfloat16, device=device)
+        if training and role != 'out':
             self.red = torch.zeros(2, self.cout, dtype=torch.float64, device=device)
             self.bcoef = torch.zeros(3, self.cout, dtype=torch.float32, device=device)
-        if training and role == 'mfma':
+        if training and role in ('mfma', 'out'):
             ntaps = self.k * self.k
             self.dw = torch.zeros(ntaps, self.cout, self.ctot, dtype=torch.float32, device=device)
 
@@ -195,16 +201,30 @@ class Block:
         out = []
         use_stats = self.has_bn and self.training
         b_in = self.srcs[0].b
-        if self.geom in ('same', 'down', 'full'):
+        frame_out = self.role == 'out'
+        dst_ptr = None if frame_out else L.ptr(self.raw)
+
+        def finish(d):
+            if frame_out:
+                d.out_f32, d.out_nc, d.out_sigmoid = L.ptr(self.x_out), self.cout_r, 1
+            else:
+                d.out_f32, d.out_nc, d.out_sigmoid = None, 0, 0
+            out.append(d)
+        if self.geom in ('same', 'down', 'full', 'sameT'):
             d = L.ConvDesc()
             self._src_fields(d)
-            off = b_in - self.p
-            self._set_taps(d, [(kh + off, kw + off) for kh in range(k) for kw in range(k)])
+            if self.geom == 'sameT':
+                # out[o] = sum_kh in[o + p - kh] W[ci][co][kh]  -> padded input coordinate o + p - kh + b
+                taps = [(self.p - kh + b_in, self.p - kw + b_in) for kh in range(k) for kw in range(k)]
+            else:
+                off = b_in - self.p
+                taps = [(kh + off, kw + off) for kh in range(k) for kw in range(k)]
+            self._set_taps(d, taps)
             d.si, d.wt, d.Cout = self.s, L.ptr(self.wt_f), self.cout
             d.N, d.OH, d.OW = N, self.OH, self.OW
-            d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox, d.Cdst, d.cdst_off = L.ptr(self.raw), self.OH, self.OW, 1, 0, 0, self.cout, 0
+            d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox, d.Cdst, d.cdst_off = dst_ptr, self.OH, self.OW, 1, 0, 0, self.cout, 0
             d.stats, d.stat_mod = (L.ptr(self.stats) if use_stats else None), self.cout
-            out.append(d)
+            finish(d)
         elif self.geom == 'up':
             assert b_in == 1
             for ph, (py, px) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
@@ -214,9 +234,9 @@ class Block:
                 d.si, d.Cout = 1, self.cout
                 d.wt = L.ptr(self.wt_f) + ph * 4 * self.cout * self.ctot * 2
                 d.N, d.OH, d.OW = N, self.Hin, self.Win
-                d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox, d.Cdst, d.cdst_off = L.ptr(self.raw), self.OH, self.OW, 2, py, px, self.cout, 0
+                d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox, d.Cdst, d.cdst_off = dst_ptr, self.OH, self.OW, 2, py, px, self.cout, 0
                 d.stats, d.stat_mod = (L.ptr(self.stats) if use_stats else None), self.cout
-                out.append(d)
+                finish(d)
         elif self.geom == 'expand':
             d = L.ConvDesc()
             self._src_fields(d)
@@ -225,7 +245,7 @@ class Block:
             d.N, d.OH, d.OW = N, 1, 1
             d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox, d.Cdst, d.cdst_off = L.ptr(self.raw), 1, 1, 1, 0, 0, k * k * self.cout, 0
             d.stats, d.stat_mod = (L.ptr(self.stats) if use_stats else None), self.cout
-            out.append(d)
+            finish(d)
         return out
 
     def dgrad_descs(self):
@@ -246,6 +266,14 @@ class Block:
             d = base()
             # dIn[i] = sum_kh dOut[i + p - kh]  -> padded coordinate i + p - kh + bd
             self._set_taps(d, [(self.p - kh + bd, self.p - kw + bd) for kh in range(k) for kw in range(k)])
+            d.si, d.wt = 1, L.ptr(self.wt_d)
+            d.N, d.OH, d.OW = N, self.Hin, self.Win
+            d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox = L.ptr(self.dcat), self.Hin, self.Win, 1, 0, 0
+            out.append(d)
+        elif self.geom == 'sameT':
+            d = base()
+            # dIn[i] = sum_kh dOut[i - p + kh] W[ci][co][kh]  -> padded coordinate i - p + kh + bd
+            self._set_taps(d, [(kh - self.p + bd, kw - self.p + bd) for kh in range(k) for kw in range(k)])
             d.si, d.wt = 1, L.ptr(self.wt_d)
             d.N, d.OH, d.OW = N, self.Hin, self.Win
             d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox = L.ptr(self.dcat), self.Hin, self.Win, 1, 0, 0
@@ -298,6 +326,11 @@ class Block:
             off = b_in - self.p
             d.dy, d.dx = L.taps([kh + off for kh, _ in nat]), L.taps([kw + off for _, kw in nat])
             d.si, d.so = self.s, 1
+            d.ooy, d.oox = L.taps([bd] * (k * k)), L.taps([bd] * (k * k))
+            d.N, d.OH, d.OW = N, self.OH, self.OW
+        elif self.geom == 'sameT':
+            d.dy, d.dx = L.taps([self.p - kh + b_in for kh, _ in nat]), L.taps([self.p - kw + b_in for _, kw in nat])
+            d.si, d.so = 1, 1
             d.ooy, d.oox = L.taps([bd] * (k * k)), L.taps([bd] * (k * k))
             d.N, d.OH, d.OW = N, self.OH, self.OW
         elif self.geom == 'up':
@@ -399,7 +432,7 @@ class ConvNetBase:
 
     def pack_weights(self, params, st):
         for blk in self.blocks:
-            if blk.role == 'mfma':
+            if blk.role in ('mfma', 'out'):
                 blk.pack(params[blk.spec['key'] + '.weight'], st)
 
 
@@ -485,41 +518,29 @@ class DecoderNet(ConvNetBase):
                 cur, ups = blk.out, sp['post_up']
             self.blocks.append(blk)
         for blk in self.blocks:
-            if blk.role == 'mfma':
-                blk._fwd = blk.fwd_descs()
-                if training:
-                    blk._dg = blk.dgrad_descs()
-                    blk._wg = blk.wgrad_desc()
+            blk._fwd = blk.fwd_descs()
+            if training:
+                blk._dg = blk.dgrad_descs()
+                blk._wg = blk.wgrad_desc()
         ob = self.blocks[-1]
         self.nc = ob.cout_r
-        d = L.ConvOutDesc()
-        f0 = ob.srcs[0]
-        assert not ob.ups
-        d.src0, d.C0, d.C0_real = L.ptr(f0.t), f0.C, f0.Cr
-        if len(ob.srcs) > 1:
-            f1 = ob.srcs[1]
-            d.src1, d.C1, d.C1_real, d.map1 = L.ptr(f1.t), f1.C, f1.Cr, L.ptr(skip_map)
-        else:
-            d.src1, d.C1, d.C1_real, d.map1 = None, 0, 0, None
-        d.N, d.H, d.W, d.Cout, d.k, d.s, d.p, d.apply_sigmoid = N, f0.H, f0.W, ob.cout_r, ob.k, ob.s, ob.p, 1
-        self.out_desc = d
-        self.x_out = torch.empty(N, ob.cout_r, ob.OH, ob.OW, dtype=torch.float32, device=device)
+        self.x_out = ob.x_out
 
     def forward(self, z_f32, params, st, sync=None):
         """z_f32: fp32 [N][nz_real]"""
         L.call('srvp_cast_f32_bf16', L.ptr(z_f32), L.ptr(self.z.t), self.N, z_f32.shape[1], self.z.C, st)
         for blk in self.blocks[:-1]:
             self._block_forward(blk, params, st, sync)
-        ob = self.blocks[-1]
-        L.call('srvp_convT_out_fwd', C.byref(self.out_desc), L.ptr(params[ob.spec['key'] + '.weight']), L.ptr(self.x_out), st)
+        # image-side output layer: MFMA conv with Cout padded to 32, sigmoid + fp32 frame store in the epilogue
+        for d in self.blocks[-1]._fwd:
+            L.call('srvp_conv_mfma', C.byref(d), st)
         return self.x_out
 
     def backward(self, d_x, params, grads, st, sync=None):
         """d_x: fp32 (N, C, 64, 64).  Returns dz bf16 [N][nz_padded]; skip gradients are left in the blocks' dcat."""
         ob = self.blocks[-1]
-        wkey = ob.spec['key'] + '.weight'
-        L.call('srvp_convT_out_bwd', C.byref(self.out_desc), L.ptr(params[wkey]), L.ptr(self.x_out), L.ptr(d_x),
-               L.ptr(ob.dcat), L.ptr(grads[wkey]), st)
+        L.call('srvp_out_dpre', L.ptr(self.x_out), L.ptr(d_x), L.ptr(ob.draw), self.N, ob.cout_r, ob.OH, ob.OW, ob.cout, 1, st)
+        self._mfma_backward(ob, grads, st)
         nxt = ob
         for i in range(len(self.blocks) - 2, -1, -1):
             blk = self.blocks[i]

@@ -77,6 +77,14 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// XCD-aware workgroup remap (MI355X: 8 XCDs, each with a private 4 MiB L2; workgroup b is dispatched to XCD b % 8).
+// Returns a logical index such that every XCD owns one CONTIGUOUS range of logical indices, so workgroups that share
+// operand panels (neighbouring logical indices) hit the same L2.  Bijective for any grid size.  Speed only.
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk) {
+    const unsigned q = nblk >> 3, r = nblk & 7u, x = b & 7u, i = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
 // ---- error reporting across the C ABI (no exceptions cross it) ----
 void srvp_set_error(const char* fmt, ...);
 #define SRVP_CHECK_LAUNCH(name)                                                         \

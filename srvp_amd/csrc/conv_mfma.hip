@@ -4,9 +4,9 @@
 //
 // One workgroup computes a BM x BN output tile; the K loop walks (tap, BK-channel chunk).  A rows are gathered
 // straight from the NHWC bf16 activation tensor(s) (16-byte = 8-channel pieces, zero border physically present in
-// memory so no bounds predicates), B rows from the tap-major packed weights.  Both tiles are register-staged into
-// padded LDS rows (conflict-free ds_read_b128 fragment reads), double-buffered with the global loads of step s+1
-// issued before the MFMAs of step s (one barrier per K step).  The fp32 accumulators feed (a) fp64-atomic
+// memory so no bounds predicates), B rows from the tap-major packed weights.  Both tiles go global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR staging, no ds_write pass) into XOR-swizzled rows (conflict-free ds_read_b128
+// fragment reads), double-buffered with the DMA of step s+1 issued before the MFMAs of step s (one barrier per K step).  The fp32 accumulators feed (a) fp64-atomic
 // per-channel sum / sum-of-squares for BatchNorm batch statistics and (b) a bf16 LDS-staged, 16-byte-wide store.
 //
 // Replaces: nn.Conv2d / nn.ConvTranspose2d forward + data-gradient (reference module/conv.py:174-179, 200-223,
@@ -18,7 +18,7 @@ namespace {
 
 struct RowInfo { int n, oy, ox; };
 
-// Compact kernel-argument block (no arrays: tap offsets are packed 2 bits each so nothing is dynamically indexed
+// Compact kernel-argument block (no arrays: tap offsets are packed 4 bits each so nothing is dynamically indexed
 // in private memory).
 struct ConvK {
     const bf16_t* src0; const bf16_t* src1; const int* map1;
@@ -27,24 +27,29 @@ struct ConvK {
     const bf16_t* wt; int Cout, N, OH, OW;
     bf16_t* dst; int DHp, DWp, so, ooy, oox, Cdst, cdst_off;
     double* stats; int stat_mod;
+    float* out_f32; int out_nc, out_sigmoid;
 };
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int BM, int BN, int BK, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) {
     constexpr int NT = WM * WN * 64;
     constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
-    constexpr int LDR = BK + 8;                 // padded LDS row (elements): (row*LDR*2/16) % 16 is a bijection
+    constexpr int RPB = 16 / CPR;               // tile rows per 256-byte LDS bank row
     constexpr int A_LD = (BM * CPR + NT - 1) / NT;
     constexpr int B_LD = (BN * CPR + NT - 1) / NT;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDC = BN + 8;
-    static_assert((BM * CPR) % NT == 0, "A tile must divide evenly over the workgroup");
-    constexpr int AB_BYTES = 2 * (BM + BN) * LDR * 2;
+    static_assert((BM * CPR) % NT == 0 && (BN * CPR) % 64 == 0, "tiles must split into whole-wave 1 KiB LDS-DMA pieces");
+    constexpr int AB_BYTES = 2 * (BM + BN) * BK * 2;
     constexpr int C_BYTES = BM * LDC * 2;
     constexpr int SMEM = AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM + WM * BN * 8];
-    bf16_t* As = reinterpret_cast<bf16_t*>(smem);                         // [2][BM][LDR]
-    bf16_t* Bs = As + 2 * BM * LDR;                                       // [2][BN][LDR]
+    // ONE shared object (a second one makes hipcc drain the LDS-DMA queue before every ds_read)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM + WM * BN * 8];
+    bf16_t* As = reinterpret_cast<bf16_t*>(smem);                         // [2][BM][BK]  (XOR-swizzled 16-B chunks)
+    bf16_t* Bs = As + 2 * BM * BK;                                        // [2][BN][BK]
     float* red = reinterpret_cast<float*>(smem + SMEM);                   // [WM][BN][2]
 
     const int tid = threadIdx.x;
@@ -52,66 +57,65 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
     const int wm = wid / WN, wn = wid % WN;
     const int Ctot = a.C0 + a.C1;
     const long long M = (long long)a.N * a.OH * a.OW;
-    // blockIdx.x -> (m tile, n tile): n fastest so that neighbouring workgroups share the same A rows in L2
+    // logical workgroup index -> (m tile, n tile): n fastest and XCD-contiguous, so the Cout/BN workgroups that gather
+    // the same A rows (and their spatial neighbours, which share the 3x3 halo) run on the same XCD / L2
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
     const int n_tiles = a.Cout / BN;
-    const long long m0 = (long long)(blockIdx.x / n_tiles) * BM;
-    const int n0 = (blockIdx.x % n_tiles) * BN;
+    const long long m0 = (long long)(lb / n_tiles) * BM;
+    const int n0 = (lb % n_tiles) * BN;
 
-    // ---- per-thread gather rows (fixed over the K loop) ----
+    // ---- per-thread gather rows (fixed over the K loop).  Tiles go global -> LDS by LDS-DMA (global_load_lds,
+    // 16 B per lane, 1 KiB per wave instruction, destination lane-linear), so the bank-conflict swizzle is applied to
+    // the SOURCE chunk index: LDS position (row, p) holds data chunk p ^ f(row), f(row) = (row / RPB) % CPR.
     RowInfo ri[A_LD];
-    int a_ch[A_LD];
+    int a_ch[A_LD], n1[A_LD];
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
         int q = tid + i * NT;
         int row = q / CPR;
-        a_ch[i] = q % CPR;
+        a_ch[i] = (q % CPR) ^ ((row / RPB) % CPR);
         long long m = m0 + row;
         if (m >= M) m = M - 1;                       // clamp: duplicates are masked at the store
         int hw = a.OH * a.OW;
         int n = (int)(m / hw);
         int r = (int)(m - (long long)n * hw);
         ri[i].n = n; ri[i].oy = r / a.OW; ri[i].ox = r - (r / a.OW) * a.OW;
+        // image index inside the second source (skip connection), resolved ONCE: an ordinary VGPR load inside the K
+        // loop would make hipcc drain the whole LDS-DMA queue (s_waitcnt vmcnt(0)) at every use
+        n1[i] = (a.C1 > 0 && a.map1) ? a.map1[n] : n;
     }
-    const int kpt = Ctot / BK;                       // K steps per tap
+    // K order: channel chunk OUTER, tap INNER -- consecutive K steps re-read the same channel chunk at the 9 (16)
+    // shifted pixel positions, i.e. mostly the same cache lines (reuse distance BM*BK*2 B = 16 KiB per workgroup),
+    // instead of coming back to a pixel one whole tap (BM*Ctot*2 B) later (30 % L2 misses measured, profiles/).
+    const int kpt = Ctot / BK;                       // channel chunks
     const int S = a.ntaps * kpt;
 
-    u32x4_t ra[A_LD], rb[B_LD];
-    auto load_step = [&](int s) {
-        int t = s / kpt;
-        int c = (s - t * kpt) * BK;
+    auto stage = [&](int s, int buf) {
+        const int cc = s / a.ntaps;
+        const int t = s - cc * a.ntaps;
+        int c = cc * BK;
         const bf16_t* src; int C, Hp, Wp, ups; bool second = c >= a.C0;
-        if (!second) { src = a.src0; C = a.C0; Hp = a.H0p; Wp = a.W0p; ups = a.ups0; }
-        else { src = a.src1; C = a.C1; Hp = a.H1p; Wp = a.W1p; ups = a.ups1; c -= a.C0; }
+        if (!second) { src = a.src0; C = a.C0; Hp = a.H0p; Wp = a.W0p; ups = a.ups0 ? 1 : 0; }
+        else { src = a.src1; C = a.C1; Hp = a.H1p; Wp = a.W1p; ups = a.ups1 ? 1 : 0; c -= a.C0; }
         const int dy = (int)((a.dy_bits >> (4 * t)) & 15), dx = (int)((a.dx_bits >> (4 * t)) & 15);
+        bf16_t* Ad = As + (size_t)buf * BM * BK + (size_t)wid * 64 * 8;       // wave-uniform LDS base of this wave's piece
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             int vy = ri[i].oy * a.si + dy, vx = ri[i].ox * a.si + dx;
-            if (ups) { vy = (vy + 1) >> 1; vx = (vx + 1) >> 1; }
-            int n = ri[i].n;
-            if (second && a.map1) n = a.map1[n];
-            size_t off = (((size_t)n * Hp + vy) * Wp + vx) * C + c + a_ch[i] * 8;
-            ra[i] = *reinterpret_cast<const u32x4_t*>(src + off);
+            vy = (vy + ups) >> ups; vx = (vx + ups) >> ups;                   // nearest x2 upsample: (u + 1) >> 1
+            const int n = second ? n1[i] : ri[i].n;
+            // 32-bit element offsets (the launcher checks the tensors have fewer than 2^32 elements)
+            unsigned off = (((unsigned)n * Hp + vy) * Wp + vx) * C + c + a_ch[i] * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + off), (lptr_t)(Ad + (size_t)i * NT * 8), 16, 0, 0);
         }
-        const bf16_t* w = a.wt + ((size_t)t * a.Cout + n0) * Ctot + (s - t * kpt) * BK;
+        const bf16_t* w = a.wt + ((size_t)t * a.Cout + n0) * Ctot + cc * BK;
+        bf16_t* Bd = Bs + (size_t)buf * BN * BK + (size_t)wid * 64 * 8;
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
             int q = tid + i * NT;
-            int row = q / CPR, ch = q % CPR;
-            if (q < BN * CPR) rb[i] = *reinterpret_cast<const u32x4_t*>(w + (size_t)row * Ctot + ch * 8);
-        }
-    };
-    auto store_step = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            int q = tid + i * NT;
-            int row = q / CPR, ch = q % CPR;
-            *reinterpret_cast<u32x4_t*>(As + ((size_t)buf * BM + row) * LDR + ch * 8) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            int q = tid + i * NT;
-            int row = q / CPR, ch = q % CPR;
-            if (q < BN * CPR) *reinterpret_cast<u32x4_t*>(Bs + ((size_t)buf * BN + row) * LDR + ch * 8) = rb[i];
+            int row = q / CPR, ch = (q % CPR) ^ ((row / RPB) % CPR);
+            if ((wid * 64 + i * NT) < BN * CPR)                               // wave-uniform predicate
+                __builtin_amdgcn_global_load_lds((gptr_t)(w + (size_t)row * Ctot + ch * 8), (lptr_t)(Bd + (size_t)i * NT * 8), 16, 0, 0);
         }
     };
 
@@ -123,30 +127,35 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_step(0);
-    store_step(0);
+    stage(0, 0);
     __syncthreads();
-    const int lrow = lane & 31, lk = (lane >> 5) * 8;
+    const int lrow = lane & 31, lkc = lane >> 5;
+    // fragment rows of this lane and their swizzle terms
+    int a_off[TM], a_sw[TM], b_off[TN], b_sw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { int r = wm * (TM * 32) + i * 32 + lrow; a_off[i] = r * BK; a_sw[i] = (r / RPB) % CPR; }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { int r = wn * (TN * 32) + j * 32 + lrow; b_off[j] = r * BK; b_sw[j] = (r / RPB) % CPR; }
     for (int s = 0; s < S; ++s) {
         const int buf = s & 1;
-        if (s + 1 < S) load_step(s + 1);
-        const bf16_t* Ab = As + ((size_t)buf * BM + wm * (TM * 32) + lrow) * LDR + lk;
-        const bf16_t* Bb = Bs + ((size_t)buf * BN + wn * (TN * 32) + lrow) * LDR + lk;
+        if (s + 1 < S) stage(s + 1, buf ^ 1);
+        const bf16_t* Ab = As + (size_t)buf * BM * BK;
+        const bf16_t* Bb = Bs + (size_t)buf * BN * BK;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             bf16x8_t af[TM], bfr[TN];
+            const int kc = kk * 2 + lkc;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + i * 32 * LDR + kk * 16);
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + a_off[i] + ((kc ^ a_sw[i]) * 8));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bb + j * 32 * LDR + kk * 16);
+            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bb + b_off[j] + ((kc ^ b_sw[j]) * 8));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (s + 1 < S) store_step(buf ^ 1);
-        __syncthreads();
+        __syncthreads();                             // also drains this step's LDS-DMA (vmcnt(0)) before the next reads
     }
 
     // ---------------- epilogue ----------------
@@ -172,6 +181,27 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
                 red[(wm * BN + col) * 2 + 1] = s2;
             }
         }
+    }
+    if (a.out_f32) {
+        // image-side output layer: the first out_nc columns are the frame channels; sigmoid (reference
+        // conv.py:273-274) and a store into the fp32 (N, C, H, W) frame tensor of module/srvp.py:226.
+        if (lcol < a.out_nc && wn == 0) {
+            const int hw = a.OH * a.OW;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    long long m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                    if (m >= M) continue;
+                    int n = (int)(m / hw);
+                    int rr = (int)(m - (long long)n * hw);
+                    int oy = rr / a.OW, ox = rr - oy * a.OW;
+                    float v = acc[i][0][r];
+                    if (a.out_sigmoid) v = 1.f / (1.f + __expf(-v));
+                    a.out_f32[(((size_t)n * a.out_nc + lcol) * a.DHp + oy * a.so + a.ooy) * a.DWp + ox * a.so + a.oox] = v;
+                }
+        }
+        return;
     }
     bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);     // [BM][LDC], reuses the A/B buffers (all waves are past the loop)
 #pragma unroll
@@ -227,6 +257,7 @@ int launch(const srvp_conv_desc* d, hipStream_t st) {
     k.wt = (const bf16_t*)d->wt; k.Cout = d->Cout; k.N = d->N; k.OH = d->OH; k.OW = d->OW;
     k.dst = (bf16_t*)d->dst; k.DHp = d->DHp; k.DWp = d->DWp; k.so = d->so; k.ooy = d->ooy; k.oox = d->oox;
     k.Cdst = d->Cdst; k.cdst_off = d->cdst_off; k.stats = d->stats; k.stat_mod = d->stat_mod;
+    k.out_f32 = d->out_f32; k.out_nc = d->out_nc; k.out_sigmoid = d->out_sigmoid;
     hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM, WN>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, st, k);
     SRVP_CHECK_LAUNCH("srvp_conv_mfma");
     return SRVP_OK;
@@ -236,13 +267,16 @@ int launch(const srvp_conv_desc* d, hipStream_t st) {
 
 extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    SRVP_REQUIRE(d && d->src0 && d->wt && d->dst, "srvp_conv_mfma: null pointer");
+    SRVP_REQUIRE(d && d->src0 && d->wt && (d->dst || d->out_f32), "srvp_conv_mfma: null pointer");
+    SRVP_REQUIRE(!d->out_f32 || (d->Cout == 32 && d->out_nc >= 1 && d->out_nc <= 32), "srvp_conv_mfma: fp32 frame output needs Cout == 32");
     SRVP_REQUIRE(d->C0 % 32 == 0 && d->C1 % 32 == 0 && d->Cout % 32 == 0 && d->C0 > 0,
                  "srvp_conv_mfma: channel counts must be padded to 32 (C0=%d C1=%d Cout=%d)", d->C0, d->C1, d->Cout);
     SRVP_REQUIRE(d->C1 == 0 || d->src1, "srvp_conv_mfma: C1>0 needs src1");
     SRVP_REQUIRE(d->ntaps >= 1 && d->ntaps <= SRVP_MAX_TAPS, "srvp_conv_mfma: ntaps=%d", d->ntaps);
     SRVP_REQUIRE(d->Cdst % 8 == 0 && d->cdst_off % 8 == 0, "srvp_conv_mfma: dst channel slice must be 16-byte aligned");
     SRVP_REQUIRE(d->stats == nullptr || d->stat_mod > 0, "srvp_conv_mfma: stat_mod");
+    SRVP_REQUIRE((long long)d->N * d->H0p * d->W0p * d->C0 < (1ll << 32) && (d->C1 == 0 || d->map1 || (long long)d->N * d->H1p * d->W1p * d->C1 < (1ll << 32)),
+                 "srvp_conv_mfma: source tensors must have fewer than 2^32 elements");
     const bool k64 = (d->C0 % 64 == 0) && (d->C1 % 64 == 0);
     if (d->Cout % 128 == 0) {
         return k64 ? launch<128, 128, 64, 2, 2>(d, st) : launch<128, 128, 32, 2, 2>(d, st);

@@ -11,7 +11,7 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------
-// C[M][N] (+)= epi( A[M][K] * B[K][N] + bias ),  generic element strides.  64x64 tile, 256 threads, 4x4 micro-tile.
+// C[M][N] (+)= epi( A[M][K] * B[K][N] + bias ),  generic element strides.
 // epi: activation, then optional multiply by (mask > 0) (ReLU derivative taken from the saved post-ReLU activation).
 // ---------------------------------------------------------------------------------------------------------
 struct GemmArgs {
@@ -23,63 +23,56 @@ struct GemmArgs {
     float alpha;
 };
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
-    constexpr int BK = 16;
-    constexpr int TM = BM / 16, TN = BN / 16;
-    __shared__ float As[BK][BM + 4];
-    __shared__ float Bs[BK][BN + 4];
-    const int tid = threadIdx.x;
-    const int tx = tid % 16, ty = tid / 16;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    float acc[TM][TN];
+// Exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: bitwise a k-ordered fmaf chain).  One workgroup = one 32x32 tile of C;
+// its 4 waves split K and are summed through LDS (the latent GEMMs are small and launch/latency bound, so the
+// lever is parallelism over K and over 32x32 tiles, not tile size).  Operands are read straight into MFMA fragments
+// with generic element strides: lane l feeds A[m0 + (l&31)][k + (l>>5)] and B[k + (l>>5)][n0 + (l&31)].
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
+    __shared__ float red[3][32][33];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int r = lane & 31, kh = lane >> 5;
+    const bool mv = (m0 + r) < g.M, nv = (n0 + r) < g.N;
+    const float* Ap = g.A + (long long)(mv ? m0 + r : 0) * g.a_rs;
+    const float* Bp = g.B + (long long)(nv ? n0 + r : 0) * g.b_cs;
+    const int kper = (((g.K + 3) / 4) + 1) & ~1;
+    const int kb = wid * kper;
+    int ke = kb + kper; if (ke > g.K) ke = g.K;
+    f32x16_t acc;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    constexpr int U = 8;
+    for (int k = kb; k < ke; k += 2 * U) {
+        float a[U], b[U];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = 0.f;
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
-        for (int q = tid; q < BM * BK; q += 256) {
-            int kk, mm;
-            if (g.a_cs == 1) { kk = q % BK; mm = q / BK; } else { mm = q % BM; kk = q / BM; }
-            int m = m0 + mm, k = k0 + kk;
-            As[kk][mm] = (m < g.M && k < g.K) ? g.A[m * g.a_rs + k * g.a_cs] : 0.f;
+        for (int u = 0; u < U; ++u) {
+            int kk = k + 2 * u + kh;
+            bool kv = kk < ke;
+            a[u] = (kv && mv) ? Ap[(long long)kk * g.a_cs] : 0.f;
+            b[u] = (kv && nv) ? Bp[(long long)kk * g.b_rs] : 0.f;
         }
-        for (int q = tid; q < BN * BK; q += 256) {
-            int kk, nn;
-            if (g.b_rs == 1) { kk = q % BK; nn = q / BK; } else { nn = q % BN; kk = q / BN; }
-            int n = n0 + nn, k = k0 + kk;
-            Bs[kk][nn] = (n < g.N && k < g.K) ? g.B[k * g.b_rs + n * g.b_cs] : 0.f;
-        }
-        __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < BK; ++kk) {
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[kk][ty + 16 * i];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[kk][tx + 16 * j];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] += a[i] * b[j];
-        }
-        __syncthreads();
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
     }
+    // C/D layout: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+    if (wid > 0) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        int m = m0 + ty + 16 * i;
-        if (m >= g.M) continue;
+        for (int i = 0; i < 16; ++i) red[wid - 1][(i & 3) + 8 * (i >> 2) + 4 * kh][r] = acc[i];
+    }
+    __syncthreads();
+    if (wid > 0) return;
+    const int n = n0 + r;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            int n = n0 + tx + 16 * j;
-            if (n >= g.N) continue;
-            float v = acc[i][j] * g.alpha;
-            if (g.bias) v += g.bias[n];
-            v = act_fwd(v, g.act);
-            if (g.mask) v = g.mask[m * g.mask_rs + n] > 0.f ? v : 0.f;
-            float* c = g.C + m * g.c_rs + n;
-            *c = g.accumulate ? *c + v : v;
-        }
+    for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * kh;
+        const int m = m0 + row;
+        if (m >= g.M || n >= g.N) continue;
+        float v = (acc[i] + red[0][row][r] + red[1][row][r] + red[2][row][r]) * g.alpha;
+        if (g.bias) v += g.bias[n];
+        v = act_fwd(v, g.act);
+        if (g.mask) v = g.mask[(long long)m * g.mask_rs + n] > 0.f ? v : 0.f;
+        float* c = g.C + (long long)m * g.c_rs + n;
+        *c = g.accumulate ? *c + v : v;
     }
 }
 
@@ -88,13 +81,8 @@ int gemm(hipStream_t st, const float* A, long long a_rs, long long a_cs, const f
          const float* mask = nullptr, long long mask_rs = 0, float alpha = 1.f) {
     if (M <= 0 || N <= 0) return SRVP_OK;
     GemmArgs g{A, a_rs, a_cs, B, b_rs, b_cs, bias, C, c_rs, mask, mask_rs, M, N, K, act, accumulate, alpha};
-    if ((long long)M * N <= 64 * 1024) {
-        dim3 grid((N + 31) / 32, (M + 31) / 32);
-        hipLaunchKernelGGL((gemm_f32_kernel<32, 32>), grid, dim3(256), 0, st, g);
-    } else {
-        dim3 grid((N + 63) / 64, (M + 63) / 64);
-        hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), grid, dim3(256), 0, st, g);
-    }
+    dim3 grid((N + 31) / 32, (M + 31) / 32);
+    hipLaunchKernelGGL(gemm_f32_mfma_kernel, grid, dim3(256), 0, st, g);
     SRVP_CHECK_LAUNCH("srvp_gemm_f32");
     return SRVP_OK;
 }

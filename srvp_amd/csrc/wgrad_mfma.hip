@@ -21,6 +21,7 @@ struct WgradK {
     const bf16_t* dout; int DHp, DWp, so, Cout;
     int N, OH, OW;
     float* dw; int splitk;
+    int lg_hw, lg_ow;          // log2 of OH*OW and OW when both are powers of two, else -1
 };
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -32,7 +33,7 @@ __device__ __forceinline__ s16x4_t lds_tr_read(const bf16_t* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)p);
 }
 
-template <int BJ, int BC, int WJ, int WC, bool USE_TR>
+template <int BJ, int BC, int WJ, int WC, bool USE_TR, bool POW2>
 __global__ __launch_bounds__(WJ * WC * 64) void wgrad_mfma_kernel(const WgradK a) {
     constexpr int NT = WJ * WC * 64;
     constexpr int BP = 32;                       // pixels per K step
@@ -48,10 +49,12 @@ __global__ __launch_bounds__(WJ * WC * 64) void wgrad_mfma_kernel(const WgradK a
     const int wj = wid / WC, wc = wid % WC;
     const int Ctot = a.C0 + a.C1;
     const int tj_n = a.Cout / BJ, tc_n = Ctot / BC;
-    int b = blockIdx.x;
+    // logical index: tap fastest, XCD-contiguous -- the ntaps workgroups of one (tile, K range) read the same gradient
+    // tile and overlapping (shifted) input tiles, so they should run back to back on ONE XCD / L2
+    int b = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int t = b % a.ntaps; b /= a.ntaps;
     const int tc = b % tc_n; b /= tc_n;
     const int tj = b % tj_n; b /= tj_n;
-    const int t = b % a.ntaps; b /= a.ntaps;
     const int split = b;
     const int j0 = tj * BJ, c0 = tc * BC;
     const long long M = (long long)a.N * a.OH * a.OW;
@@ -65,43 +68,55 @@ __global__ __launch_bounds__(WJ * WC * 64) void wgrad_mfma_kernel(const WgradK a
     const bool second = c0 >= a.C0;
     const bf16_t* src = second ? a.src1 : a.src0;
     const int C = second ? a.C1 : a.C0, Hp = second ? a.H1p : a.H0p, Wp = second ? a.W1p : a.W0p;
-    const int ups = second ? a.ups1 : a.ups0;
+    const int ups = (second ? a.ups1 : a.ups0) ? 1 : 0;
     const int cs = second ? c0 - a.C0 : c0;
     const int dy = (int)((a.dy_bits >> (4 * t)) & 15), dx = (int)((a.dx_bits >> (4 * t)) & 15);
     const int ooy = (int)((a.ooy_bits >> (4 * t)) & 15), oox = (int)((a.oox_bits >> (4 * t)) & 15);
     const int hw = a.OH * a.OW;
 
     u32x4_t rx[X_LD], ry[Y_LD];
+    // pixel index -> (image, row, column): shifts when the grid dims are powers of two (always, for 64x64 models)
+    auto decode = [&](int m, int& n, int& oy, int& ox) {
+        if constexpr (POW2) {
+            n = m >> a.lg_hw; int r = m & (hw - 1);
+            oy = r >> a.lg_ow; ox = r & (a.OW - 1);
+        } else {
+            n = m / hw; int r = m - n * hw;
+            oy = r / a.OW; ox = r - oy * a.OW;
+        }
+    };
+    // Loads are unconditional (clamped pixel index, 32-bit element offsets: the launcher checks that the tensors have
+    // fewer than 2^32 elements); rows past the end contribute nothing because their gradient row is zeroed by a select.
+    const int Mi = (int)M;
     auto load_step = [&](long long chunk) {
 #pragma unroll
         for (int i = 0; i < X_LD; ++i) {
             int q = tid + i * NT;
             int row = q / XCH, ch = q % XCH;
-            long long m = chunk * BP + row;
+            int m = (int)chunk * BP + row;
+            const bool valid = m < Mi;
+            int n, oy, ox;
+            decode(valid ? m : Mi - 1, n, oy, ox);
+            unsigned off = (((unsigned)n * a.DHp + oy * a.so + ooy) * a.DWp + ox * a.so + oox) * a.Cout + j0 + ch * 8;
             u32x4_t v = {0u, 0u, 0u, 0u};
-            if (q < BP * XCH && m < M) {
-                int n = (int)(m / hw); int r = (int)(m - (long long)n * hw);
-                int oy = r / a.OW, ox = r - oy * a.OW;
-                size_t off = (((size_t)n * a.DHp + oy * a.so + ooy) * a.DWp + ox * a.so + oox) * a.Cout + j0 + ch * 8;
-                v = *reinterpret_cast<const u32x4_t*>(a.dout + off);
-            }
+            if (q < BP * XCH) v = *reinterpret_cast<const u32x4_t*>(a.dout + off);
+            const unsigned keep = valid ? 0xffffffffu : 0u;
+            v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
             rx[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < Y_LD; ++i) {
             int q = tid + i * NT;
             int row = q / YCH, ch = q % YCH;
-            long long m = chunk * BP + row;
+            int m = (int)chunk * BP + row;
+            int n, oy, ox;
+            decode(m < Mi ? m : Mi - 1, n, oy, ox);
+            int vy = oy * a.si + dy, vx = ox * a.si + dx;
+            vy = (vy + ups) >> ups; vx = (vx + ups) >> ups;
+            if (second && a.map1) n = a.map1[n];
+            unsigned off = (((unsigned)n * Hp + vy) * Wp + vx) * C + cs + ch * 8;
             u32x4_t v = {0u, 0u, 0u, 0u};
-            if (q < BP * YCH && m < M) {
-                int n = (int)(m / hw); int r = (int)(m - (long long)n * hw);
-                int oy = r / a.OW, ox = r - oy * a.OW;
-                int vy = oy * a.si + dy, vx = ox * a.si + dx;
-                if (ups) { vy = (vy + 1) >> 1; vx = (vx + 1) >> 1; }
-                if (second && a.map1) n = a.map1[n];
-                size_t off = (((size_t)n * Hp + vy) * Wp + vx) * C + cs + ch * 8;
-                v = *reinterpret_cast<const u32x4_t*>(src + off);
-            }
+            if (q < BP * YCH) v = *reinterpret_cast<const u32x4_t*>(src + off);
             ry[i] = v;
         }
     };
@@ -202,10 +217,11 @@ template <int BJ, int BC, int WJ, int WC>
 int launch(const WgradK& k, hipStream_t st, bool use_tr) {
     long long blocks = (long long)(k.Cout / BJ) * ((k.C0 + k.C1) / BC) * k.ntaps * k.splitk;
     SRVP_REQUIRE(blocks > 0 && blocks < (1ll << 31), "srvp_wgrad_mfma: bad grid");
-    if (use_tr)
-        hipLaunchKernelGGL((wgrad_mfma_kernel<BJ, BC, WJ, WC, true>), dim3((unsigned)blocks), dim3(WJ * WC * 64), 0, st, k);
-    else
-        hipLaunchKernelGGL((wgrad_mfma_kernel<BJ, BC, WJ, WC, false>), dim3((unsigned)blocks), dim3(WJ * WC * 64), 0, st, k);
+    const bool p2 = k.lg_ow >= 0;
+    const dim3 g((unsigned)blocks), b(WJ * WC * 64);
+    if (use_tr && p2) hipLaunchKernelGGL((wgrad_mfma_kernel<BJ, BC, WJ, WC, true, true>), g, b, 0, st, k);
+    else if (use_tr) hipLaunchKernelGGL((wgrad_mfma_kernel<BJ, BC, WJ, WC, true, false>), g, b, 0, st, k);
+    else hipLaunchKernelGGL((wgrad_mfma_kernel<BJ, BC, WJ, WC, false, false>), g, b, 0, st, k);
     SRVP_CHECK_LAUNCH("srvp_wgrad_mfma");
     return SRVP_OK;
 }
@@ -224,7 +240,7 @@ extern "C" int srvp_wgrad_mfma(const srvp_wgrad_desc* d, void* stream) {
     SRVP_REQUIRE(d->ntaps >= 1 && d->ntaps <= SRVP_MAX_TAPS && d->splitk >= 1, "srvp_wgrad_mfma: ntaps/splitk");
     if (g_use_tr < 0) {
         const char* e = getenv("SRVP_WGRAD_TR");
-        g_use_tr = (e && e[0] == '0') ? 0 : 1;
+        g_use_tr = e ? atoi(e) : 1;
     }
     WgradK k;
     k.src0 = (const bf16_t*)d->src0; k.src1 = (const bf16_t*)d->src1; k.map1 = d->map1;
@@ -239,7 +255,13 @@ extern "C" int srvp_wgrad_mfma(const srvp_wgrad_desc* d, void* stream) {
     }
     k.dout = (const bf16_t*)d->dout; k.DHp = d->DHp; k.DWp = d->DWp; k.so = d->so; k.Cout = d->Cout;
     k.N = d->N; k.OH = d->OH; k.OW = d->OW; k.dw = d->dw; k.splitk = d->splitk;
-    const bool tr = g_use_tr != 0;
+    SRVP_REQUIRE((long long)d->N * d->OH * d->OW < (1ll << 31), "srvp_wgrad_mfma: too many pixels");
+    SRVP_REQUIRE((long long)d->N * d->DHp * d->DWp * d->Cout < (1ll << 32) && (long long)d->N * d->H0p * d->W0p * d->C0 < (1ll << 32),
+                 "srvp_wgrad_mfma: operand tensors must have fewer than 2^32 elements");
+    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+    k.lg_ow = lg(d->OW); k.lg_hw = lg(d->OH * d->OW);
+    if (k.lg_hw < 0) k.lg_ow = -1;
+    const bool tr = (g_use_tr & 1) != 0;
     // channel tile of the input operand must not straddle the two sources
     auto divides = [&](int bc) { return d->C0 % bc == 0 && (d->C1 == 0 || d->C1 % bc == 0); };
     const int bj = d->Cout % 128 == 0 ? 128 : (d->Cout % 64 == 0 ? 64 : 32);

@@ -254,41 +254,46 @@ def test_image_side_layers(nc, k, s, p):
     torch.cuda.synchronize()
     ref.backward(draw[:, 1:-1, 1:-1, :cout_r].permute(0, 3, 1, 2).float().cpu())
     assert rel_err(dw, wr.grad) < 1e-3
-    # ---- last layer: ConvTranspose2d(cin -> nc) + sigmoid, input = [main, skip] bf16 padded tensors
-    from srvp_amd.convnet import Feat
+    # ---- last layer: ConvTranspose2d(cin -> nc) + sigmoid on the MFMA kernel (Cout padded to 32, fp32 frame epilogue),
+    # input = [main, skip] bf16 padded tensors; backward = srvp_out_dpre + the generic MFMA wgrad / dgrad
+    from srvp_amd.convnet import Block
     Hin = 64 if s == 1 else 32
     c0r, c1r = 24, (24 if s == 2 else 0)
     f0 = make_feat(N, Hin, Hin, c0r, dev, g)
-    srcs = [f0]
-    d = L.ConvOutDesc()
-    d.src0, d.C0, d.C0_real = L.ptr(f0.t), f0.C, c0r
+    srcs, mp = [f0], None
     if c1r:
         f1 = make_feat(2, Hin, Hin, c1r, dev, g)
         mp = torch.tensor([1, 0, 1], dtype=torch.int32, device=dev)
-        d.src1, d.C1, d.C1_real, d.map1 = L.ptr(f1.t), f1.C, c1r, L.ptr(mp)
         srcs.append(f1)
-    d.N, d.H, d.W, d.Cout, d.k, d.s, d.p, d.apply_sigmoid = N, Hin, Hin, nc, k, s, p, 1
+    spec = dict(kind='convT', key='w', bnkey=None, cin=c0r + c1r, cout=nc, k=k, s=s, p=p, act='none')
+    blk = Block(spec, 'out', srcs, False, N, dev, True, skip_map=mp)
+    blk._fwd, blk._dg, blk._wg = blk.fwd_descs(), blk.dgrad_descs(), blk.wgrad_desc()
     wt = (torch.randn(c0r + c1r, nc, k, k, generator=g) * 0.2)
     wtd = wt.to(dev)
-    xo = torch.zeros(N, nc, 64, 64, device=dev)
-    L.call('srvp_convT_out_fwd', C.byref(d), L.ptr(wtd), L.ptr(xo), st)
+    blk.pack(wtd, st)
+    for d in blk._fwd:
+        L.call('srvp_conv_mfma', C.byref(d), st)
     xin = feat_nchw(f0)
     if c1r:
         xin = torch.cat([xin, feat_nchw(f1)[mp.cpu().long()]], 1)
     xin = xin.clone().requires_grad_(True)
-    wtr = wt.clone().requires_grad_(True)
+    wtr = bf(wt).clone().requires_grad_(True)
     ref = torch.sigmoid(F.conv_transpose2d(xin, wtr, None, s, p))
     torch.cuda.synchronize()
-    assert (xo.cpu() - ref).abs().max().item() < 1e-4
+    assert (blk.x_out.cpu() - ref).abs().max().item() < 1e-4
     dxo = torch.randn(N, nc, 64, 64, generator=g)
     ref.backward(dxo)
-    ctot = f0.C + (srcs[1].C if c1r else 0)
-    dact = torch.zeros(N, Hin, Hin, ctot, dtype=torch.bfloat16, device=dev)
-    dwt = torch.zeros_like(wtd)
     dxd = dxo.to(dev)
-    L.call('srvp_convT_out_bwd', C.byref(d), L.ptr(wtd), L.ptr(xo), L.ptr(dxd), L.ptr(dact), L.ptr(dwt), st)
+    L.call('srvp_out_dpre', L.ptr(blk.x_out), L.ptr(dxd), L.ptr(blk.draw), N, nc, 64, 64, blk.cout, 1, st)
+    grads = {'w.weight': torch.zeros_like(wtd)}
+    blk.dw.zero_()
+    L.call('srvp_wgrad_mfma', C.byref(blk._wg), st)
+    L.call('srvp_unpack_wgrad', L.ptr(blk.dw), L.ptr(grads['w.weight']), C.byref(blk.pu), st)
+    for d in blk._dg:
+        L.call('srvp_conv_mfma', C.byref(d), st)
     torch.cuda.synchronize()
-    assert rel_err(dwt, wtr.grad) < 2e-3
-    assert rel_err(dact[..., :c0r].permute(0, 3, 1, 2).float(), xin.grad[:, :c0r]) < 2 ** -7
+    assert rel_err(grads['w.weight'], wtr.grad) < 1e-2            # dpre is rounded to bf16 before the reduction
+    dact = blk.dcat
+    assert rel_err(dact[..., :c0r].permute(0, 3, 1, 2).float(), xin.grad[:, :c0r]) < 2 ** -6
     if c1r:
-        assert rel_err(dact[..., f0.C:f0.C + c1r].permute(0, 3, 1, 2).float(), xin.grad[:, c0r:]) < 2 ** -7
+        assert rel_err(dact[..., f0.C:f0.C + c1r].permute(0, 3, 1, 2).float(), xin.grad[:, c0r:]) < 2 ** -6
