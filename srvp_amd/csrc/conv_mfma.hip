@@ -33,7 +33,7 @@ struct ConvK {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) {
     constexpr int NT = WM * WN * 64;
     constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
@@ -43,13 +43,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDC = BN + 8;
     static_assert((BM * CPR) % NT == 0 && (BN * CPR) % 64 == 0, "tiles must split into whole-wave 1 KiB LDS-DMA pieces");
-    constexpr int AB_BYTES = 2 * (BM + BN) * BK * 2;
+    constexpr int G = A_LD + B_LD;              // LDS-DMA instructions per K step and wave (vmcnt is per wave)
+    constexpr int AB_BYTES = NBUF * (BM + BN) * BK * 2;
     constexpr int C_BYTES = BM * LDC * 2;
     constexpr int SMEM = AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES;
     // ONE shared object (a second one makes hipcc drain the LDS-DMA queue before every ds_read)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM + WM * BN * 8];
-    bf16_t* As = reinterpret_cast<bf16_t*>(smem);                         // [2][BM][BK]  (XOR-swizzled 16-B chunks)
-    bf16_t* Bs = As + 2 * BM * BK;                                        // [2][BN][BK]
+    bf16_t* As = reinterpret_cast<bf16_t*>(smem);                         // [NBUF][BM][BK]  (XOR-swizzled 16-B chunks)
+    bf16_t* Bs = As + NBUF * BM * BK;                                     // [NBUF][BN][BK]
     float* red = reinterpret_cast<float*>(smem + SMEM);                   // [WM][BN][2]
 
     const int tid = threadIdx.x;
@@ -109,13 +110,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
             __builtin_amdgcn_global_load_lds((gptr_t)(src + off), (lptr_t)(Ad + (size_t)i * NT * 8), 16, 0, 0);
         }
         const bf16_t* w = a.wt + ((size_t)t * a.Cout + n0) * Ctot + cc * BK;
-        bf16_t* Bd = Bs + (size_t)buf * BN * BK + (size_t)wid * 64 * 8;
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
-            int q = tid + i * NT;
+            // narrow weight tiles are re-loaded by the upper waves (same bytes, same LDS address) so that every wave
+            // issues exactly G DMAs per step
+            int q = (tid + i * NT) % (BN * CPR);
             int row = q / CPR, ch = (q % CPR) ^ ((row / RPB) % CPR);
-            if ((wid * 64 + i * NT) < BN * CPR)                               // wave-uniform predicate
-                __builtin_amdgcn_global_load_lds((gptr_t)(w + (size_t)row * Ctot + ch * 8), (lptr_t)(Bd + (size_t)i * NT * 8), 16, 0, 0);
+            const int qb = ((wid * 64 + i * NT) % (BN * CPR)) * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)(w + (size_t)row * Ctot + ch * 8), (lptr_t)(Bs + (size_t)buf * BN * BK + qb), 16, 0, 0);
         }
     };
 
@@ -127,8 +129,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    stage(0, 0);
-    __syncthreads();
     const int lrow = lane & 31, lkc = lane >> 5;
     // fragment rows of this lane and their swizzle terms
     int a_off[TM], a_sw[TM], b_off[TN], b_sw[TN];
@@ -136,9 +136,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
     for (int i = 0; i < TM; ++i) { int r = wm * (TM * 32) + i * 32 + lrow; a_off[i] = r * BK; a_sw[i] = (r / RPB) % CPR; }
 #pragma unroll
     for (int j = 0; j < TN; ++j) { int r = wn * (TN * 32) + j * 32 + lrow; b_off[j] = r * BK; b_sw[j] = (r / RPB) % CPR; }
+    // NBUF-deep LDS ring: the DMA runs NBUF-1 K steps ahead of the MFMAs behind COUNTED s_waitcnt vmcnt and ONE raw
+    // s_barrier per step (a __syncthreads() would drain the whole DMA queue: vmcnt(0)).
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i)
+        if (i < S) stage(i, i);
     for (int s = 0; s < S; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < S) stage(s + 1, buf ^ 1);
+        const int buf = s % NBUF;
+        if (s + NBUF - 2 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NBUF - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + NBUF - 1 < S) stage(s + NBUF - 1, (s + NBUF - 1) % NBUF);
         const bf16_t* Ab = As + (size_t)buf * BM * BK;
         const bf16_t* Bb = Bs + (size_t)buf * BN * BK;
 #pragma unroll
@@ -155,8 +164,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();                             // also drains this step's LDS-DMA (vmcnt(0)) before the next reads
     }
+    __syncthreads();                                 // every wave is done reading the ring: the epilogue reuses it
 
     // ---------------- epilogue ----------------
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
     }
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, int NBUF>
 int launch(const srvp_conv_desc* d, hipStream_t st) {
     long long M = (long long)d->N * d->OH * d->OW;
     long long mt = (M + BM - 1) / BM;
@@ -258,7 +267,7 @@ int launch(const srvp_conv_desc* d, hipStream_t st) {
     k.dst = (bf16_t*)d->dst; k.DHp = d->DHp; k.DWp = d->DWp; k.so = d->so; k.ooy = d->ooy; k.oox = d->oox;
     k.Cdst = d->Cdst; k.cdst_off = d->cdst_off; k.stats = d->stats; k.stat_mod = d->stat_mod;
     k.out_f32 = d->out_f32; k.out_nc = d->out_nc; k.out_sigmoid = d->out_sigmoid;
-    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM, WN>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, st, k);
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM, WN, NBUF>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, st, k);
     SRVP_CHECK_LAUNCH("srvp_conv_mfma");
     return SRVP_OK;
 }
@@ -278,11 +287,24 @@ extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
     SRVP_REQUIRE((long long)d->N * d->H0p * d->W0p * d->C0 < (1ll << 32) && (d->C1 == 0 || d->map1 || (long long)d->N * d->H1p * d->W1p * d->C1 < (1ll << 32)),
                  "srvp_conv_mfma: source tensors must have fewer than 2^32 elements");
     const bool k64 = (d->C0 % 64 == 0) && (d->C1 % 64 == 0);
+    static int mode = -1;       // A/B switch SRVP_CONV_MODE: 0 = BK64 x2 ring, 1 = BK32 x4, 2 = BK32 x3, 3 = BK64 x3
+    if (mode < 0) { const char* e = getenv("SRVP_CONV_MODE"); mode = e ? atoi(e) : 0; }
+    const int m = k64 ? mode : (mode == 2 ? 2 : 1);
     if (d->Cout % 128 == 0) {
-        return k64 ? launch<128, 128, 64, 2, 2>(d, st) : launch<128, 128, 32, 2, 2>(d, st);
+        switch (m) {
+            case 0: return launch<128, 128, 64, 2, 2, 2>(d, st);
+            case 1: return launch<128, 128, 32, 2, 2, 4>(d, st);
+            case 2: return launch<128, 128, 32, 2, 2, 3>(d, st);
+            default: return launch<128, 128, 64, 2, 2, 3>(d, st);
+        }
     } else if (d->Cout % 64 == 0) {
-        return k64 ? launch<128, 64, 64, 2, 2>(d, st) : launch<128, 64, 32, 2, 2>(d, st);
+        switch (m) {
+            case 0: return launch<128, 64, 64, 2, 2, 2>(d, st);
+            case 1: return launch<128, 64, 32, 2, 2, 4>(d, st);
+            case 2: return launch<128, 64, 32, 2, 2, 3>(d, st);
+            default: return launch<128, 64, 64, 2, 2, 3>(d, st);
+        }
     } else {
-        return launch<128, 32, 32, 4, 1>(d, st);
+        return launch<128, 32, 32, 4, 1, 4>(d, st);
     }
 }

@@ -34,7 +34,7 @@ __device__ __forceinline__ s16x4_t lds_tr_read(const bf16_t* p) {
 }
 
 template <int BJ, int BC, int WJ, int WC, bool USE_TR, bool POW2>
-__global__ __launch_bounds__(WJ * WC * 64) void wgrad_mfma_kernel(const WgradK a) {
+__global__ __launch_bounds__(WJ * WC * 64) void wgrad_regstage_kernel(const WgradK a) {
     constexpr int NT = WJ * WC * 64;
     constexpr int BP = 32;                       // pixels per K step
     constexpr int LDX = BJ + 32;                 // row stride (elements): +64 B keeps the 4 rows of a tr-read on distinct banks
@@ -213,15 +213,213 @@ __global__ __launch_bounds__(WJ * WC * 64) void wgrad_mfma_kernel(const WgradK a
             }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Main kernel: LDS-DMA (global_load_lds) staging into an NBUF-deep LDS ring, DMA running NBUF-1 K steps ahead of the
+// MFMAs behind COUNTED s_waitcnt vmcnt + one raw s_barrier per K step.  (Measured on the register-staged version:
+// waves parked in s_waitcnt 60-75 % of the time -- bytes in flight per CU, not bandwidth, was the limit.)
+// LDS rows are unpadded (DMA writes lane-linear); the transpose-read bank spread comes from XOR-ing the 16-byte chunk
+// index with f(row) on the SOURCE side and on the read side (same involution).
+// Requirements (else the register-staged kernel above is used): pixel count % 32 == 0, power-of-two grid dims.
+// ---------------------------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Four transpose reads (k step 0 lo/hi, k step 1 lo/hi) of one 32-channel MFMA tile from one base address, issued
+// from inline asm WITH their s_waitcnt: hipcc gives the ds_read_tr builtin no memory operand, so beside in-flight LDS-DMA
+// it would insert s_waitcnt vmcnt(0) in front of every read and serialise the DMA ring; asm reads are invisible to
+// that pass (and are counted here by hand).
+template <int OFF_HI, int OFF_KK>
+__device__ __forceinline__ void tr_read_tile(unsigned addr, s16x4_t& k0lo, s16x4_t& k0hi, s16x4_t& k1lo, s16x4_t& k1hi) {
+    asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                 "ds_read_b64_tr_b16 %1, %4 offset:%5\n\t"
+                 "ds_read_b64_tr_b16 %2, %4 offset:%6\n\t"
+                 "ds_read_b64_tr_b16 %3, %4 offset:%7\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(k0lo), "=&v"(k0hi), "=&v"(k1lo), "=&v"(k1hi)
+                 : "v"(addr), "n"(OFF_HI), "n"(OFF_KK), "n"(OFF_KK + OFF_HI)
+                 : "memory");
+}
+
+template <int CH> __device__ __forceinline__ int tr_swz(int row) {
+    // CH = 16-byte chunks per LDS row.  A transpose read touches 4 consecutive rows x 64 B: move them to 4 distinct
+    // 64-byte bank groups of the 256-byte LDS bank row.
+    if constexpr (CH >= 16) return (row & 3) << 2;
+    else if constexpr (CH == 8) return ((row >> 1) & 1) << 2;
+    else return 0;
+}
+
+template <int BJ, int BC, int WJ, int WC, int NBUF>
+__global__ __launch_bounds__(WJ * WC * 64) void wgrad_mfma_kernel(const WgradK a) {
+    constexpr int NT = WJ * WC * 64;
+    constexpr int BP = 32;
+    constexpr int XCH = BJ / 8, YCH = BC / 8;
+    constexpr int X_LD = (BP * XCH + NT - 1) / NT, Y_LD = (BP * YCH + NT - 1) / NT;
+    constexpr int G = X_LD + Y_LD;                      // LDS-DMA instructions per K step and wave
+    constexpr int TJ = BJ / WJ / 32, TC = BC / WC / 32;
+    constexpr int XB = BP * BJ, YB = BP * BC;           // elements per buffer
+    constexpr int MAXMAP = 4096;                        // skip-connection image map staged in LDS (ds_read, not vmcnt)
+    __shared__ __attribute__((aligned(1024))) bf16_t lds[NBUF * (XB + YB) + MAXMAP * 2];
+    int* maps = reinterpret_cast<int*>(lds + NBUF * (XB + YB));
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wj = wid / WC, wc = wid % WC;
+    const int Ctot = a.C0 + a.C1;
+    const int tj_n = a.Cout / BJ, tc_n = Ctot / BC;
+    int b = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int t = b % a.ntaps; b /= a.ntaps;
+    const int tc = b % tc_n; b /= tc_n;
+    const int tj = b % tj_n; b /= tj_n;
+    const int split = b;
+    const int j0 = tj * BJ, c0 = tc * BC;
+    const int M = a.N * a.OH * a.OW;
+    const int nchunks = M / BP;
+    const int per = (nchunks + a.splitk - 1) / a.splitk;
+    const int ch_beg = split * per;
+    int ch_end = ch_beg + per; if (ch_end > nchunks) ch_end = nchunks;
+    if (ch_beg >= ch_end) return;
+    const int nsteps = ch_end - ch_beg;
+
+    const bool second = c0 >= a.C0;
+    const bf16_t* src = second ? a.src1 : a.src0;
+    const int C = second ? a.C1 : a.C0, Hp = second ? a.H1p : a.H0p, Wp = second ? a.W1p : a.W0p;
+    const int ups = (second ? a.ups1 : a.ups0) ? 1 : 0;
+    const int cs = second ? c0 - a.C0 : c0;
+    const int dy = (int)((a.dy_bits >> (4 * t)) & 15), dx = (int)((a.dx_bits >> (4 * t)) & 15);
+    const int ooy = (int)((a.ooy_bits >> (4 * t)) & 15), oox = (int)((a.oox_bits >> (4 * t)) & 15);
+    const int hw = a.OH * a.OW;
+    const bool mapped = second && a.map1 != nullptr;
+
+    // fixed (row, source chunk) of this thread's DMA pieces; narrow tiles are re-loaded by the upper waves (same
+    // bytes to the same LDS address) so that every wave issues exactly G DMAs per step -- vmcnt is per wave.
+    int xrow[X_LD], xch[X_LD], yrow[Y_LD], ych[Y_LD];
+#pragma unroll
+    for (int i = 0; i < X_LD; ++i) { int q = (tid + i * NT) % (BP * XCH); xrow[i] = q / XCH; xch[i] = (q % XCH) ^ tr_swz<XCH>(q / XCH); }
+#pragma unroll
+    for (int i = 0; i < Y_LD; ++i) { int q = (tid + i * NT) % (BP * YCH); yrow[i] = q / YCH; ych[i] = (q % YCH) ^ tr_swz<YCH>(q / YCH); }
+
+    auto stage = [&](int step, int buf) {
+        const int mbase = (ch_beg + step) * BP;
+        bf16_t* Xd = lds + (size_t)buf * (XB + YB);
+        bf16_t* Yd = Xd + XB;
+#pragma unroll
+        for (int i = 0; i < X_LD; ++i) {
+            const int m = mbase + xrow[i];
+            const int n = m >> a.lg_hw, r = m & (hw - 1);
+            const int oy = r >> a.lg_ow, ox = r & (a.OW - 1);
+            unsigned off = (((unsigned)n * a.DHp + oy * a.so + ooy) * a.DWp + ox * a.so + oox) * a.Cout + j0 + xch[i] * 8;
+            const int qb = ((wid * 64 + i * NT) % (BP * XCH)) * 8;        // wave-uniform LDS element offset of this piece
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.dout + off), (lptr_t)(Xd + qb), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < Y_LD; ++i) {
+            const int m = mbase + yrow[i];
+            int n = m >> a.lg_hw; const int r = m & (hw - 1);
+            const int oy = r >> a.lg_ow, ox = r & (a.OW - 1);
+            int vy = oy * a.si + dy, vx = ox * a.si + dx;
+            vy = (vy + ups) >> ups; vx = (vx + ups) >> ups;
+            if (mapped) n = maps[n];
+            unsigned off = (((unsigned)n * Hp + vy) * Wp + vx) * C + cs + ych[i] * 8;
+            const int qb = ((wid * 64 + i * NT) % (BP * YCH)) * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + off), (lptr_t)(Yd + qb), 16, 0, 0);
+        }
+    };
+
+    if (mapped) {
+        for (int i = tid; i < a.N; i += NT) maps[i] = a.map1[i];
+        __syncthreads();
+    }
+    f32x16_t acc[TJ][TC];
+#pragma unroll
+    for (int i = 0; i < TJ; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transpose-read addressing (see lds_tr_read): lane s of a 16-lane group addresses pixel (s>>2), channels (s&3)*4..
+    // The swizzle term only depends on (s>>2)&3 (the other row terms are multiples of 4), so it is a per-lane constant.
+    const int g = lane >> 4, sl = lane & 15;
+    const int tr_c = (g & 1) * 16 + (sl & 3) * 4;       // channel within the 32-wide MFMA tile
+    const int tr_r = (g >> 1) * 8 + (sl >> 2);          // pixel within the 16-pixel k step (+4 for the second read)
+    unsigned xoff[TJ], yoff[TC];                        // byte offsets inside a buffer (k step 0, first read)
+#pragma unroll
+    for (int i = 0; i < TJ; ++i) {
+        const int c = wj * (TJ * 32) + i * 32 + tr_c;
+        xoff[i] = 2u * (unsigned)(tr_r * BJ + (((c >> 3) ^ tr_swz<XCH>(tr_r)) << 3) + (c & 7));
+    }
+#pragma unroll
+    for (int j = 0; j < TC; ++j) {
+        const int c = wc * (TC * 32) + j * 32 + tr_c;
+        yoff[j] = 2u * (unsigned)(XB + tr_r * BC + (((c >> 3) ^ tr_swz<YCH>(tr_r)) << 3) + (c & 7));
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)lds;     // LDS byte address of the ring
+
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i)
+        if (i < nsteps) stage(i, i);
+    for (int s = 0; s < nsteps; ++s) {
+        // tile s has landed when at most the NBUF-2 younger tiles' DMAs are still outstanding
+        if (s + NBUF - 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NBUF - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + NBUF - 1 < nsteps) stage(s + NBUF - 1, (s + NBUF - 1) % NBUF);
+        const unsigned bb = lds_base + (unsigned)(s % NBUF) * (unsigned)((XB + YB) * 2);
+        typedef short s16x8_t __attribute__((ext_vector_type(8)));
+        bf16x8_t xf[2][TJ], yf[2][TC];
+#pragma unroll
+        for (int i = 0; i < TJ; ++i) {
+            s16x4_t a0, a1, b0, b1;
+            tr_read_tile<4 * BJ * 2, 16 * BJ * 2>(bb + xoff[i], a0, a1, b0, b1);
+            s16x8_t v0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            s16x8_t v1 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            xf[0][i] = __builtin_bit_cast(bf16x8_t, v0); xf[1][i] = __builtin_bit_cast(bf16x8_t, v1);
+        }
+#pragma unroll
+        for (int j = 0; j < TC; ++j) {
+            s16x4_t a0, a1, b0, b1;
+            tr_read_tile<4 * BC * 2, 16 * BC * 2>(bb + yoff[j], a0, a1, b0, b1);
+            s16x8_t v0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            s16x8_t v1 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            yf[0][j] = __builtin_bit_cast(bf16x8_t, v0); yf[1][j] = __builtin_bit_cast(bf16x8_t, v1);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < TJ; ++i)
+#pragma unroll
+                for (int j = 0; j < TC; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[kk][i], yf[kk][j], acc[i][j], 0, 0, 0);
+    }
+
+    const int lcol = lane & 31, lhalf = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TJ; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int jj = j0 + wj * (TJ * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                int cc = c0 + wc * (TC * 32) + j * 32 + lcol;
+                atomicAdd(a.dw + ((size_t)t * a.Cout + jj) * Ctot + cc, acc[i][j][r]);
+            }
+}
+
 template <int BJ, int BC, int WJ, int WC>
-int launch(const WgradK& k, hipStream_t st, bool use_tr) {
+int launch(const WgradK& k, hipStream_t st, bool use_tr, bool dma_off) {
     long long blocks = (long long)(k.Cout / BJ) * ((k.C0 + k.C1) / BC) * k.ntaps * k.splitk;
     SRVP_REQUIRE(blocks > 0 && blocks < (1ll << 31), "srvp_wgrad_mfma: bad grid");
     const bool p2 = k.lg_ow >= 0;
     const dim3 g((unsigned)blocks), b(WJ * WC * 64);
-    if (use_tr && p2) hipLaunchKernelGGL((wgrad_mfma_kernel<BJ, BC, WJ, WC, true, true>), g, b, 0, st, k);
-    else if (use_tr) hipLaunchKernelGGL((wgrad_mfma_kernel<BJ, BC, WJ, WC, true, false>), g, b, 0, st, k);
-    else hipLaunchKernelGGL((wgrad_mfma_kernel<BJ, BC, WJ, WC, false, false>), g, b, 0, st, k);
+    const long long Mtot = (long long)k.N * k.OH * k.OW;
+    if (use_tr && p2 && Mtot % 32 == 0 && !dma_off && (k.map1 == nullptr || k.N <= 4096)) {
+        hipLaunchKernelGGL((wgrad_mfma_kernel<BJ, BC, WJ, WC, 4>), g, b, 0, st, k);
+        SRVP_CHECK_LAUNCH("srvp_wgrad_mfma");
+        return SRVP_OK;
+    }
+    if (use_tr && p2) hipLaunchKernelGGL((wgrad_regstage_kernel<BJ, BC, WJ, WC, true, true>), g, b, 0, st, k);
+    else if (use_tr) hipLaunchKernelGGL((wgrad_regstage_kernel<BJ, BC, WJ, WC, true, false>), g, b, 0, st, k);
+    else hipLaunchKernelGGL((wgrad_regstage_kernel<BJ, BC, WJ, WC, false, false>), g, b, 0, st, k);
     SRVP_CHECK_LAUNCH("srvp_wgrad_mfma");
     return SRVP_OK;
 }
@@ -262,17 +460,18 @@ extern "C" int srvp_wgrad_mfma(const srvp_wgrad_desc* d, void* stream) {
     k.lg_ow = lg(d->OW); k.lg_hw = lg(d->OH * d->OW);
     if (k.lg_hw < 0) k.lg_ow = -1;
     const bool tr = (g_use_tr & 1) != 0;
+    const bool dma_off = (g_use_tr & 4) != 0;     // srvp_wgrad_set_tr(5): transpose reads, register-staged kernel (A/B switch)
     // channel tile of the input operand must not straddle the two sources
     auto divides = [&](int bc) { return d->C0 % bc == 0 && (d->C1 == 0 || d->C1 % bc == 0); };
     const int bj = d->Cout % 128 == 0 ? 128 : (d->Cout % 64 == 0 ? 64 : 32);
     const int bc = divides(128) ? 128 : (divides(64) ? 64 : 32);
-    if (bj == 128 && bc == 128) return launch<128, 128, 2, 2>(k, st, tr);
-    if (bj == 128 && bc == 64) return launch<128, 64, 2, 2>(k, st, tr);
-    if (bj == 128 && bc == 32) return launch<128, 32, 4, 1>(k, st, tr);
-    if (bj == 64 && bc == 128) return launch<64, 128, 2, 2>(k, st, tr);
-    if (bj == 64 && bc == 64) return launch<64, 64, 2, 2>(k, st, tr);
-    if (bj == 64 && bc == 32) return launch<64, 32, 2, 1>(k, st, tr);
-    if (bj == 32 && bc == 128) return launch<32, 128, 1, 4>(k, st, tr);
-    if (bj == 32 && bc == 64) return launch<32, 64, 1, 2>(k, st, tr);
-    return launch<32, 32, 1, 1>(k, st, tr);
+    if (bj == 128 && bc == 128) return launch<128, 128, 2, 2>(k, st, tr, dma_off);
+    if (bj == 128 && bc == 64) return launch<128, 64, 2, 2>(k, st, tr, dma_off);
+    if (bj == 128 && bc == 32) return launch<128, 32, 4, 1>(k, st, tr, dma_off);
+    if (bj == 64 && bc == 128) return launch<64, 128, 2, 2>(k, st, tr, dma_off);
+    if (bj == 64 && bc == 64) return launch<64, 64, 2, 2>(k, st, tr, dma_off);
+    if (bj == 64 && bc == 32) return launch<64, 32, 2, 1>(k, st, tr, dma_off);
+    if (bj == 32 && bc == 128) return launch<32, 128, 1, 4>(k, st, tr, dma_off);
+    if (bj == 32 && bc == 64) return launch<32, 64, 1, 2>(k, st, tr, dma_off);
+    return launch<32, 32, 1, 1>(k, st, tr, dma_off);
 }
