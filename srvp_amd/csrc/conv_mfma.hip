@@ -143,11 +143,21 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
         if (i < S) stage(i, i);
     for (int s = 0; s < S; ++s) {
         const int buf = s % NBUF;
-        if (s + NBUF - 2 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NBUF - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (s + NBUF - 1 < S) stage(s + NBUF - 1, (s + NBUF - 1) % NBUF);
+        if constexpr (NBUF == 1) {
+            // single buffer, latency hidden by the other workgroups of the CU (3-4 resident at 34 KB of LDS each)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            stage(s, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            if (s + NBUF - 2 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NBUF > 1 ? NBUF - 2 : 0)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (s + NBUF - 1 < S) stage(s + NBUF - 1, (s + NBUF - 1) % NBUF);
+        }
         const bf16_t* Ab = As + (size_t)buf * BM * BK;
         const bf16_t* Bb = Bs + (size_t)buf * BN * BK;
 #pragma unroll
@@ -287,14 +297,18 @@ extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
     SRVP_REQUIRE((long long)d->N * d->H0p * d->W0p * d->C0 < (1ll << 32) && (d->C1 == 0 || d->map1 || (long long)d->N * d->H1p * d->W1p * d->C1 < (1ll << 32)),
                  "srvp_conv_mfma: source tensors must have fewer than 2^32 elements");
     const bool k64 = (d->C0 % 64 == 0) && (d->C1 % 64 == 0);
-    static int mode = -1;       // A/B switch SRVP_CONV_MODE: 0 = BK64 x2 ring, 1 = BK32 x4, 2 = BK32 x3, 3 = BK64 x3
-    if (mode < 0) { const char* e = getenv("SRVP_CONV_MODE"); mode = e ? atoi(e) : 0; }
-    const int m = k64 ? mode : (mode == 2 ? 2 : 1);
+    // LDS ring depth / K step (A/B switch SRVP_CONV_MODE): 5 = BK64 single buffer (default: 3 workgroups per CU hide the
+    // DMA latency better than a deeper ring at 1-2 workgroups per CU: 39.0 vs 40.9 (x2) / 43 (BK32 x3) / 46 (BK32 x4) /
+    // 56 ms (BK64 x3) per step), 0 = BK64 x2, 1 = BK32 x4, 2 = BK32 x3, 3 = BK64 x3
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("SRVP_CONV_MODE"); mode = e ? atoi(e) : 5; }
+    const int m = k64 ? mode : (mode == 2 ? 2 : 1);   // 5 = BK64, single buffer
     if (d->Cout % 128 == 0) {
         switch (m) {
             case 0: return launch<128, 128, 64, 2, 2, 2>(d, st);
             case 1: return launch<128, 128, 32, 2, 2, 4>(d, st);
             case 2: return launch<128, 128, 32, 2, 2, 3>(d, st);
+            case 5: return launch<128, 128, 64, 2, 2, 1>(d, st);
             default: return launch<128, 128, 64, 2, 2, 3>(d, st);
         }
     } else if (d->Cout % 64 == 0) {
@@ -302,6 +316,7 @@ extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
             case 0: return launch<128, 64, 64, 2, 2, 2>(d, st);
             case 1: return launch<128, 64, 32, 2, 2, 4>(d, st);
             case 2: return launch<128, 64, 32, 2, 2, 3>(d, st);
+            case 5: return launch<128, 64, 64, 2, 2, 1>(d, st);
             default: return launch<128, 64, 64, 2, 2, 3>(d, st);
         }
     } else {

@@ -87,20 +87,19 @@ int gemm(hipStream_t st, const float* A, long long a_rs, long long a_cs, const f
     return SRVP_OK;
 }
 
-__global__ void colsum_kernel(const float* A, long long a_rs, float* out, int M, int N, int accumulate) {
-    // one workgroup per 64 columns; 4 waves stride over rows
+__global__ void colsum_kernel(const float* A, long long a_rs, float* out, int M, int N, int rows_per_block) {
+    // workgroup = 64 columns x one slice of rows; 4 waves stride over the slice, one atomic per column and workgroup
     __shared__ float part[4][64];
     int n = blockIdx.x * 64 + (threadIdx.x & 63);
     int w = threadIdx.x >> 6;
+    int r0 = blockIdx.y * rows_per_block, r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
     float s = 0.f;
     if (n < N)
-        for (int m = w; m < M; m += 4) s += A[m * a_rs + n];
+        for (int m = r0 + w; m < r1; m += 4) s += A[m * a_rs + n];
     part[w][threadIdx.x & 63] = s;
     __syncthreads();
-    if (w == 0 && n < N) {
-        float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-        out[n] = accumulate ? out[n] + t : t;
-    }
+    if (w == 0 && n < N) atomicAdd(out + n, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 __global__ void act_bwd_kernel(const float* v, const float* dy, float* dx, long long n, int act, int from_output) {
@@ -302,7 +301,13 @@ extern "C" int srvp_axpby_f32(float* out, float a, const float* x, float b, cons
 
 extern "C" int srvp_colsum_f32(const float* A, int64_t a_rs, float* out, int M, int N, int accumulate, void* stream) {
     SRVP_REQUIRE(A && out, "srvp_colsum_f32: null pointer");
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, A, (long long)a_rs, out, M, N, accumulate);
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * N, (hipStream_t)stream);
+        SRVP_REQUIRE(e == hipSuccess, "srvp_colsum_f32: memset failed");
+    }
+    const int rpb = 128;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, A, (long long)a_rs,
+                       out, M, N, rpb);
     SRVP_CHECK_LAUNCH("srvp_colsum_f32");
     return SRVP_OK;
 }

@@ -196,7 +196,7 @@ def test_bn_act_fwd_bwd(mode, C_):
         # pool on the bf16-rounded activations (what the kernel pooled), gradient routed by torch's own arg-max
         a_b = bf(a).detach()
         pooled = F.max_pool2d(a_b + (a - a.detach()), 2, 2)
-        assert rel_err(feat_nchw(pool), pooled.detach()) < 1e-6
+        assert rel_err(feat_nchw(pool), pooled.detach()) < 2 ** -7      # the activations may differ by one bf16 ulp from torch.s own BN arithmetic
         (pooled * da[..., :C_].permute(0, 3, 1, 2).float().cpu()).sum().backward()
     red = torch.zeros(2, Cp, dtype=torch.float64, device=dev)
     bcoef = torch.zeros(3, Cp, device=dev)

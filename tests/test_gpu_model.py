@@ -224,3 +224,135 @@ def test_full_width_vs_oracle(archi, nc, skipco, ne, B, T):
     assert e_model < (2e-4 if vgg else 2e-6), (loss, scal_m['loss'])
     assert max_abs(x_, outs_m[0]) < (2e-2 if vgg else 5e-3)
     assert max(gerr_m.values()) < (0.5 if vgg else 0.1), worst_m
+
+
+@pytest.mark.parametrize('name', ['tiny_vgg_nc3_skip1_e2', 'tiny_vgg_nc1_skip1_e2', 'small_vgg_nc3_skip1_e2', 'tiny_dcgan_nc3_skip1_e2'])
+def test_conv_backward_teacher_forced(name):
+    """
+    Backward of the conv encoder / decoder with the FORWARD STATE PINNED to the oracle's (numerics-model) values:
+    every block's raw output, BatchNorm coefficients and activation are overwritten with the oracle's bf16-exact
+    tensors, then the HIP backward runs on the oracle's output gradient.  What is left is the backward arithmetic
+    itself (+ its own bf16 rounding of the propagated gradients, which is linear noise and does not grow chaotically),
+    so VGG can be checked as tightly as DCGAN: every parameter gradient within 3 % relative L2 (median < 1 %).
+    """
+    import srvp_amd
+    from oracle import srvp_oracle as O
+    from srvp_amd import _lib as L
+    fx = Fixture(name)
+    cfg, hp, ne = fx.cfg, fx.meta['hp'], fx.meta['n_euler']
+    x, tape = fx.t('x'), fx.tape()
+    T, B = x.shape[0], x.shape[1]
+    # ---- oracle forward under the numerics model, recording every block
+    rec = {}
+    orig = O._conv_block_bf16
+
+    def recording(h, sd, spec, training):
+        w = sd[spec['key'] + '.weight']
+        role = spec.get('role', 'mfma')
+        hh, ww = (O._bf(h), O._bf(w)) if role in ('mfma', 'out') else (h, w)
+        r = torch.nn.functional.conv2d(hh, ww, None, spec['s'], spec['p']) if spec['kind'] == 'conv' else \
+            torch.nn.functional.conv_transpose2d(hh, ww, None, spec['s'], spec['p'])
+        e = dict(raw=O._bf(r).detach() if role != 'out' else None)
+        if spec['bnkey'] is not None:
+            mean, var = r.mean(dim=(0, 2, 3)), r.var(dim=(0, 2, 3), unbiased=False)
+            inv = torch.rsqrt(var + O.BN_EPS)
+            scale = sd[spec['bnkey'] + '.weight'] * inv
+            e.update(scale=scale.detach(), shift=(sd[spec['bnkey'] + '.bias'] - mean * scale).detach(), mean=mean.detach(), inv=inv.detach())
+        out = orig(h, sd, spec, training)
+        e['out'] = out.detach()
+        rec[spec['key']] = e
+        return out
+    sd = fx.state('sd0')
+    pkeys, _ = O.split_state(sd)
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in pkeys}
+    work = dict(sd)
+    work.update(leaves)
+    O._conv_block_bf16, O.PRECISION = recording, 'bf16'
+    try:
+        outs = O.forward(work, cfg, x, T, ne, tape, True)
+        terms = O.elbo(x, outs, hp['obs_scale'], hp['beta_y'], hp['beta_z'], hp['l2_res'])
+        conv_keys = [k for k in pkeys if k.startswith(('encoder.', 'decoder.'))]
+        gref = dict(zip(conv_keys, torch.autograd.grad(terms['loss'], [leaves[k] for k in conv_keys], retain_graph=True)))
+        d_x_ref = torch.autograd.grad(terms['loss'], outs[0], retain_graph=True)[0]
+    finally:
+        O._conv_block_bf16, O.PRECISION = orig, 'fp32'
+    # ---- HIP forward (allocates the plan), then pin the conv state to the oracle's
+    model = build(fx).train()
+    model.flatten_parameters_()
+    xg = x.cuda()
+    model._forward_impl(xg, T, ne, tape, training=True)
+    pl = model._last_plan
+
+    def put_nhwc(dst, src_nchw):              # dst: [N][H][W][Cp] view, src: (N, C, H, W)
+        dst.zero_()
+        dst[..., :src_nchw.shape[1]].copy_(src_nchw.permute(0, 2, 3, 1))
+    for net in (pl['enc'], pl['dec']):
+        for blk in net.blocks:
+            e = rec[blk.spec['key']]
+            if blk.role != 'out':
+                put_nhwc(blk.raw, e['raw'].cuda())
+                if blk.has_bn:
+                    blk.coef.zero_()
+                    for i, nme in enumerate(('scale', 'shift', 'mean', 'inv')):
+                        blk.coef[i, :blk.cout_r] = e[nme].cuda()
+            if blk.out is not None:
+                f = blk.out
+                put_nhwc(f.t[:, f.b:f.b + f.H, f.b:f.b + f.W, :], e['out'].cuda())
+            if blk.pool is not None:
+                f = blk.pool
+                put_nhwc(f.t[:, f.b:f.b + f.H, f.b:f.b + f.W, :], torch.nn.functional.max_pool2d(e['out'], 2, 2).cuda())
+            if blk.role == 'out':
+                blk.x_out.copy_(torch.sigmoid(e['out']).cuda())
+    # ---- HIP backward of decoder and encoder on the oracle's gradients
+    grads = model._grads()
+    model._flat[1].zero_()
+    params = model._named_tensors()
+    st = L.stream()
+    dec, enc = pl['dec'], pl['enc']
+    dec.backward(d_x_ref.reshape(T * B, *d_x_ref.shape[2:]).cuda().contiguous(), params, grads, st, None)
+    torch.cuda.synchronize()
+    dec_err = {k: rel_l2(grads[k], gref[k]) for k in conv_keys if k.startswith('decoder.')}
+    # encoder: gradient wrt hx and the skips from the oracle graph
+    hx_ref = rec[[b.spec['key'] for b in enc.blocks][-1]]['out']
+    # (d_hx / skip gradients are re-derived by autograd through the recorded oracle graph)
+    enc_out_tensors = []
+    O._conv_block_bf16, O.PRECISION = orig, 'bf16'
+    try:
+        work2 = dict(fx.state('sd0'))
+        leaves2 = {k: work2[k].clone().requires_grad_(True) for k in pkeys}
+        work2.update(leaves2)
+        hx2, skips2 = O.encode(work2, cfg, x, True, tape.get('t_skip'))
+        hx2.retain_grad()
+        for s_ in (skips2 or []):
+            s_.retain_grad()
+        w2 = O.infer_w(work2, cfg, hx2, True, tape.get('t_w'))
+        y0, qy0 = O.infer_y(work2, cfg, hx2[:cfg['nt_inf']], tape['eps_y0'])
+        y2, z2, qz2, pz2, res2 = O.generate(work2, cfg, y0, hx2, T, ne, tape['eps_z'], True)
+        x2 = O.decode(work2, cfg, w2, y2, skips2, True)
+        t2 = O.elbo(x, (x2, y2, z2, w2, qy0, qz2, pz2, res2), hp['obs_scale'], hp['beta_y'], hp['beta_z'], hp['l2_res'])
+        t2['loss'].backward()
+    finally:
+        O.PRECISION = 'fp32'
+    d_hx = torch.zeros(T * B, srvp_amd.convnet.cpad(cfg['nhx']), device='cuda')
+    d_hx[:, :cfg['nhx']] = hx2.grad.reshape(T * B, -1).cuda()
+    skip_grads = None
+    if cfg['skipco']:
+        idx = torch.full((T * B,), -1, dtype=torch.int32, device='cuda')
+        idx[pl['skip_sel'].long()] = torch.arange(B, dtype=torch.int32, device='cuda')
+        skip_grads = {}
+        for i, s_ in enumerate(skips2):
+            g_ = s_.grad                                         # (B, C, H, W)
+            Cp = srvp_amd.convnet.cpad(g_.shape[1])
+            t_ = torch.zeros(B, g_.shape[2], g_.shape[3], Cp, dtype=torch.bfloat16, device='cuda')
+            t_[..., :g_.shape[1]] = g_.permute(0, 2, 3, 1).cuda()
+            skip_grads[i] = (t_, idx)
+    model._flat[1].zero_()
+    enc.backward(xg.view(T * B, *xg.shape[2:]), d_hx, skip_grads, params, grads, st, None)
+    torch.cuda.synchronize()
+    gref2 = {k: leaves2[k].grad for k in conv_keys if k.startswith('encoder.')}
+    enc_err = {k: rel_l2(grads[k], gref2[k]) for k in gref2}
+    errs = {**dec_err, **enc_err}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    med = sorted(errs.values())[len(errs) // 2]
+    report(test='teacher_forced_backward', name=name, worst=worst, median=med)
+    assert max(errs.values()) < 0.03 and med < 0.01, (worst, med)
