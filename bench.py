@@ -68,7 +68,11 @@ def cpu_baseline(cfg, seconds=20.0):
     """Oracle train step (forward + ELBO + backward + Adam) on the host cores, reduced batch."""
     from oracle import srvp_oracle as O
     import srvp_amd
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = min(cores, 16)          # the CPU convolutions of a 48-frame batch stop scaling (and oversubscribe) beyond that
     torch.set_num_threads(cores)
     torch.manual_seed(1)
     m = srvp_amd.StochasticLatentResidualVideoPredictor(*cfg['ctor'])

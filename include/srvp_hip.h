@@ -57,6 +57,12 @@ typedef struct {
     /* image-side output layer (conv.py:304,353 + sigmoid :273-274): when out_f32 != NULL the first out_nc columns are
      * written as fp32 into the (N, out_nc, DHp, DWp) frame tensor (optionally through a sigmoid) instead of `dst` */
     float* out_f32; int32_t out_nc, out_sigmoid;
+    /* Hoisted skip half (the skip connection is identical for every time step, module/srvp.py:222-223):
+     *   map0      : image indirection for src0 (n -> map0[n]), NULL = identity
+     *   dst_is_f32: write the fp32 accumulators to `dst` as fp32 [N][DHp][DWp][Cdst] instead of bf16
+     *   add_f32   : fp32 [add_mod][OH][OW][Cout] added to the accumulators (image n uses row n % add_mod) before
+     *               the statistics / store -- conv([h, skip]) = conv_h(h) + conv_s(skip), conv_s computed once per sample */
+    const int32_t* map0; int32_t dst_is_f32; const float* add_f32; int32_t add_mod;
 } srvp_conv_desc;
 int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
 
@@ -75,6 +81,7 @@ typedef struct {
     int32_t N, OH, OW;
     float* dw;                    /* fp32 [ntaps][Cout][C0+C1], accumulated into */
     int32_t splitk;
+    const int32_t* map0;          /* image indirection for src0 (NULL = identity) */
 } srvp_wgrad_desc;
 int srvp_wgrad_mfma(const srvp_wgrad_desc* d, void* stream);
 /* 1: fragments through ds_read_b64_tr_b16 (default), 0: 16-bit LDS reads (conservative fallback) */

@@ -31,7 +31,8 @@ class ConvDesc(C.Structure):
                 ('dst', c_vp), ('DHp', c_i32), ('DWp', c_i32), ('so', c_i32), ('ooy', c_i32), ('oox', c_i32),
                 ('Cdst', c_i32), ('cdst_off', c_i32),
                 ('stats', c_vp), ('stat_mod', c_i32),
-                ('out_f32', c_vp), ('out_nc', c_i32), ('out_sigmoid', c_i32)]
+                ('out_f32', c_vp), ('out_nc', c_i32), ('out_sigmoid', c_i32),
+                ('map0', c_vp), ('dst_is_f32', c_i32), ('add_f32', c_vp), ('add_mod', c_i32)]
 
 
 class WgradDesc(C.Structure):
@@ -42,7 +43,7 @@ class WgradDesc(C.Structure):
                 ('ntaps', c_i32), ('dy', TAPS), ('dx', TAPS),
                 ('dout', c_vp), ('DHp', c_i32), ('DWp', c_i32), ('so', c_i32), ('ooy', TAPS), ('oox', TAPS),
                 ('Cout', c_i32), ('N', c_i32), ('OH', c_i32), ('OW', c_i32),
-                ('dw', c_vp), ('splitk', c_i32)]
+                ('dw', c_vp), ('splitk', c_i32), ('map0', c_vp)]
 
 
 class BnBwdDesc(C.Structure):

@@ -67,7 +67,7 @@ def _pack_desc(taps_off, J, K, Jsegs, Ksegs, sj, sk):
 class Block:
     """One conv block (conv -> [BN] -> act) of the encoder or decoder: buffers + launch descriptors."""
 
-    def __init__(self, spec, role, srcs, ups, N, device, training, skip_map=None):
+    def __init__(self, spec, role, srcs, ups, N, device, training, skip_map=None, skip_sel=None):
         """
         role: 'in' (fp32 frames in), 'mfma', 'out' (fp32 frames out)
         srcs: list of source Feat (1 or 2) -- for role 'in' empty;  ups: nearest-x2 applied to srcs[0] by the gather
@@ -75,6 +75,7 @@ class Block:
         self.spec, self.role, self.srcs, self.ups, self.N, self.dev = spec, role, srcs, ups, N, device
         self.training = training
         self.skip_map = skip_map                      # int32 [N] image index into srcs[1]
+        self.skip_sel = skip_sel                      # int32 [B] sample -> image index into srcs[1] (hoisted skip half)
         k, s, p = spec['k'], spec['s'], spec['p']
         self.k, self.s, self.p = k, s, p
         self.kind = spec['kind']
@@ -113,7 +114,14 @@ class Block:
             else:
                 raise NotImplementedError(spec)
             assert not (self.geom in ('full', 'expand') and len(srcs) != 1)
+        # Hoisted skip half: the skip connection of a sample is the same for every time step (module/srvp.py:222-223), so
+        # conv([h_t, skip]) = conv_h(h_t) + conv_s(skip) with conv_s -- and its weight / data gradients, through the sum
+        # of the output gradient over time -- evaluated once per SAMPLE instead of once per FRAME (1/T of the FLOPs of
+        # that half; 21 % of all VGG conv FLOPs at T = 12).  Same arithmetic, different summation order.
+        self.split = (role == 'mfma' and len(srcs) == 2 and skip_sel is not None and getattr(self, 'geom', None) == 'same')
+        self.B = int(skip_sel.numel()) if self.split else 0
         self.ctot = sum(f.C for f in srcs) if srcs else 0
+        self.dcat_c = srcs[0].C if self.split else self.ctot     # channels of the input-gradient tensor `dcat`
         if role != 'out':
             self.raw = torch.empty(N, self.OH, self.OW, self.cout, dtype=torch.bfloat16, device=device)
             C_ = self.cout
@@ -132,7 +140,7 @@ class Block:
             self._alloc_weights()
         if training and role != 'in':
             # gradient wrt the (virtual, concatenated) input of this block: [N][Hin][Win][ctot] bf16, unpadded
-            self.dcat = torch.empty(N, self.Hin, self.Win, self.ctot, dtype=torch.bfloat16, device=device)
+            self.dcat = torch.empty(N, self.Hin, self.Win, self.dcat_c, dtype=torch.bfloat16, device=device)
         if training:
             self.draw_b = 0 if (role == 'mfma' and self.geom in ('full', 'expand')) else 1
             bd = self.draw_b
@@ -142,7 +150,14 @@ class Block:
             self.bcoef = torch.zeros(3, self.cout, dtype=torch.float32, device=device)
         if training and role in ('mfma', 'out'):
             ntaps = self.k * self.k
-            self.dw = torch.zeros(ntaps, self.cout, self.ctot, dtype=torch.float32, device=device)
+            self.dw = torch.zeros(ntaps, self.cout, self.dcat_c, dtype=torch.float32, device=device)
+        if self.split:
+            f1 = srcs[1]
+            self.S = torch.empty(self.B, self.OH, self.OW, self.cout, dtype=torch.float32, device=device)
+            if training:
+                self.draw_sum = torch.zeros(self.B, self.OH + 2, self.OW + 2, self.cout, dtype=torch.bfloat16, device=device)
+                self.dsel = torch.empty(self.B, self.Hin, self.Win, f1.C, dtype=torch.bfloat16, device=device)
+                self.dw_s = torch.zeros(self.k * self.k, self.cout, f1.C, dtype=torch.float32, device=device)
 
     # ------------------------------------------------------------------ weights
     def _alloc_weights(self):
@@ -168,6 +183,20 @@ class Block:
             order_d = [kh * k + kw for py in (0, 1) for px in (0, 1) for kh, _ in PHASE[py] for kw, _ in PHASE[px]]
         else:
             order_d = nat
+        if self.split:
+            c1p = self.srcs[1].C
+            h, sg = (c0p, c0r, 0), (c1p, c1r, 0)
+            self.pf = _pack_desc(nat, co_p, c0p, osegs, h, sj_f, sk_f)
+            self.pd = _pack_desc(nat, c0p, co_p, h, osegs, sk_f, sj_f)
+            self.pu = self.pf
+            self.pf_s = _pack_desc(nat, co_p, c1p, osegs, sg, sj_f, sk_f)
+            self.pd_s = _pack_desc(nat, c1p, co_p, sg, osegs, sk_f, sj_f)
+            self.s_off = c0r * sk_f                  # element offset of the skip half inside the fp32 weight
+            self.wt_f = torch.empty(kk, co_p, c0p, dtype=torch.bfloat16, device=dev)
+            self.wt_f_s = torch.empty(kk, co_p, c1p, dtype=torch.bfloat16, device=dev)
+            self.wt_d = torch.empty(kk, c0p, co_p, dtype=torch.bfloat16, device=dev) if self.training else None
+            self.wt_d_s = torch.empty(kk, c1p, co_p, dtype=torch.bfloat16, device=dev) if self.training else None
+            return
         self.pf = _pack_desc(order_f, co_p, self.ctot, osegs, isegs, sj_f, sk_f)
         self.pd = _pack_desc(order_d, self.ctot, co_p, isegs, osegs, sk_f, sj_f)
         self.pu = _pack_desc(nat, co_p, self.ctot, osegs, isegs, sj_f, sk_f)
@@ -178,12 +207,24 @@ class Block:
         L.call('srvp_pack_weight', L.ptr(w), L.ptr(self.wt_f), C.byref(self.pf), st)
         if self.wt_d is not None:
             L.call('srvp_pack_weight', L.ptr(w), L.ptr(self.wt_d), C.byref(self.pd), st)
+        if self.split:
+            ws = L.ptr(w) + 4 * self.s_off
+            L.call('srvp_pack_weight', ws, L.ptr(self.wt_f_s), C.byref(self.pf_s), st)
+            if self.wt_d_s is not None:
+                L.call('srvp_pack_weight', ws, L.ptr(self.wt_d_s), C.byref(self.pd_s), st)
 
     # ------------------------------------------------------------------ descriptors
-    def _src_fields(self, d):
+    def _src_fields(self, d, which=None):
+        """which: None = all sources; 'h' / 's' = main / skip half only (hoisted skip)."""
+        if which == 's':
+            f1 = self.srcs[1]
+            d.src0, d.C0, d.H0p, d.W0p, d.ups0 = L.ptr(f1.t), f1.C, f1.Hp, f1.Wp, 0
+            d.src1, d.C1, d.H1p, d.W1p, d.ups1, d.map1 = None, 0, 1, 1, 0, None
+            d.map0 = L.ptr(self.skip_sel)
+            return
         f0 = self.srcs[0]
         d.src0, d.C0, d.H0p, d.W0p, d.ups0 = L.ptr(f0.t), f0.C, f0.Hp, f0.Wp, 1 if self.ups else 0
-        if len(self.srcs) > 1:
+        if len(self.srcs) > 1 and which != 'h':
             f1 = self.srcs[1]
             d.src1, d.C1, d.H1p, d.W1p, d.ups1 = L.ptr(f1.t), f1.C, f1.Hp, f1.Wp, 0
             d.map1 = L.ptr(self.skip_map)
@@ -210,7 +251,27 @@ class Block:
             else:
                 d.out_f32, d.out_nc, d.out_sigmoid = None, 0, 0
             out.append(d)
-        if self.geom in ('same', 'down', 'full', 'sameT'):
+        if self.split:
+            off = b_in - self.p
+            taps = [(kh + off, kw + off) for kh in range(k) for kw in range(k)]
+            ds = L.ConvDesc()                     # conv_s(skip): once per sample, fp32 out
+            self._src_fields(ds, 's')
+            self._set_taps(ds, taps)
+            ds.si, ds.wt, ds.Cout = 1, L.ptr(self.wt_f_s), self.cout
+            ds.N, ds.OH, ds.OW = self.B, self.OH, self.OW
+            ds.dst, ds.DHp, ds.DWp, ds.so, ds.ooy, ds.oox, ds.Cdst, ds.cdst_off = L.ptr(self.S), self.OH, self.OW, 1, 0, 0, self.cout, 0
+            ds.dst_is_f32, ds.stats, ds.stat_mod = 1, None, 1
+            out.append(ds)
+            d = L.ConvDesc()                      # conv_h(h_t) + S[sample]
+            self._src_fields(d, 'h')
+            self._set_taps(d, taps)
+            d.si, d.wt, d.Cout = 1, L.ptr(self.wt_f), self.cout
+            d.N, d.OH, d.OW = N, self.OH, self.OW
+            d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox, d.Cdst, d.cdst_off = dst_ptr, self.OH, self.OW, 1, 0, 0, self.cout, 0
+            d.stats, d.stat_mod = (L.ptr(self.stats) if use_stats else None), self.cout
+            d.add_f32, d.add_mod = L.ptr(self.S), self.B
+            finish(d)
+        elif self.geom in ('same', 'down', 'full', 'sameT'):
             d = L.ConvDesc()
             self._src_fields(d)
             if self.geom == 'sameT':
@@ -265,11 +326,24 @@ class Block:
         if self.geom == 'same':
             d = base()
             # dIn[i] = sum_kh dOut[i + p - kh]  -> padded coordinate i + p - kh + bd
-            self._set_taps(d, [(self.p - kh + bd, self.p - kw + bd) for kh in range(k) for kw in range(k)])
+            taps = [(self.p - kh + bd, self.p - kw + bd) for kh in range(k) for kw in range(k)]
+            self._set_taps(d, taps)
             d.si, d.wt = 1, L.ptr(self.wt_d)
             d.N, d.OH, d.OW = N, self.Hin, self.Win
+            d.Cout, d.Cdst = self.dcat_c, self.dcat_c
             d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox = L.ptr(self.dcat), self.Hin, self.Win, 1, 0, 0
             out.append(d)
+            if self.split:
+                # gradient wrt the skip tensor of each sample = data-gradient of the time-summed output gradient
+                d2 = base()
+                d2.src0 = L.ptr(self.draw_sum)
+                self._set_taps(d2, taps)
+                d2.si, d2.wt = 1, L.ptr(self.wt_d_s)
+                d2.N, d2.OH, d2.OW = self.B, self.Hin, self.Win
+                c1p = self.srcs[1].C
+                d2.Cout, d2.Cdst = c1p, c1p
+                d2.dst, d2.DHp, d2.DWp, d2.so, d2.ooy, d2.oox = L.ptr(self.dsel), self.Hin, self.Win, 1, 0, 0
+                out.append(d2)
         elif self.geom == 'sameT':
             d = base()
             # dIn[i] = sum_kh dOut[i - p + kh] W[ci][co][kh]  -> padded coordinate i - p + kh + bd
@@ -314,9 +388,14 @@ class Block:
         return out
 
     def wgrad_desc(self):
+        if self.split:
+            return [self._wgrad_one('h'), self._wgrad_one('s')]
+        return self._wgrad_one(None)
+
+    def _wgrad_one(self, which):
         k, N, bd = self.k, self.N, self.draw_b
         d = L.WgradDesc()
-        self._src_fields(d)
+        self._src_fields(d, which)
         b_in = self.srcs[0].b
         nat = [(kh, kw) for kh in range(k) for kw in range(k)]
         d.ntaps = k * k
@@ -344,6 +423,11 @@ class Block:
             d.ooy, d.oox = L.taps([kh for kh, _ in nat]), L.taps([kw for _, kw in nat])
             d.N, d.OH, d.OW = N, 1, 1
         d.dw = L.ptr(self.dw)
+        ctot = self.ctot
+        if which == 's':
+            d.dout, d.N, d.dw, ctot = L.ptr(self.draw_sum), self.B, L.ptr(self.dw_s), self.srcs[1].C
+        elif which == 'h':
+            ctot = self.srcs[0].C
         # split-K: enough workgroups to fill the chip, but no more than one per 4 pixel chunks
         M = d.N * d.OH * d.OW
         bj = 128 if self.cout % 128 == 0 else (64 if self.cout % 64 == 0 else 32)
@@ -353,7 +437,7 @@ class Block:
             if c0 % cand == 0 and (c1 == 0 or c1 % cand == 0):
                 bc = cand
                 break
-        tiles = (self.cout // bj) * (self.ctot // bc) * k * k
+        tiles = (self.cout // bj) * (ctot // bc) * k * k
         chunks = (M + 31) // 32
         d.splitk = int(max(1, min((1024 + tiles - 1) // tiles, chunks // 4 if chunks >= 4 else 1)))
         return d
@@ -423,9 +507,21 @@ class ConvNetBase:
         L.call('srvp_bn_bwd_apply', C.byref(d), L.ptr(blk.bcoef), L.ptr(blk.draw), blk.draw_b, st)
 
     def _mfma_backward(self, blk, grads, st, need_dgrad=True):
+        gw = grads[blk.spec['key'] + '.weight']
         blk.dw.zero_()
-        L.call('srvp_wgrad_mfma', C.byref(blk._wg), st)
-        L.call('srvp_unpack_wgrad', L.ptr(blk.dw), L.ptr(grads[blk.spec['key'] + '.weight']), C.byref(blk.pu), st)
+        if blk.split:
+            # time-summed output gradient per sample (feeds the skip half's weight and data gradients)
+            T = blk.N // blk.B
+            L.call('srvp_skip_grad_reduce', L.ptr(blk.draw), blk.cout, 0, blk.cout, (blk.OH + 2) * (blk.OW + 2), T, blk.B,
+                   L.ptr(blk.draw_sum), st)
+            blk.dw_s.zero_()
+            L.call('srvp_wgrad_mfma', C.byref(blk._wg[0]), st)
+            L.call('srvp_wgrad_mfma', C.byref(blk._wg[1]), st)
+            L.call('srvp_unpack_wgrad', L.ptr(blk.dw), L.ptr(gw), C.byref(blk.pf), st)
+            L.call('srvp_unpack_wgrad', L.ptr(blk.dw_s), L.ptr(gw) + 4 * blk.s_off, C.byref(blk.pf_s), st)
+        else:
+            L.call('srvp_wgrad_mfma', C.byref(blk._wg), st)
+            L.call('srvp_unpack_wgrad', L.ptr(blk.dw), L.ptr(gw), C.byref(blk.pu), st)
         if need_dgrad:
             for d in blk._dg:
                 L.call('srvp_conv_mfma', C.byref(d), st)
@@ -494,13 +590,15 @@ class EncoderNet(ConvNetBase):
             else:
                 self._mfma_backward(blk, grads, st)
                 pooled = blk.spec['pre'] == 'pool'
-                da = dict(t=blk.dcat, mode=2 if pooled else 0, cstride=blk.ctot, coff=0, border=0)
+                da = dict(t=blk.dcat, mode=2 if pooled else 0, cstride=blk.dcat_c, coff=0, border=0)
 
 
 class DecoderNet(ConvNetBase):
     """conv.py:249-275 on N = nt*B latent rows: z (N, nz) -> x_ fp32 (N, C, 64, 64); skips come from an EncoderNet."""
 
-    def __init__(self, specs, N, device, training, skip_feats=None, skip_map=None):
+    def __init__(self, specs, N, device, training, skip_feats=None, skip_map=None, skip_sel=None):
+        """skip_map: int32 [N] frame -> image of the skip tensors; skip_sel: int32 [B] sample -> image (enables the
+        hoisted skip half; frames are ordered t*B + b)."""
         self.N, self.dev, self.training = N, device, training
         self.blocks = []
         z_r = specs[0]['cin']
@@ -512,7 +610,8 @@ class DecoderNet(ConvNetBase):
             if sp['cat'] is not None:
                 srcs.append(skip_feats[sp['cat']])
             blk = Block(sp, 'out' if last else 'mfma', srcs, ups, N, device, training,
-                        skip_map=skip_map if sp['cat'] is not None else None)
+                        skip_map=skip_map if sp['cat'] is not None else None,
+                        skip_sel=skip_sel if sp['cat'] is not None else None)
             if not last:
                 blk.out = Feat(N, blk.OH, blk.OW, blk.cout_r, device)
                 cur, ups = blk.out, sp['post_up']
@@ -544,17 +643,25 @@ class DecoderNet(ConvNetBase):
         nxt = ob
         for i in range(len(self.blocks) - 2, -1, -1):
             blk = self.blocks[i]
-            da = dict(t=nxt.dcat, mode=1 if blk.spec['post_up'] else 0, cstride=nxt.ctot, coff=0, border=0)
+            da = dict(t=nxt.dcat, mode=1 if blk.spec['post_up'] else 0, cstride=nxt.dcat_c, coff=0, border=0)
             self._bn_backward(blk, params, grads, da, st, sync)
             self._mfma_backward(blk, grads, st)
             nxt = blk
         return self.blocks[0].dcat.view(self.N, -1)
 
-    def skip_grad_sources(self):
-        """{stage: (dcat tensor, cstride, coff, C, H*W)} for the blocks that consumed a skip connection."""
+    def skip_grads(self, T, B, st):
+        """{decoder skip index: bf16 [B][H*W][C] gradient wrt the skip tensor of each sample} (srvp.py:222-223: the skip
+        is expanded over time, so its gradient is the sum over the time steps)."""
         out = {}
         for blk in self.blocks:
-            if blk.spec['cat'] is not None:
-                f1 = blk.srcs[1]
-                out[blk.spec['cat']] = (blk.dcat, blk.ctot, blk.srcs[0].C, f1.C, f1.H * f1.W)
+            if blk.spec['cat'] is None:
+                continue
+            f1 = blk.srcs[1]
+            if blk.split:
+                out[blk.spec['cat']] = blk.dsel.view(B, f1.H * f1.W, f1.C)
+            else:
+                if not hasattr(blk, 'dsel'):
+                    blk.dsel = torch.empty(B, f1.H * f1.W, f1.C, dtype=torch.bfloat16, device=self.dev)
+                L.call('srvp_skip_grad_reduce', L.ptr(blk.dcat), blk.ctot, blk.srcs[0].C, f1.C, f1.H * f1.W, T, B, L.ptr(blk.dsel), st)
+                out[blk.spec['cat']] = blk.dsel
         return out

@@ -28,6 +28,7 @@ struct ConvK {
     bf16_t* dst; int DHp, DWp, so, ooy, oox, Cdst, cdst_off;
     double* stats; int stat_mod;
     float* out_f32; int out_nc, out_sigmoid;
+    const int* map0; int dst_is_f32; const float* add_f32; int add_mod;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
         // image index inside the second source (skip connection), resolved ONCE: an ordinary VGPR load inside the K
         // loop would make hipcc drain the whole LDS-DMA queue (s_waitcnt vmcnt(0)) at every use
         n1[i] = (a.C1 > 0 && a.map1) ? a.map1[n] : n;
+        if (a.map0) ri[i].n = a.map0[n];             // src0 indirection (hoisted skip half: images = samples)
     }
     // K order: channel chunk OUTER, tap INNER -- consecutive K steps re-read the same channel chunk at the 9 (16)
     // shifted pixel positions, i.e. mostly the same cache lines (reuse distance BM*BK*2 B = 16 KiB per workgroup),
@@ -180,6 +182,41 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
     // ---------------- epilogue ----------------
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int lcol = lane & 31, lhalf = lane >> 5;
+    if (a.add_f32) {
+        // + conv_s(skip) of this sample (fp32, computed once per sample by a dst_is_f32 launch)
+        const int hw = a.OH * a.OW;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                long long m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                if (m >= M) continue;
+                int n = (int)(m / hw);
+                int rr = (int)(m - (long long)n * hw);
+                const float* sp = a.add_f32 + ((size_t)(n % a.add_mod) * hw + rr) * a.Cout + n0 + wn * (TN * 32) + lcol;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j][r] += sp[j * 32];
+            }
+    }
+    if (a.dst_is_f32) {
+        float* dstf = reinterpret_cast<float*>(a.dst);
+        const int hw = a.OH * a.OW;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                long long m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                if (m >= M) continue;
+                int n = (int)(m / hw);
+                int rr = (int)(m - (long long)n * hw);
+                int oy = rr / a.OW, ox = rr - oy * a.OW;
+                float* dp = dstf + (((size_t)n * a.DHp + oy * a.so + a.ooy) * a.DWp + ox * a.so + a.oox) * a.Cdst + a.cdst_off + n0 +
+                            wn * (TN * 32) + lcol;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) dp[j * 32] = acc[i][j][r];
+            }
+        return;
+    }
     if (a.stats) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -277,6 +314,7 @@ int launch(const srvp_conv_desc* d, hipStream_t st) {
     k.dst = (bf16_t*)d->dst; k.DHp = d->DHp; k.DWp = d->DWp; k.so = d->so; k.ooy = d->ooy; k.oox = d->oox;
     k.Cdst = d->Cdst; k.cdst_off = d->cdst_off; k.stats = d->stats; k.stat_mod = d->stat_mod;
     k.out_f32 = d->out_f32; k.out_nc = d->out_nc; k.out_sigmoid = d->out_sigmoid;
+    k.map0 = d->map0; k.dst_is_f32 = d->dst_is_f32; k.add_f32 = d->add_f32; k.add_mod = d->add_mod;
     hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM, WN, NBUF>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, st, k);
     SRVP_CHECK_LAUNCH("srvp_conv_mfma");
     return SRVP_OK;

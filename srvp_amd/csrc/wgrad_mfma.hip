@@ -21,6 +21,7 @@ struct WgradK {
     const bf16_t* dout; int DHp, DWp, so, Cout;
     int N, OH, OW;
     float* dw; int splitk;
+    const int* map0;
     int lg_hw, lg_ow;          // log2 of OH*OW and OW when both are powers of two, else -1
 };
 
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(WJ * WC * 64) void wgrad_regstage_kernel(const Wgra
             decode(m < Mi ? m : Mi - 1, n, oy, ox);
             int vy = oy * a.si + dy, vx = ox * a.si + dx;
             vy = (vy + ups) >> ups; vx = (vx + ups) >> ups;
-            if (second && a.map1) n = a.map1[n];
+            if (second ? a.map1 != nullptr : a.map0 != nullptr) n = (second ? a.map1 : a.map0)[n];
             unsigned off = (((unsigned)n * Hp + vy) * Wp + vx) * C + cs + ch * 8;
             u32x4_t v = {0u, 0u, 0u, 0u};
             if (q < BP * YCH) v = *reinterpret_cast<const u32x4_t*>(src + off);
@@ -287,7 +288,8 @@ __global__ __launch_bounds__(WJ * WC * 64) void wgrad_mfma_kernel(const WgradK a
     const int dy = (int)((a.dy_bits >> (4 * t)) & 15), dx = (int)((a.dx_bits >> (4 * t)) & 15);
     const int ooy = (int)((a.ooy_bits >> (4 * t)) & 15), oox = (int)((a.oox_bits >> (4 * t)) & 15);
     const int hw = a.OH * a.OW;
-    const bool mapped = second && a.map1 != nullptr;
+    const int* mp = second ? a.map1 : a.map0;        // image indirection of this block's source
+    const bool mapped = mp != nullptr;
 
     // fixed (row, source chunk) of this thread's DMA pieces; narrow tiles are re-loaded by the upper waves (same
     // bytes to the same LDS address) so that every wave issues exactly G DMAs per step -- vmcnt is per wave.
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(WJ * WC * 64) void wgrad_mfma_kernel(const WgradK a
     };
 
     if (mapped) {
-        for (int i = tid; i < a.N; i += NT) maps[i] = a.map1[i];
+        for (int i = tid; i < a.N; i += NT) maps[i] = mp[i];
         __syncthreads();
     }
     f32x16_t acc[TJ][TC];
@@ -412,7 +414,7 @@ int launch(const WgradK& k, hipStream_t st, bool use_tr, bool dma_off) {
     const bool p2 = k.lg_ow >= 0;
     const dim3 g((unsigned)blocks), b(WJ * WC * 64);
     const long long Mtot = (long long)k.N * k.OH * k.OW;
-    if (use_tr && p2 && Mtot % 32 == 0 && !dma_off && (k.map1 == nullptr || k.N <= 4096)) {
+    if (use_tr && p2 && Mtot % 32 == 0 && !dma_off && ((k.map1 == nullptr && k.map0 == nullptr) || k.N <= 4096)) {
         hipLaunchKernelGGL((wgrad_mfma_kernel<BJ, BC, WJ, WC, 4>), g, b, 0, st, k);
         SRVP_CHECK_LAUNCH("srvp_wgrad_mfma");
         return SRVP_OK;
@@ -441,7 +443,7 @@ extern "C" int srvp_wgrad_mfma(const srvp_wgrad_desc* d, void* stream) {
         g_use_tr = e ? atoi(e) : 1;
     }
     WgradK k;
-    k.src0 = (const bf16_t*)d->src0; k.src1 = (const bf16_t*)d->src1; k.map1 = d->map1;
+    k.src0 = (const bf16_t*)d->src0; k.src1 = (const bf16_t*)d->src1; k.map1 = d->map1; k.map0 = d->map0;
     k.C0 = d->C0; k.C1 = d->C1; k.H0p = d->H0p; k.W0p = d->W0p; k.H1p = d->H1p; k.W1p = d->W1p;
     k.ups0 = d->ups0; k.ups1 = d->ups1; k.si = d->si; k.ntaps = d->ntaps;
     k.dy_bits = k.dx_bits = k.ooy_bits = k.oox_bits = 0;

@@ -204,9 +204,11 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             dev = self._device()
             enc = EncoderNet(self._enc_blocks, T * B, dev, training) if T > 0 else None
             skip_map = torch.zeros(nt * B, dtype=torch.int32, device=dev) if self.skipco else None
-            dec = DecoderNet(self._dec_blocks, nt * B, dev, training, enc.skips if (self.skipco and enc) else None, skip_map)
+            skip_sel = torch.zeros(B, dtype=torch.int32, device=dev) if self.skipco else None
+            dec = DecoderNet(self._dec_blocks, nt * B, dev, training, enc.skips if (self.skipco and enc) else None, skip_map,
+                             skip_sel)
             lat = LatentNet(self._cfg(), T, B, nt, n_euler, dev, training)
-            pl = dict(enc=enc, dec=dec, lat=lat, skip_map=skip_map)
+            pl = dict(enc=enc, dec=dec, lat=lat, skip_map=skip_map, skip_sel_t=skip_sel)
             # keep at most two training plans alive (they own all activation memory)
             if training:
                 for k in [k for k in self._plans if isinstance(k[0], int) and k[4]]:
@@ -262,6 +264,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             else:
                 sel = (T - 1) * B + ar
             pl['skip_map'].copy_(sel.repeat(nt))
+            pl['skip_sel_t'].copy_(sel)
             pl['skip_sel'] = sel
         w = lat.infer_w(hx, params, tape.get('t_w') if training else None, st)
         y0, q_y0 = lat.infer_y(hx[:self.nt_inf], params, tape['eps_y0'], st)
@@ -303,9 +306,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             skip_grads = {}
             idx = torch.full((T * B,), -1, dtype=torch.int32, device=d_hx.device)
             idx[pl['skip_sel'].long()] = torch.arange(B, dtype=torch.int32, device=d_hx.device)
-            for stage, (dcat, cstride, coff, Cc, HW) in dec.skip_grad_sources().items():
-                dsel = pl.setdefault(('dsel', stage), torch.empty(B, HW, Cc, dtype=torch.bfloat16, device=d_hx.device))
-                L.call('srvp_skip_grad_reduce', L.ptr(dcat), cstride, coff, Cc, HW, nt, B, L.ptr(dsel), st)
+            for stage, dsel in dec.skip_grads(nt, B, st).items():
                 skip_grads[stage] = (dsel, idx)
         nhp = cpad(self.nhx)
         if nhp != self.nhx:
@@ -372,7 +373,8 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             if self.skipco:
                 feats = {i: Feat(B, s.shape[2], s.shape[3], s.shape[1], dev) for i, s in enumerate(skip)}
                 skip_map = torch.arange(B, dtype=torch.int32, device=dev).repeat(nt)
-            dec = DecoderNet(self._dec_blocks, nt * B, dev, False, feats, skip_map)
+            dec = DecoderNet(self._dec_blocks, nt * B, dev, False, feats, skip_map,
+                             torch.arange(B, dtype=torch.int32, device=dev) if self.skipco else None)
             pl = dict(dec=dec, feats=feats)
             self._plans[key] = pl
         st = L.stream()

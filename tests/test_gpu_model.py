@@ -186,7 +186,7 @@ def test_full_width_vs_oracle(archi, nc, skipco, ne, B, T):
     if skipco:
         tape['t_skip'] = torch.randint(T, (B,), generator=g)
     hp = dict(obs_scale=0.2 if archi == 'vgg' else 1.0, beta_y=1.0, beta_z=1.0, l2_res=1.0)
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(8)          # NOT os.cpu_count(): hundreds of threads oversubscribe the small CPU convolutions
     scal, outs_ref, grads_ref = O.train_step({k: v.clone() for k, v in sd.items()}, O.make_cfg(*ctor), x, ne, tape, hp)
     O.PRECISION = 'bf16'
     try:
