@@ -65,6 +65,9 @@ typedef struct {
     const int32_t* map0; int32_t dst_is_f32; const float* add_f32; int32_t add_mod;
 } srvp_conv_desc;
 int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
+/* 1 (default): 3x3 stride-1 single-source convolutions run on the halo-tiled kernel (input patch staged in LDS once
+ * per channel chunk, taps = LDS offsets); 0: every convolution on the generic tap-gather kernel.  Same results, bit for bit. */
+int srvp_conv_set_halo(int on);
 
 /* Weight gradient of the same tap-table convolution (autograd of the modules above):
  *   dW[t][j][c] += sum_{n,oy,ox} dout[n, oy*so+ooy[t], ox*so+oox[t], j] * in_t[n, oy, ox, c]     (fp32 atomics)

@@ -34,6 +34,125 @@ struct ConvK {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// Shared epilogue of the MFMA convolution kernels.  `rowmap(row, n, oy, ox)` decodes tile row -> output pixel and
+// returns false for rows beyond the problem (masked).  smem is reused for the bf16 staging tile [BM][BN + 8]; the
+// caller has synchronised the workgroup after its last read of smem.
+// C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <int BM, int BN, int WM, int WN, int TM, int TN, class RowMap>
+__device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[TM][TN], const ConvK& a, unsigned char* smem, float* red, int n0,
+                                              const RowMap& rowmap) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int LDC = BN + 8;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int lcol = lane & 31, lhalf = lane >> 5;
+    const int hw = a.OH * a.OW;
+    if (a.add_f32) {
+        // + conv_s(skip) of this sample (fp32, computed once per sample by a dst_is_f32 launch)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int n, oy, ox;
+                if (!rowmap(wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf, n, oy, ox)) continue;
+                const float* sp = a.add_f32 + ((size_t)(n % a.add_mod) * hw + oy * a.OW + ox) * a.Cout + n0 + wn * (TN * 32) + lcol;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j][r] += sp[j * 32];
+            }
+    }
+    if (a.dst_is_f32) {
+        float* dstf = reinterpret_cast<float*>(a.dst);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int n, oy, ox;
+                if (!rowmap(wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf, n, oy, ox)) continue;
+                float* dp = dstf + (((size_t)n * a.DHp + oy * a.so + a.ooy) * a.DWp + ox * a.so + a.oox) * a.Cdst + a.cdst_off + n0 +
+                            wn * (TN * 32) + lcol;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) dp[j * 32] = acc[i][j][r];
+            }
+        return;
+    }
+    if (a.stats) {
+        bool ok[TM][16];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int n, oy, ox;
+                ok[i][r] = rowmap(wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf, n, oy, ox);
+            }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = ok[i][r] ? acc[i][j][r] : 0.f;
+                    s1 += v; s2 += v * v;
+                }
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (lhalf == 0) {
+                int col = wn * (TN * 32) + j * 32 + lcol;
+                red[(wm * BN + col) * 2 + 0] = s1;
+                red[(wm * BN + col) * 2 + 1] = s2;
+            }
+        }
+    }
+    if (a.out_f32) {
+        // image-side output layer: the first out_nc columns are the frame channels; sigmoid (reference
+        // conv.py:273-274) and a store into the fp32 (N, C, H, W) frame tensor of module/srvp.py:226.
+        if (lcol < a.out_nc && wn == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int n, oy, ox;
+                    if (!rowmap(wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf, n, oy, ox)) continue;
+                    float v = acc[i][0][r];
+                    if (a.out_sigmoid) v = 1.f / (1.f + __expf(-v));
+                    a.out_f32[(((size_t)n * a.out_nc + lcol) * a.DHp + oy * a.so + a.ooy) * a.DWp + ox * a.so + a.oox] = v;
+                }
+        }
+        return;
+    }
+    bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);     // [BM][LDC], reuses the A/B buffers (all waves are past the loop)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                int col = wn * (TN * 32) + j * 32 + lcol;
+                Cs[row * LDC + col] = f2bf(acc[i][j][r]);
+            }
+    __syncthreads();
+    if (a.stats && tid < BN) {
+        double s1 = 0., s2 = 0.;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { s1 += red[(w * BN + tid) * 2]; s2 += red[(w * BN + tid) * 2 + 1]; }
+        int ch = (n0 + tid) % a.stat_mod;
+        atomicAdd(a.stats + ch, s1);
+        atomicAdd(a.stats + a.stat_mod + ch, s2);
+    }
+    constexpr int CCH = BN / 8;
+    bf16_t* dst = a.dst;
+    for (int q = tid; q < BM * CCH; q += NT) {
+        int row = q / CCH, ch = q % CCH;
+        int n, oy, ox;
+        if (!rowmap(row, n, oy, ox)) continue;
+        size_t off = (((size_t)n * a.DHp + oy * a.so + a.ooy) * a.DWp + ox * a.so + a.oox) * a.Cdst + a.cdst_off + n0 + ch * 8;
+        *reinterpret_cast<u32x4_t*>(dst + off) = *reinterpret_cast<const u32x4_t*>(Cs + row * LDC + ch * 8);
+    }
+}
+
+
 template <int BM, int BN, int BK, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) {
     constexpr int NT = WM * WN * 64;
@@ -180,127 +299,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
     __syncthreads();                                 // every wave is done reading the ring: the epilogue reuses it
 
     // ---------------- epilogue ----------------
-    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int lcol = lane & 31, lhalf = lane >> 5;
-    if (a.add_f32) {
-        // + conv_s(skip) of this sample (fp32, computed once per sample by a dst_is_f32 launch)
-        const int hw = a.OH * a.OW;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                long long m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                if (m >= M) continue;
-                int n = (int)(m / hw);
-                int rr = (int)(m - (long long)n * hw);
-                const float* sp = a.add_f32 + ((size_t)(n % a.add_mod) * hw + rr) * a.Cout + n0 + wn * (TN * 32) + lcol;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j][r] += sp[j * 32];
-            }
-    }
-    if (a.dst_is_f32) {
-        float* dstf = reinterpret_cast<float*>(a.dst);
-        const int hw = a.OH * a.OW;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                long long m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                if (m >= M) continue;
-                int n = (int)(m / hw);
-                int rr = (int)(m - (long long)n * hw);
-                int oy = rr / a.OW, ox = rr - oy * a.OW;
-                float* dp = dstf + (((size_t)n * a.DHp + oy * a.so + a.ooy) * a.DWp + ox * a.so + a.oox) * a.Cdst + a.cdst_off + n0 +
-                            wn * (TN * 32) + lcol;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) dp[j * 32] = acc[i][j][r];
-            }
-        return;
-    }
-    if (a.stats) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    long long m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                    float v = (m < M) ? acc[i][j][r] : 0.f;
-                    s1 += v; s2 += v * v;
-                }
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
-            if (lhalf == 0) {
-                int col = wn * (TN * 32) + j * 32 + lcol;
-                red[(wm * BN + col) * 2 + 0] = s1;
-                red[(wm * BN + col) * 2 + 1] = s2;
-            }
-        }
-    }
-    if (a.out_f32) {
-        // image-side output layer: the first out_nc columns are the frame channels; sigmoid (reference
-        // conv.py:273-274) and a store into the fp32 (N, C, H, W) frame tensor of module/srvp.py:226.
-        if (lcol < a.out_nc && wn == 0) {
-            const int hw = a.OH * a.OW;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    long long m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                    if (m >= M) continue;
-                    int n = (int)(m / hw);
-                    int rr = (int)(m - (long long)n * hw);
-                    int oy = rr / a.OW, ox = rr - oy * a.OW;
-                    float v = acc[i][0][r];
-                    if (a.out_sigmoid) v = 1.f / (1.f + __expf(-v));
-                    a.out_f32[(((size_t)n * a.out_nc + lcol) * a.DHp + oy * a.so + a.ooy) * a.DWp + ox * a.so + a.oox] = v;
-                }
-        }
-        return;
-    }
-    bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);     // [BM][LDC], reuses the A/B buffers (all waves are past the loop)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                int col = wn * (TN * 32) + j * 32 + lcol;
-                Cs[row * LDC + col] = f2bf(acc[i][j][r]);
-            }
-    __syncthreads();
-    if (a.stats && tid < BN) {
-        double s1 = 0., s2 = 0.;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) { s1 += red[(w * BN + tid) * 2]; s2 += red[(w * BN + tid) * 2 + 1]; }
-        int ch = (n0 + tid) % a.stat_mod;
-        atomicAdd(a.stats + ch, s1);
-        atomicAdd(a.stats + a.stat_mod + ch, s2);
-    }
-    constexpr int CCH = BN / 8;
-    bf16_t* dst = a.dst;
-    for (int q = tid; q < BM * CCH; q += NT) {
-        int row = q / CCH, ch = q % CCH;
+    const int hw_ = a.OH * a.OW;
+    auto rowmap = [&](int row, int& n, int& oy, int& ox) -> bool {
         long long m = m0 + row;
-        if (m >= M) continue;
-        int hw = a.OH * a.OW;
-        int n = (int)(m / hw);
-        int r = (int)(m - (long long)n * hw);
-        int oy = r / a.OW, ox = r - oy * a.OW;
-        size_t off = (((size_t)n * a.DHp + oy * a.so + a.ooy) * a.DWp + ox * a.so + a.oox) * a.Cdst + a.cdst_off + n0 + ch * 8;
-        *reinterpret_cast<u32x4_t*>(dst + off) = *reinterpret_cast<const u32x4_t*>(Cs + row * LDC + ch * 8);
-    }
+        if (m >= M) return false;
+        n = (int)(m / hw_);
+        int r = (int)(m - (long long)n * hw_);
+        oy = r / a.OW; ox = r - oy * a.OW;
+        return true;
+    };
+    conv_epilogue<BM, BN, WM, WN, TM, TN>(acc, a, smem, red, n0, rowmap);
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NBUF>
-int launch(const srvp_conv_desc* d, hipStream_t st) {
-    long long M = (long long)d->N * d->OH * d->OW;
-    long long mt = (M + BM - 1) / BM;
-    long long blocks = mt * (d->Cout / BN);
-    SRVP_REQUIRE(blocks > 0 && blocks < (1ll << 31), "srvp_conv_mfma: bad grid %lld", blocks);
-    ConvK k;
+static int fill_convk(const srvp_conv_desc* d, ConvK& k) {
     k.src0 = (const bf16_t*)d->src0; k.src1 = (const bf16_t*)d->src1; k.map1 = d->map1;
     k.C0 = d->C0; k.C1 = d->C1; k.H0p = d->H0p; k.W0p = d->W0p; k.H1p = d->H1p; k.W1p = d->W1p;
     k.ups0 = d->ups0; k.ups1 = d->ups1; k.si = d->si; k.ntaps = d->ntaps;
@@ -315,12 +326,224 @@ int launch(const srvp_conv_desc* d, hipStream_t st) {
     k.Cdst = d->Cdst; k.cdst_off = d->cdst_off; k.stats = d->stats; k.stat_mod = d->stat_mod;
     k.out_f32 = d->out_f32; k.out_nc = d->out_nc; k.out_sigmoid = d->out_sigmoid;
     k.map0 = d->map0; k.dst_is_f32 = d->dst_is_f32; k.add_f32 = d->add_f32; k.add_mod = d->add_mod;
+    return SRVP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Halo-tiled 3x3 stride-1 convolution ("same" convs, their data-gradients, and the nearest-x2-upsampled variants):
+// the workgroup owns a 256-pixel SPATIAL tile (16x16 pixels of one image, or whole 8x8 / 4x4 images) and stages the
+// input patch including its 1-pixel halo in LDS ONCE per 64-channel chunk; the 9 taps are then LDS address offsets,
+// so the activation traffic from L2 drops ~6.5x versus re-gathering the rows per tap (the generic kernel above), and
+// only the (small) weight tiles stream through a 2-deep LDS-DMA ring, one tap ahead of the MFMAs.
+//
+// Patch layout in LDS: [pixel][64 ch] (128-byte rows, 16-byte chunks XOR-swizzled by (pixel >> 1) & 7).  Two modes:
+//   halo    (tile smaller than the image): pixel = py * PW + px over the (fh+2) x (fw+2) source window;
+//   compact (tile = IMG whole images): rows of PW = fw+1 pixels, fh+1 rows per image: the right border pixel of a
+//           row IS the left border pixel of the next row and the bottom border row of an image IS the top border row
+//           of the next one (all zeros, physically present in the source), which keeps four 8x8 images at 334 pixels.
+struct HaloK {
+    ConvK a;
+    int TH, TW, lgTW, lgTHW, IMG, PW, IS, Ppix, NA, tiles_x, tiles_y;
+};
+
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_halo_kernel(const HaloK p) {
+    constexpr int BM = 256, BK = 64, NT = 256, CPR = 8;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int NA_MAX = 11;                           // 11 * 256 16-byte pieces = 352 pixels >= 334
+    constexpr int A_BYTES = NA_MAX * NT * 16;
+    constexpr int B_LD = BN * CPR / NT;
+    constexpr int B_BYTES = 2 * BN * BK * 2;
+    constexpr int LDC = BN + 8;
+    constexpr int C_BYTES = BM * LDC * 2;
+    constexpr int SMEM = (A_BYTES + B_BYTES) > C_BYTES ? (A_BYTES + B_BYTES) : C_BYTES;
+    static_assert(WM * WN == 4 && (BN * CPR) % NT == 0, "4 waves; weight tile = whole 1 KiB DMA pieces per wave");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM + WM * BN * 8];
+    unsigned char* Ab = smem;                                             // [<=352 px][64] bf16
+    bf16_t* Bs = reinterpret_cast<bf16_t*>(smem + A_BYTES);               // [2][BN][64]
+    float* red = reinterpret_cast<float*>(smem + SMEM);
+
+    const ConvK& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int n_tiles = a.Cout / BN;
+    const int n0 = (lb % n_tiles) * BN;
+    unsigned sp = lb / n_tiles;
+    const int tx = sp % p.tiles_x; sp /= p.tiles_x;
+    const int ty = sp % p.tiles_y;
+    const int nb0 = (sp / p.tiles_y) * p.IMG;
+    const int y0 = ty * p.TH, x0 = tx * p.TW;
+    const int ups = a.ups0 ? 1 : 0;
+    const int sy0 = y0 >> ups, sx0 = x0 >> ups;
+    const int C = a.C0;
+
+    // ---- patch DMA sources (fixed over the K loop except for the channel-chunk offset)
+    unsigned aoff[NA_MAX];
+#pragma unroll
+    for (int i = 0; i < NA_MAX; ++i) {
+        const int q = tid + i * NT;
+        const int pix = q >> 3, pos = q & 7;
+        int img = pix / p.IS;
+        const int rem = pix - img * p.IS;
+        int py = rem / p.PW, px = rem - py * p.PW;
+        int Y = sy0 + py, X = sx0 + px;
+        if (pix >= p.Ppix || img >= p.IMG) { img = 0; Y = 0; X = 0; }      // padding / trailing pieces: a zero border pixel
+        int n = nb0 + img;
+        if (n >= a.N) n = a.N - 1;
+        if (a.map0) n = a.map0[n];
+        aoff[i] = (((unsigned)n * a.H0p + Y) * a.W0p + X) * C + ((pos ^ ((pix >> 1) & 7)) * 8);
+    }
+    // ---- fragment rows of this lane
+    const int lrow = lane & 31, lkc = lane >> 5;
+    int abase[TM], aoy[TM], aox[TM], b_off[TN], b_sw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * (TM * 32) + i * 32 + lrow;
+        abase[i] = (r >> p.lgTHW) * p.IS;
+        aoy[i] = (r >> p.lgTW) & (p.TH - 1);
+        aox[i] = r & (p.TW - 1);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { const int r = wn * (TN * 32) + j * 32 + lrow; b_off[j] = r * BK; b_sw[j] = (r >> 1) & 7; }
+
+    const int ntaps = a.ntaps;
+    const int S = ntaps * (C / BK);
+    auto stage_a = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < NA_MAX; ++i)
+            if (i < p.NA)
+                __builtin_amdgcn_global_load_lds((gptr_t)(a.src0 + aoff[i] + cc * BK), (lptr_t)(Ab + ((size_t)i * NT + wid * 64) * 16), 16, 0, 0);
+    };
+    auto stage_b = [&](int s) {
+        const int cc = s / ntaps, t = s - cc * ntaps;
+        const bf16_t* w = a.wt + ((size_t)t * a.Cout + n0) * C + cc * BK;
+        bf16_t* Bd = Bs + (size_t)(s & 1) * BN * BK;
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int q = tid + i * NT;
+            const int row = q >> 3, ch = (q & 7) ^ ((row >> 1) & 7);
+            __builtin_amdgcn_global_load_lds((gptr_t)(w + (size_t)row * C + ch * 8), (lptr_t)(Bd + ((size_t)i * NT + wid * 64) * 8), 16, 0, 0);
+        }
+    };
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    stage_a(0);
+    stage_b(0);
+    int t = 0;
+    for (int s = 0; s < S; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // patch + weights of step s landed; everyone is past step s-1
+        asm volatile("" ::: "memory");
+        const bool last_tap = (t == ntaps - 1);
+        if (!last_tap) stage_b(s + 1);                    // next tap of the same chunk streams in under the MFMAs
+        const int dy = (int)((a.dy_bits >> (4 * t)) & 15), dx = (int)((a.dx_bits >> (4 * t)) & 15);
+        int apix[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int vy = (aoy[i] + dy + ups) >> ups, vx = (aox[i] + dx + ups) >> ups;
+            apix[i] = abase[i] + vy * p.PW + vx;
+        }
+        const bf16_t* Bb = Bs + (size_t)(s & 1) * BN * BK;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8_t af[TM], bfr[TN];
+            const int kc = kk * 2 + lkc;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + (size_t)apix[i] * 128 + ((kc ^ ((apix[i] >> 1) & 7)) * 16));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bb + b_off[j] + ((kc ^ b_sw[j]) * 8));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (last_tap) {
+            t = 0;
+            if (s + 1 < S) {
+                __builtin_amdgcn_s_barrier();             // every wave is done with this chunk's patch
+                asm volatile("" ::: "memory");
+                stage_a((s + 1) / ntaps);
+                stage_b(s + 1);
+            }
+        } else {
+            ++t;
+        }
+    }
+    __syncthreads();
+
+    auto rowmap = [&](int row, int& n, int& oy, int& ox) -> bool {
+        n = nb0 + (row >> p.lgTHW);
+        oy = y0 + ((row >> p.lgTW) & (p.TH - 1));
+        ox = x0 + (row & (p.TW - 1));
+        return n < a.N;
+    };
+    conv_epilogue<BM, BN, WM, WN, TM, TN>(acc, a, smem, red, n0, rowmap);
+}
+
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+static int g_halo = -1;      // -1: read SRVP_CONV_HALO on first use; 0 = generic kernel only; 1 = halo kernel where eligible
+
+// Tile geometry of the halo kernel for this descriptor; false if the descriptor is not a 3x3 stride-1 single-source
+// convolution on a 1-pixel-bordered tensor (or its patch does not fit) -- the generic kernel takes it then.
+static bool halo_geometry(const srvp_conv_desc* d, HaloK& h) {
+    if (g_halo < 0) { const char* e = getenv("SRVP_CONV_HALO"); g_halo = e ? atoi(e) : 1; }
+    if (!g_halo) return false;
+    if (d->ntaps != 9 || d->si != 1 || d->C1 != 0 || d->C0 % 64 != 0) return false;
+    for (int t = 0; t < 9; ++t) if (d->dy[t] < 0 || d->dy[t] > 2 || d->dx[t] < 0 || d->dx[t] > 2) return false;
+    const int OH = d->OH, OW = d->OW, ups = d->ups0 ? 1 : 0;
+    if (OH < 2 || OW < 2 || (OH & (OH - 1)) || (OW & (OW - 1))) return false;
+    if (d->H0p != (OH >> ups) + 2 || d->W0p != (OW >> ups) + 2) return false;
+    const bool compact = OH * OW <= 256;
+    if (!compact && (OH % 16 || OW % 16)) return false;
+    h.TH = compact ? OH : 16; h.TW = compact ? OW : 16;
+    h.IMG = 256 / (h.TH * h.TW);
+    h.lgTW = ilog2(h.TW); h.lgTHW = ilog2(h.TH * h.TW);
+    const int fh = h.TH >> ups, fw = h.TW >> ups;
+    if (compact) { h.PW = fw + 1; h.IS = (fh + 1) * h.PW; h.Ppix = h.IMG * h.IS + h.PW + 1; }
+    else { h.PW = fw + 2; h.IS = (fh + 2) * h.PW; h.Ppix = h.IS; }
+    h.NA = (h.Ppix * 8 + 255) / 256;
+    if (h.NA > 11) return false;
+    h.tiles_x = OW / h.TW; h.tiles_y = OH / h.TH;
+    return true;
+}
+
+template <int BN, int WM, int WN>
+int launch_halo(const srvp_conv_desc* d, HaloK& h, hipStream_t st) {
+    if (int rc = fill_convk(d, h.a)) return rc;
+    long long blocks = (long long)((d->N + h.IMG - 1) / h.IMG) * h.tiles_x * h.tiles_y * (d->Cout / BN);
+    SRVP_REQUIRE(blocks > 0 && blocks < (1ll << 31), "srvp_conv_mfma(halo): bad grid %lld", blocks);
+    hipLaunchKernelGGL((conv_halo_kernel<BN, WM, WN>), dim3((unsigned)blocks), dim3(256), 0, st, h);
+    SRVP_CHECK_LAUNCH("srvp_conv_mfma(halo)");
+    return SRVP_OK;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int NBUF>
+int launch(const srvp_conv_desc* d, hipStream_t st) {
+    long long M = (long long)d->N * d->OH * d->OW;
+    long long mt = (M + BM - 1) / BM;
+    long long blocks = mt * (d->Cout / BN);
+    SRVP_REQUIRE(blocks > 0 && blocks < (1ll << 31), "srvp_conv_mfma: bad grid %lld", blocks);
+    ConvK k;
+    if (int rc = fill_convk(d, k)) return rc;
     hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM, WN, NBUF>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, st, k);
     SRVP_CHECK_LAUNCH("srvp_conv_mfma");
     return SRVP_OK;
 }
 
 }  // namespace
+
+extern "C" int srvp_conv_set_halo(int on) { g_halo = on; return SRVP_OK; }
 
 extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -334,6 +557,12 @@ extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
     SRVP_REQUIRE(d->stats == nullptr || d->stat_mod > 0, "srvp_conv_mfma: stat_mod");
     SRVP_REQUIRE((long long)d->N * d->H0p * d->W0p * d->C0 < (1ll << 32) && (d->C1 == 0 || d->map1 || (long long)d->N * d->H1p * d->W1p * d->C1 < (1ll << 32)),
                  "srvp_conv_mfma: source tensors must have fewer than 2^32 elements");
+    HaloK h;
+    if (halo_geometry(d, h)) {
+        if (d->Cout % 128 == 0) return launch_halo<128, 2, 2>(d, h, st);
+        if (d->Cout % 64 == 0) return launch_halo<64, 4, 1>(d, h, st);
+        return launch_halo<32, 4, 1>(d, h, st);
+    }
     const bool k64 = (d->C0 % 64 == 0) && (d->C1 % 64 == 0);
     // LDS ring depth / K step (A/B switch SRVP_CONV_MODE): 5 = BK64 single buffer (default: 3 workgroups per CU hide the
     // DMA latency better than a deeper ring at 1-2 workgroups per CU: 39.0 vs 40.9 (x2) / 43 (BK32 x3) / 46 (BK32 x4) /

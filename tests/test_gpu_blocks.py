@@ -40,6 +40,10 @@ CASES = [
     ('conv', 3, 1, 1, 64, 0, False, 32, 64, 2),        # BN=64
     ('conv', 3, 1, 1, 128, 128, True, 8, 128, 3),      # upsample + skip concat (decoder stage entry)
     ('conv', 3, 1, 1, 24, 24, True, 8, 40, 2),         # padded channels everywhere, BK=32
+    ('conv', 3, 1, 1, 64, 0, True, 8, 128, 3),         # halo kernel: upsampled source, whole 16x16 images
+    ('conv', 3, 1, 1, 64, 0, False, 64, 64, 1),        # halo kernel: 16x16 interior tiles of a 64x64 image
+    ('conv', 3, 1, 1, 128, 0, False, 8, 64, 6),        # halo kernel: four 8x8 images per tile, ragged image count
+    ('conv', 3, 1, 1, 64, 0, True, 4, 64, 5),          # halo kernel: 4x4 -> 8x8 upsampled, ragged
     ('conv', 4, 2, 1, 64, 0, False, 16, 128, 2),       # DCGAN encoder stride 2
     ('conv', 4, 1, 0, 64, 0, False, 4, 128, 5),        # encoder last_conv ("full")
     ('convT', 4, 2, 1, 64, 64, False, 8, 64, 2),       # DCGAN decoder (4 phases) with skip
@@ -121,6 +125,104 @@ def test_block_conv_fwd_bwd(case, use_tr):
     if c1r:
         d1 = dcat[..., c0p:c0p + c1r].permute(0, 3, 1, 2)
         assert rel_err(d1, xin.grad[:, c0r:]) < 2 ** -7
+
+
+HALO_CASES = [
+    # c0r, cout, Hs, ups, N, role
+    (64, 64, 64, False, 2, 'mfma'), (128, 128, 32, False, 3, 'mfma'), (64, 256, 16, False, 5, 'mfma'),
+    (128, 64, 8, False, 6, 'mfma'), (192, 96, 8, False, 7, 'mfma'),
+    (64, 128, 4, True, 5, 'mfma'), (64, 64, 8, True, 3, 'mfma'), (128, 64, 16, True, 2, 'mfma'), (64, 64, 32, True, 1, 'mfma'),
+    (64, 3, 64, False, 2, 'out'), (64, 1, 32, False, 3, 'out'),
+]
+
+
+@pytest.mark.parametrize('case', HALO_CASES, ids=[f'{c[0]}to{c[1]}_{c[2]}{"up" if c[3] else ""}_n{c[4]}_{c[5]}' for c in HALO_CASES])
+def test_conv_halo_matches_generic(case):
+    """The halo-tiled 3x3 kernel and the generic tap-gather kernel accumulate in the same order: bit-identical raw
+    outputs / frames / data-gradients; BN statistics equal up to the fp32 per-tile partial sums."""
+    from srvp_amd import _lib as L
+    from srvp_amd.convnet import Block
+    c0r, cout, Hs, ups, N, role = case
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(11)
+    f0 = make_feat(N, Hs, Hs, c0r, dev, g)
+    kind = 'convT' if role == 'out' else 'conv'
+    spec = dict(kind=kind, key='w', bnkey=None if role == 'out' else 'bn', cin=c0r, cout=cout, k=3, s=1, p=1,
+                act='sigmoid' if role == 'out' else 'leaky_relu')
+    blk = Block(spec, role, [f0], ups, N, dev, True)
+    blk._fwd, blk._dg = blk.fwd_descs(), blk.dgrad_descs()
+    wshape = (cout, c0r, 3, 3) if kind == 'conv' else (c0r, cout, 3, 3)
+    w = (torch.randn(*wshape, generator=g) * 0.1).to(dev)
+    st = L.stream()
+    blk.pack(w, st)
+    bd = blk.draw_b
+    blk.draw[:, bd:bd + blk.OH, bd:bd + blk.OW, :cout].copy_(torch.randn(N, blk.OH, blk.OW, cout, generator=g) * 0.5)
+    res = {}
+    try:
+        for halo in (1, 0):
+            L.call('srvp_conv_set_halo', halo)
+            out = blk.x_out if role == 'out' else blk.raw
+            out.fill_(7.0)
+            blk.dcat.fill_(7.0)
+            if role != 'out':
+                blk.stats.zero_()
+            for d in blk._fwd + blk._dg:
+                L.call('srvp_conv_mfma', C.byref(d), st)
+            torch.cuda.synchronize()
+            res[halo] = (out.clone(), blk.dcat.clone(), blk.stats.clone() if role != 'out' else None)
+    finally:
+        L.call('srvp_conv_set_halo', 1)
+    if blk.cout % 64 == 0:
+        assert torch.equal(res[1][0], res[0][0])
+    else:
+        # Cout = 32 (mod 64) runs the generic kernel with 32-channel K chunks: different fp32 summation order
+        assert rel_err(res[1][0].float(), res[0][0].float()) < (1e-5 if role == 'out' else 2 ** -7)
+    assert torch.equal(res[1][1], res[0][1])
+    assert res[1][0].float().abs().max().item() not in (0.0, 7.0)
+    if role != 'out':
+        assert rel_err(res[1][2], res[0][2]) < 1e-6          # per-tile partial sums are fp32, tile shapes differ
+
+
+def test_conv_halo_split_skip():
+    """Hoisted skip half through the halo kernel (map0 sample indirection, fp32 S output, S added in the epilogue)."""
+    from srvp_amd import _lib as L
+    from srvp_amd.convnet import Block
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(12)
+    T, B, Hs = 3, 2, 8
+    N = T * B
+    f0 = make_feat(N, Hs, Hs, 64, dev, g)
+    f1 = make_feat(5, 2 * Hs, 2 * Hs, 128, dev, g)
+    sel = torch.tensor([3, 1], dtype=torch.int32, device=dev)
+    smap = sel.repeat(T)
+    spec = dict(kind='conv', key='w', bnkey='bn', cin=192, cout=128, k=3, s=1, p=1, act='leaky_relu')
+    blk = Block(spec, 'mfma', [f0, f1], True, N, dev, True, skip_map=smap, skip_sel=sel)
+    assert blk.split
+    blk._fwd, blk._dg = blk.fwd_descs(), blk.dgrad_descs()
+    w = (torch.randn(128, 192, 3, 3, generator=g) * 0.1).to(dev)
+    st = L.stream()
+    blk.pack(w, st)
+    blk.draw[:, 1:-1, 1:-1].copy_(torch.randn(N, 16, 16, 128, generator=g) * 0.5)
+    blk.draw_sum[:, 1:-1, 1:-1].copy_(torch.randn(B, 16, 16, 128, generator=g) * 0.5)
+    res = {}
+    try:
+        for halo in (1, 0):
+            L.call('srvp_conv_set_halo', halo)
+            blk.raw.fill_(7.0); blk.S.fill_(7.0); blk.dcat.fill_(7.0); blk.dsel.fill_(7.0)
+            blk.stats.zero_()
+            for d in blk._fwd + blk._dg:
+                L.call('srvp_conv_mfma', C.byref(d), st)
+            torch.cuda.synchronize()
+            res[halo] = [t.clone() for t in (blk.raw, blk.S, blk.dcat, blk.dsel)]
+    finally:
+        L.call('srvp_conv_set_halo', 1)
+    for a, b in zip(res[1], res[0]):
+        assert torch.equal(a, b)
+    # and against torch on the concatenated input
+    x0 = F.interpolate(feat_nchw(f0), scale_factor=2, mode='nearest')
+    xin = torch.cat([x0, feat_nchw(f1)[smap.cpu().long()]], 1)
+    ref = F.conv2d(xin, bf(w.cpu()), None, 1, 1)
+    assert rel_err(blk.raw.permute(0, 3, 1, 2).float().cpu(), ref) < 2 ** -7
 
 
 @pytest.mark.parametrize('mode', ['plain', 'ups', 'pool', 'skip'])
