@@ -34,6 +34,36 @@ struct ConvK {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// Accumulator start values: zero, or (hoisted skip half) conv_s(skip) of the frame's sample -- the fp32 S tensor of a
+// dst_is_f32 launch.  Loading it HERE puts the latency of these reads under the first tile DMA instead of exposing it
+// in the epilogue.
+template <int WM, int WN, int TM, int TN, class RowMap>
+__device__ __forceinline__ void conv_acc_init(f32x16_t (&acc)[TM][TN], const ConvK& a, int n0, const RowMap& rowmap) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int lcol = lane & 31, lhalf = lane >> 5;
+    const int hw = a.OH * a.OW;
+    if (!a.add_f32) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int n = 0, oy = 0, ox = 0;
+            const bool ok = rowmap(wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf, n, oy, ox);
+            const float* sp = a.add_f32 + ((size_t)(n % a.add_mod) * hw + oy * a.OW + ox) * a.Cout + n0 + wn * (TN * 32) + lcol;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j][r] = ok ? sp[j * 32] : 0.f;
+        }
+}
+
 // Shared epilogue of the MFMA convolution kernels.  `rowmap(row, n, oy, ox)` decodes tile row -> output pixel and
 // returns false for rows beyond the problem (masked).  smem is reused for the bf16 staging tile [BM][BN + 8]; the
 // caller has synchronised the workgroup after its last read of smem.
@@ -48,19 +78,6 @@ __device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[TM][TN], const Con
     const int wm = wid / WN, wn = wid % WN;
     const int lcol = lane & 31, lhalf = lane >> 5;
     const int hw = a.OH * a.OW;
-    if (a.add_f32) {
-        // + conv_s(skip) of this sample (fp32, computed once per sample by a dst_is_f32 launch)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int n, oy, ox;
-                if (!rowmap(wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf, n, oy, ox)) continue;
-                const float* sp = a.add_f32 + ((size_t)(n % a.add_mod) * hw + oy * a.OW + ox) * a.Cout + n0 + wn * (TN * 32) + lcol;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j][r] += sp[j * 32];
-            }
-    }
     if (a.dst_is_f32) {
         float* dstf = reinterpret_cast<float*>(a.dst);
 #pragma unroll
@@ -242,13 +259,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
         }
     };
 
+    const int hw_ = a.OH * a.OW;
+    auto rowmap = [&](int row, int& n, int& oy, int& ox) -> bool {
+        long long m = m0 + row;
+        if (m >= M) return false;
+        n = (int)(m / hw_);
+        int r = (int)(m - (long long)n * hw_);
+        oy = r / a.OW; ox = r - oy * a.OW;
+        return true;
+    };
     f32x16_t acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    conv_acc_init<WM, WN, TM, TN>(acc, a, n0, rowmap);
 
     const int lrow = lane & 31, lkc = lane >> 5;
     // fragment rows of this lane and their swizzle terms
@@ -299,15 +320,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
     __syncthreads();                                 // every wave is done reading the ring: the epilogue reuses it
 
     // ---------------- epilogue ----------------
-    const int hw_ = a.OH * a.OW;
-    auto rowmap = [&](int row, int& n, int& oy, int& ox) -> bool {
-        long long m = m0 + row;
-        if (m >= M) return false;
-        n = (int)(m / hw_);
-        int r = (int)(m - (long long)n * hw_);
-        oy = r / a.OW; ox = r - oy * a.OW;
-        return true;
-    };
     conv_epilogue<BM, BN, WM, WN, TM, TN>(acc, a, smem, red, n0, rowmap);
 }
 
@@ -336,7 +348,8 @@ static int fill_convk(const srvp_conv_desc* d, ConvK& k) {
 // so the activation traffic from L2 drops ~6.5x versus re-gathering the rows per tap (the generic kernel above), and
 // only the (small) weight tiles stream through a 2-deep LDS-DMA ring, one tap ahead of the MFMAs.
 //
-// Patch layout in LDS: [pixel][64 ch] (128-byte rows, 16-byte chunks XOR-swizzled by (pixel >> 1) & 7).  Two modes:
+// Patch layout in LDS: [pixel][64 ch] (128-byte rows, 16-byte chunks XOR-swizzled by a function g(py, px) of the patch
+// coordinates chosen per geometry so that the ds_read_b128 fragment reads of all 9 taps are bank-conflict free).  Two modes:
 //   halo    (tile smaller than the image): pixel = py * PW + px over the (fh+2) x (fw+2) source window;
 //   compact (tile = IMG whole images): rows of PW = fw+1 pixels, fh+1 rows per image: the right border pixel of a
 //           row IS the left border pixel of the next row and the bottom border row of an image IS the top border row
@@ -344,6 +357,8 @@ static int fill_convk(const srvp_conv_desc* d, ConvK& k) {
 struct HaloK {
     ConvK a;
     int TH, TW, lgTW, lgTHW, IMG, PW, IS, Ppix, NA, tiles_x, tiles_y;
+    int Tn;                           // > 1: time steps per sample for the S-sharing workgroup order
+    int sw_sh, sw_c1, sw_c2;          // chunk swizzle g(py, px) = ((px >> sw_sh) + sw_c1 * py + sw_c2 * (py >> 1)) & 7
 };
 
 template <int BN, int WM, int WN>
@@ -370,9 +385,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     const int n_tiles = a.Cout / BN;
     const int n0 = (lb % n_tiles) * BN;
     unsigned sp = lb / n_tiles;
+    // hoisted-skip launches (+ S[n % add_mod]): the frames t*B + b of one sample b are made CONSECUTIVE workgroups, so
+    // the fp32 S tile of (b, spatial tile) is read from HBM once and then from L2 for the other T - 1 time steps
+    int tslot = 0, Gb = 0;
+    if (p.Tn > 1) { tslot = sp % p.Tn; sp /= p.Tn; Gb = a.add_mod / p.IMG; }
     const int tx = sp % p.tiles_x; sp /= p.tiles_x;
     const int ty = sp % p.tiles_y;
-    const int nb0 = (sp / p.tiles_y) * p.IMG;
+    const int nb0 = (tslot * Gb + sp / p.tiles_y) * p.IMG;
     const int y0 = ty * p.TH, x0 = tx * p.TW;
     const int ups = a.ups0 ? 1 : 0;
     const int sy0 = y0 >> ups, sx0 = x0 >> ups;
@@ -392,7 +411,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         int n = nb0 + img;
         if (n >= a.N) n = a.N - 1;
         if (a.map0) n = a.map0[n];
-        aoff[i] = (((unsigned)n * a.H0p + Y) * a.W0p + X) * C + ((pos ^ ((pix >> 1) & 7)) * 8);
+        const int g = ((px >> p.sw_sh) + p.sw_c1 * py + p.sw_c2 * (py >> 1)) & 7;
+        aoff[i] = (((unsigned)n * a.H0p + Y) * a.W0p + X) * C + ((pos ^ g) * 8);
     }
     // ---- fragment rows of this lane
     const int lrow = lane & 31, lkc = lane >> 5;
@@ -427,13 +447,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         }
     };
 
+    auto rowmap = [&](int row, int& n, int& oy, int& ox) -> bool {
+        n = nb0 + (row >> p.lgTHW);
+        oy = y0 + ((row >> p.lgTW) & (p.TH - 1));
+        ox = x0 + (row & (p.TW - 1));
+        return n < a.N;
+    };
     f32x16_t acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    conv_acc_init<WM, WN, TM, TN>(acc, a, n0, rowmap);
 
     stage_a(0);
     stage_b(0);
@@ -445,27 +466,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         const bool last_tap = (t == ntaps - 1);
         if (!last_tap) stage_b(s + 1);                    // next tap of the same chunk streams in under the MFMAs
         const int dy = (int)((a.dy_bits >> (4 * t)) & 15), dx = (int)((a.dx_bits >> (4 * t)) & 15);
-        int apix[TM];
+        int apix[TM], asw[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int vy = (aoy[i] + dy + ups) >> ups, vx = (aox[i] + dx + ups) >> ups;
             apix[i] = abase[i] + vy * p.PW + vx;
+            asw[i] = ((vx >> p.sw_sh) + p.sw_c1 * vy + p.sw_c2 * (vy >> 1)) & 7;
         }
         const bf16_t* Bb = Bs + (size_t)(s & 1) * BN * BK;
+        // software pipeline over the four 16-wide K slices: the fragments of slice kk+1 are in flight under the MFMAs of kk
+        bf16x8_t af[2][TM], bfr[2][TN];
+        const unsigned char* arow[TM];
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8_t af[TM], bfr[TN];
+        for (int i = 0; i < TM; ++i) arow[i] = Ab + (size_t)apix[i] * 128;
+        auto load_frags = [&](int kk, bf16x8_t (&fa)[TM], bf16x8_t (&fb)[TN]) {
             const int kc = kk * 2 + lkc;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + (size_t)apix[i] * 128 + ((kc ^ ((apix[i] >> 1) & 7)) * 16));
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(arow[i] + ((kc ^ asw[i]) * 16));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bb + b_off[j] + ((kc ^ b_sw[j]) * 8));
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(Bb + b_off[j] + ((kc ^ b_sw[j]) * 8));
+        };
+        load_frags(0, af[0], bfr[0]);
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            if (kk + 1 < BK / 16) load_frags(kk + 1, af[(kk + 1) & 1], bfr[(kk + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (last_tap) {
             t = 0;
@@ -481,12 +512,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     }
     __syncthreads();
 
-    auto rowmap = [&](int row, int& n, int& oy, int& ox) -> bool {
-        n = nb0 + (row >> p.lgTHW);
-        oy = y0 + ((row >> p.lgTW) & (p.TH - 1));
-        ox = x0 + (row & (p.TW - 1));
-        return n < a.N;
-    };
     conv_epilogue<BM, BN, WM, WN, TM, TN>(acc, a, smem, red, n0, rowmap);
 }
 
@@ -514,7 +539,12 @@ static bool halo_geometry(const srvp_conv_desc* d, HaloK& h) {
     else { h.PW = fw + 2; h.IS = (fh + 2) * h.PW; h.Ppix = h.IS; }
     h.NA = (h.Ppix * 8 + 255) / 256;
     if (h.NA > 11) return false;
+    // conflict-free ds_read_b128 fragment reads for every tap (exhaustive search over this family per geometry)
+    if (ups) { if (fw >= 8) { h.sw_sh = 1; h.sw_c1 = 4; h.sw_c2 = 0; } else { h.sw_sh = 0; h.sw_c1 = 0; h.sw_c2 = 4; } }
+    else if (compact) { h.sw_sh = 0; h.sw_c1 = 0; h.sw_c2 = 0; }
+    else { h.sw_sh = 1; h.sw_c1 = 0; h.sw_c2 = 0; }
     h.tiles_x = OW / h.TW; h.tiles_y = OH / h.TH;
+    h.Tn = (d->add_f32 && d->add_mod > 0 && d->N % d->add_mod == 0 && d->add_mod % h.IMG == 0) ? d->N / d->add_mod : 1;
     return true;
 }
 

@@ -47,6 +47,8 @@ for name, net in (('enc', pl['enc']), ('dec', pl['dec'])):
     for i, blk in enumerate(net.blocks):
         if blk.role == 'in':
             continue
+        if os.environ.get('ONLY') and f'{name}{i:02d}' not in os.environ['ONLY'].split(','):
+            continue
         row = f'{name}{i:02d} {blk.geom:6s}{"*" if blk.split else " "} {blk.Hin:2d}->{blk.OH:2d} c{blk.ctot}->{blk.cout}'
         res = []
         for kind, descs in (('fwd', blk._fwd), ('dg', blk._dg)):
