@@ -89,6 +89,9 @@ typedef struct {
 int srvp_wgrad_mfma(const srvp_wgrad_desc* d, void* stream);
 /* 1: fragments through ds_read_b64_tr_b16 (default), 0: 16-bit LDS reads (conservative fallback) */
 int srvp_wgrad_set_tr(int on);
+/* 1 (default): 3x3 stride-1 single-source weight gradients with 64-multiple channel counts run on the halo-tiled kernel
+ * (all 9 taps per workgroup, operands staged once); 0: per-tap kernel for everything */
+int srvp_wgrad_set_halo(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm2d (training / eval) + activation, split around the grid-wide reduction (conv.py:103-106).

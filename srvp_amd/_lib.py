@@ -82,6 +82,7 @@ _SIGS = {
     'srvp_conv_set_halo': ([c_i32], c_i32),
     'srvp_wgrad_mfma': ([C.POINTER(WgradDesc), c_vp], c_i32),
     'srvp_wgrad_set_tr': ([c_i32], c_i32),
+    'srvp_wgrad_set_halo': ([c_i32], c_i32),
     'srvp_bn_finalize': ([c_vp, c_f64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_vp], c_i32),
     'srvp_bn_eval_coeffs': ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp], c_i32),
     'srvp_bn_act': ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp], c_i32),

@@ -37,8 +37,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // Accumulator start values: zero, or (hoisted skip half) conv_s(skip) of the frame's sample -- the fp32 S tensor of a
 // dst_is_f32 launch.  Loading it HERE puts the latency of these reads under the first tile DMA instead of exposing it
 // in the epilogue.
-template <int WM, int WN, int TM, int TN, class RowMap>
-__device__ __forceinline__ void conv_acc_init(f32x16_t (&acc)[TM][TN], const ConvK& a, int n0, const RowMap& rowmap) {
+template <int WM, int WN, int TM, int TN, class RowMap, class SampleOf>
+__device__ __forceinline__ void conv_acc_init(f32x16_t (&acc)[TM][TN], const ConvK& a, int n0, const RowMap& rowmap,
+                                              const SampleOf& sample_of) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int lcol = lane & 31, lhalf = lane >> 5;
@@ -58,7 +59,7 @@ __device__ __forceinline__ void conv_acc_init(f32x16_t (&acc)[TM][TN], const Con
         for (int r = 0; r < 16; ++r) {
             int n = 0, oy = 0, ox = 0;
             const bool ok = rowmap(wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf, n, oy, ox);
-            const float* sp = a.add_f32 + ((size_t)(n % a.add_mod) * hw + oy * a.OW + ox) * a.Cout + n0 + wn * (TN * 32) + lcol;
+            const float* sp = a.add_f32 + ((size_t)sample_of(n) * hw + oy * a.OW + ox) * a.Cout + n0 + wn * (TN * 32) + lcol;
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j][r] = ok ? sp[j * 32] : 0.f;
         }
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
         return true;
     };
     f32x16_t acc[TM][TN];
-    conv_acc_init<WM, WN, TM, TN>(acc, a, n0, rowmap);
+    conv_acc_init<WM, WN, TM, TN>(acc, a, n0, rowmap, [&](int n) { return n % a.add_mod; });
 
     const int lrow = lane & 31, lkc = lane >> 5;
     // fragment rows of this lane and their swizzle terms
@@ -357,15 +358,16 @@ static int fill_convk(const srvp_conv_desc* d, ConvK& k) {
 struct HaloK {
     ConvK a;
     int TH, TW, lgTW, lgTHW, IMG, PW, IS, Ppix, NA, tiles_x, tiles_y;
+    unsigned rIS, rPW;                // ceil(2^32 / IS), ceil(2^32 / PW)
     int Tn;                           // > 1: time steps per sample for the S-sharing workgroup order
     int sw_sh, sw_c1, sw_c2;          // chunk swizzle g(py, px) = ((px >> sw_sh) + sw_c1 * py + sw_c2 * (py >> 1)) & 7
 };
 
-template <int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_halo_kernel(const HaloK p) {
-    constexpr int BM = 256, BK = 64, NT = 256, CPR = 8;
+    constexpr int BK = 64, NT = 256, CPR = 8;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int NA_MAX = 11;                           // 11 * 256 16-byte pieces = 352 pixels >= 334
+    constexpr int NA_MAX = BM == 256 ? 11 : 6;           // 256-pixel tiles: 11 * 256 16-byte pieces = 352 pixels >= 334; 128: 192 >= 180
     constexpr int A_BYTES = NA_MAX * NT * 16;
     constexpr int B_LD = BN * CPR / NT;
     constexpr int B_BYTES = 2 * BN * BK * 2;
@@ -401,11 +403,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     unsigned aoff[NA_MAX];
 #pragma unroll
     for (int i = 0; i < NA_MAX; ++i) {
+        if (i >= p.NA) { aoff[i] = 0; continue; }
         const int q = tid + i * NT;
         const int pix = q >> 3, pos = q & 7;
-        int img = pix / p.IS;
+        // exact small-integer divisions by the launch constants IS, PW through host-computed reciprocals ceil(2^32 / d)
+        int img = (int)__umulhi((unsigned)pix, p.rIS);
         const int rem = pix - img * p.IS;
-        int py = rem / p.PW, px = rem - py * p.PW;
+        int py = (int)__umulhi((unsigned)rem, p.rPW), px = rem - py * p.PW;
         int Y = sy0 + py, X = sx0 + px;
         if (pix >= p.Ppix || img >= p.IMG) { img = 0; Y = 0; X = 0; }      // padding / trailing pieces: a zero border pixel
         int n = nb0 + img;
@@ -454,7 +458,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         return n < a.N;
     };
     f32x16_t acc[TM][TN];
-    conv_acc_init<WM, WN, TM, TN>(acc, a, n0, rowmap);
+    // Tn > 1: frames are t * add_mod + sample, so the sample index needs no division
+    const int nsub = p.Tn > 1 ? tslot * a.add_mod : 0;
+    conv_acc_init<WM, WN, TM, TN>(acc, a, n0, rowmap, [&](int n) { return p.Tn > 1 ? n - nsub : n % a.add_mod; });
 
     stage_a(0);
     stage_b(0);
@@ -521,7 +527,7 @@ static int g_halo = -1;      // -1: read SRVP_CONV_HALO on first use; 0 = generi
 
 // Tile geometry of the halo kernel for this descriptor; false if the descriptor is not a 3x3 stride-1 single-source
 // convolution on a 1-pixel-bordered tensor (or its patch does not fit) -- the generic kernel takes it then.
-static bool halo_geometry(const srvp_conv_desc* d, HaloK& h) {
+static bool halo_geometry(const srvp_conv_desc* d, HaloK& h, int BM) {
     if (g_halo < 0) { const char* e = getenv("SRVP_CONV_HALO"); g_halo = e ? atoi(e) : 1; }
     if (!g_halo) return false;
     if (d->ntaps != 9 || d->si != 1 || d->C1 != 0 || d->C0 % 64 != 0) return false;
@@ -529,16 +535,17 @@ static bool halo_geometry(const srvp_conv_desc* d, HaloK& h) {
     const int OH = d->OH, OW = d->OW, ups = d->ups0 ? 1 : 0;
     if (OH < 2 || OW < 2 || (OH & (OH - 1)) || (OW & (OW - 1))) return false;
     if (d->H0p != (OH >> ups) + 2 || d->W0p != (OW >> ups) + 2) return false;
-    const bool compact = OH * OW <= 256;
+    const bool compact = OH * OW <= BM;
     if (!compact && (OH % 16 || OW % 16)) return false;
-    h.TH = compact ? OH : 16; h.TW = compact ? OW : 16;
-    h.IMG = 256 / (h.TH * h.TW);
+    h.TH = compact ? OH : BM / 16; h.TW = compact ? OW : 16;
+    h.IMG = BM / (h.TH * h.TW);
     h.lgTW = ilog2(h.TW); h.lgTHW = ilog2(h.TH * h.TW);
     const int fh = h.TH >> ups, fw = h.TW >> ups;
     if (compact) { h.PW = fw + 1; h.IS = (fh + 1) * h.PW; h.Ppix = h.IMG * h.IS + h.PW + 1; }
     else { h.PW = fw + 2; h.IS = (fh + 2) * h.PW; h.Ppix = h.IS; }
     h.NA = (h.Ppix * 8 + 255) / 256;
-    if (h.NA > 11) return false;
+    if (h.NA > (BM == 256 ? 11 : 6)) return false;
+    h.rIS = (unsigned)(((1ull << 32) + h.IS - 1) / h.IS); h.rPW = (unsigned)(((1ull << 32) + h.PW - 1) / h.PW);
     // conflict-free ds_read_b128 fragment reads for every tap (exhaustive search over this family per geometry)
     if (ups) { if (fw >= 8) { h.sw_sh = 1; h.sw_c1 = 4; h.sw_c2 = 0; } else { h.sw_sh = 0; h.sw_c1 = 0; h.sw_c2 = 4; } }
     else if (compact) { h.sw_sh = 0; h.sw_c1 = 0; h.sw_c2 = 0; }
@@ -548,12 +555,12 @@ static bool halo_geometry(const srvp_conv_desc* d, HaloK& h) {
     return true;
 }
 
-template <int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN>
 int launch_halo(const srvp_conv_desc* d, HaloK& h, hipStream_t st) {
     if (int rc = fill_convk(d, h.a)) return rc;
     long long blocks = (long long)((d->N + h.IMG - 1) / h.IMG) * h.tiles_x * h.tiles_y * (d->Cout / BN);
     SRVP_REQUIRE(blocks > 0 && blocks < (1ll << 31), "srvp_conv_mfma(halo): bad grid %lld", blocks);
-    hipLaunchKernelGGL((conv_halo_kernel<BN, WM, WN>), dim3((unsigned)blocks), dim3(256), 0, st, h);
+    hipLaunchKernelGGL((conv_halo_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(256), 0, st, h);
     SRVP_CHECK_LAUNCH("srvp_conv_mfma(halo)");
     return SRVP_OK;
 }
@@ -588,10 +595,16 @@ extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
     SRVP_REQUIRE((long long)d->N * d->H0p * d->W0p * d->C0 < (1ll << 32) && (d->C1 == 0 || d->map1 || (long long)d->N * d->H1p * d->W1p * d->C1 < (1ll << 32)),
                  "srvp_conv_mfma: source tensors must have fewer than 2^32 elements");
     HaloK h;
-    if (halo_geometry(d, h)) {
-        if (d->Cout % 128 == 0) return launch_halo<128, 2, 2>(d, h, st);
-        if (d->Cout % 64 == 0) return launch_halo<64, 4, 1>(d, h, st);
-        return launch_halo<32, 4, 1>(d, h, st);
+    static int bm128 = -1;      // A/B switch: 128-pixel tiles for the narrow (Cout < 128) layers
+    if (bm128 < 0) { const char* e = getenv("SRVP_HALO_BM128"); bm128 = e ? atoi(e) : 0; }
+    if (bm128 && d->Cout % 128 != 0 && halo_geometry(d, h, 128)) {
+        if (d->Cout % 64 == 0) return (bm128 & 2) ? launch_halo<128, 64, 4, 1>(d, h, st) : launch_halo<128, 64, 2, 2>(d, h, st);
+        return launch_halo<128, 32, 4, 1>(d, h, st);
+    }
+    if (halo_geometry(d, h, 256)) {
+        if (d->Cout % 128 == 0) return launch_halo<256, 128, 2, 2>(d, h, st);
+        if (d->Cout % 64 == 0) return launch_halo<256, 64, 4, 1>(d, h, st);
+        return launch_halo<256, 32, 4, 1>(d, h, st);
     }
     const bool k64 = (d->C0 % 64 == 0) && (d->C1 % 64 == 0);
     // LDS ring depth / K step (A/B switch SRVP_CONV_MODE): 5 = BK64 single buffer (default: 3 workgroups per CU hide the

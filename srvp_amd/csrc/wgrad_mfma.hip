@@ -407,6 +407,207 @@ __global__ __launch_bounds__(WJ * WC * 64) void wgrad_mfma_kernel(const WgradK a
             }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Halo-tiled weight gradient of the 3x3 stride-1 convolutions: ONE workgroup accumulates all 9 taps of a 64 x 64
+// (Cout x Cin) tile.  Per K step it stages 32 output-gradient pixels (a 2x16 or 4x8 spatial tile) and the input patch
+// INCLUDING its halo once ([<=72 px][64 ch]); the 9 taps are LDS address offsets of the transpose reads, so the input
+// operand is fetched once instead of 9 times and the output gradient once instead of 9 times (L2->LDS bytes per FLOP
+// down ~3x versus the per-tap kernel above, whose waves sat in s_waitcnt 60-75 % of the time).  Each wave owns one
+// 32x32 tile for the 9 taps (144 accumulator registers).  Same 4-deep LDS-DMA ring / counted vmcnt / raw barrier
+// pipeline and the same ds_read_b64_tr_b16 fragment reads; split-K over spatial tiles, fp32 atomics.
+// ---------------------------------------------------------------------------------------------------------------
+struct WgradHaloK {
+    WgradK a;
+    int lgTW, RH, PW, Ppix, lg_nxb, lg_nyb, ntiles, oo;   // oo: border offset of dout (ooy = oox)
+};
+
+template <bool UPS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_halo_kernel(const WgradHaloK p) {
+    constexpr int NT = 256, NBUF = 4, BJ = 64, BC = 64;
+    constexpr int XBYTES = 32 * BJ * 2;                  // 4 KiB: [32 px][64 ch]
+    constexpr int YPIECES = 3 * NT;                      // 96 px * 8 chunks
+    constexpr int YBYTES = YPIECES * 16;                 // 12 KiB
+    constexpr int STAGE = XBYTES + YBYTES;
+    constexpr int G = 4;                                 // LDS-DMA instructions per stage and wave
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NBUF * STAGE];
+    const WgradK& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int jt = wid >> 1, ct = wid & 1;
+    const int tc_n = a.C0 / BC, tj_n = a.Cout / BJ;
+    int b = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int tc = b % tc_n; b /= tc_n;
+    const int tj = b % tj_n; b /= tj_n;
+    const int split = b;
+    const int j0 = tj * BJ, c0 = tc * BC;
+    const int per = (p.ntiles + a.splitk - 1) / a.splitk;
+    const int t_beg = split * per;
+    int t_end = t_beg + per; if (t_end > p.ntiles) t_end = p.ntiles;
+    if (t_beg >= t_end) return;
+    const int nsteps = t_end - t_beg;
+    const int TW = 1 << p.lgTW, PW = p.PW;
+    const int ups = UPS ? 1 : 0;
+
+    // ---- DMA pieces of this thread: lane-constant parts of the source offsets
+    unsigned xlane, ylane[3];
+    {
+        const int pk = tid >> 3, pos = tid & 7;
+        const int ty = pk >> p.lgTW, tx = pk & (TW - 1);
+        xlane = (unsigned)((ty * a.DWp + tx) * a.Cout + ((pos ^ (((pk >> 1) & 1) << 2)) * 8));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int q = tid + i * NT;
+            int pix = q >> 3;
+            const int posy = q & 7;
+            const int sw = ((pix >> 1) & 1) << 2;
+            if (pix >= p.Ppix) pix = 0;                  // filler pieces: re-load pixel 0 (never read)
+            const int py = pix / PW, px = pix - py * PW;
+            ylane[i] = (unsigned)((py * a.W0p + px) * a.C0 + ((posy ^ sw) * 8));
+        }
+    }
+    auto stage = [&](int step, int buf) {
+        const int tau = t_beg + step;
+        const int xb = tau & ((1 << p.lg_nxb) - 1);
+        const int yb = (tau >> p.lg_nxb) & ((1 << p.lg_nyb) - 1);
+        const int n = tau >> (p.lg_nxb + p.lg_nyb);
+        const int y0 = yb * p.RH, x0 = xb << p.lgTW;
+        const int ns = a.map0 ? a.map0[n] : n;           // uniform index: a scalar load
+        const unsigned xbase = (((unsigned)n * a.DHp + y0 + p.oo) * a.DWp + x0 + p.oo) * a.Cout + j0;
+        const unsigned ybase = (((unsigned)ns * a.H0p + (y0 >> ups)) * a.W0p + (x0 >> ups)) * a.C0 + c0;
+        unsigned char* sb = lds + (size_t)buf * STAGE;
+        __builtin_amdgcn_global_load_lds((gptr_t)(a.dout + xbase + xlane), (lptr_t)(sb + wid * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.src0 + ybase + ylane[i]), (lptr_t)(sb + XBYTES + (i * NT + wid * 64) * 16), 16, 0, 0);
+    };
+
+    f32x16_t acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // ---- transpose-read addressing (see lds_tr_read): lane s of a 16-lane group addresses pixel (s>>2), channels (s&3)*4..
+    const int g = lane >> 4, sl = lane & 15;
+    const int tr_c = (g & 1) * 16 + (sl & 3) * 4;
+    const int tr_r = (g >> 1) * 8 + (sl >> 2);           // pixel within a 16-pixel K slice (+4: second read, +16: second slice)
+    // dout tile (linear [32 px][64 ch]): rows tr_r, +4, +16, +20 share the swizzle term
+    const int cx = jt * 32 + tr_c;
+    const unsigned xoff = (unsigned)(tr_r * 128 + ((((cx >> 3) ^ (((tr_r >> 1) & 1) << 2))) << 4) + (cx & 7) * 2);
+    // input patch: address(P, c) = P*128 + ((c>>3) ^ 4*((P>>1)&1))*16 + (c&7)*2 = ybase_c + P*128 + bit8(P*128) * ydelta
+    const int cy = ct * 32 + tr_c;
+    const unsigned ybase_c = (unsigned)(XBYTES + (cy >> 3) * 16 + (cy & 7) * 2);
+    const int ydelta = ((cy >> 3) & 4) ? -64 : 64;
+    const int ty0 = tr_r >> p.lgTW, tx0 = tr_r & (TW - 1);
+    const int ty1 = ty0 + (16 >> p.lgTW);                // pixel row of the second 16-pixel slice
+    const unsigned lds_base = (unsigned)(uintptr_t)lds;
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i)
+        if (i < nsteps) stage(i, i);
+    for (int s = 0; s < nsteps; ++s) {
+        if (s + NBUF - 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NBUF - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + NBUF - 1 < nsteps) stage(s + NBUF - 1, (s + NBUF - 1) % NBUF);
+        const unsigned bb = lds_base + (unsigned)(s % NBUF) * (unsigned)STAGE;
+        bf16x8_t xf[2];
+        {
+            s16x4_t a0, a1, b0, b1;
+            tr_read_tile<4 * 128, 16 * 128>(bb + xoff, a0, a1, b0, b1);
+            s16x8_t v0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            s16x8_t v1 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            xf[0] = __builtin_bit_cast(bf16x8_t, v0); xf[1] = __builtin_bit_cast(bf16x8_t, v1);
+        }
+        const unsigned yb0 = bb + ybase_c;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = (int)((a.dy_bits >> (4 * t)) & 15), dx = (int)((a.dx_bits >> (4 * t)) & 15);
+            unsigned ad[4];
+            if constexpr (!UPS) {
+                const unsigned P0 = (unsigned)((ty0 + dy) * PW + tx0 + dx) << 7, P1 = (unsigned)((ty1 + dy) * PW + tx0 + dx) << 7;
+                ad[0] = yb0 + P0 + ((P0 >> 8) & 1) * ydelta;   // +4 pixels keeps (P>>1)&1
+                ad[1] = ad[0] + 4 * 128;
+                ad[2] = yb0 + P1 + ((P1 >> 8) & 1) * ydelta;
+                ad[3] = ad[2] + 4 * 128;
+            } else {
+                const int sy0 = (ty0 + dy + 1) >> 1, sy1 = (ty1 + dy + 1) >> 1, sx0 = (tx0 + dx + 1) >> 1;
+                const unsigned P00 = (unsigned)(sy0 * PW + sx0) << 7, P10 = (unsigned)(sy1 * PW + sx0) << 7;
+                const unsigned P01 = P00 + 2 * 128, P11 = P10 + 2 * 128;      // tx + 4 -> source x + 2
+                ad[0] = yb0 + P00 + ((P00 >> 8) & 1) * ydelta;
+                ad[1] = yb0 + P01 + ((P01 >> 8) & 1) * ydelta;
+                ad[2] = yb0 + P10 + ((P10 >> 8) & 1) * ydelta;
+                ad[3] = yb0 + P11 + ((P11 >> 8) & 1) * ydelta;
+            }
+            s16x4_t a0, a1, b0, b1;
+            asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                         "ds_read_b64_tr_b16 %1, %5\n\t"
+                         "ds_read_b64_tr_b16 %2, %6\n\t"
+                         "ds_read_b64_tr_b16 %3, %7\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1)
+                         : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3])
+                         : "memory");
+            s16x8_t v0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            s16x8_t v1 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], __builtin_bit_cast(bf16x8_t, v0), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[1], __builtin_bit_cast(bf16x8_t, v1), acc[t], 0, 0, 0);
+        }
+    }
+
+    const int lcol = lane & 31, lhalf = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jj = j0 + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+            const int cc = c0 + ct * 32 + lcol;
+            atomicAdd(a.dw + ((size_t)t * a.Cout + jj) * a.C0 + cc, acc[t][r]);
+        }
+}
+
+int g_wgrad_halo = -1;       // -1: SRVP_WGRAD_HALO env (default 1)
+
+// Launch the halo kernel if the descriptor is a 3x3 stride-1 single-source weight gradient it covers.
+static int try_launch_halo(const srvp_wgrad_desc* d, const WgradK& k, hipStream_t st, bool& done) {
+    done = false;
+    if (g_wgrad_halo < 0) { const char* e = getenv("SRVP_WGRAD_HALO"); g_wgrad_halo = e ? atoi(e) : 1; }
+    if (!g_wgrad_halo) return SRVP_OK;
+    if (d->ntaps != 9 || d->si != 1 || d->so != 1 || d->C1 != 0 || d->C0 % 64 || d->Cout % 64) return SRVP_OK;
+    for (int t = 0; t < 9; ++t)
+        if (d->dy[t] < 0 || d->dy[t] > 2 || d->dx[t] < 0 || d->dx[t] > 2 || d->ooy[t] != d->ooy[0] || d->oox[t] != d->ooy[0]) return SRVP_OK;
+    const int OH = d->OH, OW = d->OW, ups = d->ups0 ? 1 : 0;
+    if (OW < 8 || (OW & (OW - 1)) || (OH & (OH - 1))) return SRVP_OK;
+    if (d->H0p != (OH >> ups) + 2 || d->W0p != (OW >> ups) + 2) return SRVP_OK;
+    if (d->DHp != OH + 2 * d->ooy[0] || d->DWp != OW + 2 * d->ooy[0]) return SRVP_OK;
+    WgradHaloK h;
+    h.a = k;
+    const int TW = OW >= 16 ? 16 : 8;
+    h.lgTW = TW == 16 ? 4 : 3;
+    h.RH = 32 / TW;
+    if (OH % h.RH) return SRVP_OK;
+    h.PW = (TW >> ups) + 2;
+    h.Ppix = ((h.RH >> ups) + 2) * h.PW;
+    if (h.Ppix > 96) return SRVP_OK;
+    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    h.lg_nxb = lg(OW / TW); h.lg_nyb = lg(OH / h.RH);
+    h.ntiles = d->N * (OH / h.RH) * (OW / TW);
+    h.oo = d->ooy[0];
+    const int pairs = (d->Cout / 64) * (d->C0 / 64);
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("SRVP_WGRAD_HALO_WGS"); target = e ? atoi(e) : 512; }
+    int splitk = (target + pairs - 1) / pairs;
+    if (splitk > h.ntiles / 8) splitk = h.ntiles / 8 > 0 ? h.ntiles / 8 : 1;
+    h.a.splitk = splitk;
+    const long long blocks = (long long)pairs * splitk;
+    if (ups) hipLaunchKernelGGL((wgrad_halo_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, h);
+    else hipLaunchKernelGGL((wgrad_halo_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, h);
+    SRVP_CHECK_LAUNCH("srvp_wgrad_mfma(halo)");
+    done = true;
+    return SRVP_OK;
+}
+
 template <int BJ, int BC, int WJ, int WC>
 int launch(const WgradK& k, hipStream_t st, bool use_tr, bool dma_off) {
     long long blocks = (long long)(k.Cout / BJ) * ((k.C0 + k.C1) / BC) * k.ntaps * k.splitk;
@@ -431,6 +632,7 @@ int g_use_tr = -1;
 }  // namespace
 
 extern "C" int srvp_wgrad_set_tr(int on) { g_use_tr = on; return SRVP_OK; }
+extern "C" int srvp_wgrad_set_halo(int on) { g_wgrad_halo = on; return SRVP_OK; }
 
 extern "C" int srvp_wgrad_mfma(const srvp_wgrad_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -462,6 +664,11 @@ extern "C" int srvp_wgrad_mfma(const srvp_wgrad_desc* d, void* stream) {
     k.lg_ow = lg(d->OW); k.lg_hw = lg(d->OH * d->OW);
     if (k.lg_hw < 0) k.lg_ow = -1;
     const bool tr = (g_use_tr & 1) != 0;
+    if (tr && !(g_use_tr & 4)) {
+        bool done = false;
+        if (int rc = try_launch_halo(d, k, st, done)) return rc;
+        if (done) return SRVP_OK;
+    }
     const bool dma_off = (g_use_tr & 4) != 0;     // srvp_wgrad_set_tr(5): transpose reads, register-staged kernel (A/B switch)
     // channel tile of the input operand must not straddle the two sources
     auto divides = [&](int bc) { return d->C0 % bc == 0 && (d->C1 == 0 || d->C1 % bc == 0); };
