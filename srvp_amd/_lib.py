@@ -162,11 +162,12 @@ def stream():
 
 
 PROFILE = None      # set to a dict by bench.py: name -> list of (start_event, end_event) on the launch stream
+PROFILE_ONLY = None  # optional set of entry-point names to time (None = all); keeps the event overhead out of a timed run
 
 
 def call(name, *args):
     fn = getattr(load(), name)
-    if PROFILE is None:
+    if PROFILE is None or (PROFILE_ONLY is not None and name not in PROFILE_ONLY):
         check(fn(*args), name)
         return
     # torch.cuda.Event records on torch's current stream, which is the stream every launch is issued on (stream())

@@ -149,12 +149,239 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// First-layer forward / weight gradient on the matrix cores in EXACT fp32 (v_mfma_f32_32x32x2_f32 runs at the fp32
+// vector rate and is bit-equivalent to an fmaf chain, so the "image-side layers are fp32" statement stands): the
+// VALU kernels above sit at ~10 % of the HBM roofline of this layer (1.2 GB of bf16 activations per pass) because
+// they spend their time on LDS operand traffic and bounds predicates.  Frames are 64x64 (module/conv.py:129-154
+// hard-codes the 64x64 encoders); kernel 3x3 s1 p1 (VGG) or 4x4 s2 p1 (DCGAN); Cin in {1, 3}; Cout <= 64.
+// A workgroup walks `tiles_per_wg` consecutive 128-pixel output tiles (whole output rows of one image): the input
+// patch incl. halo is staged zero-padded in LDS, K = Cin*k*k (padded to even) is walked two taps per MFMA.
+// ---------------------------------------------------------------------------------------------------------
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+
+template <int KS, int S, int CIN> struct InGeom {
+    static constexpr int H = 64, W = 64;
+    static constexpr int OH = H / S, OW = W / S;
+    static constexpr int TR = 128 / OW;                  // output rows per 128-pixel tile
+    static constexpr int TPI = OH / TR;                  // tiles per image
+    static constexpr int PH = (TR - 1) * S + KS;         // patch rows
+    static constexpr int PWp = W + 2;                    // patch columns (x = -1 .. 64)
+    static constexpr int K = CIN * KS * KS;
+    static constexpr int STEPS = (K + 1) / 2;
+    __host__ __device__ static constexpr int off(int kidx) {           // patch offset of K index (ci, kh, kw)
+        return kidx >= K ? 0 : ((kidx / (KS * KS)) * PH + (kidx / KS) % KS) * PWp + kidx % KS;
+    }
+};
+
+template <int KS, int S, int CIN>
+__device__ __forceinline__ void in_load_patch(const float* __restrict__ x, float* xs, int n, int tile_in_img) {
+    typedef InGeom<KS, S, CIN> Gm;
+    const int iy0 = tile_in_img * Gm::TR * S - 1;
+    for (int i = threadIdx.x; i < CIN * Gm::PH * Gm::PWp; i += 256) {
+        const int c = i % Gm::PWp, r = (i / Gm::PWp) % Gm::PH, ci = i / (Gm::PWp * Gm::PH);
+        const int iy = iy0 + r, ix = c - 1;
+        const bool ok = iy >= 0 && iy < Gm::H && ix >= 0 && ix < Gm::W;
+        xs[i] = ok ? x[(((size_t)n * CIN + ci) * Gm::H + iy) * Gm::W + ix] : 0.f;
+    }
+}
+
+template <int KS, int S, int CIN>
+__global__ __launch_bounds__(256) void conv_in_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               bf16_t* __restrict__ raw, double* stats, int N, int Cout,
+                                                               int Cout_real, int tiles_per_wg) {
+    typedef InGeom<KS, S, CIN> Gm;
+    constexpr int LDC = 64 + 8;
+    __shared__ float wsh[Gm::STEPS * 2][64];             // B operand [k][cout], zero for padded k / cout
+    __shared__ float xs[CIN * Gm::PH * Gm::PWp];
+    __shared__ __attribute__((aligned(16))) bf16_t Cs[128 * LDC];
+    __shared__ float red[4][64][2];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lcol = lane & 31, lhalf = lane >> 5;
+    for (int i = tid; i < Gm::STEPS * 2 * 64; i += 256) {
+        const int co = i & 63, k = i >> 6;
+        wsh[k][co] = (k < Gm::K && co < Cout_real) ? w[(size_t)co * Gm::K + k] : 0.f;
+    }
+    const int ntl = Cout / 32;                            // 1 or 2 column tiles
+    const int m = wid * 32 + lcol;                        // this lane's pixel (A operand row) inside the tile
+    const int abase = ((m / Gm::OW) * S) * Gm::PWp + (m % Gm::OW) * S;
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    const long long ntiles = (long long)N * Gm::TPI;
+    const long long t0 = (long long)blockIdx.x * tiles_per_wg;
+    for (int it = 0; it < tiles_per_wg; ++it) {
+        const long long tile = t0 + it;
+        if (tile >= ntiles) break;
+        const int n = (int)(tile / Gm::TPI), tin = (int)(tile % Gm::TPI);
+        __syncthreads();                                  // previous tile's patch / staging are no longer read
+        in_load_patch<KS, S, CIN>(x, xs, n, tin);
+        __syncthreads();
+        f32x16v acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < Gm::STEPS; ++st) {
+            const float av = xs[abase + (lhalf ? Gm::off(2 * st + 1) : Gm::off(2 * st))];
+            const float b0 = wsh[2 * st + lhalf][lcol];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
+            if (ntl > 1) {
+                const float b1 = wsh[2 * st + lhalf][32 + lcol];
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1], 0, 0, 0);
+            }
+        }
+        // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j >= ntl) break;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[j][r];
+                s1[j] += v; s2[j] += v * v;
+                Cs[(wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * LDC + j * 32 + lcol] = f2bf(v);
+            }
+        }
+        __syncthreads();
+        // the 128 pixels of a tile are contiguous in the NHWC output: 128 * Cout bf16
+        bf16_t* dst = raw + (size_t)tile * 128 * Cout;
+        const int cch = Cout / 8;
+        for (int q = tid; q < 128 * cch; q += 256) {
+            const int row = q / cch, ch = q % cch;
+            *reinterpret_cast<u32x4_t*>(dst + (size_t)row * Cout + ch * 8) = *reinterpret_cast<const u32x4_t*>(Cs + row * LDC + ch * 8);
+        }
+    }
+    if (!stats) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float a = s1[j] + __shfl_xor(s1[j], 32), b = s2[j] + __shfl_xor(s2[j], 32);
+        if (lhalf == 0) { red[wid][j * 32 + lcol][0] = a; red[wid][j * 32 + lcol][1] = b; }
+    }
+    __syncthreads();
+    if (tid < Cout) {
+        double a = 0., b = 0.;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) { a += red[wv][tid][0]; b += red[wv][tid][1]; }
+        atomicAdd(stats + tid, a);
+        atomicAdd(stats + Cout + tid, b);
+    }
+}
+
+// dw[co][k] += sum_pix draw[pix][co] * patch[pix][k]:  A = draw^T (32 couts x 2 pixels), B = patch (2 pixels x 32 K
+// indices; K <= 32 per column tile, 48 needs two), accumulated over all tiles of the workgroup, then reduced over
+// the four waves (which split the 128 pixels of a tile) through LDS and added to dw with one atomic per weight.
+template <int KS, int S, int CIN>
+__global__ __launch_bounds__(256) void conv_in_wgrad_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ draw,
+                                                                 float* dw, int N, int Cout, int Cout_real, int tiles_per_wg) {
+    typedef InGeom<KS, S, CIN> Gm;
+    constexpr int KT = (Gm::K + 31) / 32;                 // column tiles over the K indices (1 or 2)
+    constexpr int XS_BYTES = ((CIN * Gm::PH * Gm::PWp * 4 + 15) / 16) * 16, GS_BYTES = 128 * 64 * 2;
+    constexpr int PART_BYTES = 4 * 64 * (KT * 32 + 1) * 4;
+    constexpr int SM = (XS_BYTES + GS_BYTES) > PART_BYTES ? (XS_BYTES + GS_BYTES) : PART_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char sm[SM];
+    float* xs = reinterpret_cast<float*>(sm);                                        // input patch
+    bf16_t* gs = reinterpret_cast<bf16_t*>(sm + XS_BYTES);                           // draw tile [128 px][Cout]
+    float (*part)[64][KT * 32 + 1] = reinterpret_cast<float (*)[64][KT * 32 + 1]>(sm);   // wave partials (after the loop)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lcol = lane & 31, lhalf = lane >> 5;
+    const int ntl = Cout / 32;
+    // B operand offsets of this lane's K indices
+    int boff[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const int kidx = kt * 32 + lcol;
+        boff[kt] = kidx >= Gm::K ? -1 : ((kidx / (KS * KS)) * Gm::PH + (kidx / KS) % KS) * Gm::PWp + kidx % KS;
+    }
+    f32x16v acc[2][KT];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][kt][r] = 0.f;
+    const long long ntiles = (long long)N * Gm::TPI;
+    const long long t0 = (long long)blockIdx.x * tiles_per_wg;
+    const int cch = Cout / 8;
+    for (int it = 0; it < tiles_per_wg; ++it) {
+        const long long tile = t0 + it;
+        if (tile >= ntiles) break;
+        const int n = (int)(tile / Gm::TPI), tin = (int)(tile % Gm::TPI);
+        __syncthreads();
+        in_load_patch<KS, S, CIN>(x, xs, n, tin);
+        // draw tile: bordered tensor [N][OH+2][OW+2][Cout], rows tin*TR .. +TR-1 of image n
+        for (int q = tid; q < 128 * cch; q += 256) {
+            const int row = q / cch, ch = q % cch;
+            const int oy = tin * Gm::TR + row / Gm::OW, ox = row % Gm::OW;
+            *reinterpret_cast<u32x4_t*>(gs + row * Cout + ch * 8) =
+                *reinterpret_cast<const u32x4_t*>(draw + (((size_t)n * (Gm::OH + 2) + oy + 1) * (Gm::OW + 2) + ox + 1) * Cout + ch * 8);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int st = 0; st < 16; ++st) {                 // this wave's 32 pixels, two per MFMA
+            const int mpix = wid * 32 + st * 2 + lhalf;
+            const int pb = ((mpix / Gm::OW) * S) * Gm::PWp + (mpix % Gm::OW) * S;
+            float bv[KT];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) bv[kt] = boff[kt] >= 0 ? xs[pb + boff[kt]] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j >= ntl) break;
+                const float av = bf2f(gs[mpix * Cout + j * 32 + lcol]);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) acc[j][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[kt], acc[j][kt], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                part[wid][j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf][kt * 32 + lcol] = acc[j][kt][r];
+    __syncthreads();
+    for (int q = tid; q < Cout_real * Gm::K; q += 256) {
+        const int co = q / Gm::K, k = q % Gm::K;
+        atomicAdd(dw + (size_t)co * Gm::K + k, part[0][co][k] + part[1][co][k] + part[2][co][k] + part[3][co][k]);
+    }
+}
+
+template <int KS, int S, int CIN>
+static void launch_in_fwd(const float* x, const float* w, bf16_t* raw, double* stats, int N, int Cout, int Cout_real, hipStream_t st) {
+    const long long ntiles = (long long)N * InGeom<KS, S, CIN>::TPI;
+    const int tpw = ntiles >= 32768 ? 8 : (ntiles >= 16 ? 2 : 1);
+    hipLaunchKernelGGL((conv_in_fwd_mfma_kernel<KS, S, CIN>), dim3((unsigned)((ntiles + tpw - 1) / tpw)), dim3(256), 0, st, x, w, raw, stats, N,
+                       Cout, Cout_real, tpw);
+}
+template <int KS, int S, int CIN>
+static void launch_in_wgrad(const float* x, const bf16_t* draw, float* dw, int N, int Cout, int Cout_real, hipStream_t st) {
+    const long long ntiles = (long long)N * InGeom<KS, S, CIN>::TPI;
+    const int tpw = ntiles >= 32768 ? 16 : (ntiles >= 16 ? 2 : 1);
+    hipLaunchKernelGGL((conv_in_wgrad_mfma_kernel<KS, S, CIN>), dim3((unsigned)((ntiles + tpw - 1) / tpw)), dim3(256), 0, st, x, draw, dw, N,
+                       Cout, Cout_real, tpw);
+}
+static bool in_mfma_ok(int Cin, int H, int W, int Cout, int k, int s, int p) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SRVP_CONV_IN_MFMA"); on = e ? atoi(e) : 1; }
+    return on && H == 64 && W == 64 && (Cin == 1 || Cin == 3) && (Cout == 32 || Cout == 64) && p == 1 && ((k == 3 && s == 1) || (k == 4 && s == 2));
+}
+
 }  // namespace
 
 extern "C" int srvp_conv_in_fwd(const float* x, const float* w, void* raw, double* stats, int N, int Cin, int H, int W,
                                 int Cout, int Cout_real, int k, int s, int p, void* stream) {
     SRVP_REQUIRE(x && w && raw, "srvp_conv_in_fwd: null pointer");
     SRVP_REQUIRE(Cin >= 1 && Cin <= MAXC && k <= MAXK && Cout % 8 == 0 && Cout / 8 <= 256, "srvp_conv_in_fwd: unsupported shape");
+    if (in_mfma_ok(Cin, H, W, Cout, k, s, p)) {
+        hipStream_t st = (hipStream_t)stream;
+        if (k == 3 && Cin == 3) launch_in_fwd<3, 1, 3>(x, w, (bf16_t*)raw, stats, N, Cout, Cout_real, st);
+        else if (k == 3) launch_in_fwd<3, 1, 1>(x, w, (bf16_t*)raw, stats, N, Cout, Cout_real, st);
+        else if (Cin == 3) launch_in_fwd<4, 2, 3>(x, w, (bf16_t*)raw, stats, N, Cout, Cout_real, st);
+        else launch_in_fwd<4, 2, 1>(x, w, (bf16_t*)raw, stats, N, Cout, Cout_real, st);
+        SRVP_CHECK_LAUNCH("srvp_conv_in_fwd(mfma)");
+        return SRVP_OK;
+    }
     int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
     size_t sh = (size_t)Cin * k * k * Cout * sizeof(float);
     long long P = (long long)N * OH * OW;
@@ -174,6 +401,15 @@ extern "C" int srvp_conv_in_wgrad(const float* x, const void* draw, float* dw, i
     SRVP_REQUIRE(Cin >= 1 && Cin <= MAXC && k <= MAXK && Cout % 8 == 0, "srvp_conv_in_wgrad: unsupported shape");
     int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
     SRVP_REQUIRE(k == 3 || k == 4, "srvp_conv_in_wgrad: k=%d unsupported", k);
+    if (in_mfma_ok(Cin, H, W, Cout, k, s, p)) {
+        hipStream_t st = (hipStream_t)stream;
+        if (k == 3 && Cin == 3) launch_in_wgrad<3, 1, 3>(x, (const bf16_t*)draw, dw, N, Cout, Cout_real, st);
+        else if (k == 3) launch_in_wgrad<3, 1, 1>(x, (const bf16_t*)draw, dw, N, Cout, Cout_real, st);
+        else if (Cin == 3) launch_in_wgrad<4, 2, 3>(x, (const bf16_t*)draw, dw, N, Cout, Cout_real, st);
+        else launch_in_wgrad<4, 2, 1>(x, (const bf16_t*)draw, dw, N, Cout, Cout_real, st);
+        SRVP_CHECK_LAUNCH("srvp_conv_in_wgrad(mfma)");
+        return SRVP_OK;
+    }
     const int G = (Cout / 8) * Cin;
     SRVP_REQUIRE(G <= 256, "srvp_conv_in_wgrad: Cout*Cin too large");
     const int SPB = 256 / G;
