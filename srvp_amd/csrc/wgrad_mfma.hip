@@ -421,10 +421,14 @@ struct WgradHaloK {
     int lgTW, RH, PW, Ppix, lg_nxb, lg_nyb, ntiles, oo;   // oo: border offset of dout (ooy = oox)
 };
 
-template <bool UPS>
+template <bool UPS, int BJ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_halo_kernel(const WgradHaloK p) {
-    constexpr int NT = 256, NBUF = 4, BJ = 64, BC = 64;
-    constexpr int XBYTES = 32 * BJ * 2;                  // 4 KiB: [32 px][64 ch]
+    // BJ = 64: wave = (cout tile, cin tile), all 9 taps.  BJ = 32 (image-side layer, Cout padded to 32): wave = (cin tile,
+    // tap group 0-4 / 5-8); the second group computes one duplicate tap that is not written back.
+    constexpr int NT = 256, NBUF = 4, BC = 64;
+    constexpr int NTW = BJ == 64 ? 9 : 5;                // taps per wave
+    constexpr int XROW = BJ * 2;                         // bytes per dout pixel row
+    constexpr int XBYTES = 32 * XROW;                    // [32 px][BJ ch]
     constexpr int YPIECES = 3 * NT;                      // 96 px * 8 chunks
     constexpr int YBYTES = YPIECES * 16;                 // 12 KiB
     constexpr int STAGE = XBYTES + YBYTES;
@@ -432,7 +436,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NBUF * STAGE];
     const WgradK& a = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int jt = wid >> 1, ct = wid & 1;
+    const int jt = BJ == 64 ? (wid >> 1) : 0, ct = wid & 1;
+    const int tap0 = BJ == 64 ? 0 : (wid >> 1) * 5;
     const int tc_n = a.C0 / BC, tj_n = a.Cout / BJ;
     int b = (int)xcd_remap(blockIdx.x, gridDim.x);
     const int tc = b % tc_n; b /= tc_n;
@@ -450,9 +455,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     // ---- DMA pieces of this thread: lane-constant parts of the source offsets
     unsigned xlane, ylane[3];
     {
-        const int pk = tid >> 3, pos = tid & 7;
+        // BJ = 32: 128 pieces of 64-byte rows (no swizzle needed: 4 rows = one 256-byte bank row); the upper two waves
+        // re-load the same pieces so that every wave issues the same number of DMAs per stage
+        const int xq = BJ == 64 ? tid : (tid & 127);
+        const int pk = BJ == 64 ? (xq >> 3) : (xq >> 2), pos = BJ == 64 ? (xq & 7) : (xq & 3);
         const int ty = pk >> p.lgTW, tx = pk & (TW - 1);
-        xlane = (unsigned)((ty * a.DWp + tx) * a.Cout + ((pos ^ (((pk >> 1) & 1) << 2)) * 8));
+        xlane = (unsigned)((ty * a.DWp + tx) * a.Cout + ((BJ == 64 ? (pos ^ (((pk >> 1) & 1) << 2)) : pos) * 8));
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int q = tid + i * NT;
@@ -474,15 +482,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         const unsigned xbase = (((unsigned)n * a.DHp + y0 + p.oo) * a.DWp + x0 + p.oo) * a.Cout + j0;
         const unsigned ybase = (((unsigned)ns * a.H0p + (y0 >> ups)) * a.W0p + (x0 >> ups)) * a.C0 + c0;
         unsigned char* sb = lds + (size_t)buf * STAGE;
-        __builtin_amdgcn_global_load_lds((gptr_t)(a.dout + xbase + xlane), (lptr_t)(sb + wid * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(a.dout + xbase + xlane), (lptr_t)(sb + (BJ == 64 ? wid : (wid & 1)) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(a.src0 + ybase + ylane[i]), (lptr_t)(sb + XBYTES + (i * NT + wid * 64) * 16), 16, 0, 0);
     };
 
-    f32x16_t acc[9];
+    f32x16_t acc[NTW];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NTW; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -492,7 +500,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     const int tr_r = (g >> 1) * 8 + (sl >> 2);           // pixel within a 16-pixel K slice (+4: second read, +16: second slice)
     // dout tile (linear [32 px][64 ch]): rows tr_r, +4, +16, +20 share the swizzle term
     const int cx = jt * 32 + tr_c;
-    const unsigned xoff = (unsigned)(tr_r * 128 + ((((cx >> 3) ^ (((tr_r >> 1) & 1) << 2))) << 4) + (cx & 7) * 2);
+    const unsigned xoff = BJ == 64 ? (unsigned)(tr_r * 128 + ((((cx >> 3) ^ (((tr_r >> 1) & 1) << 2))) << 4) + (cx & 7) * 2)
+                                   : (unsigned)(tr_r * 64 + (cx >> 3) * 16 + (cx & 7) * 2);
     // input patch: address(P, c) = P*128 + ((c>>3) ^ 4*((P>>1)&1))*16 + (c&7)*2 = ybase_c + P*128 + bit8(P*128) * ydelta
     const int cy = ct * 32 + tr_c;
     const unsigned ybase_c = (unsigned)(XBYTES + (cy >> 3) * 16 + (cy & 7) * 2);
@@ -502,6 +511,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     const unsigned lds_base = (unsigned)(uintptr_t)lds;
     typedef short s16x8_t __attribute__((ext_vector_type(8)));
 
+    // per-tap transpose-read offsets inside a stage (K-step invariant): the inner loop only adds the ring base
+    constexpr int NAD = UPS ? 4 : 2;
+    unsigned toff[NTW][NAD];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int tg = (tap0 + t) > 8 ? 8 : tap0 + t;
+        const int dy = (int)((a.dy_bits >> (4 * tg)) & 15), dx = (int)((a.dx_bits >> (4 * tg)) & 15);
+        if constexpr (!UPS) {
+            const unsigned P0 = (unsigned)((ty0 + dy) * PW + tx0 + dx) << 7, P1 = (unsigned)((ty1 + dy) * PW + tx0 + dx) << 7;
+            toff[t][0] = ybase_c + P0 + ((P0 >> 8) & 1) * ydelta;
+            toff[t][1] = ybase_c + P1 + ((P1 >> 8) & 1) * ydelta;
+        } else {
+            const int sy0 = (ty0 + dy + 1) >> 1, sy1 = (ty1 + dy + 1) >> 1, sx0 = (tx0 + dx + 1) >> 1;
+            const unsigned P00 = (unsigned)(sy0 * PW + sx0) << 7, P10 = (unsigned)(sy1 * PW + sx0) << 7;
+            const unsigned P01 = P00 + 2 * 128, P11 = P10 + 2 * 128;      // tx + 4 -> source x + 2
+            toff[t][0] = ybase_c + P00 + ((P00 >> 8) & 1) * ydelta;
+            toff[t][1] = ybase_c + P01 + ((P01 >> 8) & 1) * ydelta;
+            toff[t][2] = ybase_c + P10 + ((P10 >> 8) & 1) * ydelta;
+            toff[t][3] = ybase_c + P11 + ((P11 >> 8) & 1) * ydelta;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i)
         if (i < nsteps) stage(i, i);
@@ -515,42 +545,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         bf16x8_t xf[2];
         {
             s16x4_t a0, a1, b0, b1;
-            tr_read_tile<4 * 128, 16 * 128>(bb + xoff, a0, a1, b0, b1);
+            tr_read_tile<4 * XROW, 16 * XROW>(bb + xoff, a0, a1, b0, b1);
             s16x8_t v0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
             s16x8_t v1 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
             xf[0] = __builtin_bit_cast(bf16x8_t, v0); xf[1] = __builtin_bit_cast(bf16x8_t, v1);
         }
-        const unsigned yb0 = bb + ybase_c;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int dy = (int)((a.dy_bits >> (4 * t)) & 15), dx = (int)((a.dx_bits >> (4 * t)) & 15);
-            unsigned ad[4];
+        // software pipeline over the taps: the four transpose reads of tap t+1 are issued before the MFMAs of tap t (LDS
+        // returns in order, so lgkmcnt(4) = "tap t has landed"); the waits carry the fragment registers as operands so
+        // that the compiler keeps issue -> wait -> MFMA in this order.
+        s16x4_t y0[2], y1[2], y2[2], y3[2];
+        auto issue = [&](int t, s16x4_t& r0, s16x4_t& r1, s16x4_t& r2, s16x4_t& r3) {
             if constexpr (!UPS) {
-                const unsigned P0 = (unsigned)((ty0 + dy) * PW + tx0 + dx) << 7, P1 = (unsigned)((ty1 + dy) * PW + tx0 + dx) << 7;
-                ad[0] = yb0 + P0 + ((P0 >> 8) & 1) * ydelta;   // +4 pixels keeps (P>>1)&1
-                ad[1] = ad[0] + 4 * 128;
-                ad[2] = yb0 + P1 + ((P1 >> 8) & 1) * ydelta;
-                ad[3] = ad[2] + 4 * 128;
+                // second / fourth read = +4 pixels (same (P>>1)&1 swizzle term): immediate offsets
+                const unsigned a0 = bb + toff[t][0], a1 = bb + toff[t][1];
+                asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                             "ds_read_b64_tr_b16 %1, %4 offset:512\n\t"
+                             "ds_read_b64_tr_b16 %2, %5\n\t"
+                             "ds_read_b64_tr_b16 %3, %5 offset:512"
+                             : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                             : "v"(a0), "v"(a1)
+                             : "memory");
             } else {
-                const int sy0 = (ty0 + dy + 1) >> 1, sy1 = (ty1 + dy + 1) >> 1, sx0 = (tx0 + dx + 1) >> 1;
-                const unsigned P00 = (unsigned)(sy0 * PW + sx0) << 7, P10 = (unsigned)(sy1 * PW + sx0) << 7;
-                const unsigned P01 = P00 + 2 * 128, P11 = P10 + 2 * 128;      // tx + 4 -> source x + 2
-                ad[0] = yb0 + P00 + ((P00 >> 8) & 1) * ydelta;
-                ad[1] = yb0 + P01 + ((P01 >> 8) & 1) * ydelta;
-                ad[2] = yb0 + P10 + ((P10 >> 8) & 1) * ydelta;
-                ad[3] = yb0 + P11 + ((P11 >> 8) & 1) * ydelta;
+                unsigned ad[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) ad[h] = bb + toff[t][h];
+                asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                             "ds_read_b64_tr_b16 %1, %5\n\t"
+                             "ds_read_b64_tr_b16 %2, %6\n\t"
+                             "ds_read_b64_tr_b16 %3, %7"
+                             : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                             : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3])
+                             : "memory");
             }
-            s16x4_t a0, a1, b0, b1;
-            asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
-                         "ds_read_b64_tr_b16 %1, %5\n\t"
-                         "ds_read_b64_tr_b16 %2, %6\n\t"
-                         "ds_read_b64_tr_b16 %3, %7\n\t"
-                         "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1)
-                         : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3])
-                         : "memory");
-            s16x8_t v0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-            s16x8_t v1 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        };
+        issue(0, y0[0], y1[0], y2[0], y3[0]);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int c = t & 1, n = c ^ 1;
+            if (t < NTW - 1) {
+                issue(t + 1, y0[n], y1[n], y2[n], y3[n]);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(y0[c]), "+v"(y1[c]), "+v"(y2[c]), "+v"(y3[c])::"memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y0[c]), "+v"(y1[c]), "+v"(y2[c]), "+v"(y3[c])::"memory");
+            }
+            s16x8_t v0 = {y0[c][0], y0[c][1], y0[c][2], y0[c][3], y1[c][0], y1[c][1], y1[c][2], y1[c][3]};
+            s16x8_t v1 = {y2[c][0], y2[c][1], y2[c][2], y2[c][3], y3[c][0], y3[c][1], y3[c][2], y3[c][3]};
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], __builtin_bit_cast(bf16x8_t, v0), acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[1], __builtin_bit_cast(bf16x8_t, v1), acc[t], 0, 0, 0);
         }
@@ -558,13 +597,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 
     const int lcol = lane & 31, lhalf = lane >> 5;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NTW; ++t) {
+        if (tap0 + t > 8) break;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int jj = j0 + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
             const int cc = c0 + ct * 32 + lcol;
-            atomicAdd(a.dw + ((size_t)t * a.Cout + jj) * a.C0 + cc, acc[t][r]);
+            atomicAdd(a.dw + ((size_t)(tap0 + t) * a.Cout + jj) * a.C0 + cc, acc[t][r]);
         }
+    }
 }
 
 int g_wgrad_halo = -1;       // -1: SRVP_WGRAD_HALO env (default 1)
@@ -574,7 +615,7 @@ static int try_launch_halo(const srvp_wgrad_desc* d, const WgradK& k, hipStream_
     done = false;
     if (g_wgrad_halo < 0) { const char* e = getenv("SRVP_WGRAD_HALO"); g_wgrad_halo = e ? atoi(e) : 1; }
     if (!g_wgrad_halo) return SRVP_OK;
-    if (d->ntaps != 9 || d->si != 1 || d->so != 1 || d->C1 != 0 || d->C0 % 64 || d->Cout % 64) return SRVP_OK;
+    if (d->ntaps != 9 || d->si != 1 || d->so != 1 || d->C1 != 0 || d->C0 % 64 || (d->Cout % 64 && d->Cout != 32)) return SRVP_OK;
     for (int t = 0; t < 9; ++t)
         if (d->dy[t] < 0 || d->dy[t] > 2 || d->dx[t] < 0 || d->dx[t] > 2 || d->ooy[t] != d->ooy[0] || d->oox[t] != d->ooy[0]) return SRVP_OK;
     const int OH = d->OH, OW = d->OW, ups = d->ups0 ? 1 : 0;
@@ -594,15 +635,19 @@ static int try_launch_halo(const srvp_wgrad_desc* d, const WgradK& k, hipStream_
     h.lg_nxb = lg(OW / TW); h.lg_nyb = lg(OH / h.RH);
     h.ntiles = d->N * (OH / h.RH) * (OW / TW);
     h.oo = d->ooy[0];
-    const int pairs = (d->Cout / 64) * (d->C0 / 64);
+    const int bj = d->Cout == 32 ? 32 : 64;
+    const int pairs = (d->Cout / bj) * (d->C0 / 64);
     static int target = -1;
     if (target < 0) { const char* e = getenv("SRVP_WGRAD_HALO_WGS"); target = e ? atoi(e) : 512; }
     int splitk = (target + pairs - 1) / pairs;
     if (splitk > h.ntiles / 8) splitk = h.ntiles / 8 > 0 ? h.ntiles / 8 : 1;
     h.a.splitk = splitk;
     const long long blocks = (long long)pairs * splitk;
-    if (ups) hipLaunchKernelGGL((wgrad_halo_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, h);
-    else hipLaunchKernelGGL((wgrad_halo_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, h);
+    if (bj == 32) {
+        if (ups) hipLaunchKernelGGL((wgrad_halo_kernel<true, 32>), dim3((unsigned)blocks), dim3(256), 0, st, h);
+        else hipLaunchKernelGGL((wgrad_halo_kernel<false, 32>), dim3((unsigned)blocks), dim3(256), 0, st, h);
+    } else if (ups) hipLaunchKernelGGL((wgrad_halo_kernel<true, 64>), dim3((unsigned)blocks), dim3(256), 0, st, h);
+    else hipLaunchKernelGGL((wgrad_halo_kernel<false, 64>), dim3((unsigned)blocks), dim3(256), 0, st, h);
     SRVP_CHECK_LAUNCH("srvp_wgrad_mfma(halo)");
     done = true;
     return SRVP_OK;

@@ -44,6 +44,8 @@ CASES = [
     ('conv', 3, 1, 1, 64, 0, False, 64, 64, 1),        # halo kernel: 16x16 interior tiles of a 64x64 image
     ('conv', 3, 1, 1, 128, 0, False, 8, 64, 6),        # halo kernel: four 8x8 images per tile, ragged image count
     ('conv', 3, 1, 1, 64, 0, True, 4, 64, 5),          # halo kernel: 4x4 -> 8x8 upsampled, ragged
+    ('conv', 3, 1, 1, 64, 0, False, 32, 24, 2),        # Cout padded to 32: tap-split halo wgrad
+    ('conv', 3, 1, 1, 128, 0, True, 16, 20, 1),        # same, upsampled source
     ('conv', 4, 2, 1, 64, 0, False, 16, 128, 2),       # DCGAN encoder stride 2
     ('conv', 4, 1, 0, 64, 0, False, 4, 128, 5),        # encoder last_conv ("full")
     ('convT', 4, 2, 1, 64, 64, False, 8, 64, 2),       # DCGAN decoder (4 phases) with skip
