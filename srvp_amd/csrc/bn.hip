@@ -45,34 +45,55 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 // ---------------------------------------------------------------------------------------------------------
 // forward: act = f(scale*raw + shift)
 // ---------------------------------------------------------------------------------------------------------
+// Pixel walker: pixel index p -> (n, y, x) without divisions inside the loop: decode once, then advance by the
+// (constant) grid stride with carries.
+struct PixWalk {
+    int n, y, x, dn, dy, dx, H, W;
+    __device__ __forceinline__ void init(unsigned p0, unsigned stride, int H_, int W_) {
+        H = H_; W = W_;
+        x = (int)(p0 % (unsigned)W); unsigned q = p0 / (unsigned)W; y = (int)(q % (unsigned)H); n = (int)(q / (unsigned)H);
+        dx = (int)(stride % (unsigned)W); q = stride / (unsigned)W; dy = (int)(q % (unsigned)H); dn = (int)(q / (unsigned)H);
+    }
+    __device__ __forceinline__ void next() {
+        x += dx; if (x >= W) { x -= W; ++y; }
+        y += dy; if (y >= H) { y -= H; ++n; }
+        n += dn;
+    }
+};
+
 template <bool POOL>
 __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ raw, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, int act, int N, int H, int W, int C,
                                                      bf16_t* __restrict__ dst, int db, bf16_t* __restrict__ dpool, int pb,
                                                      float* __restrict__ dst_f32) {
     const int CG = C / 8;
+    const int PPB = blockDim.x / CG;             // (pooled) pixels handled in parallel by one workgroup
+    const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+    if (pl >= PPB) return;
     const int OH = POOL ? H / 2 : H, OW = POOL ? W / 2 : W;
-    const long long total = (long long)N * OH * OW * CG;
-    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
-        int cg = (int)(it % CG);
-        long long p = it / CG;
-        int x = (int)(p % OW); p /= OW;
-        int y = (int)(p % OH);
-        int n = (int)(p / OH);
-        float sc[8], sh[8];
+    const unsigned P = (unsigned)N * OH * OW, stride = gridDim.x * PPB;
+    float sc[8], sh[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { sc[e] = scale[cg * 8 + e]; sh[e] = shift[cg * 8 + e]; }
+    for (int e = 0; e < 8; ++e) { sc[e] = scale[cg * 8 + e]; sh[e] = shift[cg * 8 + e]; }
+    PixWalk w;
+    w.init(blockIdx.x * PPB + pl, stride, OH, OW);
+    constexpr int R = POOL ? 2 : 1;
+    for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
+        const int n = w.n, y = w.y, x = w.x;
+        u32x4_t v[R * R];
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+                v[i * R + j] = *reinterpret_cast<const u32x4_t*>(raw + (((size_t)n * H + y * R + i) * W + x * R + j) * C + cg * 8);
         float mx[8];
-        constexpr int R = POOL ? 2 : 1;
 #pragma unroll
         for (int i = 0; i < R; ++i)
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                int yy = y * R + i, xx = x * R + j;
-                size_t off = (((size_t)n * H + yy) * W + xx) * C + cg * 8;
-                u32x4_t v = *reinterpret_cast<const u32x4_t*>(raw + off);
+                const int yy = y * R + i, xx = x * R + j;
                 float f[8];
-                unpack8(v, f);
+                unpack8(v[i * R + j], f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = act_fwd(f[e] * sc[e] + sh[e], act);
                 u32x4_t o = pack8(f);
@@ -81,6 +102,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ 
                     *reinterpret_cast<u32x4_t*>(dst + doff) = o;
                 }
                 if (dst_f32) {
+                    const size_t off = (((size_t)n * H + yy) * W + xx) * C + cg * 8;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) dst_f32[off + e] = f[e];
                 }
@@ -111,6 +133,7 @@ struct BnBwdK {
 };
 
 // g[8] = dA * f'(pre) for pixel (n,y,x), channel group cg; also returns raw values
+template <int MODE>
 __device__ __forceinline__ void bn_bwd_g(const BnBwdK& a, int n, int y, int x, int cg, const float* sc, const float* sh,
                                          float* g, float* rawf) {
     const int C = a.C, H = a.H, W = a.W;
@@ -125,10 +148,10 @@ __device__ __forceinline__ void bn_bwd_g(const BnBwdK& a, int n, int y, int x, i
         for (int e = 0; e < 8; ++e) d[e] = da[off + e];
     } else {
         const bf16_t* da = (const bf16_t*)a.da;
-        if (a.da_mode == 0) {
+        if constexpr (MODE == 0) {
             size_t off = (((size_t)n * (H + 2 * db) + y + db) * (W + 2 * db) + x + db) * cs + co;
             unpack8(*reinterpret_cast<const u32x4_t*>(da + off), d);
-        } else if (a.da_mode == 1) {
+        } else if constexpr (MODE == 1) {
             const int H2 = 2 * H, W2 = 2 * W;
 #pragma unroll
             for (int e = 0; e < 8; ++e) d[e] = 0.f;
@@ -182,6 +205,50 @@ __device__ __forceinline__ void bn_bwd_g(const BnBwdK& a, int n, int y, int x, i
     for (int e = 0; e < 8; ++e) g[e] = d[e] * act_bwd(rawf[e] * sc[e] + sh[e], a.act_kind);
 }
 
+// Pooled consumer (da_mode 2), whole 2x2 window (py, px) of image n at once: g[q][8] / raw[q][8] for the window pixels
+// q = 2*i + j.  Arg-max routing with torch's first-max tie rule (scan order (0,0),(0,1),(1,0),(1,1)).
+__device__ __forceinline__ void bn_bwd_g_window(const BnBwdK& a, int n, int py, int px, int cg, const float* sc, const float* sh,
+                                                float (*g)[8], float (*rawf)[8]) {
+    const int C = a.C, H = a.H, W = a.W, db = a.da_border, ab = a.act_border;
+    const int Hh = H / 2, Wh = W / 2;
+    float t[8], w4[4][8];
+    unpack8(*reinterpret_cast<const u32x4_t*>((const bf16_t*)a.da + (((size_t)n * (Hh + 2 * db) + py + db) * (Wh + 2 * db) + px + db) * a.da_cstride +
+                                              a.da_coff + cg * 8), t);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int y = 2 * py + (q >> 1), x = 2 * px + (q & 1);
+        unpack8(*reinterpret_cast<const u32x4_t*>(a.act + (((size_t)n * (H + 2 * ab) + y + ab) * (W + 2 * ab) + x + ab) * C + cg * 8), w4[q]);
+        unpack8(*reinterpret_cast<const u32x4_t*>(a.raw + (((size_t)n * H + y) * W + x) * C + cg * 8), rawf[q]);
+    }
+    float d[4][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int best = 0; float bv = w4[0][e];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) if (w4[q][e] > bv) { bv = w4[q][e]; best = q; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q][e] = (best == q) ? t[e] : 0.f;
+    }
+    if (a.da2) {
+        const int idx = a.da2_idx ? a.da2_idx[n] : n;
+        if (idx >= 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int y = 2 * py + (q >> 1), x = 2 * px + (q & 1);
+                float u[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>(a.da2 + (((size_t)idx * H + y) * W + x) * C + cg * 8), u);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d[q][e] += u[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[q][e] = d[q][e] * act_bwd(rawf[q][e] * sc[e] + sh[e], a.act_kind);
+}
+
+template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdK a, double* red) {
     const int CG = a.C / 8;
     const int PPB = blockDim.x / CG;             // pixels handled in parallel by one workgroup
@@ -197,14 +264,30 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdK a, doub
             sc[e] = a.scale[cg * 8 + e]; sh[e] = a.shift[cg * 8 + e];
             mu[e] = a.mean ? a.mean[cg * 8 + e] : 0.f; is[e] = a.invstd ? a.invstd[cg * 8 + e] : 0.f;
         }
-        const long long P = (long long)a.N * a.H * a.W;
-        for (long long p = (long long)blockIdx.x * PPB + pl; p < P; p += (long long)gridDim.x * PPB) {
-            int x = (int)(p % a.W); long long q = p / a.W;
-            int y = (int)(q % a.H); int n = (int)(q / a.H);
-            float g[8], rawf[8];
-            bn_bwd_g(a, n, y, x, cg, sc, sh, g, rawf);
+        if constexpr (MODE == 2) {
+            // pooled: one thread per 2x2 window (window activations and the pooled gradient are read once)
+            const unsigned P = (unsigned)a.N * (a.H / 2) * (a.W / 2), stride = gridDim.x * PPB;
+            PixWalk w;
+            w.init(blockIdx.x * PPB + pl, stride, a.H / 2, a.W / 2);
+            for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
+                float g[4][8], rawf[4][8];
+                bn_bwd_g_window(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s1[e] += g[e]; s2[e] += g[e] * (rawf[e] - mu[e]) * is[e]; }
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { s1[e] += g[q][e]; s2[e] += g[q][e] * (rawf[q][e] - mu[e]) * is[e]; }
+            }
+        } else {
+            const unsigned P = (unsigned)a.N * a.H * a.W, stride = gridDim.x * PPB;
+            PixWalk w;
+            w.init(blockIdx.x * PPB + pl, stride, a.H, a.W);
+#pragma unroll 2
+            for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
+                float g[8], rawf[8];
+                bn_bwd_g<MODE>(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s1[e] += g[e]; s2[e] += g[e] * (rawf[e] - mu[e]) * is[e]; }
+            }
         }
     }
 #pragma unroll
@@ -237,6 +320,7 @@ __global__ void bn_bwd_finalize_kernel(const double* red, double count, const fl
     coef[c] = (float)k1; coef[C + c] = (float)k2; coef[2 * C + c] = (float)k3;
 }
 
+template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK a, const float* __restrict__ coef,
                                                            bf16_t* __restrict__ draw, int db) {
     const int CG = a.C / 8;
@@ -249,12 +333,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK a, const
         sc[e] = a.scale[cg * 8 + e]; sh[e] = a.shift[cg * 8 + e];
         k1[e] = coef[cg * 8 + e]; k2[e] = coef[a.C + cg * 8 + e]; k3[e] = coef[2 * a.C + cg * 8 + e];
     }
-    const long long P = (long long)a.N * a.H * a.W;
-    for (long long p = (long long)blockIdx.x * PPB + pl; p < P; p += (long long)gridDim.x * PPB) {
-        int x = (int)(p % a.W); long long q = p / a.W;
-        int y = (int)(q % a.H); int n = (int)(q / a.H);
+    if constexpr (MODE == 2) {
+        const unsigned P = (unsigned)a.N * (a.H / 2) * (a.W / 2), stride = gridDim.x * PPB;
+        PixWalk w;
+        w.init(blockIdx.x * PPB + pl, stride, a.H / 2, a.W / 2);
+        for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
+            float g[4][8], rawf[4][8];
+            bn_bwd_g_window(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = k1[e] * g[q][e] + k2[e] + k3[e] * rawf[q][e];
+                size_t off = (((size_t)w.n * (a.H + 2 * db) + 2 * w.y + (q >> 1) + db) * (a.W + 2 * db) + 2 * w.x + (q & 1) + db) * a.C + cg * 8;
+                *reinterpret_cast<u32x4_t*>(draw + off) = pack8(o);
+            }
+        }
+        return;
+    }
+    const unsigned P = (unsigned)a.N * a.H * a.W, stride = gridDim.x * PPB;
+    PixWalk w;
+    w.init(blockIdx.x * PPB + pl, stride, a.H, a.W);
+#pragma unroll 2
+    for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
+        const int n = w.n, y = w.y, x = w.x;
         float g[8], rawf[8], o[8];
-        bn_bwd_g(a, n, y, x, cg, sc, sh, g, rawf);
+        bn_bwd_g<MODE>(a, n, y, x, cg, sc, sh, g, rawf);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = k1[e] * g[e] + k2[e] + k3[e] * rawf[e];
         size_t off = (((size_t)n * (a.H + 2 * db) + y + db) * (a.W + 2 * db) + x + db) * a.C + cg * 8;
@@ -277,7 +381,7 @@ int fill_k(const srvp_bnbwd_desc* d, BnBwdK& k) {
 
 inline unsigned grid_for(long long work_items, int per_block) {
     long long b = (work_items + per_block - 1) / per_block;
-    if (b > 2048) b = 2048;
+    if (b > 4096) b = 4096;
     if (b < 1) b = 1;
     return (unsigned)b;
 }
@@ -310,12 +414,14 @@ extern "C" int srvp_bn_act(const void* raw, const float* scale, const float* shi
     hipStream_t st = (hipStream_t)stream;
     if (dst_pool) {
         SRVP_REQUIRE(H % 2 == 0 && W % 2 == 0, "srvp_bn_act: pooling needs even H, W");
-        long long total = (long long)N * (H / 2) * (W / 2) * (C / 8);
-        hipLaunchKernelGGL(bn_act_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)raw, scale, shift,
+        long long total = (long long)N * (H / 2) * (W / 2);
+        SRVP_REQUIRE(C / 8 <= 256 && (long long)N * H * W < (1ll << 31), "srvp_bn_act: C=%d / size unsupported", C);
+        hipLaunchKernelGGL(bn_act_kernel<true>, dim3(grid_for(total, (256 / (C / 8)) * 2)), dim3(256), 0, st, (const bf16_t*)raw, scale, shift,
                            act, N, H, W, C, (bf16_t*)dst, dst_border, (bf16_t*)dst_pool, pool_border, dst_f32);
     } else {
-        long long total = (long long)N * H * W * (C / 8);
-        hipLaunchKernelGGL(bn_act_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)raw, scale, shift,
+        long long total = (long long)N * H * W;
+        SRVP_REQUIRE(C / 8 <= 256 && total < (1ll << 31), "srvp_bn_act: C=%d / size unsupported", C);
+        hipLaunchKernelGGL(bn_act_kernel<false>, dim3(grid_for(total, (256 / (C / 8)) * 4)), dim3(256), 0, st, (const bf16_t*)raw, scale, shift,
                            act, N, H, W, C, (bf16_t*)dst, dst_border, (bf16_t*)nullptr, 0, dst_f32);
     }
     SRVP_CHECK_LAUNCH("srvp_bn_act");
@@ -329,7 +435,12 @@ extern "C" int srvp_bn_bwd_reduce(const srvp_bnbwd_desc* d, double* red, void* s
     SRVP_REQUIRE(red, "srvp_bn_bwd_reduce: null red");
     const int CG = k.C / 8, PPB = 256 / CG;
     long long P = (long long)k.N * k.H * k.W;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for(P, PPB * 8)), dim3(256), 0, (hipStream_t)stream, k, red);
+    SRVP_REQUIRE(P < (1ll << 31), "srvp_bn_bwd_reduce: too many pixels");
+    if (k.da_mode == 2) P /= 4;
+    const dim3 g(grid_for(P, PPB * (k.da_mode == 2 ? 2 : 8)));
+    if (k.da_mode == 0) hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, g, dim3(256), 0, (hipStream_t)stream, k, red);
+    else if (k.da_mode == 1) hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, g, dim3(256), 0, (hipStream_t)stream, k, red);
+    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, g, dim3(256), 0, (hipStream_t)stream, k, red);
     SRVP_CHECK_LAUNCH("srvp_bn_bwd_reduce");
     return SRVP_OK;
 }
@@ -351,8 +462,12 @@ extern "C" int srvp_bn_bwd_apply(const srvp_bnbwd_desc* d, const float* coef, vo
     SRVP_REQUIRE(coef && draw, "srvp_bn_bwd_apply: null pointer");
     const int CG = k.C / 8, PPB = 256 / CG;
     long long P = (long long)k.N * k.H * k.W;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(P, PPB * 4)), dim3(256), 0, (hipStream_t)stream, k, coef,
-                       (bf16_t*)draw, dst_border);
+    SRVP_REQUIRE(P < (1ll << 31), "srvp_bn_bwd_apply: too many pixels");
+    if (k.da_mode == 2) P /= 4;
+    const dim3 g(grid_for(P, PPB * (k.da_mode == 2 ? 1 : 4)));
+    if (k.da_mode == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, g, dim3(256), 0, (hipStream_t)stream, k, coef, (bf16_t*)draw, dst_border);
+    else if (k.da_mode == 1) hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, g, dim3(256), 0, (hipStream_t)stream, k, coef, (bf16_t*)draw, dst_border);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, g, dim3(256), 0, (hipStream_t)stream, k, coef, (bf16_t*)draw, dst_border);
     SRVP_CHECK_LAUNCH("srvp_bn_bwd_apply");
     return SRVP_OK;
 }
