@@ -27,6 +27,7 @@ struct GemmArgs {
 // its 4 waves split K and are summed through LDS (the latent GEMMs are small and launch/latency bound, so the
 // lever is parallelism over K and over 32x32 tiles, not tile size).  Operands are read straight into MFMA fragments
 // with generic element strides: lane l feeds A[m0 + (l&31)][k + (l>>5)] and B[k + (l>>5)][n0 + (l&31)].
+template <bool AVEC, bool BVEC>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
     __shared__ float red[3][32][33];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -35,24 +36,41 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
     const bool mv = (m0 + r) < g.M, nv = (n0 + r) < g.N;
     const float* Ap = g.A + (long long)(mv ? m0 + r : 0) * g.a_rs;
     const float* Bp = g.B + (long long)(nv ? n0 + r : 0) * g.b_cs;
-    const int kper = (((g.K + 3) / 4) + 1) & ~1;
+    // K split over the 4 waves in multiples of 8 (the VEC path walks K in 8-wide groups: 4 per half-wave)
+    const int kper = (((g.K + 3) / 4) + 7) & ~7;
     const int kb = wid * kper;
     int ke = kb + kper; if (ke > g.K) ke = g.K;
     f32x16_t acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    constexpr int U = 8;
-    for (int k = kb; k < ke; k += 2 * U) {
-        float a[U], b[U];
+    // These GEMMs are tiny (M = batch rows) and latency bound: ALL operand loads of a 128-wide K chunk are issued
+    // before the first MFMA (one memory round trip per chunk instead of one per 16 k).  The MFMA K order is free as
+    // long as A and B agree: half-wave kh takes the k indices 8j + 4kh + {0..3}, one float4 load for an operand that is
+    // K-contiguous and 16-byte aligned (AVEC / BVEC), four lane-coalesced 4-byte loads otherwise.
+    constexpr int CH = 128;
+    for (int kc = kb; kc < ke; kc += CH) {
+        f32x4_t a4[CH / 8], b4[CH / 8];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int kk = k + 2 * u + kh;
-            bool kv = kk < ke;
-            a[u] = (kv && mv) ? Ap[(long long)kk * g.a_cs] : 0.f;
-            b[u] = (kv && nv) ? Bp[(long long)kk * g.b_rs] : 0.f;
+        for (int j = 0; j < CH / 8; ++j) {
+            const int kk = kc + 8 * j + 4 * kh;
+            if constexpr (AVEC) {
+                // K % 4 == 0 and kper % 8 == 0: a float4 is all-in or all-out
+                a4[j] = (kk < ke && mv) ? *reinterpret_cast<const f32x4_t*>(Ap + kk) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a4[j][i] = (kk + i < ke && mv) ? Ap[(long long)(kk + i) * g.a_cs] : 0.f;
+            }
+            if constexpr (BVEC) {
+                b4[j] = (kk < ke && nv) ? *reinterpret_cast<const f32x4_t*>(Bp + kk) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b4[j][i] = (kk + i < ke && nv) ? Bp[(long long)(kk + i) * g.b_rs] : 0.f;
+            }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+        for (int j = 0; j < CH / 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j][i], b4[j][i], acc, 0, 0, 0);
     }
     // C/D layout: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
     if (wid > 0) {
@@ -82,7 +100,12 @@ int gemm(hipStream_t st, const float* A, long long a_rs, long long a_cs, const f
     if (M <= 0 || N <= 0) return SRVP_OK;
     GemmArgs g{A, a_rs, a_cs, B, b_rs, b_cs, bias, C, c_rs, mask, mask_rs, M, N, K, act, accumulate, alpha};
     dim3 grid((N + 31) / 32, (M + 31) / 32);
-    hipLaunchKernelGGL(gemm_f32_mfma_kernel, grid, dim3(256), 0, st, g);
+    const bool av = a_cs == 1 && K % 4 == 0 && a_rs % 4 == 0 && ((uintptr_t)A % 16) == 0;
+    const bool bv = b_rs == 1 && K % 4 == 0 && b_cs % 4 == 0 && ((uintptr_t)B % 16) == 0;
+    if (av && bv) hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, true>), grid, dim3(256), 0, st, g);
+    else if (av) hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, false>), grid, dim3(256), 0, st, g);
+    else if (bv) hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, true>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, false>), grid, dim3(256), 0, st, g);
     SRVP_CHECK_LAUNCH("srvp_gemm_f32");
     return SRVP_OK;
 }
