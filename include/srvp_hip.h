@@ -158,6 +158,10 @@ typedef struct {
     int32_t J0, J0r, J1r;
     int32_t K0, K0r, K1r;
     int64_t sj, sk;
+    /* optional: packed tap t = SUM of the source taps s (element offset s) whose bit is set in tap_set[t] (0 = plain
+     * tap_off[t] mapping).  Used by the sub-pixel form of "nearest x2 upsample then 3x3 conv" (conv.py:331-349), where
+     * each of the 2x2 / 4x4 effective taps is a sum of original taps; unpack adds a packed gradient to every tap of its set. */
+    int32_t tap_set[SRVP_MAX_TAPS];
 } srvp_pack_desc;
 int srvp_pack_weight(const float* src, void* dst, const srvp_pack_desc* d, void* stream);
 /* fp32 gradient: w_grad[ jr*sj + kr*sk + tap_off[t] ] += packed_grad[t][j][k]  (inverse mapping, for dW) */

@@ -58,7 +58,7 @@ class BnBwdDesc(C.Structure):
 class PackDesc(C.Structure):
     _fields_ = [('ntaps', c_i32), ('tap_off', TAPS), ('J', c_i32), ('K', c_i32),
                 ('J0', c_i32), ('J0r', c_i32), ('J1r', c_i32), ('K0', c_i32), ('K0r', c_i32), ('K1r', c_i32),
-                ('sj', c_i64), ('sk', c_i64)]
+                ('sj', c_i64), ('sk', c_i64), ('tap_set', TAPS)]
 
 
 class RolloutDesc(C.Structure):

@@ -10,12 +10,29 @@ inside the consuming kernel.  BatchNorm is split around its grid-wide reduction:
 used for allocation and streams only.
 """
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib as L
 
 CP = 32                      # channel padding granule
+SUBPIX = os.environ.get('SRVP_SUBPIX', '1') != '0'
+# Sub-pixel form of "nearest x2 upsample, then 3x3 conv" (conv.py:331-349): output phase a in {0,1} of a row pair reads
+# two low-resolution rows with SUMS of the original taps -- R[a][u] = kernel rows folded into effective tap u -- and
+# the gradient wrt the low-resolution input is a 4x4 stride-2 conv of the output gradient with D[dy] folded rows.
+# 4/9 of the MACs of convolving the materialised (or index-mapped) upsampled tensor, same result up to the rounding
+# of the folded weights (summed in fp32 from the fp32 masters, rounded to bf16 once).
+SUB_R = {0: [(0,), (1, 2)], 1: [(0, 1), (2,)]}
+SUB_D = [(2,), (1, 2), (0, 1), (0,)]
+
+
+def _tapset(rows, cols, k=3):
+    m = 0
+    for kh in rows:
+        for kw in cols:
+            m |= 1 << (kh * k + kw)
+    return m
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 ACT = {'none': L.ACT_NONE, 'leaky_relu': L.ACT_LRELU, 'tanh': L.ACT_TANH, 'relu': L.ACT_RELU, 'sigmoid': L.ACT_SIGMOID}
 # transposed conv 4x4 s2 p1 (and data-gradient of conv 4x4 s2 p1): output parity -> [(kernel index, padded input offset)]
@@ -53,10 +70,12 @@ class Feat:
         self.interior().copy_(x.permute(0, 2, 3, 1))
 
 
-def _pack_desc(taps_off, J, K, Jsegs, Ksegs, sj, sk):
+def _pack_desc(taps_off, J, K, Jsegs, Ksegs, sj, sk, tap_sets=None):
     d = L.PackDesc()
     d.ntaps = len(taps_off)
     d.tap_off = L.taps(taps_off)
+    if tap_sets is not None:
+        d.tap_set = L.taps(tap_sets)
     d.J, d.K = J, K
     d.J0, d.J0r, d.J1r = Jsegs
     d.K0, d.K0r, d.K1r = Ksegs
@@ -120,6 +139,9 @@ class Block:
         # that half; 21 % of all VGG conv FLOPs at T = 12).  Same arithmetic, different summation order.
         self.split = (role == 'mfma' and len(srcs) == 2 and skip_sel is not None and getattr(self, 'geom', None) == 'same')
         self.B = int(skip_sel.numel()) if self.split else 0
+        # sub-pixel evaluation of the upsampled 3x3 conv (main input only; a hoisted skip half stays a plain conv)
+        self.subpix = bool(SUBPIX and role == 'mfma' and ups and getattr(self, 'geom', None) == 'same' and
+                           (len(srcs) == 1 or self.split) and self.k == 3)
         self.ctot = sum(f.C for f in srcs) if srcs else 0
         self.dcat_c = srcs[0].C if self.split else self.ctot     # channels of the input-gradient tensor `dcat`
         if role != 'out':
@@ -140,7 +162,9 @@ class Block:
             self._alloc_weights()
         if training and role != 'in':
             # gradient wrt the (virtual, concatenated) input of this block: [N][Hin][Win][ctot] bf16, unpadded
-            self.dcat = torch.empty(N, self.Hin, self.Win, self.dcat_c, dtype=torch.bfloat16, device=device)
+            # (sub-pixel blocks: gradient wrt the LOW-resolution source, i.e. already summed over each 2x2 upsample cell)
+            dh, dw_ = (srcs[0].H, srcs[0].W) if self.subpix else (self.Hin, self.Win)
+            self.dcat = torch.empty(N, dh, dw_, self.dcat_c, dtype=torch.bfloat16, device=device)
         if training:
             self.draw_b = 0 if (role == 'mfma' and self.geom in ('full', 'expand')) else 1
             bd = self.draw_b
@@ -149,7 +173,7 @@ class Block:
             self.red = torch.zeros(2, self.cout, dtype=torch.float64, device=device)
             self.bcoef = torch.zeros(3, self.cout, dtype=torch.float32, device=device)
         if training and role in ('mfma', 'out'):
-            ntaps = self.k * self.k
+            ntaps = 16 if self.subpix else self.k * self.k
             self.dw = torch.zeros(ntaps, self.cout, self.dcat_c, dtype=torch.float32, device=device)
         if self.split:
             f1 = srcs[1]
@@ -183,19 +207,37 @@ class Block:
             order_d = [kh * k + kw for py in (0, 1) for px in (0, 1) for kh, _ in PHASE[py] for kw, _ in PHASE[px]]
         else:
             order_d = nat
+        if self.subpix:
+            # forward / wgrad entry t = (a*2+b)*4 + u*2+v; dgrad entry t = dy*4 + dx
+            fsets = [_tapset(SUB_R[a][u], SUB_R[b][v]) for a in (0, 1) for b in (0, 1) for u in (0, 1) for v in (0, 1)]
+            dsets = [_tapset(SUB_D[dy], SUB_D[dx]) for dy in range(4) for dx in range(4)]
+            z16 = [0] * 16
+            h = (c0p, c0r, 0)
         if self.split:
             c1p = self.srcs[1].C
             h, sg = (c0p, c0r, 0), (c1p, c1r, 0)
-            self.pf = _pack_desc(nat, co_p, c0p, osegs, h, sj_f, sk_f)
-            self.pd = _pack_desc(nat, c0p, co_p, h, osegs, sk_f, sj_f)
+            if self.subpix:
+                self.pf = _pack_desc(z16, co_p, c0p, osegs, h, sj_f, sk_f, fsets)
+                self.pd = _pack_desc(z16, c0p, co_p, h, osegs, sk_f, sj_f, dsets)
+            else:
+                self.pf = _pack_desc(nat, co_p, c0p, osegs, h, sj_f, sk_f)
+                self.pd = _pack_desc(nat, c0p, co_p, h, osegs, sk_f, sj_f)
             self.pu = self.pf
             self.pf_s = _pack_desc(nat, co_p, c1p, osegs, sg, sj_f, sk_f)
             self.pd_s = _pack_desc(nat, c1p, co_p, sg, osegs, sk_f, sj_f)
             self.s_off = c0r * sk_f                  # element offset of the skip half inside the fp32 weight
-            self.wt_f = torch.empty(kk, co_p, c0p, dtype=torch.bfloat16, device=dev)
+            kh_ = 16 if self.subpix else kk
+            self.wt_f = torch.empty(kh_, co_p, c0p, dtype=torch.bfloat16, device=dev)
             self.wt_f_s = torch.empty(kk, co_p, c1p, dtype=torch.bfloat16, device=dev)
-            self.wt_d = torch.empty(kk, c0p, co_p, dtype=torch.bfloat16, device=dev) if self.training else None
+            self.wt_d = torch.empty(kh_, c0p, co_p, dtype=torch.bfloat16, device=dev) if self.training else None
             self.wt_d_s = torch.empty(kk, c1p, co_p, dtype=torch.bfloat16, device=dev) if self.training else None
+            return
+        if self.subpix:
+            self.pf = _pack_desc(z16, co_p, c0p, osegs, h, sj_f, sk_f, fsets)
+            self.pd = _pack_desc(z16, c0p, co_p, h, osegs, sk_f, sj_f, dsets)
+            self.pu = self.pf
+            self.wt_f = torch.empty(16, co_p, c0p, dtype=torch.bfloat16, device=dev)
+            self.wt_d = torch.empty(16, c0p, co_p, dtype=torch.bfloat16, device=dev) if self.training else None
             return
         self.pf = _pack_desc(order_f, co_p, self.ctot, osegs, isegs, sj_f, sk_f)
         self.pd = _pack_desc(order_d, self.ctot, co_p, isegs, osegs, sk_f, sj_f)
@@ -262,6 +304,11 @@ class Block:
             ds.dst, ds.DHp, ds.DWp, ds.so, ds.ooy, ds.oox, ds.Cdst, ds.cdst_off = L.ptr(self.S), self.OH, self.OW, 1, 0, 0, self.cout, 0
             ds.dst_is_f32, ds.stats, ds.stat_mod = 1, None, 1
             out.append(ds)
+            if self.subpix:
+                for d in self._subpix_fwd(dst_ptr, use_stats):
+                    d.add_f32, d.add_mod = L.ptr(self.S), self.B
+                    finish(d)
+                return out
             d = L.ConvDesc()                      # conv_h(h_t) + S[sample]
             self._src_fields(d, 'h')
             self._set_taps(d, taps)
@@ -271,6 +318,9 @@ class Block:
             d.stats, d.stat_mod = (L.ptr(self.stats) if use_stats else None), self.cout
             d.add_f32, d.add_mod = L.ptr(self.S), self.B
             finish(d)
+        elif self.subpix:
+            for d in self._subpix_fwd(dst_ptr, use_stats):
+                finish(d)
         elif self.geom in ('same', 'down', 'full', 'sameT'):
             d = L.ConvDesc()
             self._src_fields(d)
@@ -309,6 +359,24 @@ class Block:
             finish(d)
         return out
 
+    def _subpix_fwd(self, dst_ptr, use_stats):
+        """Four phase convolutions (2x2 folded taps on the low-resolution source, outputs interleaved at stride 2)."""
+        f0 = self.srcs[0]
+        assert f0.b == 1
+        out = []
+        for ph, (a, b) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+            d = L.ConvDesc()
+            d.src0, d.C0, d.H0p, d.W0p, d.ups0 = L.ptr(f0.t), f0.C, f0.Hp, f0.Wp, 0
+            d.src1, d.C1, d.H1p, d.W1p, d.ups1, d.map1 = None, 0, 1, 1, 0, None
+            self._set_taps(d, [(a + u, b + v) for u in (0, 1) for v in (0, 1)])
+            d.si, d.Cout = 1, self.cout
+            d.wt = L.ptr(self.wt_f) + ph * 4 * self.cout * f0.C * 2
+            d.N, d.OH, d.OW = self.N, f0.H, f0.W
+            d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox, d.Cdst, d.cdst_off = dst_ptr, self.OH, self.OW, 2, a, b, self.cout, 0
+            d.stats, d.stat_mod = (L.ptr(self.stats) if use_stats else None), self.cout
+            out.append(d)
+        return out
+
     def dgrad_descs(self):
         """ConvDesc list computing dcat = gradient wrt the block input from draw."""
         k, N, bd = self.k, self.N, self.draw_b
@@ -327,11 +395,21 @@ class Block:
             d = base()
             # dIn[i] = sum_kh dOut[i + p - kh]  -> padded coordinate i + p - kh + bd
             taps = [(self.p - kh + bd, self.p - kw + bd) for kh in range(k) for kw in range(k)]
-            self._set_taps(d, taps)
-            d.si, d.wt = 1, L.ptr(self.wt_d)
-            d.N, d.OH, d.OW = N, self.Hin, self.Win
-            d.Cout, d.Cdst = self.dcat_c, self.dcat_c
-            d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox = L.ptr(self.dcat), self.Hin, self.Win, 1, 0, 0
+            if self.subpix:
+                # gradient wrt the low-resolution source: 4x4 stride-2 conv of draw with folded taps (padded row 2 i + dy)
+                assert bd == 1
+                f0 = self.srcs[0]
+                self._set_taps(d, [(dy, dx) for dy in range(4) for dx in range(4)])
+                d.si, d.wt = 2, L.ptr(self.wt_d)
+                d.N, d.OH, d.OW = N, f0.H, f0.W
+                d.Cout, d.Cdst = self.dcat_c, self.dcat_c
+                d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox = L.ptr(self.dcat), f0.H, f0.W, 1, 0, 0
+            else:
+                self._set_taps(d, taps)
+                d.si, d.wt = 1, L.ptr(self.wt_d)
+                d.N, d.OH, d.OW = N, self.Hin, self.Win
+                d.Cout, d.Cdst = self.dcat_c, self.dcat_c
+                d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox = L.ptr(self.dcat), self.Hin, self.Win, 1, 0, 0
             out.append(d)
             if self.split:
                 # gradient wrt the skip tensor of each sample = data-gradient of the time-summed output gradient
@@ -401,7 +479,17 @@ class Block:
         d.ntaps = k * k
         d.dout, d.Cout = L.ptr(self.draw), self.cout
         d.DHp, d.DWp = self.OH + 2 * bd, self.OW + 2 * bd
-        if self.geom in ('same', 'down', 'full'):
+        if self.subpix and which != 's':
+            # 16 (phase, folded tap) weight gradients: low-resolution input taps, output gradient sampled at stride 2
+            f0 = self.srcs[0]
+            ent = [(a, b, u, v) for a in (0, 1) for b in (0, 1) for u in (0, 1) for v in (0, 1)]
+            d.ups0 = 0
+            d.ntaps = 16
+            d.dy, d.dx = L.taps([a + u for a, b, u, v in ent]), L.taps([b + v for a, b, u, v in ent])
+            d.si, d.so = 1, 2
+            d.ooy, d.oox = L.taps([a + bd for a, b, u, v in ent]), L.taps([b + bd for a, b, u, v in ent])
+            d.N, d.OH, d.OW = N, f0.H, f0.W
+        elif self.geom in ('same', 'down', 'full'):
             off = b_in - self.p
             d.dy, d.dx = L.taps([kh + off for kh, _ in nat]), L.taps([kw + off for _, kw in nat])
             d.si, d.so = self.s, 1
@@ -437,7 +525,7 @@ class Block:
             if c0 % cand == 0 and (c1 == 0 or c1 % cand == 0):
                 bc = cand
                 break
-        tiles = (self.cout // bj) * (ctot // bc) * k * k
+        tiles = (self.cout // bj) * (ctot // bc) * d.ntaps
         chunks = (M + 31) // 32
         d.splitk = int(max(1, min((1024 + tiles - 1) // tiles, chunks // 4 if chunks >= 4 else 1)))
         return d
@@ -643,7 +731,8 @@ class DecoderNet(ConvNetBase):
         nxt = ob
         for i in range(len(self.blocks) - 2, -1, -1):
             blk = self.blocks[i]
-            da = dict(t=nxt.dcat, mode=1 if blk.spec['post_up'] else 0, cstride=nxt.dcat_c, coff=0, border=0)
+            # (a sub-pixel consumer hands back the gradient already summed over each 2x2 upsample cell)
+            da = dict(t=nxt.dcat, mode=1 if (blk.spec['post_up'] and not nxt.subpix) else 0, cstride=nxt.dcat_c, coff=0, border=0)
             self._bn_backward(blk, params, grads, da, st, sync)
             self._mfma_backward(blk, grads, st)
             nxt = blk

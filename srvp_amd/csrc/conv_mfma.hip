@@ -59,7 +59,8 @@ __device__ __forceinline__ void conv_acc_init(f32x16_t (&acc)[TM][TN], const Con
         for (int r = 0; r < 16; ++r) {
             int n = 0, oy = 0, ox = 0;
             const bool ok = rowmap(wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf, n, oy, ox);
-            const float* sp = a.add_f32 + ((size_t)sample_of(n) * hw + oy * a.OW + ox) * a.Cout + n0 + wn * (TN * 32) + lcol;
+            // S has the layout of the (unbordered) destination: [sample][DHp][DWp][Cout] at the strided output position
+            const float* sp = a.add_f32 + (((size_t)sample_of(n) * a.DHp + oy * a.so + a.ooy) * a.DWp + ox * a.so + a.oox) * a.Cout + n0 + wn * (TN * 32) + lcol;
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j][r] = ok ? sp[j * 32] : 0.f;
         }
@@ -530,8 +531,8 @@ static int g_halo = -1;      // -1: read SRVP_CONV_HALO on first use; 0 = generi
 static bool halo_geometry(const srvp_conv_desc* d, HaloK& h, int BM) {
     if (g_halo < 0) { const char* e = getenv("SRVP_CONV_HALO"); g_halo = e ? atoi(e) : 1; }
     if (!g_halo) return false;
-    if (d->ntaps != 9 || d->si != 1 || d->C1 != 0 || d->C0 % 64 != 0) return false;
-    for (int t = 0; t < 9; ++t) if (d->dy[t] < 0 || d->dy[t] > 2 || d->dx[t] < 0 || d->dx[t] > 2) return false;
+    if (d->ntaps > 9 || d->si != 1 || d->C1 != 0 || d->C0 % 64 != 0) return false;
+    for (int t = 0; t < d->ntaps; ++t) if (d->dy[t] < 0 || d->dy[t] > 2 || d->dx[t] < 0 || d->dx[t] > 2) return false;
     const int OH = d->OH, OW = d->OW, ups = d->ups0 ? 1 : 0;
     if (OH < 2 || OW < 2 || (OH & (OH - 1)) || (OW & (OW - 1))) return false;
     if (d->H0p != (OH >> ups) + 2 || d->W0p != (OW >> ups) + 2) return false;

@@ -15,6 +15,7 @@ struct PackArgs {
     int J0, J0r, J1r;         // J axis = segment 0 (padded J0, real J0r) followed by segment 1 (real J1r)
     int K0, K0r, K1r;
     long long sj, sk;         // element strides of the real j / k index in the fp32 tensor
+    int tap_set[SRVP_MAX_TAPS];   // != 0: packed tap = sum of the source taps in the bit set
 };
 
 __device__ __forceinline__ int real_index(int i, int seg0_pad, int seg0_real, int seg1_real) {
@@ -32,10 +33,12 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, bf16_t* __rest
     int jr = real_index(j, a.J0, a.J0r, a.J1r), kr = real_index(k, a.K0, a.K0r, a.K1r);
     float v = 0.f;
     if (jr >= 0 && kr >= 0) {
-        int off = 0;
+        int off = 0, set = 0;
 #pragma unroll
-        for (int u = 0; u < SRVP_MAX_TAPS; ++u) if (u == t) off = a.tap_off[u];
-        v = src[jr * a.sj + kr * a.sk + off];
+        for (int u = 0; u < SRVP_MAX_TAPS; ++u) if (u == t) { off = a.tap_off[u]; set = a.tap_set[u]; }
+        if (set == 0) v = src[jr * a.sj + kr * a.sk + off];
+        else
+            for (int sidx = 0; sidx < 16; ++sidx) if ((set >> sidx) & 1) v += src[jr * a.sj + kr * a.sk + sidx];   // fp32 sum, one rounding
     }
     dst[i] = f2bf(v);
 }
@@ -48,16 +51,18 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __rest
     int j = (int)(q % a.J); int t = (int)(q / a.J);
     int jr = real_index(j, a.J0, a.J0r, a.J1r), kr = real_index(k, a.K0, a.K0r, a.K1r);
     if (jr < 0 || kr < 0) return;
-    int off = 0;
+    int off = 0, set = 0;
 #pragma unroll
-    for (int u = 0; u < SRVP_MAX_TAPS; ++u) if (u == t) off = a.tap_off[u];
-    dst[jr * a.sj + kr * a.sk + off] += src[i];     // every (t,j,k) maps to a distinct element: no atomics needed
+    for (int u = 0; u < SRVP_MAX_TAPS; ++u) if (u == t) { off = a.tap_off[u]; set = a.tap_set[u]; }
+    if (set == 0) { dst[jr * a.sj + kr * a.sk + off] += src[i]; return; }   // every (t,j,k) maps to a distinct element: no atomics
+    for (int sidx = 0; sidx < 16; ++sidx)
+        if ((set >> sidx) & 1) atomicAdd(dst + jr * a.sj + kr * a.sk + sidx, src[i]);     // several packed taps share a source tap
 }
 
 int fill_pack(const srvp_pack_desc* d, PackArgs& a) {
     SRVP_REQUIRE(d && d->ntaps >= 1 && d->ntaps <= SRVP_MAX_TAPS, "srvp_pack: ntaps");
     a.ntaps = d->ntaps;
-    for (int t = 0; t < SRVP_MAX_TAPS; ++t) a.tap_off[t] = t < d->ntaps ? d->tap_off[t] : 0;
+    for (int t = 0; t < SRVP_MAX_TAPS; ++t) { a.tap_off[t] = t < d->ntaps ? d->tap_off[t] : 0; a.tap_set[t] = t < d->ntaps ? d->tap_set[t] : 0; }
     a.J = d->J; a.K = d->K; a.J0 = d->J0; a.J0r = d->J0r; a.J1r = d->J1r; a.K0 = d->K0; a.K0r = d->K0r; a.K1r = d->K1r;
     a.sj = d->sj; a.sk = d->sk;
     return SRVP_OK;

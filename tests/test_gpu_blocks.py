@@ -103,8 +103,11 @@ def test_block_conv_fwd_bwd(case, use_tr):
     assert blk.raw[..., cout:].abs().max().item() == 0 if blk.cout > cout else True
     s1 = ref.sum(dim=(0, 2, 3)).double()
     s2 = (ref.double() ** 2).sum(dim=(0, 2, 3))
-    assert rel_err(blk.stats[0, :cout], s1) < 1e-3 * max(1.0, (s2.sqrt().max() / (s1.abs().max() + 1e-9)).item())
-    assert rel_err(blk.stats[1, :cout], s2) < 1e-3
+    # (sub-pixel blocks round the FOLDED weights to bf16, the reference rounds each weight: a systematic 2^-9-level
+    # difference of the outputs that does not average out in the sums)
+    stol = 4e-3 if blk.subpix else 1e-3
+    assert rel_err(blk.stats[0, :cout], s1) < stol * max(1.0, (s2.sqrt().max() / (s1.abs().max() + 1e-9)).item())
+    assert rel_err(blk.stats[1, :cout], s2) < stol
     # ---- backward
     bd = blk.draw_b
     dr = torch.randn(N, blk.OH, blk.OW, cout, generator=g) * 0.5
@@ -123,7 +126,10 @@ def test_block_conv_fwd_bwd(case, use_tr):
     dcat = blk.dcat.float().cpu()                       # [N][Hin][Win][ctot]
     c0p = f0.C
     d0 = dcat[..., :c0r].permute(0, 3, 1, 2)
-    assert rel_err(d0, xin.grad[:, :c0r]) < 2 ** -7, rel_err(d0, xin.grad[:, :c0r])
+    g0 = xin.grad[:, :c0r]
+    if blk.subpix:
+        g0 = F.avg_pool2d(g0, 2) * 4                    # sub-pixel blocks return the gradient wrt the low-res source
+    assert rel_err(d0, g0) < 2 ** -7, rel_err(d0, g0)
     if c1r:
         d1 = dcat[..., c0p:c0p + c1r].permute(0, 3, 1, 2)
         assert rel_err(d1, xin.grad[:, c0r:]) < 2 ** -7
