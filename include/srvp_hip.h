@@ -63,11 +63,15 @@ typedef struct {
      *   add_f32   : fp32 [add_mod][OH][OW][Cout] added to the accumulators (image n uses row n % add_mod) before
      *               the statistics / store -- conv([h, skip]) = conv_h(h) + conv_s(skip), conv_s computed once per sample */
     const int32_t* map0; int32_t dst_is_f32; const float* add_f32; int32_t add_mod;
+    int32_t wt_fragmajor;         /* wt is packed MFMA-fragment-major (srvp_pack_desc.layout 1): required by, and only valid
+                                   * for, launches that srvp_conv_wants_fragmajor() accepts */
 } srvp_conv_desc;
 int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
 /* 1 (default): 3x3 stride-1 single-source convolutions run on the halo-tiled kernel (input patch staged in LDS once
  * per channel chunk, taps = LDS offsets); 0: every convolution on the generic tap-gather kernel.  Same results, bit for bit. */
 int srvp_conv_set_halo(int on);
+/* 1 if this descriptor will run on the halo-tiled kernel, which wants its weights fragment-major (pack layout 1) */
+int srvp_conv_wants_fragmajor(const srvp_conv_desc* d);
 
 /* Weight gradient of the same tap-table convolution (autograd of the modules above):
  *   dW[t][j][c] += sum_{n,oy,ox} dout[n, oy*so+ooy[t], ox*so+oox[t], j] * in_t[n, oy, ox, c]     (fp32 atomics)
@@ -162,6 +166,11 @@ typedef struct {
      * tap_off[t] mapping).  Used by the sub-pixel form of "nearest x2 upsample then 3x3 conv" (conv.py:331-349), where
      * each of the 2x2 / 4x4 effective taps is a sum of original taps; unpack adds a packed gradient to every tap of its set. */
     int32_t tap_set[SRVP_MAX_TAPS];
+    /* 0: tap-major [t][J][K].  1: MFMA-fragment-major [t][K/64][4 (16-wide k slices)][J/32][64 lanes][8]: lane l of a
+     * fragment holds row j = 32*jt + (l & 31), k = 64*cc + 16*kk + 8*(l >> 5) .. +7 -- one B operand of
+     * v_mfma_f32_32x32x16_bf16 is then ONE contiguous 1 KiB load (the halo-tiled convolution reads its weights straight
+     * from L2 into registers in this order).  Needs J % 32 == 0 and K % 64 == 0. */
+    int32_t layout;
 } srvp_pack_desc;
 int srvp_pack_weight(const float* src, void* dst, const srvp_pack_desc* d, void* stream);
 /* fp32 gradient: w_grad[ jr*sj + kr*sk + tap_off[t] ] += packed_grad[t][j][k]  (inverse mapping, for dW) */

@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
                 ('Cdst', c_i32), ('cdst_off', c_i32),
                 ('stats', c_vp), ('stat_mod', c_i32),
                 ('out_f32', c_vp), ('out_nc', c_i32), ('out_sigmoid', c_i32),
-                ('map0', c_vp), ('dst_is_f32', c_i32), ('add_f32', c_vp), ('add_mod', c_i32)]
+                ('map0', c_vp), ('dst_is_f32', c_i32), ('add_f32', c_vp), ('add_mod', c_i32), ('wt_fragmajor', c_i32)]
 
 
 class WgradDesc(C.Structure):
@@ -58,7 +58,7 @@ class BnBwdDesc(C.Structure):
 class PackDesc(C.Structure):
     _fields_ = [('ntaps', c_i32), ('tap_off', TAPS), ('J', c_i32), ('K', c_i32),
                 ('J0', c_i32), ('J0r', c_i32), ('J1r', c_i32), ('K0', c_i32), ('K0r', c_i32), ('K1r', c_i32),
-                ('sj', c_i64), ('sk', c_i64), ('tap_set', TAPS)]
+                ('sj', c_i64), ('sk', c_i64), ('tap_set', TAPS), ('layout', c_i32)]
 
 
 class RolloutDesc(C.Structure):
@@ -80,6 +80,7 @@ _SIGS = {
     'srvp_version': ([], c_i32),
     'srvp_conv_mfma': ([C.POINTER(ConvDesc), c_vp], c_i32),
     'srvp_conv_set_halo': ([c_i32], c_i32),
+    'srvp_conv_wants_fragmajor': ([C.POINTER(ConvDesc)], c_i32),
     'srvp_wgrad_mfma': ([C.POINTER(WgradDesc), c_vp], c_i32),
     'srvp_wgrad_set_tr': ([c_i32], c_i32),
     'srvp_wgrad_set_halo': ([c_i32], c_i32),

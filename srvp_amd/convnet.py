@@ -273,6 +273,18 @@ class Block:
         else:
             d.src1, d.C1, d.H1p, d.W1p, d.ups1, d.map1 = None, 0, 1, 1, 0, None
 
+    @staticmethod
+    def _set_layout(descs, pack_desc):
+        """Launches that run on the halo-tiled kernel read their weights MFMA-fragment-major: ask the library, mark the
+        descriptors and the pack descriptor of that weight buffer (all launches sharing a buffer agree by construction)."""
+        if not descs:
+            return
+        want = [int(L.load().srvp_conv_wants_fragmajor(C.byref(d))) for d in descs]
+        assert len(set(want)) == 1, want
+        for d in descs:
+            d.wt_fragmajor = want[0]
+        pack_desc.layout = want[0]
+
     def _set_taps(self, d, taps):
         d.ntaps = len(taps)
         d.dy = L.taps([t[0] for t in taps])
@@ -280,6 +292,15 @@ class Block:
 
     def fwd_descs(self):
         """List of ConvDesc for the forward convolution (4 for the transposed stride-2 phases, else 1)."""
+        out = self._fwd_descs_raw()
+        if self.split:
+            self._set_layout(out[:1], self.pf_s)       # conv_s(skip)
+            self._set_layout(out[1:], self.pf)
+        else:
+            self._set_layout(out, self.pf)
+        return out
+
+    def _fwd_descs_raw(self):
         k, N = self.k, self.N
         out = []
         use_stats = self.has_bn and self.training
@@ -379,6 +400,15 @@ class Block:
 
     def dgrad_descs(self):
         """ConvDesc list computing dcat = gradient wrt the block input from draw."""
+        out = self._dgrad_descs_raw()
+        if self.split:
+            self._set_layout(out[:1], self.pd)
+            self._set_layout(out[1:], self.pd_s)       # gradient wrt the skip tensor
+        else:
+            self._set_layout(out, self.pd)
+        return out
+
+    def _dgrad_descs_raw(self):
         k, N, bd = self.k, self.N, self.draw_b
         out = []
 

@@ -348,7 +348,7 @@ static int fill_convk(const srvp_conv_desc* d, ConvK& k) {
 // the workgroup owns a 256-pixel SPATIAL tile (16x16 pixels of one image, or whole 8x8 / 4x4 images) and stages the
 // input patch including its 1-pixel halo in LDS ONCE per 64-channel chunk; the 9 taps are then LDS address offsets,
 // so the activation traffic from L2 drops ~6.5x versus re-gathering the rows per tap (the generic kernel above), and
-// only the (small) weight tiles stream through a 2-deep LDS-DMA ring, one tap ahead of the MFMAs.
+// the weights never touch LDS: B fragments are loaded from L2 straight into registers (fragment-major packing).
 //
 // Patch layout in LDS: [pixel][64 ch] (128-byte rows, 16-byte chunks XOR-swizzled by a function g(py, px) of the patch
 // coordinates chosen per geometry so that the ds_read_b128 fragment reads of all 9 taps are bank-conflict free).  Two modes:
@@ -370,15 +370,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NA_MAX = BM == 256 ? 11 : 6;           // 256-pixel tiles: 11 * 256 16-byte pieces = 352 pixels >= 334; 128: 192 >= 180
     constexpr int A_BYTES = NA_MAX * NT * 16;
-    constexpr int B_LD = BN * CPR / NT;
-    constexpr int B_BYTES = 2 * BN * BK * 2;
     constexpr int LDC = BN + 8;
     constexpr int C_BYTES = BM * LDC * 2;
-    constexpr int SMEM = (A_BYTES + B_BYTES) > C_BYTES ? (A_BYTES + B_BYTES) : C_BYTES;
-    static_assert(WM * WN == 4 && (BN * CPR) % NT == 0, "4 waves; weight tile = whole 1 KiB DMA pieces per wave");
+    constexpr int SMEM = A_BYTES > C_BYTES ? A_BYTES : C_BYTES;
+    static_assert(WM * WN == 4, "4 waves");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM + WM * BN * 8];
     unsigned char* Ab = smem;                                             // [<=352 px][64] bf16
-    bf16_t* Bs = reinterpret_cast<bf16_t*>(smem + A_BYTES);               // [2][BN][64]
     float* red = reinterpret_cast<float*>(smem + SMEM);
 
     const ConvK& a = p.a;
@@ -421,7 +418,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     }
     // ---- fragment rows of this lane
     const int lrow = lane & 31, lkc = lane >> 5;
-    int abase[TM], aoy[TM], aox[TM], b_off[TN], b_sw[TN];
+    int abase[TM], aoy[TM], aox[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int r = wm * (TM * 32) + i * 32 + lrow;
@@ -429,8 +426,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         aoy[i] = (r >> p.lgTW) & (p.TH - 1);
         aox[i] = r & (p.TW - 1);
     }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) { const int r = wn * (TN * 32) + j * 32 + lrow; b_off[j] = r * BK; b_sw[j] = (r >> 1) & 7; }
 
     const int ntaps = a.ntaps;
     const int S = ntaps * (C / BK);
@@ -440,16 +435,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             if (i < p.NA)
                 __builtin_amdgcn_global_load_lds((gptr_t)(a.src0 + aoff[i] + cc * BK), (lptr_t)(Ab + ((size_t)i * NT + wid * 64) * 16), 16, 0, 0);
     };
-    auto stage_b = [&](int s) {
+    // ---- weights: MFMA B fragments straight from L2/L1 into registers (pack layout 1: one contiguous 1 KiB load per
+    // fragment), never through LDS.  Measured on the LDS-staged versions: writing the 16 KiB weight tile per tap into LDS
+    // (LDS-DMA or ds_write_b128 alike) cost 20-30 % of the kernel -- the LDS was the contended unit (patch DMA writes +
+    // 24 fragment reads per tap and wave + the tile writes), and the per-tap barrier came with it.  Now the LDS holds the
+    // patch only and the waves synchronise once per 64-channel chunk.
+    // Group g = (step s = (chunk, tap), 16-wide k slice kk): address of fragment j of group g
+    const int JT = a.Cout >> 5;                          // 32-wide column tiles of the packed tensor
+    const int wn_u = __builtin_amdgcn_readfirstlane(wn);  // wave-uniform (kept in SGPRs)
+    const char* wbase = reinterpret_cast<const char*>(a.wt + (size_t)((n0 >> 5) + wn_u * TN) * 512);
+    const unsigned lane_b = (unsigned)lane * 16u;        // this lane's 16 bytes inside a 1 KiB fragment
+    // the fragment stream is walked with SCALAR byte offsets (wave-uniform): slice kk of step (chunk cc, tap t) lives at
+    // ((t * NC + cc) * 4 + kk) * JT KiB; only the per-lane part sits in VGPRs
+    const unsigned slice_b = (unsigned)JT * 1024u;        // bytes per 16-wide k slice (all column tiles)
+    const unsigned tap_b = (unsigned)(C >> 6) * 4u * slice_b;
+    auto step_off = [&](int s) -> unsigned {              // byte offset of step s, slice 0 (clamped: run-off prefetches)
+        if (s >= S) s = S - 1;
         const int cc = s / ntaps, t = s - cc * ntaps;
-        const bf16_t* w = a.wt + ((size_t)t * a.Cout + n0) * C + cc * BK;
-        bf16_t* Bd = Bs + (size_t)(s & 1) * BN * BK;
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const int q = tid + i * NT;
-            const int row = q >> 3, ch = (q & 7) ^ ((row >> 1) & 7);
-            __builtin_amdgcn_global_load_lds((gptr_t)(w + (size_t)row * C + ch * 8), (lptr_t)(Bd + ((size_t)i * NT + wid * 64) * 8), 16, 0, 0);
-        }
+        return (unsigned)t * tap_b + (unsigned)cc * 4u * slice_b;
     };
 
     auto rowmap = [&](int row, int& n, int& oy, int& ox) -> bool {
@@ -463,60 +466,72 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     const int nsub = p.Tn > 1 ? tslot * a.add_mod : 0;
     conv_acc_init<WM, WN, TM, TN>(acc, a, n0, rowmap, [&](int n) { return p.Tn > 1 ? n - nsub : n % a.add_mod; });
 
+    // B fragment ring: slot kk holds slice kk of the current step; loads run two slices ahead (vmcnt counted by hand:
+    // the loads are inline asm so that hipcc neither reorders them nor drains them at the LDS-DMA instructions)
+    u32x4_t bq[4][TN];
+    auto issue_b = [&](unsigned soff, int kk, u32x4_t (&dst)[TN]) {
+        const char* sb = wbase + (soff + (unsigned)kk * slice_b);     // scalar base of slice kk; column tile j at +j KiB
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst[0]) : "v"(lane_b), "s"(sb) : "memory");
+        if constexpr (TN == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"(dst[1]) : "v"(lane_b), "s"(sb) : "memory");
+    };
+    const int NC = C / BK;
+    unsigned soff = step_off(0);
+    issue_b(soff, 0, bq[0]);
+    issue_b(soff, 1, bq[1]);
     stage_a(0);
-    stage_b(0);
-    int t = 0;
-    for (int s = 0; s < S; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                     // patch + weights of step s landed; everyone is past step s-1
+    int s = 0;
+    for (int cc = 0; cc < NC; ++cc) {
+        // new chunk: its patch DMA (and everything older) has landed, visible to all waves.  The wait is the BUILTIN so
+        // that hipcc's own waitcnt pass knows the LDS-DMA is retired -- with an opaque asm wait it re-inserts vmcnt(0)
+        // before the fragment reads of every tap, which drains the weight prefetch ring.
+        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const bool last_tap = (t == ntaps - 1);
-        if (!last_tap) stage_b(s + 1);                    // next tap of the same chunk streams in under the MFMAs
-        const int dy = (int)((a.dy_bits >> (4 * t)) & 15), dx = (int)((a.dx_bits >> (4 * t)) & 15);
-        int apix[TM], asw[TM];
+        for (int t = 0; t < ntaps; ++t, ++s) {
+            const unsigned soff_n = step_off(s + 1);
+            const int dy = (int)((a.dy_bits >> (4 * t)) & 15), dx = (int)((a.dx_bits >> (4 * t)) & 15);
+            int apix[TM], asw[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int vy = (aoy[i] + dy + ups) >> ups, vx = (aox[i] + dx + ups) >> ups;
-            apix[i] = abase[i] + vy * p.PW + vx;
-            asw[i] = ((vx >> p.sw_sh) + p.sw_c1 * vy + p.sw_c2 * (vy >> 1)) & 7;
-        }
-        const bf16_t* Bb = Bs + (size_t)(s & 1) * BN * BK;
-        // software pipeline over the four 16-wide K slices: the fragments of slice kk+1 are in flight under the MFMAs of kk
-        bf16x8_t af[2][TM], bfr[2][TN];
-        const unsigned char* arow[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) arow[i] = Ab + (size_t)apix[i] * 128;
-        auto load_frags = [&](int kk, bf16x8_t (&fa)[TM], bf16x8_t (&fb)[TN]) {
-            const int kc = kk * 2 + lkc;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(arow[i] + ((kc ^ asw[i]) * 16));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(Bb + b_off[j] + ((kc ^ b_sw[j]) * 8));
-        };
-        load_frags(0, af[0], bfr[0]);
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            if (kk + 1 < BK / 16) load_frags(kk + 1, af[(kk + 1) & 1], bfr[(kk + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (last_tap) {
-            t = 0;
-            if (s + 1 < S) {
-                __builtin_amdgcn_s_barrier();             // every wave is done with this chunk's patch
-                asm volatile("" ::: "memory");
-                stage_a((s + 1) / ntaps);
-                stage_b(s + 1);
+            for (int i = 0; i < TM; ++i) {
+                const int vy = (aoy[i] + dy + ups) >> ups, vx = (aox[i] + dx + ups) >> ups;
+                apix[i] = abase[i] + vy * p.PW + vx;
+                asw[i] = ((vx >> p.sw_sh) + p.sw_c1 * vy + p.sw_c2 * (vy >> 1)) & 7;
             }
-        } else {
-            ++t;
+            bf16x8_t af[2][TM];
+            const unsigned char* arow[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) arow[i] = Ab + (size_t)apix[i] * 128;
+            auto load_a = [&](int kk, bf16x8_t (&fa)[TM]) {
+                const int kc = kk * 2 + lkc;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(arow[i] + ((kc ^ asw[i]) * 16));
+            };
+            load_a(0, af[0]);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                // weights two slices ahead (slot (kk+2)&3 was consumed two slices ago)
+                if (kk < 2) issue_b(soff, kk + 2, bq[kk + 2]); else issue_b(soff_n, kk - 2, bq[kk - 2]);
+                if (kk + 1 < 4) load_a(kk + 1, af[(kk + 1) & 1]);
+                // slice kk has landed when only the 2 younger slices (2*TN loads) are outstanding
+                if constexpr (TN == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(bq[kk][0]), "+v"(bq[kk][1])::"memory");
+                else asm volatile("s_waitcnt vmcnt(2)" : "+v"(bq[kk][0])::"memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], __builtin_bit_cast(bf16x8_t, bq[kk][j]), acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            soff = soff_n;
+        }
+        if (cc + 1 < NC) {
+            __builtin_amdgcn_s_barrier();                 // every wave is done with this chunk's patch
+            asm volatile("" ::: "memory");
+            stage_a(cc + 1);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // run-off prefetches
     __syncthreads();
 
     conv_epilogue<BM, BN, WM, WN, TM, TN>(acc, a, smem, red, n0, rowmap);
@@ -559,6 +574,7 @@ static bool halo_geometry(const srvp_conv_desc* d, HaloK& h, int BM) {
 template <int BM, int BN, int WM, int WN>
 int launch_halo(const srvp_conv_desc* d, HaloK& h, hipStream_t st) {
     if (int rc = fill_convk(d, h.a)) return rc;
+    SRVP_REQUIRE(d->wt_fragmajor == 1, "srvp_conv_mfma: this launch runs on the halo kernel and needs fragment-major weights (srvp_conv_wants_fragmajor)");
     long long blocks = (long long)((d->N + h.IMG - 1) / h.IMG) * h.tiles_x * h.tiles_y * (d->Cout / BN);
     SRVP_REQUIRE(blocks > 0 && blocks < (1ll << 31), "srvp_conv_mfma(halo): bad grid %lld", blocks);
     hipLaunchKernelGGL((conv_halo_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(256), 0, st, h);
@@ -582,6 +598,15 @@ int launch(const srvp_conv_desc* d, hipStream_t st) {
 }  // namespace
 
 extern "C" int srvp_conv_set_halo(int on) { g_halo = on; return SRVP_OK; }
+
+extern "C" int srvp_conv_wants_fragmajor(const srvp_conv_desc* d) {
+    HaloK h;
+    static int bm128 = -1;
+    if (bm128 < 0) { const char* e = getenv("SRVP_HALO_BM128"); bm128 = e ? atoi(e) : 0; }
+    if (!d) return 0;
+    if (bm128 && d->Cout % 128 != 0 && halo_geometry(d, h, 128)) return 1;
+    return halo_geometry(d, h, 256) ? 1 : 0;
+}
 
 extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -607,6 +632,7 @@ extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
         if (d->Cout % 64 == 0) return launch_halo<256, 64, 4, 1>(d, h, st);
         return launch_halo<256, 32, 4, 1>(d, h, st);
     }
+    SRVP_REQUIRE(d->wt_fragmajor == 0, "srvp_conv_mfma: fragment-major weights on a launch that runs on the generic kernel");
     const bool k64 = (d->C0 % 64 == 0) && (d->C1 % 64 == 0);
     // LDS ring depth / K step (A/B switch SRVP_CONV_MODE): 5 = BK64 single buffer (default: 3 workgroups per CU hide the
     // DMA latency better than a deeper ring at 1-2 workgroups per CU: 39.0 vs 40.9 (x2) / 43 (BK32 x3) / 46 (BK32 x4) /

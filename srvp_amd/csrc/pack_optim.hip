@@ -16,6 +16,7 @@ struct PackArgs {
     int K0, K0r, K1r;
     long long sj, sk;         // element strides of the real j / k index in the fp32 tensor
     int tap_set[SRVP_MAX_TAPS];   // != 0: packed tap = sum of the source taps in the bit set
+    int layout;                   // 0 tap-major, 1 MFMA-fragment-major (see srvp_hip.h)
 };
 
 __device__ __forceinline__ int real_index(int i, int seg0_pad, int seg0_real, int seg1_real) {
@@ -40,7 +41,12 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, bf16_t* __rest
         else
             for (int sidx = 0; sidx < 16; ++sidx) if ((set >> sidx) & 1) v += src[jr * a.sj + kr * a.sk + sidx];   // fp32 sum, one rounding
     }
-    dst[i] = f2bf(v);
+    long long o = i;
+    if (a.layout == 1) {
+        const int cc = k >> 6, kk = (k >> 4) & 3, kh = (k >> 3) & 1;
+        o = ((((long long)(t * (a.K >> 6) + cc) * 4 + kk) * (a.J >> 5) + (j >> 5)) * 64 + kh * 32 + (j & 31)) * 8 + (k & 7);
+    }
+    dst[o] = f2bf(v);
 }
 
 __global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst, const PackArgs a) {
@@ -65,6 +71,8 @@ int fill_pack(const srvp_pack_desc* d, PackArgs& a) {
     for (int t = 0; t < SRVP_MAX_TAPS; ++t) { a.tap_off[t] = t < d->ntaps ? d->tap_off[t] : 0; a.tap_set[t] = t < d->ntaps ? d->tap_set[t] : 0; }
     a.J = d->J; a.K = d->K; a.J0 = d->J0; a.J0r = d->J0r; a.J1r = d->J1r; a.K0 = d->K0; a.K0r = d->K0r; a.K1r = d->K1r;
     a.sj = d->sj; a.sk = d->sk;
+    a.layout = d->layout;
+    SRVP_REQUIRE(d->layout == 0 || (d->layout == 1 && d->J % 32 == 0 && d->K % 64 == 0), "srvp_pack: layout %d needs J %% 32 == 0, K %% 64 == 0", d->layout);
     return SRVP_OK;
 }
 

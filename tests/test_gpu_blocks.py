@@ -158,17 +158,17 @@ def test_conv_halo_matches_generic(case):
     spec = dict(kind=kind, key='w', bnkey=None if role == 'out' else 'bn', cin=c0r, cout=cout, k=3, s=1, p=1,
                 act='sigmoid' if role == 'out' else 'leaky_relu')
     blk = Block(spec, role, [f0], ups, N, dev, True)
-    blk._fwd, blk._dg = blk.fwd_descs(), blk.dgrad_descs()
     wshape = (cout, c0r, 3, 3) if kind == 'conv' else (c0r, cout, 3, 3)
     w = (torch.randn(*wshape, generator=g) * 0.1).to(dev)
     st = L.stream()
-    blk.pack(w, st)
     bd = blk.draw_b
     blk.draw[:, bd:bd + blk.OH, bd:bd + blk.OW, :cout].copy_(torch.randn(N, blk.OH, blk.OW, cout, generator=g) * 0.5)
     res = {}
     try:
         for halo in (1, 0):
             L.call('srvp_conv_set_halo', halo)
+            blk._fwd, blk._dg = blk.fwd_descs(), blk.dgrad_descs()      # the weight layout follows the kernel choice
+            blk.pack(w, st)
             out = blk.x_out if role == 'out' else blk.raw
             out.fill_(7.0)
             blk.dcat.fill_(7.0)
@@ -206,16 +206,16 @@ def test_conv_halo_split_skip():
     spec = dict(kind='conv', key='w', bnkey='bn', cin=192, cout=128, k=3, s=1, p=1, act='leaky_relu')
     blk = Block(spec, 'mfma', [f0, f1], True, N, dev, True, skip_map=smap, skip_sel=sel)
     assert blk.split
-    blk._fwd, blk._dg = blk.fwd_descs(), blk.dgrad_descs()
     w = (torch.randn(128, 192, 3, 3, generator=g) * 0.1).to(dev)
     st = L.stream()
-    blk.pack(w, st)
     blk.draw[:, 1:-1, 1:-1].copy_(torch.randn(N, 16, 16, 128, generator=g) * 0.5)
     blk.draw_sum[:, 1:-1, 1:-1].copy_(torch.randn(B, 16, 16, 128, generator=g) * 0.5)
     res = {}
     try:
         for halo in (1, 0):
             L.call('srvp_conv_set_halo', halo)
+            blk._fwd, blk._dg = blk.fwd_descs(), blk.dgrad_descs()
+            blk.pack(w, st)
             blk.raw.fill_(7.0); blk.S.fill_(7.0); blk.dcat.fill_(7.0); blk.dsel.fill_(7.0)
             blk.stats.zero_()
             for d in blk._fwd + blk._dg:
