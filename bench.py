@@ -200,11 +200,20 @@ def main():
             per[name] = sum(a.elapsed_time(b) for a, b in evs) / args.steps      # ms per step
         dom = 'srvp_conv_mfma'
         ach = (fl['fwd_mfma'] + fl['dgrad_mfma']) / (per[dom] * 1e-3) / 1e12
-        line['roofline'] = {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (srvp_conv_mfma: forward + data-gradient implicit GEMMs)',
+        # HBM bytes per launch of the same kernel class: PMC counters cannot be collected from inside this process, so the
+        # number comes from the committed summary of a separate `rocprofv3 --pmc` pass of this very command
+        # (tools/hbm_traffic.py -> profiles/r01_hbm_traffic.json, corrections of MI355X_MICROARCH.md's HBM section)
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')
+        if args.config == 'bair' and B == 192 and os.path.exists(tpath):
+            traffic = json.load(open(tpath))['srvp_conv_mfma']['bytes_per_launch']
+        line['roofline'] = {'bound': 'mfma', 'kernel': 'conv_halo_kernel / conv_mfma_kernel (srvp_conv_mfma: forward + data-gradient implicit GEMMs)',
                             'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
-                            'traffic': None, 'launches_per_step': len(prof[dom]) // args.steps, 'ms_per_step': per[dom]}
+                            'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC pass, profiles/r01_hbm_traffic.json)',
+                            'algorithmic_flops_per_launch': (fl['fwd_mfma'] + fl['dgrad_mfma']) / max(1, len(prof[dom]) // args.steps),
+                            'launches_per_step': len(prof[dom]) // args.steps, 'ms_per_step': per[dom]}
         wg = fl['wgrad_mfma'] / (per['srvp_wgrad_mfma'] * 1e-3) / 1e12
-        line['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'wgrad_mfma_kernel', 'achieved': wg, 'peak': PEAK_BF16_TFLOPS,
+        line['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'wgrad_halo_kernel / wgrad_mfma_kernel', 'achieved': wg, 'peak': PEAK_BF16_TFLOPS,
                                   'unit': 'TFLOP/s', 'frac': wg / PEAK_BF16_TFLOPS, 'ms_per_step': per['srvp_wgrad_mfma']}
         if table:
             full = {name: sum(a.elapsed_time(b) for a, b in evs) / 2 for name, evs in table.items()}
