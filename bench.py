@@ -127,7 +127,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     sync = None
-    if world > 1:
+    if world > 1 or os.environ.get('SRVP_FORCE_COLLECTIVES') == '1':
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         sync = sdist.init_process_group('nccl')
 

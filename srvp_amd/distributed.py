@@ -20,10 +20,13 @@ class Sync:
         self.world = dist.get_world_size(group)
         self.handles = []
         self.sync_bn = True
+        # SRVP_FORCE_COLLECTIVES=1: issue every collective even on a single rank (exercises the RCCL call path on a
+        # 1-GPU box: tests/test_gpu_model.py::test_single_rank_collectives)
+        self.force = os.environ.get('SRVP_FORCE_COLLECTIVES', '0') == '1'
 
     def allreduce_stats(self, t, count):
         """In-place sum of a small fp64 statistics tensor over ranks; returns the global element count."""
-        if self.sync_bn and self.world > 1:
+        if self.sync_bn and (self.world > 1 or self.force):
             dist.all_reduce(t, group=self.group)
             return count * self.world
         return count
@@ -40,7 +43,7 @@ class Sync:
         return enc_end, dec_end, off
 
     def grads_ready(self, what, model):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         flat_g = model._flat[1]
         enc_end, dec_end, total = self._slices(model)
@@ -72,7 +75,7 @@ class DataParallel(torch.nn.Module):
         self.module = module
         module.sync = sync
         # same initial parameters / buffers on every rank (DDP broadcasts from rank 0)
-        if sync.world > 1:
+        if sync.world > 1 or sync.force:
             module.flatten_parameters_()
             dist.broadcast(module._flat[0], 0, group=sync.group)
             for b in module.buffers():

@@ -356,3 +356,24 @@ def test_conv_backward_teacher_forced(name):
     med = sorted(errs.values())[len(errs) // 2]
     report(test='teacher_forced_backward', name=name, worst=worst, median=med)
     assert max(errs.values()) < 0.03 and med < 0.01, (worst, med)
+
+
+def test_single_rank_collectives(tmp_path):
+    """bench.py under torch.distributed.run with ONE rank and every collective forced on (RCCL all-reduce of the BN
+    statistics and of the flat gradient slices, rank-0 broadcast): same loss as the plain single-process run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '8',
+            '--no-cpu-baseline', '--no-kernel-timing']
+    plain = subprocess.run(base, capture_output=True, text=True, timeout=600, cwd=root)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    env = dict(os.environ, SRVP_FORCE_COLLECTIVES='1', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29517'] + base[1:]
+    dist = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert dist.returncode == 0, dist.stderr[-2000:]
+    l0 = json.loads(plain.stdout.strip().splitlines()[-1])['loss']
+    l1 = json.loads(dist.stdout.strip().splitlines()[-1])['loss']
+    assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)
