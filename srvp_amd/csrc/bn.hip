@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ 
         for (int i = 0; i < R; ++i)
 #pragma unroll
             for (int j = 0; j < R; ++j)
-                v[i * R + j] = *reinterpret_cast<const u32x4_t*>(raw + (((size_t)n * H + y * R + i) * W + x * R + j) * C + cg * 8);
+                v[i * R + j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(raw + (((size_t)n * H + y * R + i) * W + x * R + j) * C + cg * 8));
         float mx[8];
 #pragma unroll
         for (int i = 0; i < R; ++i)
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ 
                 u32x4_t o = pack8(f);
                 if (dst) {
                     size_t doff = (((size_t)n * (H + 2 * db) + yy + db) * (W + 2 * db) + xx + db) * C + cg * 8;
-                    *reinterpret_cast<u32x4_t*>(dst + doff) = o;
+                    __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t*>(dst + doff));
                 }
                 if (dst_f32) {
                     const size_t off = (((size_t)n * H + yy) * W + xx) * C + cg * 8;
@@ -138,7 +138,7 @@ __device__ __forceinline__ void bn_bwd_g(const BnBwdK& a, int n, int y, int x, i
                                          float* g, float* rawf) {
     const int C = a.C, H = a.H, W = a.W;
     size_t roff = (((size_t)n * H + y) * W + x) * C + cg * 8;
-    unpack8(*reinterpret_cast<const u32x4_t*>(a.raw + roff), rawf);
+    unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(a.raw + roff)), rawf);
     float d[8];
     const int db = a.da_border, cs = a.da_cstride, co = a.da_coff + cg * 8;
     if (a.da_is_f32) {
@@ -150,7 +150,7 @@ __device__ __forceinline__ void bn_bwd_g(const BnBwdK& a, int n, int y, int x, i
         const bf16_t* da = (const bf16_t*)a.da;
         if constexpr (MODE == 0) {
             size_t off = (((size_t)n * (H + 2 * db) + y + db) * (W + 2 * db) + x + db) * cs + co;
-            unpack8(*reinterpret_cast<const u32x4_t*>(da + off), d);
+            unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(da + off)), d);
         } else if constexpr (MODE == 1) {
             const int H2 = 2 * H, W2 = 2 * W;
 #pragma unroll
