@@ -7,5 +7,5 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum"; do
   rm -rf /tmp/pmc
   rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmc -o p -- python /root/repo/tools/layer_times.py > /tmp/pmc_run.log 2>&1
-  python /root/repo/tools/pmc_summary.py /tmp/pmc 6 2>&1 | grep -A1 -E "conv_halo|conv_mfma_kernel|wgrad_mfma" 
+  python /root/repo/tools/pmc_summary.py /tmp/pmc 6 2>&1 | grep -A1 -E "conv_halo|conv_mfma_kernel|wgrad_mfma|wgrad_halo" 
 done
