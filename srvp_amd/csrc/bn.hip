@@ -279,14 +279,46 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdK a, doub
             }
         } else {
             const unsigned P = (unsigned)a.N * a.H * a.W, stride = gridDim.x * PPB;
-            PixWalk w;
-            w.init(blockIdx.x * PPB + pl, stride, a.H, a.W);
-#pragma unroll 2
-            for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
-                float g[8], rawf[8];
-                bn_bwd_g<MODE>(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
+            if (MODE == 0 && !a.da_is_f32 && !a.da2 && a.da_border == 0) {
+                // plain consumer, unbordered gradient: both tensors are linear in the pixel index -- four pixels per
+                // iteration with all eight 16-byte loads issued up front (memory-level parallelism; the generic loop
+                // below has one pixel in flight per thread because its loads sit behind the loop-exit test)
+                constexpr int U = 4;
+                const bf16_t* da = (const bf16_t*)a.da;
+                const unsigned p0 = blockIdx.x * PPB + pl;
+                for (unsigned p = p0; p < P; p += U * stride) {
+                    u32x4_t rv[U], dv[U];
+                    bool ok[U];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { s1[e] += g[e]; s2[e] += g[e] * (rawf[e] - mu[e]) * is[e]; }
+                    for (int u = 0; u < U; ++u) {
+                        const unsigned pu = p + u * stride;
+                        ok[u] = pu < P;
+                        const size_t pc = ok[u] ? pu : p0;
+                        rv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(a.raw + pc * a.C + cg * 8));
+                        dv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(da + pc * a.da_cstride + a.da_coff + cg * 8));
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        float rawf[8], d[8];
+                        unpack8(rv[u], rawf); unpack8(dv[u], d);
+                        const float m = ok[u] ? 1.f : 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float g = m * d[e] * act_bwd(rawf[e] * sc[e] + sh[e], a.act_kind);
+                            s1[e] += g; s2[e] += g * (rawf[e] - mu[e]) * is[e];
+                        }
+                    }
+                }
+            } else {
+                PixWalk w;
+                w.init(blockIdx.x * PPB + pl, stride, a.H, a.W);
+#pragma unroll 2
+                for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
+                    float g[8], rawf[8];
+                    bn_bwd_g<MODE>(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { s1[e] += g[e]; s2[e] += g[e] * (rawf[e] - mu[e]) * is[e]; }
+                }
             }
         }
     }
