@@ -433,7 +433,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     constexpr int YBYTES = YPIECES * 16;                 // 12 KiB
     constexpr int STAGE = XBYTES + YBYTES;
     constexpr int G = 4;                                 // LDS-DMA instructions per stage and wave
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[NBUF * STAGE];
+    constexpr int MAXMAP = 2048;                         // image map of a mapped source, staged in LDS (ds_read: lgkmcnt, not vmcnt)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NBUF * STAGE + MAXMAP * 4];
+    int* maps = reinterpret_cast<int*>(lds + NBUF * STAGE);
     const WgradK& a = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int jt = BJ == 64 ? (wid >> 1) : 0, ct = wid & 1;
@@ -472,22 +474,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             ylane[i] = (unsigned)((py * a.W0p + px) * a.C0 + ((posy ^ sw) * 8));
         }
     }
+    // LDS-DMA is the scarce path (~1 KiB per ~100 cycles per CU): a wave only issues the patch pieces that exist
+    // (the 2x16 tile's patch is 576 pieces = 2.25 rounds of 256, the 4x8 tile's 480 = 1.9), so the DMA count per
+    // stage -- and with it the counted vmcnt -- is per wave: 1 (gradient tile) + ny
+    const int ny = __builtin_amdgcn_readfirstlane((p.Ppix * 8 - wid * 64 + NT - 1) / NT);      // rounds with a real piece for this wave
     auto stage = [&](int step, int buf) {
         const int tau = t_beg + step;
         const int xb = tau & ((1 << p.lg_nxb) - 1);
         const int yb = (tau >> p.lg_nxb) & ((1 << p.lg_nyb) - 1);
         const int n = tau >> (p.lg_nxb + p.lg_nyb);
         const int y0 = yb * p.RH, x0 = xb << p.lgTW;
-        const int ns = a.map0 ? a.map0[n] : n;           // uniform index: a scalar load
+        const int ns = a.map0 ? maps[n] : n;             // LDS copy: a global load here would sit in the DMA's vmcnt queue
         const unsigned xbase = (((unsigned)n * a.DHp + y0 + p.oo) * a.DWp + x0 + p.oo) * a.Cout + j0;
         const unsigned ybase = (((unsigned)ns * a.H0p + (y0 >> ups)) * a.W0p + (x0 >> ups)) * a.C0 + c0;
         unsigned char* sb = lds + (size_t)buf * STAGE;
         __builtin_amdgcn_global_load_lds((gptr_t)(a.dout + xbase + xlane), (lptr_t)(sb + (BJ == 64 ? wid : (wid & 1)) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.src0 + ybase + ylane[i]), (lptr_t)(sb + XBYTES + (i * NT + wid * 64) * 16), 16, 0, 0);
+            if (i < ny)
+                __builtin_amdgcn_global_load_lds((gptr_t)(a.src0 + ybase + ylane[i]), (lptr_t)(sb + XBYTES + (i * NT + wid * 64) * 16), 16, 0, 0);
     };
 
+    if (a.map0) {
+        for (int i = tid; i < a.N; i += NT) maps[i] = a.map0[i];
+        __syncthreads();
+    }
     f32x16_t acc[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t)
@@ -536,8 +547,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     for (int i = 0; i < NBUF - 1; ++i)
         if (i < nsteps) stage(i, i);
     for (int s = 0; s < nsteps; ++s) {
-        if (s + NBUF - 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NBUF - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (s + NBUF - 2 < nsteps) {
+            // tile s has landed when only the NBUF-2 younger stages ((1 + ny) DMAs each) are outstanding
+            if (ny == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NBUF - 2)) : "memory");
+            else if (ny == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (NBUF - 2)) : "memory");
+            else if (ny == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NBUF - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * (NBUF - 2)) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (s + NBUF - 1 < nsteps) stage(s + NBUF - 1, (s + NBUF - 1) % NBUF);
@@ -630,7 +648,7 @@ static int try_launch_halo(const srvp_wgrad_desc* d, const WgradK& k, hipStream_
     if (OH % h.RH) return SRVP_OK;
     h.PW = (TW >> ups) + 2;
     h.Ppix = ((h.RH >> ups) + 2) * h.PW;
-    if (h.Ppix > 96) return SRVP_OK;
+    if (h.Ppix > 96 || (d->map0 && d->N > 2048)) return SRVP_OK;
     auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
     h.lg_nxb = lg(OW / TW); h.lg_nyb = lg(OH / h.RH);
     h.ntiles = d->N * (OH / h.RH) * (OW / TW);
