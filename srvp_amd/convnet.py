@@ -756,8 +756,19 @@ class DecoderNet(ConvNetBase):
     def backward(self, d_x, params, grads, st, sync=None):
         """d_x: fp32 (N, C, 64, 64).  Returns dz bf16 [N][nz_padded]; skip gradients are left in the blocks' dcat."""
         ob = self.blocks[-1]
-        L.call('srvp_out_dpre', L.ptr(self.x_out), L.ptr(d_x), L.ptr(ob.draw), self.N, ob.cout_r, ob.OH, ob.OW, ob.cout, 1, st)
-        self._mfma_backward(ob, grads, st)
+        # The data-gradient of the image-side layer contracts over nc*k*k <= 48 values per pixel: as an MFMA conv on the
+        # padded bf16 gradient it wastes 10x the work.  It IS the first-layer forward kernel with the gradient frames as
+        # the "image" and the ConvTranspose weight (Cin, nc, k, k) read as (O, I, k, k): exact fp32 on the matrix cores.
+        f32_dgrad = (ob.k, ob.s, ob.p) in ((3, 1, 1), (4, 2, 1)) and ob.ctot in (32, 64) and len(ob.srcs) == 1 and ob.cout_r in (1, 3) \
+            and ob.OH == 64
+        if f32_dgrad and not hasattr(self, 'dpre_f32'):
+            self.dpre_f32 = torch.empty(self.N, ob.cout_r, ob.OH, ob.OW, dtype=torch.float32, device=self.dev)
+        L.call('srvp_out_dpre', L.ptr(self.x_out), L.ptr(d_x), L.ptr(ob.draw), L.ptr(self.dpre_f32) if f32_dgrad else None,
+               self.N, ob.cout_r, ob.OH, ob.OW, ob.cout, 1, st)
+        self._mfma_backward(ob, grads, st, need_dgrad=not f32_dgrad)
+        if f32_dgrad:
+            L.call('srvp_conv_in_fwd', L.ptr(self.dpre_f32), L.ptr(params[ob.spec['key'] + '.weight']), L.ptr(ob.dcat), None,
+                   self.N, ob.cout_r, 64, 64, ob.ctot, ob.cin_r[0], ob.k, ob.s, ob.p, st)
         nxt = ob
         for i in range(len(self.blocks) - 2, -1, -1):
             blk = self.blocks[i]

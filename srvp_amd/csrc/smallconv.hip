@@ -436,8 +436,8 @@ extern "C" int srvp_conv_in_wgrad(const float* x, const void* draw, float* dw, i
 // ---------------------------------------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void out_dpre_kernel(const float* __restrict__ xo, const float* __restrict__ dxo,
-                                                       bf16_t* __restrict__ draw, int N, int nc, int H, int W, int C,
-                                                       int sigmoid) {
+                                                       bf16_t* __restrict__ draw, float* __restrict__ dpre_f32, int N, int nc,
+                                                       int H, int W, int C, int sigmoid) {
     const int CG = C / 8;
     const long long total = (long long)N * H * W * CG;
     for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
@@ -453,6 +453,7 @@ __global__ __launch_bounds__(256) void out_dpre_kernel(const float* __restrict__
                 size_t o = (((size_t)n * nc + c) * H + y) * W + x;
                 v = dxo[o];
                 if (sigmoid) { float s = xo[o]; v *= s * (1.f - s); }
+                if (dpre_f32) dpre_f32[o] = v;        // fp32 frame-layout copy: "image" of the fp32-MFMA data-gradient
             }
             f[e] = v;
         }
@@ -462,13 +463,13 @@ __global__ __launch_bounds__(256) void out_dpre_kernel(const float* __restrict__
 }
 }  // namespace
 
-extern "C" int srvp_out_dpre(const float* x_out, const float* dx_out, void* draw, int N, int nc, int H, int W, int C,
-                             int apply_sigmoid, void* stream) {
+extern "C" int srvp_out_dpre(const float* x_out, const float* dx_out, void* draw, float* dpre_f32, int N, int nc, int H, int W,
+                             int C, int apply_sigmoid, void* stream) {
     SRVP_REQUIRE(x_out && dx_out && draw && C % 8 == 0 && nc <= C, "srvp_out_dpre: bad args");
     long long total = (long long)N * H * W * (C / 8);
     long long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(out_dpre_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_out, dx_out, (bf16_t*)draw,
-                       N, nc, H, W, C, apply_sigmoid);
+                       dpre_f32, N, nc, H, W, C, apply_sigmoid);
     SRVP_CHECK_LAUNCH("srvp_out_dpre");
     return SRVP_OK;
 }

@@ -394,7 +394,7 @@ def test_image_side_layers(nc, k, s, p):
     dxo = torch.randn(N, nc, 64, 64, generator=g)
     ref.backward(dxo)
     dxd = dxo.to(dev)
-    L.call('srvp_out_dpre', L.ptr(blk.x_out), L.ptr(dxd), L.ptr(blk.draw), N, nc, 64, 64, blk.cout, 1, st)
+    L.call('srvp_out_dpre', L.ptr(blk.x_out), L.ptr(dxd), L.ptr(blk.draw), None, N, nc, 64, 64, blk.cout, 1, st)
     grads = {'w.weight': torch.zeros_like(wtd)}
     blk.dw.zero_()
     L.call('srvp_wgrad_mfma', C.byref(blk._wg), st)
