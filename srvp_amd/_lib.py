@@ -61,6 +61,10 @@ class PackDesc(C.Structure):
                 ('sj', c_i64), ('sk', c_i64), ('tap_set', TAPS), ('layout', c_i32)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [('src', c_vp), ('dst', c_vp), ('d', PackDesc)]
+
+
 class RolloutDesc(C.Structure):
     _fields_ = [('B', c_i32), ('ny', c_i32), ('nz', c_i32), ('nh', c_i32), ('nl', c_i32),
                 ('nsteps', c_i32), ('n_euler', c_i32), ('n_data_frames', c_i32), ('dt', c_f32),
@@ -94,6 +98,8 @@ _SIGS = {
     'srvp_conv_in_wgrad': ([c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp], c_i32),
     'srvp_out_dpre': ([c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_pack_weight': ([c_vp, c_vp, C.POINTER(PackDesc), c_vp], c_i32),
+    'srvp_pack_weight_multi': ([c_vp, c_i32, c_i64, c_vp], c_i32),
+    'srvp_unpack_wgrad_multi': ([c_vp, c_i32, c_i64, c_vp], c_i32),
     'srvp_unpack_wgrad': ([c_vp, c_vp, C.POINTER(PackDesc), c_vp], c_i32),
     'srvp_gemm_f32': ([c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_axpby_f32': ([c_vp, c_f32, c_vp, c_f32, c_vp, c_i64, c_vp], c_i32),

@@ -245,6 +245,24 @@ class Block:
         self.wt_f = torch.empty(kk, co_p, self.ctot, dtype=torch.bfloat16, device=dev)
         self.wt_d = torch.empty(kk, self.ctot, co_p, dtype=torch.bfloat16, device=dev) if self.training else None
 
+    def pack_jobs(self, w):
+        """[(fp32 source pointer, packed destination tensor, pack descriptor)] of this block's weight buffers."""
+        jobs = [(L.ptr(w), self.wt_f, self.pf)]
+        if self.wt_d is not None:
+            jobs.append((L.ptr(w), self.wt_d, self.pd))
+        if self.split:
+            ws = L.ptr(w) + 4 * self.s_off
+            jobs.append((ws, self.wt_f_s, self.pf_s))
+            if self.wt_d_s is not None:
+                jobs.append((ws, self.wt_d_s, self.pd_s))
+        return jobs
+
+    def unpack_jobs(self, gw):
+        """[(packed fp32 gradient tensor, fp32 gradient pointer, descriptor)]: inverse mapping for the weight gradient."""
+        if self.split:
+            return [(self.dw, L.ptr(gw), self.pf), (self.dw_s, L.ptr(gw) + 4 * self.s_off, self.pf_s)]
+        return [(self.dw, L.ptr(gw), self.pu)]
+
     def pack(self, w, st):
         L.call('srvp_pack_weight', L.ptr(w), L.ptr(self.wt_f), C.byref(self.pf), st)
         if self.wt_d is not None:
@@ -588,8 +606,6 @@ class ConvNetBase:
                L.ptr(blk.out_f32), st)
 
     def _block_forward(self, blk, params, st, sync, x=None):
-        if blk.has_bn and blk.training:
-            blk.stats.zero_()
         if blk.role == 'in':
             w = params[blk.spec['key'] + '.weight']
             L.call('srvp_conv_in_fwd', L.ptr(x), L.ptr(w), L.ptr(blk.raw),
@@ -612,7 +628,6 @@ class ConvNetBase:
         d.da2, d.da2_idx = L.ptr(da.get('da2')), L.ptr(da.get('da2_idx'))
         d.N, d.H, d.W, d.C = blk.N, blk.OH, blk.OW, blk.cout
         if blk.has_bn:
-            blk.red.zero_()
             L.call('srvp_bn_bwd_reduce', C.byref(d), L.ptr(blk.red), st)
             count = float(blk.N * blk.OH * blk.OW)
             if sync is not None:
@@ -625,29 +640,64 @@ class ConvNetBase:
         L.call('srvp_bn_bwd_apply', C.byref(d), L.ptr(blk.bcoef), L.ptr(blk.draw), blk.draw_b, st)
 
     def _mfma_backward(self, blk, grads, st, need_dgrad=True):
-        gw = grads[blk.spec['key'] + '.weight']
-        blk.dw.zero_()
         if blk.split:
             # time-summed output gradient per sample (feeds the skip half's weight and data gradients)
             T = blk.N // blk.B
             L.call('srvp_skip_grad_reduce', L.ptr(blk.draw), blk.cout, 0, blk.cout, (blk.OH + 2) * (blk.OW + 2), T, blk.B,
                    L.ptr(blk.draw_sum), st)
-            blk.dw_s.zero_()
             L.call('srvp_wgrad_mfma', C.byref(blk._wg[0]), st)
             L.call('srvp_wgrad_mfma', C.byref(blk._wg[1]), st)
-            L.call('srvp_unpack_wgrad', L.ptr(blk.dw), L.ptr(gw), C.byref(blk.pf), st)
-            L.call('srvp_unpack_wgrad', L.ptr(blk.dw_s), L.ptr(gw) + 4 * blk.s_off, C.byref(blk.pf_s), st)
         else:
             L.call('srvp_wgrad_mfma', C.byref(blk._wg), st)
-            L.call('srvp_unpack_wgrad', L.ptr(blk.dw), L.ptr(gw), C.byref(blk.pu), st)
         if need_dgrad:
             for d in blk._dg:
                 L.call('srvp_conv_mfma', C.byref(d), st)
 
+    # ---- whole-network launches: every layer's pack / unpack in ONE kernel (device-resident job table, rebuilt only when a
+    # pointer or layout changes) and one multi-tensor zero for the accumulators -- ~140 tiny launches per step otherwise
+    @staticmethod
+    def _job_table(jobs, dev, cache, src_is_tensor):
+        key = tuple((s.data_ptr() if src_is_tensor else s, d if src_is_tensor else d.data_ptr(), pd.layout) for s, d, pd in jobs)
+        if cache.get('key') != key:
+            arr = (L.PackJob * len(jobs))()
+            mx = 0
+            for i, (s, d, pd) in enumerate(jobs):
+                arr[i].src = s.data_ptr() if src_is_tensor else s
+                arr[i].dst = d if src_is_tensor else d.data_ptr()
+                arr[i].d = pd
+                mx = max(mx, pd.ntaps * pd.J * pd.K)
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            cache.update(key=key, table=raw.to(dev), n=len(jobs), mx=mx, keep=[t for j in jobs for t in j[:2] if torch.is_tensor(t)])
+        return cache
+
     def pack_weights(self, params, st):
-        for blk in self.blocks:
-            if blk.role in ('mfma', 'out'):
-                blk.pack(params[blk.spec['key'] + '.weight'], st)
+        jobs = [j for blk in self.blocks if blk.role in ('mfma', 'out') for j in blk.pack_jobs(params[blk.spec['key'] + '.weight'])]
+        if not jobs:
+            return
+        c = self._job_table(jobs, self.dev, self.__dict__.setdefault('_pack_cache', {}), False)
+        L.call('srvp_pack_weight_multi', L.ptr(c['table']), c['n'], c['mx'], st)
+
+    def unpack_wgrads(self, grads, st):
+        jobs = [j for blk in self.blocks if blk.role in ('mfma', 'out') for j in blk.unpack_jobs(grads[blk.spec['key'] + '.weight'])]
+        if not jobs:
+            return
+        c = self._job_table(jobs, self.dev, self.__dict__.setdefault('_unpack_cache', {}), True)
+        L.call('srvp_unpack_wgrad_multi', L.ptr(c['table']), c['n'], c['mx'], st)
+
+    def zero_forward_accumulators(self):
+        z = self.__dict__.get('_z_fwd')
+        if z is None:
+            z = self._z_fwd = [b.stats for b in self.blocks if hasattr(b, 'stats')]
+        if z:
+            torch._foreach_zero_(z)
+
+    def zero_backward_accumulators(self):
+        z = self.__dict__.get('_z_bwd')
+        if z is None:
+            z = self._z_bwd = [t for b in self.blocks for t in (getattr(b, 'red', None), getattr(b, 'dw', None), getattr(b, 'dw_s', None))
+                               if t is not None]
+        if z:
+            torch._foreach_zero_(z)
 
 
 class EncoderNet(ConvNetBase):
@@ -685,6 +735,8 @@ class EncoderNet(ConvNetBase):
         self.nh_r = specs[-1]['cout']
 
     def forward(self, x, params, st, sync=None):
+        if self.training:
+            self.zero_forward_accumulators()
         for blk in self.blocks:
             self._block_forward(blk, params, st, sync, x=x)
         return self.blocks[-1].out_f32[:, :self.nh_r]
@@ -694,6 +746,7 @@ class EncoderNet(ConvNetBase):
         d_hx: fp32 [N][nh_padded] gradient of the encoder output; skip_grads: {stage: (dsel bf16 [B][H][W][C], idx int32 [N])}
         """
         nb = len(self.blocks)
+        self.zero_backward_accumulators()
         da = dict(t=d_hx, mode=0, cstride=d_hx.shape[1], coff=0, border=0, f32=True)
         for i in range(nb - 1, -1, -1):
             blk = self.blocks[i]
@@ -709,6 +762,7 @@ class EncoderNet(ConvNetBase):
                 self._mfma_backward(blk, grads, st)
                 pooled = blk.spec['pre'] == 'pool'
                 da = dict(t=blk.dcat, mode=2 if pooled else 0, cstride=blk.dcat_c, coff=0, border=0)
+        self.unpack_wgrads(grads, st)
 
 
 class DecoderNet(ConvNetBase):
@@ -746,6 +800,8 @@ class DecoderNet(ConvNetBase):
     def forward(self, z_f32, params, st, sync=None):
         """z_f32: fp32 [N][nz_real]"""
         L.call('srvp_cast_f32_bf16', L.ptr(z_f32), L.ptr(self.z.t), self.N, z_f32.shape[1], self.z.C, st)
+        if self.training:
+            self.zero_forward_accumulators()
         for blk in self.blocks[:-1]:
             self._block_forward(blk, params, st, sync)
         # image-side output layer: MFMA conv with Cout padded to 32, sigmoid + fp32 frame store in the epilogue
@@ -756,6 +812,7 @@ class DecoderNet(ConvNetBase):
     def backward(self, d_x, params, grads, st, sync=None):
         """d_x: fp32 (N, C, 64, 64).  Returns dz bf16 [N][nz_padded]; skip gradients are left in the blocks' dcat."""
         ob = self.blocks[-1]
+        self.zero_backward_accumulators()
         # The data-gradient of the image-side layer contracts over nc*k*k <= 48 values per pixel: as an MFMA conv on the
         # padded bf16 gradient it wastes 10x the work.  It IS the first-layer forward kernel with the gradient frames as
         # the "image" and the ConvTranspose weight (Cin, nc, k, k) read as (O, I, k, k): exact fp32 on the matrix cores.
@@ -777,6 +834,7 @@ class DecoderNet(ConvNetBase):
             self._bn_backward(blk, params, grads, da, st, sync)
             self._mfma_backward(blk, grads, st)
             nxt = blk
+        self.unpack_wgrads(grads, st)
         return self.blocks[0].dcat.view(self.N, -1)
 
     def skip_grads(self, T, B, st):

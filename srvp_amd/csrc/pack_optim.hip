@@ -25,10 +25,7 @@ __device__ __forceinline__ int real_index(int i, int seg0_pad, int seg0_real, in
     return i1 < seg1_real ? seg0_real + i1 : -1;
 }
 
-__global__ void pack_weight_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, const PackArgs a) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long total = (long long)a.ntaps * a.J * a.K;
-    if (i >= total) return;
+__device__ __forceinline__ void pack_one(const float* __restrict__ src, bf16_t* __restrict__ dst, const PackArgs& a, long long i) {
     int k = (int)(i % a.K); long long q = i / a.K;
     int j = (int)(q % a.J); int t = (int)(q / a.J);
     int jr = real_index(j, a.J0, a.J0r, a.J1r), kr = real_index(k, a.K0, a.K0r, a.K1r);
@@ -49,10 +46,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, bf16_t* __rest
     dst[o] = f2bf(v);
 }
 
-__global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst, const PackArgs a) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long total = (long long)a.ntaps * a.J * a.K;
-    if (i >= total) return;
+__device__ __forceinline__ void unpack_one(const float* __restrict__ src, float* __restrict__ dst, const PackArgs& a, long long i) {
     int k = (int)(i % a.K); long long q = i / a.K;
     int j = (int)(q % a.J); int t = (int)(q / a.J);
     int jr = real_index(j, a.J0, a.J0r, a.J1r), kr = real_index(k, a.K0, a.K0r, a.K1r);
@@ -63,6 +57,41 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __rest
     if (set == 0) { dst[jr * a.sj + kr * a.sk + off] += src[i]; return; }   // every (t,j,k) maps to a distinct element: no atomics
     for (int sidx = 0; sidx < 16; ++sidx)
         if ((set >> sidx) & 1) atomicAdd(dst + jr * a.sj + kr * a.sk + sidx, src[i]);     // several packed taps share a source tap
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, const PackArgs a) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long long)a.ntaps * a.J * a.K) pack_one(src, dst, a, i);
+}
+__global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst, const PackArgs a) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long long)a.ntaps * a.J * a.K) unpack_one(src, dst, a, i);
+}
+
+// All layers in ONE launch: blockIdx.y = job (a device-resident table of srvp_pack_job), grid-stride over its elements.
+// (40 + 30 tiny launches per step were ~1.2 ms of dispatch latency.)
+__device__ __forceinline__ void job_args(const srvp_pack_job& j, PackArgs& a) {
+    a.ntaps = j.d.ntaps;
+#pragma unroll
+    for (int t = 0; t < SRVP_MAX_TAPS; ++t) { a.tap_off[t] = j.d.tap_off[t]; a.tap_set[t] = j.d.tap_set[t]; }
+    a.J = j.d.J; a.K = j.d.K; a.J0 = j.d.J0; a.J0r = j.d.J0r; a.J1r = j.d.J1r; a.K0 = j.d.K0; a.K0r = j.d.K0r; a.K1r = j.d.K1r;
+    a.sj = j.d.sj; a.sk = j.d.sk; a.layout = j.d.layout;
+}
+__global__ void pack_multi_kernel(const srvp_pack_job* __restrict__ jobs) {
+    PackArgs a;
+    const srvp_pack_job& j = jobs[blockIdx.y];
+    job_args(j, a);
+    const long long total = (long long)a.ntaps * a.J * a.K;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        pack_one((const float*)j.src, (bf16_t*)j.dst, a, i);
+}
+__global__ void unpack_multi_kernel(const srvp_pack_job* __restrict__ jobs) {
+    PackArgs a;
+    const srvp_pack_job& j = jobs[blockIdx.y];
+    job_args(j, a);
+    const long long total = (long long)a.ntaps * a.J * a.K;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        unpack_one((const float*)j.src, (float*)j.dst, a, i);
 }
 
 int fill_pack(const srvp_pack_desc* d, PackArgs& a) {
@@ -245,6 +274,22 @@ extern "C" int srvp_unpack_wgrad(const float* src, float* dst, const srvp_pack_d
     long long total = (long long)a.ntaps * a.J * a.K;
     hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, a);
     SRVP_CHECK_LAUNCH("srvp_unpack_wgrad");
+    return SRVP_OK;
+}
+
+extern "C" int srvp_pack_weight_multi(const srvp_pack_job* jobs_dev, int njobs, int64_t max_total, void* stream) {
+    SRVP_REQUIRE(jobs_dev && njobs > 0 && max_total > 0, "srvp_pack_weight_multi: bad args");
+    long long bx = (max_total + 255) / 256; if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)bx, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+    SRVP_CHECK_LAUNCH("srvp_pack_weight_multi");
+    return SRVP_OK;
+}
+
+extern "C" int srvp_unpack_wgrad_multi(const srvp_pack_job* jobs_dev, int njobs, int64_t max_total, void* stream) {
+    SRVP_REQUIRE(jobs_dev && njobs > 0 && max_total > 0, "srvp_unpack_wgrad_multi: bad args");
+    long long bx = (max_total + 255) / 256; if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(unpack_multi_kernel, dim3((unsigned)bx, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+    SRVP_CHECK_LAUNCH("srvp_unpack_wgrad_multi");
     return SRVP_OK;
 }
 
