@@ -157,7 +157,7 @@ def main():
     if not args.no_kernel_timing:
         # HIP events around the launches of the two dominant kernel classes only (~110 per step); timing every launch
         # (329 per step) costs ~3 ms per step of host-side event records, so the full table is taken in an extra pass
-        L.PROFILE, L.PROFILE_ONLY = {}, {'srvp_conv_mfma', 'srvp_wgrad_mfma'}
+        L.PROFILE, L.PROFILE_ONLY = {}, {'srvp_conv_mfma', 'srvp_conv_mfma_multi', 'srvp_wgrad_mfma'}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -199,6 +199,9 @@ def main():
         for name, evs in prof.items():
             per[name] = sum(a.elapsed_time(b) for a, b in evs) / args.steps      # ms per step
         dom = 'srvp_conv_mfma'
+        # (srvp_conv_mfma_multi = the same kernels, four sub-pixel phase launches issued as one grid)
+        per[dom] = per.get(dom, 0.0) + per.pop('srvp_conv_mfma_multi', 0.0)
+        nlaunch = (len(prof.get(dom, [])) + 4 * len(prof.get('srvp_conv_mfma_multi', []))) // args.steps
         ach = (fl['fwd_mfma'] + fl['dgrad_mfma']) / (per[dom] * 1e-3) / 1e12
         # HBM bytes per launch of the same kernel class: PMC counters cannot be collected from inside this process, so the
         # number comes from the committed summary of a separate `rocprofv3 --pmc` pass of this very command
@@ -210,8 +213,8 @@ def main():
         line['roofline'] = {'bound': 'mfma', 'kernel': 'conv_halo_kernel / conv_mfma_kernel (srvp_conv_mfma: forward + data-gradient implicit GEMMs)',
                             'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
                             'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC pass, profiles/r01_hbm_traffic.json)',
-                            'algorithmic_flops_per_launch': (fl['fwd_mfma'] + fl['dgrad_mfma']) / max(1, len(prof[dom]) // args.steps),
-                            'launches_per_step': len(prof[dom]) // args.steps, 'ms_per_step': per[dom]}
+                            'algorithmic_flops_per_launch': (fl['fwd_mfma'] + fl['dgrad_mfma']) / max(1, nlaunch),
+                            'launches_per_step': nlaunch, 'ms_per_step': per[dom]}
         wg = fl['wgrad_mfma'] / (per['srvp_wgrad_mfma'] * 1e-3) / 1e12
         line['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'wgrad_halo_kernel / wgrad_mfma_kernel', 'achieved': wg, 'peak': PEAK_BF16_TFLOPS,
                                   'unit': 'TFLOP/s', 'frac': wg / PEAK_BF16_TFLOPS, 'ms_per_step': per['srvp_wgrad_mfma']}

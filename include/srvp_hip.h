@@ -72,6 +72,9 @@ int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
 int srvp_conv_set_halo(int on);
 /* 1 if this descriptor will run on the halo-tiled kernel, which wants its weights fragment-major (pack layout 1) */
 int srvp_conv_wants_fragmajor(const srvp_conv_desc* d);
+/* d[0..n-1]: as n calls of srvp_conv_mfma; launches that run on the same halo-kernel variant with the same grid (the four
+ * output phases of a sub-pixel upsample convolution) are issued as ONE grid */
+int srvp_conv_mfma_multi(const srvp_conv_desc* d, int n, void* stream);
 
 /* Weight gradient of the same tap-table convolution (autograd of the modules above):
  *   dW[t][j][c] += sum_{n,oy,ox} dout[n, oy*so+ooy[t], ox*so+oox[t], j] * in_t[n, oy, ox, c]     (fp32 atomics)

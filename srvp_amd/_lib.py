@@ -85,6 +85,7 @@ _SIGS = {
     'srvp_conv_mfma': ([C.POINTER(ConvDesc), c_vp], c_i32),
     'srvp_conv_set_halo': ([c_i32], c_i32),
     'srvp_conv_wants_fragmajor': ([C.POINTER(ConvDesc)], c_i32),
+    'srvp_conv_mfma_multi': ([C.POINTER(ConvDesc), c_i32, c_vp], c_i32),
     'srvp_wgrad_mfma': ([C.POINTER(WgradDesc), c_vp], c_i32),
     'srvp_wgrad_set_tr': ([c_i32], c_i32),
     'srvp_wgrad_set_halo': ([c_i32], c_i32),

@@ -310,6 +310,7 @@ class Block:
 
     def fwd_descs(self):
         """List of ConvDesc for the forward convolution (4 for the transposed stride-2 phases, else 1)."""
+        self.__dict__.pop('_fwd_arr', None)
         out = self._fwd_descs_raw()
         if self.split:
             self._set_layout(out[:1], self.pf_s)       # conv_s(skip)
@@ -611,6 +612,14 @@ class ConvNetBase:
             L.call('srvp_conv_in_fwd', L.ptr(x), L.ptr(w), L.ptr(blk.raw),
                    L.ptr(blk.stats) if (blk.has_bn and blk.training) else None,
                    blk.N, blk.cin_r[0], 64, 64, blk.cout, blk.cout_r, blk.k, blk.s, blk.p, st)
+        elif blk.subpix:
+            # [conv_s(skip) when split], then the four output phases as one grid
+            for d in blk._fwd[:-4]:
+                L.call('srvp_conv_mfma', C.byref(d), st)
+            arr = blk.__dict__.get('_fwd_arr')
+            if arr is None:
+                arr = blk._fwd_arr = (L.ConvDesc * 4)(*blk._fwd[-4:])
+            L.call('srvp_conv_mfma_multi', arr, 4, st)
         else:
             for d in blk._fwd:
                 L.call('srvp_conv_mfma', C.byref(d), st)

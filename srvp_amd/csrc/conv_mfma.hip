@@ -364,11 +364,19 @@ struct HaloK {
     int sw_sh, sw_c1, sw_c2;          // chunk swizzle g(py, px) = ((px >> sw_sh) + sw_c1 * py + sw_c2 * (py >> 1)) & 7
 };
 
+// Up to four launches that differ only in their descriptors (the four output phases of a sub-pixel upsample conv) run as
+// ONE grid: blockIdx.y selects the descriptor.
+struct HaloKN { HaloK k[4]; };
+
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_halo_kernel(const HaloK p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_halo_kernel(const HaloKN pk) {
+    const HaloK& p = pk.k[blockIdx.y];
     constexpr int BK = 64, NT = 256, CPR = 8;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int NA_MAX = BM == 256 ? 11 : 6;           // 256-pixel tiles: 11 * 256 16-byte pieces = 352 pixels >= 334; 128: 192 >= 180
+    // patch pieces per thread: 256-pixel tiles 11 * 256 16-byte pieces = 352 pixels >= 334 (13 = 416 pixels for the
+    // 128-column variant, whose epilogue staging is larger than the patch anyway: sixteen 4x4 images + borders = 406);
+    // 128-pixel tiles: 192 >= 180
+    constexpr int NA_MAX = BM == 256 ? (BN == 128 ? 13 : 11) : 6;
     constexpr int A_BYTES = NA_MAX * NT * 16;
     constexpr int LDC = BN + 8;
     constexpr int C_BYTES = BM * LDC * 2;
@@ -560,7 +568,7 @@ static bool halo_geometry(const srvp_conv_desc* d, HaloK& h, int BM) {
     if (compact) { h.PW = fw + 1; h.IS = (fh + 1) * h.PW; h.Ppix = h.IMG * h.IS + h.PW + 1; }
     else { h.PW = fw + 2; h.IS = (fh + 2) * h.PW; h.Ppix = h.IS; }
     h.NA = (h.Ppix * 8 + 255) / 256;
-    if (h.NA > (BM == 256 ? 11 : 6)) return false;
+    if (h.NA > (BM == 256 ? (d->Cout % 128 == 0 ? 13 : 11) : 6)) return false;
     h.rIS = (unsigned)(((1ull << 32) + h.IS - 1) / h.IS); h.rPW = (unsigned)(((1ull << 32) + h.PW - 1) / h.PW);
     // conflict-free ds_read_b128 fragment reads for every tap (exhaustive search over this family per geometry)
     if (ups) { if (fw >= 8) { h.sw_sh = 1; h.sw_c1 = 4; h.sw_c2 = 0; } else { h.sw_sh = 0; h.sw_c1 = 0; h.sw_c2 = 4; } }
@@ -572,14 +580,42 @@ static bool halo_geometry(const srvp_conv_desc* d, HaloK& h, int BM) {
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch_halo(const srvp_conv_desc* d, HaloK& h, hipStream_t st) {
-    if (int rc = fill_convk(d, h.a)) return rc;
-    SRVP_REQUIRE(d->wt_fragmajor == 1, "srvp_conv_mfma: this launch runs on the halo kernel and needs fragment-major weights (srvp_conv_wants_fragmajor)");
-    long long blocks = (long long)((d->N + h.IMG - 1) / h.IMG) * h.tiles_x * h.tiles_y * (d->Cout / BN);
+int launch_halo_n(const srvp_conv_desc* d, int n, int bm, hipStream_t st) {
+    HaloKN hn;
+    long long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        HaloK& h = hn.k[i];
+        SRVP_REQUIRE(halo_geometry(d + i, h, bm), "srvp_conv_mfma(halo): descriptor %d is not eligible", i);
+        if (int rc = fill_convk(d + i, h.a)) return rc;
+        SRVP_REQUIRE(d[i].wt_fragmajor == 1, "srvp_conv_mfma: this launch runs on the halo kernel and needs fragment-major weights (srvp_conv_wants_fragmajor)");
+        const long long b = (long long)((d[i].N + h.IMG - 1) / h.IMG) * h.tiles_x * h.tiles_y * (d[i].Cout / BN);
+        SRVP_REQUIRE(i == 0 || b == blocks, "srvp_conv_mfma(halo): descriptors of one launch must have the same grid");
+        blocks = b;
+    }
+    for (int i = n; i < 4; ++i) hn.k[i] = hn.k[0];
     SRVP_REQUIRE(blocks > 0 && blocks < (1ll << 31), "srvp_conv_mfma(halo): bad grid %lld", blocks);
-    hipLaunchKernelGGL((conv_halo_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(256), 0, st, h);
+    hipLaunchKernelGGL((conv_halo_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, st, hn);
     SRVP_CHECK_LAUNCH("srvp_conv_mfma(halo)");
     return SRVP_OK;
+}
+
+// 0: not a halo launch; else the tile size (128 / 256) the dispatcher picks for this descriptor
+static int halo_variant(const srvp_conv_desc* d) {
+    HaloK h;
+    static int bm128 = -1;      // A/B switch: 128-pixel tiles for the narrow (Cout < 128) layers
+    if (bm128 < 0) { const char* e = getenv("SRVP_HALO_BM128"); bm128 = e ? atoi(e) : 0; }
+    if (bm128 && d->Cout % 128 != 0 && halo_geometry(d, h, 128)) return (bm128 & 2) ? 129 : 128;
+    return halo_geometry(d, h, 256) ? 256 : 0;
+}
+
+static int launch_halo_any(const srvp_conv_desc* d, int n, int variant, hipStream_t st) {
+    if (variant == 256) {
+        if (d->Cout % 128 == 0) return launch_halo_n<256, 128, 2, 2>(d, n, 256, st);
+        if (d->Cout % 64 == 0) return launch_halo_n<256, 64, 4, 1>(d, n, 256, st);
+        return launch_halo_n<256, 32, 4, 1>(d, n, 256, st);
+    }
+    if (d->Cout % 64 == 0) return variant == 129 ? launch_halo_n<128, 64, 4, 1>(d, n, 128, st) : launch_halo_n<128, 64, 2, 2>(d, n, 128, st);
+    return launch_halo_n<128, 32, 4, 1>(d, n, 128, st);
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NBUF>
@@ -599,13 +635,23 @@ int launch(const srvp_conv_desc* d, hipStream_t st) {
 
 extern "C" int srvp_conv_set_halo(int on) { g_halo = on; return SRVP_OK; }
 
-extern "C" int srvp_conv_wants_fragmajor(const srvp_conv_desc* d) {
-    HaloK h;
-    static int bm128 = -1;
-    if (bm128 < 0) { const char* e = getenv("SRVP_HALO_BM128"); bm128 = e ? atoi(e) : 0; }
-    if (!d) return 0;
-    if (bm128 && d->Cout % 128 != 0 && halo_geometry(d, h, 128)) return 1;
-    return halo_geometry(d, h, 256) ? 1 : 0;
+extern "C" int srvp_conv_wants_fragmajor(const srvp_conv_desc* d) { return d && halo_variant(d) ? 1 : 0; }
+
+extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
+
+// n <= 4 launches as one grid when they all run on the same halo kernel variant with the same grid (the output phases of
+// a sub-pixel upsample conv); otherwise simply n launches.
+extern "C" int srvp_conv_mfma_multi(const srvp_conv_desc* d, int n, void* stream) {
+    SRVP_REQUIRE(d && n >= 1, "srvp_conv_mfma_multi: bad args");
+    bool same = n <= 4;
+    const int v = halo_variant(d);
+    for (int i = 1; i < n && same; ++i)
+        same = halo_variant(d + i) == v && d[i].Cout == d[0].Cout && d[i].N == d[0].N && d[i].OH == d[0].OH && d[i].OW == d[0].OW &&
+               d[i].C0 == d[0].C0 && d[i].ntaps == d[0].ntaps && (d[i].add_f32 != nullptr) == (d[0].add_f32 != nullptr) && d[i].add_mod == d[0].add_mod;
+    if (v && same && n > 1 && d->src0 && d->wt) return launch_halo_any(d, n, v, (hipStream_t)stream);
+    for (int i = 0; i < n; ++i)
+        if (int rc = srvp_conv_mfma(d + i, stream)) return rc;
+    return SRVP_OK;
 }
 
 extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
@@ -620,18 +666,7 @@ extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
     SRVP_REQUIRE(d->stats == nullptr || d->stat_mod > 0, "srvp_conv_mfma: stat_mod");
     SRVP_REQUIRE((long long)d->N * d->H0p * d->W0p * d->C0 < (1ll << 32) && (d->C1 == 0 || d->map1 || (long long)d->N * d->H1p * d->W1p * d->C1 < (1ll << 32)),
                  "srvp_conv_mfma: source tensors must have fewer than 2^32 elements");
-    HaloK h;
-    static int bm128 = -1;      // A/B switch: 128-pixel tiles for the narrow (Cout < 128) layers
-    if (bm128 < 0) { const char* e = getenv("SRVP_HALO_BM128"); bm128 = e ? atoi(e) : 0; }
-    if (bm128 && d->Cout % 128 != 0 && halo_geometry(d, h, 128)) {
-        if (d->Cout % 64 == 0) return (bm128 & 2) ? launch_halo<128, 64, 4, 1>(d, h, st) : launch_halo<128, 64, 2, 2>(d, h, st);
-        return launch_halo<128, 32, 4, 1>(d, h, st);
-    }
-    if (halo_geometry(d, h, 256)) {
-        if (d->Cout % 128 == 0) return launch_halo<256, 128, 2, 2>(d, h, st);
-        if (d->Cout % 64 == 0) return launch_halo<256, 64, 4, 1>(d, h, st);
-        return launch_halo<256, 32, 4, 1>(d, h, st);
-    }
+    if (const int v = halo_variant(d)) return launch_halo_any(d, 1, v, st);
     SRVP_REQUIRE(d->wt_fragmajor == 0, "srvp_conv_mfma: fragment-major weights on a launch that runs on the generic kernel");
     const bool k64 = (d->C0 % 64 == 0) && (d->C1 % 64 == 0);
     // LDS ring depth / K step (A/B switch SRVP_CONV_MODE): 5 = BK64 single buffer (default: 3 workgroups per CU hide the
