@@ -229,6 +229,9 @@ typedef struct {
     float* hid_pz;                         /* [nl-1][F][B][nh] or NULL */
     float* scratch_hid;                    /* [nl-1][B][nh], used when hid_* is NULL */
     float* scratch_out;                    /* [B][max(ny, 2nz)] */
+    int32_t pz_external;                   /* 1: every frame is a posterior frame and the caller evaluates p_z (forward and
+                                            * backward) BATCHED over all frames outside the serial chain -- the prior MLP only
+                                            * feeds the KL term then (srvp.py:383-390), its input is the stored state */
 } srvp_rollout_desc;
 int srvp_rollout_fwd(const srvp_rollout_desc* d, void* stream);
 typedef struct {

@@ -71,7 +71,8 @@ class RolloutDesc(C.Structure):
                 ('dyn_w', P8), ('dyn_b', P8), ('pz_w', P8), ('pz_b', P8),
                 ('y0', c_vp), ('q_z_params', c_vp), ('eps_z', c_vp),
                 ('y_all', c_vp), ('z', c_vp), ('p_z_params', c_vp), ('res', c_vp),
-                ('inp_all', c_vp), ('hid_dyn', c_vp), ('hid_pz', c_vp), ('scratch_hid', c_vp), ('scratch_out', c_vp)]
+                ('inp_all', c_vp), ('hid_dyn', c_vp), ('hid_pz', c_vp), ('scratch_hid', c_vp), ('scratch_out', c_vp),
+                ('pz_external', c_i32)]
 
 
 class RolloutBwdDesc(C.Structure):

@@ -407,6 +407,8 @@ extern "C" int srvp_rollout_fwd(const srvp_rollout_desc* d, void* stream) {
                  "srvp_rollout_fwd: null pointer");
     SRVP_REQUIRE(d->nl >= 2 && d->nl <= 8 && d->n_euler >= 1, "srvp_rollout_fwd: nl=%d n_euler=%d", d->nl, d->n_euler);
     SRVP_REQUIRE((d->hid_dyn && d->hid_pz) || d->scratch_hid, "srvp_rollout_fwd: no hidden-activation storage");
+    SRVP_REQUIRE(!d->pz_external || (d->q_z_params && d->n_data_frames > (d->nsteps + d->n_euler - 1) / d->n_euler),
+                 "srvp_rollout_fwd: pz_external needs posterior parameters for every frame");
     const int B = d->B, ny = d->ny, nz = d->nz, nh = d->nh, nl = d->nl;
     const size_t ys = (size_t)B * ny, zs = (size_t)B * nz, hl = (size_t)B * nh;
     const int nin = ny + nz;
@@ -420,8 +422,10 @@ extern "C" int srvp_rollout_fwd(const srvp_rollout_desc* d, void* stream) {
             float* pz = d->p_z_params + (size_t)f * B * 2 * nz;
             float* hid = d->hid_pz ? d->hid_pz + (size_t)f * hl : d->scratch_hid;
             size_t ls = d->hid_pz ? (size_t)F * hl : hl;
-            int rc = mlp_fwd(st, d->pz_w, d->pz_b, nl, ny, nh, 2 * nz, y_prev, B, hid, ls, pz);
-            if (rc) return rc;
+            if (!d->pz_external) {
+                int rc = mlp_fwd(st, d->pz_w, d->pz_b, nl, ny, nh, 2 * nz, y_prev, B, hid, ls, pz);
+                if (rc) return rc;
+            }
             const bool posterior = (f + 1) < d->n_data_frames;
             const float* params = posterior ? d->q_z_params + (size_t)f * B * 2 * nz : pz;
             hipLaunchKernelGGL(rsample_fwd_kernel, g1((long long)zs), dim3(256), 0, st, params, d->eps_z + zs * f, d->z + zs * f,
@@ -475,6 +479,13 @@ extern "C" int srvp_rollout_bwd(const srvp_rollout_bwd_desc* d, void* stream) {
             // gradient wrt z of this frame is complete
             if (d->d_z) hipLaunchKernelGGL(add_inplace_kernel, g1((long long)zs), dim3(256), 0, st, dz_acc, d->d_z + zs * fr, (int)zs);
             const bool posterior = (fr + 1) < f.n_data_frames;
+            if (f.pz_external) {
+                // p_z backward is batched by the caller (its input gradient is already in d_y_all): only the sample's
+                // gradient wrt the posterior parameters is part of the chain
+                hipLaunchKernelGGL(rsample_bwd_kernel, g1((long long)zs), dim3(256), 0, st, f.q_z_params + (size_t)fr * B * 2 * nz,
+                                   f.eps_z + zs * fr, dz_acc, d->d_qz + (size_t)fr * B * 2 * nz, (long long)B, nz, 0, (long long)2 * nz);
+                continue;
+            }
             float* pdel = d->dhid_pz + (size_t)fr * B * dwp;
             float* pout = pdel + (size_t)(nl - 1) * dls_p;
             hipLaunchKernelGGL(rows_copy_kernel, g1((long long)B * 2 * nz), dim3(256), 0, st, pout, dwp,

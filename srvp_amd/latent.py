@@ -38,6 +38,10 @@ def axpby(st, out, a, x, b=0.0, y=None):
     L.call('srvp_axpby_f32', L.ptr(out), float(a), L.ptr(x), float(b), L.ptr(y), out.numel(), st)
 
 
+import os
+PZ_BATCHED = os.environ.get('SRVP_PZ_BATCHED', '1') != '0'
+
+
 def mlp_keys(prefix, n):
     return [f'{prefix}.module.{i}.{0 if i == 0 else 1}' for i in range(n)]
 
@@ -84,6 +88,8 @@ class LatentNet:
         if training:
             self.hid_dyn = z(nlr - 1, max(S, 1), B, nhr)
             self.hid_pz = z(nlr - 1, max(F, 1), B, nhr)
+            self._pz_in = z(max(F, 1) * B, ny)
+            self._pz_dx = z(max(F, 1) * B, ny)
             self.scratch_hid = None
             dwd, dwp = max(nhr, ny), max(nhr, 2 * nz)
             self.dwd, self.dwp = dwd, dwp
@@ -173,7 +179,20 @@ class LatentNet:
         """srvp.py:325-413 (remove_intermediate=True); the LSTM/q_z part must have run if n_data > 1."""
         if self.S > 0:
             self._rd = self._rollout_desc(params, n_data, eps_z, y0)
+            # training (every frame has data): z always comes from the posterior, so the prior MLP p_z(y_t) only feeds the KL
+            # term -- it leaves the serial chain and runs once, batched over all frames, on the stored states
+            self.pz_ext = bool(self.training and n_data >= self.nt and PZ_BATCHED and self.dwp == self.cfg['nh_res'])
+            self._rd.pz_external = 1 if self.pz_ext else 0
             L.call('srvp_rollout_fwd', C.byref(self._rd), st)
+            if self.pz_ext:
+                B, F, nlr, ny, nz, nhr = self.B, self.F, self.nl_res, self.cfg['ny'], self.cfg['nz'], self.cfg['nh_res']
+                cur = self._pz_in
+                cur.view(F, B, ny).copy_(self.y_all[0:self.S:self.ne])      # states at the frame starts as contiguous rows
+                for l, k in enumerate(mlp_keys('p_z', nlr)):
+                    last = l == nlr - 1
+                    out = self.p_z.view(F * B, 2 * nz) if last else self.hid_pz[l].view(F * B, nhr)
+                    linear_fwd(st, cur, params[k + '.weight'], params[k + '.bias'], out, L.ACT_NONE if last else L.ACT_RELU)
+                    cur = out
         else:
             self.y_all[0].copy_(y0)
         y = self.y_all[::self.ne]
@@ -200,6 +219,25 @@ class LatentNet:
         bd.d_y0, bd.d_qz, bd.dhid_dyn, bd.dhid_pz, bd.work = (L.ptr(self.d_y0), L.ptr(self.d_qz_samp), L.ptr(self.dhid_dyn),
                                                                L.ptr(self.dhid_pz), L.ptr(self.work))
         self.d_qz_samp.zero_()
+        if getattr(self, 'pz_ext', False) and S > 0:
+            # batched p_z backward (see generate): deltas of every frame at once, input gradient into d_y_all[f * ne]
+            keys = mlp_keys('p_z', nlr)
+            dwp = self.dwp
+            top = self.dhid_pz[nlr - 1].view(F * B, dwp)
+            if d_pz is not None:
+                top[:, :2 * nz].copy_(d_pz.reshape(F * B, 2 * nz))
+            else:
+                top.zero_()
+            for l in range(nlr - 1, 0, -1):
+                w = params[keys[l] + '.weight']                        # [cout][nhr]
+                cout = 2 * nz if l == nlr - 1 else nhr
+                dst = self.dhid_pz[l - 1].view(F * B, dwp)             # dwp == nhr (checked when pz_ext was chosen)
+                _gemm(st, self.dhid_pz[l].view(F * B, dwp), dwp, 1, w, nhr, 1, None, dst, dwp, F * B, nhr, cout)
+                L.call('srvp_act_bwd_f32', L.ptr(self.hid_pz[l - 1]), L.ptr(dst), L.ptr(dst), F * B * nhr, L.ACT_RELU, 1, st)
+            _gemm(st, self.dhid_pz[0].view(F * B, dwp), dwp, 1, params[keys[0] + '.weight'], ny, 1, None, self._pz_dx, ny, F * B, ny, nhr)
+            for f in range(F):
+                tgt = self.d_y_all[f * ne]
+                L.call('srvp_axpby_f32', L.ptr(tgt), 1.0, L.ptr(tgt), 1.0, L.ptr(self._pz_dx[f * B:(f + 1) * B]), B * ny, st)
         L.call('srvp_rollout_bwd', C.byref(bd), st)
         # weight gradients of dynamics / p_z: one GEMM per layer over all (step, sample) rows
         for name, nrow, width, dh, hid, inp, nin, nout in (
