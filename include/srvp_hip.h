@@ -245,6 +245,7 @@ typedef struct {
     float* dhid_dyn;                       /* [nl][nsteps][B][max(nh,ny)] per-layer pre-activation deltas */
     float* dhid_pz;                        /* [nl][F][B][max(nh,2nz)] */
     float* work;                           /* 3*B*ny + B*(ny+nz) + B*nz floats */
+    float* dinp_all;                       /* [nsteps][B][ny+nz] per-step input gradients (pz_external chains) or NULL */
 } srvp_rollout_bwd_desc;
 int srvp_rollout_bwd(const srvp_rollout_bwd_desc* d, void* stream);
 

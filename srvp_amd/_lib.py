@@ -78,7 +78,7 @@ class RolloutDesc(C.Structure):
 class RolloutBwdDesc(C.Structure):
     _fields_ = [('f', RolloutDesc),
                 ('d_y_all', c_vp), ('d_z', c_vp), ('d_pz', c_vp), ('d_res', c_vp),
-                ('d_y0', c_vp), ('d_qz', c_vp), ('dhid_dyn', c_vp), ('dhid_pz', c_vp), ('work', c_vp)]
+                ('d_y0', c_vp), ('d_qz', c_vp), ('dhid_dyn', c_vp), ('dhid_pz', c_vp), ('work', c_vp), ('dinp_all', c_vp)]
 
 
 _SIGS = {

@@ -220,6 +220,58 @@ __global__ void euler_bwd_split_kernel(const float* dy, const float* dinp, float
         *o = first_of_frame_in_reverse ? dinp[i] : *o + dinp[i];
     }
 }
+// ---- posterior-only (pz_external) chains: everything that is not serial leaves the per-step sequence
+// inp_all[i][b][ny + c] = z[i / ne][b][c] for every step; y part of step 0 = y0
+__global__ void fill_inp_kernel(const float* z, const float* y0, float* inp_all, int S, int ne, int B, int ny, int nz) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = ny + nz;
+    if (i >= (long long)S * B * w) return;
+    const int c = (int)(i % w); long long q = i / w;
+    const int b = (int)(q % B), st = (int)(q / B);
+    if (c >= ny) inp_all[i] = z[((size_t)(st / ne) * B + b) * nz + c - ny];
+    else if (st == 0) inp_all[i] = y0[b * ny + c];
+}
+// res = dt*out ; y_next = y + res, also written as the y part of the next step's MLP input
+__global__ void euler_update2_kernel(const float* y, const float* out, float dt, float* res, float* y_next, float* inp_next, int B,
+                                     int ny, int nin) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * ny) return;
+    const float r = dt * out[i];
+    res[i] = r;
+    const float v = y[i] + r;
+    y_next[i] = v;
+    if (inp_next) { const int b = i / ny, c = i - b * ny; inp_next[(size_t)b * nin + c] = v; }
+}
+// backward of step i finished (dinp = gradient wrt [y_i, z]): carry = dy + dinp[:, :ny]; and the seed of step i-1:
+// dy = d_y_all[i] + carry ; dout(i-1) = dt * (d_res[i-1] + dy)
+__global__ void euler_bwd_chain_kernel(float* dy, const float* dinp, float* carry, const float* d_y_i, const float* d_res_prev, float dt,
+                                       float* dout_prev, int B, int ny, int nin, int dout_rs) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * ny) return;
+    const int b = i / ny, c = i - b * ny;
+    const float cr = dy[i] + dinp[(size_t)b * nin + c];
+    carry[i] = cr;
+    if (dout_prev) {
+        const float v = (d_y_i ? d_y_i[i] : 0.f) + cr;
+        dy[i] = v;
+        dout_prev[(size_t)b * dout_rs + c] = dt * ((d_res_prev ? d_res_prev[i] : 0.f) + v);
+    }
+}
+// gradient wrt z of every frame = sum over its sub-steps of dinp[:, ny:] (+ d_z), then the posterior sample's backward
+__global__ void dz_finalize_kernel(const float* dinp_all, const float* d_z, const float* q_params, const float* eps, float* d_qz, int F,
+                                   int S, int ne, int B, int ny, int nz) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)F * B * nz) return;
+    const int c = (int)(i % nz); long long q = i / nz;
+    const int b = (int)(q % B), f = (int)(q / B);
+    const int nin = ny + nz;
+    float g = d_z ? d_z[i] : 0.f;
+    for (int s = f * ne; s < (f + 1) * ne && s < S; ++s) g += dinp_all[((size_t)s * B + b) * nin + ny + c];
+    const float raw = q_params[((size_t)f * B + b) * 2 * nz + nz + c];
+    const float ds = raw > 20.f ? 1.f : sigmoid_f(raw);
+    float* o = d_qz + ((size_t)f * B + b) * 2 * nz;
+    o[c] = g; o[nz + c] = g * eps[i] * ds;
+}
 __global__ void add_inplace_kernel(float* a, const float* b, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] += b[i];
@@ -415,6 +467,21 @@ extern "C" int srvp_rollout_fwd(const srvp_rollout_desc* d, void* stream) {
     const int F = (d->nsteps + d->n_euler - 1) / d->n_euler;
     hipError_t e = hipMemcpyAsync(d->y_all, d->y0, sizeof(float) * ys, hipMemcpyDeviceToDevice, st);
     SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd: copy failed");
+    if (d->pz_external && d->hid_dyn) {
+        // posterior-only chain: all samples and the z halves of every MLP input up front, then nl GEMMs + one update per step
+        hipLaunchKernelGGL(rsample_fwd_kernel, g1((long long)F * zs), dim3(256), 0, st, d->q_z_params, d->eps_z, d->z, (long long)F * B, nz);
+        hipLaunchKernelGGL(fill_inp_kernel, g1((long long)d->nsteps * B * nin), dim3(256), 0, st, d->z, d->y0, d->inp_all, d->nsteps,
+                           d->n_euler, B, ny, nz);
+        for (int i = 0; i < d->nsteps; ++i) {
+            float* inp = d->inp_all + (size_t)i * B * nin;
+            int rc = mlp_fwd(st, d->dyn_w, d->dyn_b, nl, nin, nh, ny, inp, B, d->hid_dyn + (size_t)i * hl, (size_t)d->nsteps * hl, d->scratch_out);
+            if (rc) return rc;
+            hipLaunchKernelGGL(euler_update2_kernel, g1((long long)ys), dim3(256), 0, st, d->y_all + ys * i, d->scratch_out, d->dt,
+                               d->res + ys * i, d->y_all + ys * (i + 1), i + 1 < d->nsteps ? inp + (size_t)B * nin : (float*)nullptr, B, ny, nin);
+        }
+        SRVP_CHECK_LAUNCH("srvp_rollout_fwd");
+        return SRVP_OK;
+    }
     for (int i = 0; i < d->nsteps; ++i) {
         const int f = i / d->n_euler;             // 0-based frame slot (frame index f+1)
         const float* y_prev = d->y_all + ys * i;
@@ -464,6 +531,28 @@ extern "C" int srvp_rollout_bwd(const srvp_rollout_bwd_desc* d, void* stream) {
     float* dypz = dz_acc + zs;
     hipError_t e = hipMemsetAsync(carry, 0, sizeof(float) * ys, st);
     SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_bwd: memset failed");
+    if (f.pz_external && d->dinp_all) {
+        // posterior-only chain: seed of the last step, then per step nl GEMMs + ONE kernel (close step i, seed step i-1); the
+        // gradients wrt z and the posterior samples' backward are finished for all frames at once afterwards
+        const int S = f.nsteps;
+        hipLaunchKernelGGL(euler_bwd_seed_kernel, g1((long long)ys), dim3(256), 0, st, d->d_y_all + ys * S, carry,
+                           d->d_res ? d->d_res + ys * (S - 1) : nullptr, f.dt, dy, d->dhid_dyn + (size_t)(S - 1) * B * dwd + (size_t)(nl - 1) * dls_d,
+                           B, ny, dwd);
+        for (int i = S - 1; i >= 0; --i) {
+            float* deltas = d->dhid_dyn + (size_t)i * B * dwd;
+            float* dinp_i = d->dinp_all + (size_t)i * B * nin;
+            int rc = mlp_bwd(st, f.dyn_w, nl, nin, nh, ny, B, f.hid_dyn + (size_t)i * hl, (size_t)S * hl, deltas, dls_d, dwd, dinp_i);
+            if (rc) return rc;
+            hipLaunchKernelGGL(euler_bwd_chain_kernel, g1((long long)ys), dim3(256), 0, st, dy, dinp_i, carry, d->d_y_all + ys * i,
+                               (i > 0 && d->d_res) ? d->d_res + ys * (i - 1) : (const float*)nullptr, f.dt,
+                               i > 0 ? d->dhid_dyn + (size_t)(i - 1) * B * dwd + (size_t)(nl - 1) * dls_d : (float*)nullptr, B, ny, nin, dwd);
+        }
+        hipLaunchKernelGGL(dz_finalize_kernel, g1((long long)F * zs), dim3(256), 0, st, d->dinp_all, d->d_z, f.q_z_params, f.eps_z, d->d_qz,
+                           F, S, f.n_euler, B, ny, nz);
+        hipLaunchKernelGGL(add3_kernel, g1((long long)ys), dim3(256), 0, st, d->d_y0, d->d_y_all, carry, (int)ys);
+        SRVP_CHECK_LAUNCH("srvp_rollout_bwd");
+        return SRVP_OK;
+    }
     for (int i = f.nsteps - 1; i >= 0; --i) {
         const int fr = i / f.n_euler;
         const bool last_sub = (i % f.n_euler) == f.n_euler - 1 || i == f.nsteps - 1;   // first visited sub-step of the frame

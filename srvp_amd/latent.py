@@ -96,6 +96,7 @@ class LatentNet:
             self.dhid_dyn = z(nlr, max(S, 1), B, dwd)
             self.dhid_pz = z(nlr, max(F, 1), B, dwp)
             self.work = z(3 * B * ny + B * (ny + nz) + B * nz)
+            self.dinp_all = z(max(S, 1), B, ny + nz)
             self.d_y_all = z(S + 1, B, ny)
             self.d_y0 = z(B, ny)
             self.d_qz_samp = z(max(F, 1), B, 2 * nz)
@@ -218,6 +219,7 @@ class LatentNet:
         bd.d_y_all, bd.d_z, bd.d_pz, bd.d_res = L.ptr(self.d_y_all), L.ptr(d_z), L.ptr(d_pz), L.ptr(d_res)
         bd.d_y0, bd.d_qz, bd.dhid_dyn, bd.dhid_pz, bd.work = (L.ptr(self.d_y0), L.ptr(self.d_qz_samp), L.ptr(self.dhid_dyn),
                                                                L.ptr(self.dhid_pz), L.ptr(self.work))
+        bd.dinp_all = L.ptr(self.dinp_all)
         self.d_qz_samp.zero_()
         if getattr(self, 'pz_ext', False) and S > 0:
             # batched p_z backward (see generate): deltas of every frame at once, input gradient into d_y_all[f * ne]
