@@ -648,16 +648,19 @@ class ConvNetBase:
             L.call('srvp_bn_bwd_finalize', None, 1.0, None, None, None, None, None, L.ptr(blk.bcoef), blk.cout, blk.cout_r, 0, st)
         L.call('srvp_bn_bwd_apply', C.byref(d), L.ptr(blk.bcoef), L.ptr(blk.draw), blk.draw_b, st)
 
-    def _mfma_backward(self, blk, grads, st, need_dgrad=True):
+    @staticmethod
+    def _wgrad(blk, st):
+        for d in (blk._wg if isinstance(blk._wg, list) else [blk._wg]):
+            L.call('srvp_wgrad_mfma', C.byref(d), st)
+
+    def _mfma_backward(self, blk, grads, st, need_dgrad=True, wgrad=True):
         if blk.split:
             # time-summed output gradient per sample (feeds the skip half's weight and data gradients)
             T = blk.N // blk.B
             L.call('srvp_skip_grad_reduce', L.ptr(blk.draw), blk.cout, 0, blk.cout, (blk.OH + 2) * (blk.OW + 2), T, blk.B,
                    L.ptr(blk.draw_sum), st)
-            L.call('srvp_wgrad_mfma', C.byref(blk._wg[0]), st)
-            L.call('srvp_wgrad_mfma', C.byref(blk._wg[1]), st)
-        else:
-            L.call('srvp_wgrad_mfma', C.byref(blk._wg), st)
+        if wgrad:
+            self._wgrad(blk, st)
         if need_dgrad:
             for d in blk._dg:
                 L.call('srvp_conv_mfma', C.byref(d), st)
@@ -818,7 +821,14 @@ class DecoderNet(ConvNetBase):
             L.call('srvp_conv_mfma', C.byref(d), st)
         return self.x_out
 
-    def backward(self, d_x, params, grads, st, sync=None):
+    def deferred_wgrads(self, grads, st):
+        """The weight gradients of a backward(..., defer_wgrad=True): nothing downstream but the optimizer needs them, so the
+        caller runs them on a second stream, concurrently with the latency-bound latent backward that follows."""
+        for blk in self.blocks:
+            self._wgrad(blk, st)
+        self.unpack_wgrads(grads, st)
+
+    def backward(self, d_x, params, grads, st, sync=None, defer_wgrad=False):
         """d_x: fp32 (N, C, 64, 64).  Returns dz bf16 [N][nz_padded]; skip gradients are left in the blocks' dcat."""
         ob = self.blocks[-1]
         self.zero_backward_accumulators()
@@ -831,7 +841,7 @@ class DecoderNet(ConvNetBase):
             self.dpre_f32 = torch.empty(self.N, ob.cout_r, ob.OH, ob.OW, dtype=torch.float32, device=self.dev)
         L.call('srvp_out_dpre', L.ptr(self.x_out), L.ptr(d_x), L.ptr(ob.draw), L.ptr(self.dpre_f32) if f32_dgrad else None,
                self.N, ob.cout_r, ob.OH, ob.OW, ob.cout, 1, st)
-        self._mfma_backward(ob, grads, st, need_dgrad=not f32_dgrad)
+        self._mfma_backward(ob, grads, st, need_dgrad=not f32_dgrad, wgrad=not defer_wgrad)
         if f32_dgrad:
             L.call('srvp_conv_in_fwd', L.ptr(self.dpre_f32), L.ptr(params[ob.spec['key'] + '.weight']), L.ptr(ob.dcat), None,
                    self.N, ob.cout_r, 64, 64, ob.ctot, ob.cin_r[0], ob.k, ob.s, ob.p, st)
@@ -841,9 +851,10 @@ class DecoderNet(ConvNetBase):
             # (a sub-pixel consumer hands back the gradient already summed over each 2x2 upsample cell)
             da = dict(t=nxt.dcat, mode=1 if (blk.spec['post_up'] and not nxt.subpix) else 0, cstride=nxt.dcat_c, coff=0, border=0)
             self._bn_backward(blk, params, grads, da, st, sync)
-            self._mfma_backward(blk, grads, st)
+            self._mfma_backward(blk, grads, st, wgrad=not defer_wgrad)
             nxt = blk
-        self.unpack_wgrads(grads, st)
+        if not defer_wgrad:
+            self.unpack_wgrads(grads, st)
         return self.blocks[0].dcat.view(self.N, -1)
 
     def skip_grads(self, T, B, st):

@@ -16,6 +16,8 @@ Differences from the reference, all documented in DESIGN.md:
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -37,6 +39,9 @@ def _set_module(root, path, module):
             cur.add_module(p, nxt)
         cur = nxt
     cur.add_module(parts[-1], module)
+
+
+OVERLAP_WGRAD = os.environ.get('SRVP_OVERLAP_WGRAD', '1') != '0'
 
 
 class _Holder(nn.Module):
@@ -289,7 +294,22 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         cz = lambda t: None if t is None else t.contiguous().float()
         if d_x is None:
             d_x = torch.zeros_like(dec.x_out)
-        dz = dec.backward(cz(d_x).view(nt * B, *dec.x_out.shape[1:]), params, grads, st, self.sync)
+        # The decoder's weight gradients feed nothing but the optimizer: they run on a second stream, concurrently with the
+        # latent backward (a ~3 ms chain of tiny dependent kernels that leaves the GPU almost idle) and the encoder backward
+        overlap = OVERLAP_WGRAD
+        dz = dec.backward(cz(d_x).view(nt * B, *dec.x_out.shape[1:]), params, grads, st, self.sync, defer_wgrad=overlap)
+        if overlap:
+            if getattr(self, '_side_stream', None) is None:
+                self._side_stream = torch.cuda.Stream()
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self._side_stream):
+                self._side_stream.wait_event(ev)
+                dec.deferred_wgrads(grads, L.stream())
+                if self.sync is not None:
+                    self.sync.grads_ready('decoder', self)
+                wg_done = torch.cuda.Event()
+                wg_done.record()
         dzf = dz[:, :self.nh_inf + self.ny].float()
         d_w_tot = dzf[:, :self.nh_inf].reshape(nt, B, self.nh_inf).sum(0)
         if d_w is not None:
@@ -297,7 +317,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         d_y_tot = dzf[:, self.nh_inf:].reshape(nt, B, self.ny)
         if d_y is not None:
             d_y_tot = d_y_tot + d_y
-        if self.sync is not None:
+        if self.sync is not None and not overlap:
             self.sync.grads_ready('decoder', self)
         d_hx = lat.backward(pl['hx'], params, grads, tape['eps_y0'], tape['eps_z'], d_y_tot.contiguous(), d_w_tot.contiguous(),
                             cz(d_qy0), cz(d_qz), cz(d_pz), cz(d_res), None, st)
@@ -315,6 +335,8 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         else:
             d_hx_p = d_hx
         enc.backward(pl['x'].view(T * B, *pl['x'].shape[2:]), d_hx_p, skip_grads, params, grads, st, self.sync)
+        if overlap:
+            torch.cuda.current_stream().wait_event(wg_done)
         if self.sync is not None:
             self.sync.grads_ready('all', self)
 
