@@ -299,6 +299,10 @@ class Block:
             return
         want = [int(L.load().srvp_conv_wants_fragmajor(C.byref(d))) for d in descs]
         assert len(set(want)) == 1, want
+        if sum(d.ntaps for d in descs) != pack_desc.ntaps:
+            # the launch re-reads the packed tensor under another shape (the 4x4 -> 1x1 / 1x1 -> 4x4 layers run as plain
+            # GEMMs over [taps * channels]): only the tap-major layout survives that reinterpretation
+            want = [0]
         for d in descs:
             d.wt_fragmajor = want[0]
         pack_desc.layout = want[0]

@@ -172,7 +172,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[TM][TN], const Con
 }
 
 
-template <int BM, int BN, int BK, int WM, int WN, int NBUF>
+// BDIRECT (single-buffer BK = 64 variant only): the weights are packed MFMA-fragment-major and go from L2 straight into
+// registers, like in the halo kernel below -- only the gathered A rows use the (scarce) LDS-DMA path and the LDS.
+template <int BM, int BN, int BK, int WM, int WN, int NBUF, bool BDIRECT = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) {
     constexpr int NT = WM * WN * 64;
     constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
@@ -182,8 +184,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDC = BN + 8;
     static_assert((BM * CPR) % NT == 0 && (BN * CPR) % 64 == 0, "tiles must split into whole-wave 1 KiB LDS-DMA pieces");
+    static_assert(!BDIRECT || (NBUF == 1 && BK == 64), "BDIRECT: single-buffer BK = 64 variant");
     constexpr int G = A_LD + B_LD;              // LDS-DMA instructions per K step and wave (vmcnt is per wave)
-    constexpr int AB_BYTES = NBUF * (BM + BN) * BK * 2;
+    constexpr int AB_BYTES = NBUF * (BM + (BDIRECT ? 0 : BN)) * BK * 2;
     constexpr int C_BYTES = BM * LDC * 2;
     constexpr int SMEM = AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES;
     // ONE shared object (a second one makes hipcc drain the LDS-DMA queue before every ds_read)
@@ -249,6 +252,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
             unsigned off = (((unsigned)n * Hp + vy) * Wp + vx) * C + c + a_ch[i] * 8;
             __builtin_amdgcn_global_load_lds((gptr_t)(src + off), (lptr_t)(Ad + (size_t)i * NT * 8), 16, 0, 0);
         }
+        if constexpr (BDIRECT) return;
         const bf16_t* w = a.wt + ((size_t)t * a.Cout + n0) * Ctot + cc * BK;
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
@@ -280,6 +284,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
     for (int i = 0; i < TM; ++i) { int r = wm * (TM * 32) + i * 32 + lrow; a_off[i] = r * BK; a_sw[i] = (r / RPB) % CPR; }
 #pragma unroll
     for (int j = 0; j < TN; ++j) { int r = wn * (TN * 32) + j * 32 + lrow; b_off[j] = r * BK; b_sw[j] = (r / RPB) % CPR; }
+    u32x4_t bq[4][TN];
+    const int JT = a.Cout >> 5;
+    const bf16_t* wlane = a.wt + (size_t)((n0 >> 5) + wn * TN) * 512 + lane * 8;
     // NBUF-deep LDS ring: the DMA runs NBUF-1 K steps ahead of the MFMAs behind COUNTED s_waitcnt vmcnt and ONE raw
     // s_barrier per step (a __syncthreads() would drain the whole DMA queue: vmcnt(0)).
 #pragma unroll
@@ -291,6 +298,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
             // single buffer, latency hidden by the other workgroups of the CU (3-4 resident at 34 KB of LDS each)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if constexpr (BDIRECT) {
+                // all B fragments of this step (4 k slices x TN column tiles, 1 KiB each), in flight with the A DMA
+                const int cc = s / a.ntaps, t = s - cc * a.ntaps;
+                const bf16_t* wb = wlane + (size_t)((t * kpt + cc) * 4) * JT * 512;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bq[kk][j] = *reinterpret_cast<const u32x4_t*>(wb + ((size_t)kk * JT + j) * 512);
+            }
             stage(s, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -311,7 +327,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + a_off[i] + ((kc ^ a_sw[i]) * 8));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bb + b_off[j] + ((kc ^ b_sw[j]) * 8));
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (BDIRECT) bfr[j] = __builtin_bit_cast(bf16x8_t, bq[kk][j]);
+                else bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bb + b_off[j] + ((kc ^ b_sw[j]) * 8));
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -599,6 +618,18 @@ int launch_halo_n(const srvp_conv_desc* d, int n, int bm, hipStream_t st) {
     return SRVP_OK;
 }
 
+static int generic_mode() {
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("SRVP_CONV_MODE"); mode = e ? atoi(e) : 5; }
+    return mode;
+}
+// generic kernel, default single-buffer BK = 64 variant: weights fragment-major, read from L2 into registers
+static bool generic_wants_fragmajor(const srvp_conv_desc* d) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SRVP_CONV_BDIRECT"); on = e ? atoi(e) : 1; }
+    return on && generic_mode() == 5 && d->C0 % 64 == 0 && d->C1 % 64 == 0 && d->Cout % 64 == 0;
+}
+
 // 0: not a halo launch; else the tile size (128 / 256) the dispatcher picks for this descriptor
 static int halo_variant(const srvp_conv_desc* d) {
     HaloK h;
@@ -618,7 +649,7 @@ static int launch_halo_any(const srvp_conv_desc* d, int n, int variant, hipStrea
     return launch_halo_n<128, 32, 4, 1>(d, n, 128, st);
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NBUF>
+template <int BM, int BN, int BK, int WM, int WN, int NBUF, bool BDIRECT = false>
 int launch(const srvp_conv_desc* d, hipStream_t st) {
     long long M = (long long)d->N * d->OH * d->OW;
     long long mt = (M + BM - 1) / BM;
@@ -626,7 +657,7 @@ int launch(const srvp_conv_desc* d, hipStream_t st) {
     SRVP_REQUIRE(blocks > 0 && blocks < (1ll << 31), "srvp_conv_mfma: bad grid %lld", blocks);
     ConvK k;
     if (int rc = fill_convk(d, k)) return rc;
-    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM, WN, NBUF>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, st, k);
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM, WN, NBUF, BDIRECT>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, st, k);
     SRVP_CHECK_LAUNCH("srvp_conv_mfma");
     return SRVP_OK;
 }
@@ -635,7 +666,7 @@ int launch(const srvp_conv_desc* d, hipStream_t st) {
 
 extern "C" int srvp_conv_set_halo(int on) { g_halo = on; return SRVP_OK; }
 
-extern "C" int srvp_conv_wants_fragmajor(const srvp_conv_desc* d) { return d && halo_variant(d) ? 1 : 0; }
+extern "C" int srvp_conv_wants_fragmajor(const srvp_conv_desc* d) { return d && (halo_variant(d) || generic_wants_fragmajor(d)) ? 1 : 0; }
 
 extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
 
@@ -667,13 +698,17 @@ extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
     SRVP_REQUIRE((long long)d->N * d->H0p * d->W0p * d->C0 < (1ll << 32) && (d->C1 == 0 || d->map1 || (long long)d->N * d->H1p * d->W1p * d->C1 < (1ll << 32)),
                  "srvp_conv_mfma: source tensors must have fewer than 2^32 elements");
     if (const int v = halo_variant(d)) return launch_halo_any(d, 1, v, st);
-    SRVP_REQUIRE(d->wt_fragmajor == 0, "srvp_conv_mfma: fragment-major weights on a launch that runs on the generic kernel");
     const bool k64 = (d->C0 % 64 == 0) && (d->C1 % 64 == 0);
     // LDS ring depth / K step (A/B switch SRVP_CONV_MODE): 5 = BK64 single buffer (default: 3 workgroups per CU hide the
     // DMA latency better than a deeper ring at 1-2 workgroups per CU: 39.0 vs 40.9 (x2) / 43 (BK32 x3) / 46 (BK32 x4) /
     // 56 ms (BK64 x3) per step), 0 = BK64 x2, 1 = BK32 x4, 2 = BK32 x3, 3 = BK64 x3
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("SRVP_CONV_MODE"); mode = e ? atoi(e) : 5; }
+    const int mode = generic_mode();
+    // (the caller may keep tap-major weights on a launch that could take fragment-major ones: both variants exist)
+    SRVP_REQUIRE(d->wt_fragmajor == 0 || generic_wants_fragmajor(d), "srvp_conv_mfma: fragment-major weights on a launch whose kernel reads them tap-major (srvp_conv_wants_fragmajor)");
+    if (d->wt_fragmajor) {
+        if (d->Cout % 128 == 0) return launch<128, 128, 64, 2, 2, 1, true>(d, st);
+        return launch<128, 64, 64, 2, 2, 1, true>(d, st);
+    }
     const int m = k64 ? mode : (mode == 2 ? 2 : 1);   // 5 = BK64, single buffer
     if (d->Cout % 128 == 0) {
         switch (m) {
