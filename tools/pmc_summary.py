@@ -7,7 +7,7 @@ from collections import defaultdict
 
 db = sqlite3.connect(glob.glob(sys.argv[1] + '/**/*.db', recursive=True)[0])
 cur = db.cursor()
-t0 = list(cur.execute("select max(end) from counters_collection where kernel_name like '%adam%'"))[0][0] or 0
+t0 = 0 if len(sys.argv) > 3 else (list(cur.execute("select max(end) from counters_collection where kernel_name like '%adam%'"))[0][0] or 0)
 rows = list(cur.execute("select kernel_name, counter_name, sum(value), count(*), sum(end-start)/1e6 from counters_collection "
                         "where start > ? group by kernel_name, counter_name", (t0,)))
 d = defaultdict(dict)
