@@ -187,7 +187,7 @@ __device__ __forceinline__ void in_load_patch(const float* __restrict__ x, float
     }
 }
 
-template <int KS, int S, int CIN>
+template <int KS, int S, int CIN, int NTL>
 __global__ __launch_bounds__(256) void conv_in_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                bf16_t* __restrict__ raw, double* stats, int N, int Cout,
                                                                int Cout_real, int tiles_per_wg) {
@@ -203,7 +203,8 @@ __global__ __launch_bounds__(256) void conv_in_fwd_mfma_kernel(const float* __re
         const int co = i & 63, k = i >> 6;
         wsh[k][co] = (k < Gm::K && co < Cout_real) ? w[(size_t)co * Gm::K + k] : 0.f;
     }
-    const int ntl = Cout / 32;                            // 1 or 2 column tiles
+    constexpr int ntl = NTL;                              // column tiles (compile time: a runtime test around the MFMAs makes
+                                                          // hipcc shuttle the accumulators through AGPR moves every step)
     const int m = wid * 32 + lcol;                        // this lane's pixel (A operand row) inside the tile
     const int abase = ((m / Gm::OW) * S) * Gm::PWp + (m % Gm::OW) * S;
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
@@ -216,9 +217,9 @@ __global__ __launch_bounds__(256) void conv_in_fwd_mfma_kernel(const float* __re
         __syncthreads();                                  // previous tile's patch / staging are no longer read
         in_load_patch<KS, S, CIN>(x, xs, n, tin);
         __syncthreads();
-        f32x16v acc[2];
+        f32x16v acc[NTL];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NTL; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 #pragma unroll
@@ -226,15 +227,14 @@ __global__ __launch_bounds__(256) void conv_in_fwd_mfma_kernel(const float* __re
             const float av = xs[abase + (lhalf ? Gm::off(2 * st + 1) : Gm::off(2 * st))];
             const float b0 = wsh[2 * st + lhalf][lcol];
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
-            if (ntl > 1) {
+            if constexpr (NTL > 1) {
                 const float b1 = wsh[2 * st + lhalf][32 + lcol];
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1], 0, 0, 0);
             }
         }
         // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (j >= ntl) break;
+        for (int j = 0; j < NTL; ++j) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = acc[j][r];
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void conv_in_fwd_mfma_kernel(const float* __re
 // dw[co][k] += sum_pix draw[pix][co] * patch[pix][k]:  A = draw^T (32 couts x 2 pixels), B = patch (2 pixels x 32 K
 // indices; K <= 32 per column tile, 48 needs two), accumulated over all tiles of the workgroup, then reduced over
 // the four waves (which split the 128 pixels of a tile) through LDS and added to dw with one atomic per weight.
-template <int KS, int S, int CIN>
+template <int KS, int S, int CIN, int NTL>
 __global__ __launch_bounds__(256) void conv_in_wgrad_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ draw,
                                                                  float* dw, int N, int Cout, int Cout_real, int tiles_per_wg) {
     typedef InGeom<KS, S, CIN> Gm;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_mfma_kernel(const float* __
     float (*part)[64][KT * 32 + 1] = reinterpret_cast<float (*)[64][KT * 32 + 1]>(sm);   // wave partials (after the loop)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lcol = lane & 31, lhalf = lane >> 5;
-    const int ntl = Cout / 32;
+    constexpr int ntl = NTL;
     // B operand offsets of this lane's K indices
     int boff[KT];
 #pragma unroll
@@ -292,9 +292,9 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_mfma_kernel(const float* __
         const int kidx = kt * 32 + lcol;
         boff[kt] = kidx >= Gm::K ? -1 : ((kidx / (KS * KS)) * Gm::PH + (kidx / KS) % KS) * Gm::PWp + kidx % KS;
     }
-    f32x16v acc[2][KT];
+    f32x16v acc[NTL][KT];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NTL; ++j)
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -324,8 +324,7 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_mfma_kernel(const float* __
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) bv[kt] = boff[kt] >= 0 ? xs[pb + boff[kt]] : 0.f;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (j >= ntl) break;
+            for (int j = 0; j < NTL; ++j) {
                 const float av = bf2f(gs[mpix * Cout + j * 32 + lcol]);
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) acc[j][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[kt], acc[j][kt], 0, 0, 0);
@@ -334,7 +333,7 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_mfma_kernel(const float* __
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NTL; ++j)
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -351,15 +350,23 @@ template <int KS, int S, int CIN>
 static void launch_in_fwd(const float* x, const float* w, bf16_t* raw, double* stats, int N, int Cout, int Cout_real, hipStream_t st) {
     const long long ntiles = (long long)N * InGeom<KS, S, CIN>::TPI;
     const int tpw = ntiles >= 32768 ? 8 : (ntiles >= 16 ? 2 : 1);
-    hipLaunchKernelGGL((conv_in_fwd_mfma_kernel<KS, S, CIN>), dim3((unsigned)((ntiles + tpw - 1) / tpw)), dim3(256), 0, st, x, w, raw, stats, N,
-                       Cout, Cout_real, tpw);
+    if (Cout == 64)
+        hipLaunchKernelGGL((conv_in_fwd_mfma_kernel<KS, S, CIN, 2>), dim3((unsigned)((ntiles + tpw - 1) / tpw)), dim3(256), 0, st, x, w, raw, stats,
+                           N, Cout, Cout_real, tpw);
+    else
+        hipLaunchKernelGGL((conv_in_fwd_mfma_kernel<KS, S, CIN, 1>), dim3((unsigned)((ntiles + tpw - 1) / tpw)), dim3(256), 0, st, x, w, raw, stats,
+                           N, Cout, Cout_real, tpw);
 }
 template <int KS, int S, int CIN>
 static void launch_in_wgrad(const float* x, const bf16_t* draw, float* dw, int N, int Cout, int Cout_real, hipStream_t st) {
     const long long ntiles = (long long)N * InGeom<KS, S, CIN>::TPI;
     const int tpw = ntiles >= 32768 ? 16 : (ntiles >= 16 ? 2 : 1);
-    hipLaunchKernelGGL((conv_in_wgrad_mfma_kernel<KS, S, CIN>), dim3((unsigned)((ntiles + tpw - 1) / tpw)), dim3(256), 0, st, x, draw, dw, N,
-                       Cout, Cout_real, tpw);
+    if (Cout == 64)
+        hipLaunchKernelGGL((conv_in_wgrad_mfma_kernel<KS, S, CIN, 2>), dim3((unsigned)((ntiles + tpw - 1) / tpw)), dim3(256), 0, st, x, draw, dw, N,
+                           Cout, Cout_real, tpw);
+    else
+        hipLaunchKernelGGL((conv_in_wgrad_mfma_kernel<KS, S, CIN, 1>), dim3((unsigned)((ntiles + tpw - 1) / tpw)), dim3(256), 0, st, x, draw, dw, N,
+                           Cout, Cout_real, tpw);
 }
 static bool in_mfma_ok(int Cin, int H, int W, int Cout, int k, int s, int p) {
     static int on = -1;
