@@ -222,16 +222,18 @@ __global__ __launch_bounds__(256) void conv_in_fwd_mfma_kernel(const float* __re
         for (int j = 0; j < NTL; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        // all operands of the tile first (3 * STEPS LDS reads in flight), then the MFMA chain without waits in between
+        float av[Gm::STEPS], bv[NTL][Gm::STEPS];
 #pragma unroll
         for (int st = 0; st < Gm::STEPS; ++st) {
-            const float av = xs[abase + (lhalf ? Gm::off(2 * st + 1) : Gm::off(2 * st))];
-            const float b0 = wsh[2 * st + lhalf][lcol];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
-            if constexpr (NTL > 1) {
-                const float b1 = wsh[2 * st + lhalf][32 + lcol];
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1], 0, 0, 0);
-            }
+            av[st] = xs[abase + (lhalf ? Gm::off(2 * st + 1) : Gm::off(2 * st))];
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) bv[j][st] = wsh[2 * st + lhalf][j * 32 + lcol];
         }
+#pragma unroll
+        for (int st = 0; st < Gm::STEPS; ++st)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], bv[j][st], acc[j], 0, 0, 0);
         // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
