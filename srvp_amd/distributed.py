@@ -15,8 +15,12 @@ import torch.distributed as dist
 
 
 class Sync:
-    def __init__(self, group=None):
+    def __init__(self, group=None, stat_group=None):
         self.group = group
+        # BatchNorm statistics travel on their OWN communicator: RCCL executes the collectives of one communicator in issue
+        # order, and the decoder's gradient slice (issued from the second stream, behind ~5 ms of weight-gradient kernels)
+        # would otherwise hold up every statistics all-reduce of the encoder backward issued after it
+        self.stat_group = stat_group if stat_group is not None else group
         self.world = dist.get_world_size(group)
         self.handles = []
         self.sync_bn = True
@@ -27,7 +31,7 @@ class Sync:
     def allreduce_stats(self, t, count):
         """In-place sum of a small fp64 statistics tensor over ranks; returns the global element count."""
         if self.sync_bn and (self.world > 1 or self.force):
-            dist.all_reduce(t, group=self.group)
+            dist.all_reduce(t, group=self.stat_group)
             return count * self.world
         return count
 
@@ -64,7 +68,7 @@ def init_process_group(backend=None):
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         dist.init_process_group(backend=backend)
-    return Sync()
+    return Sync(stat_group=dist.new_group() if dist.get_world_size() > 1 else None)
 
 
 class DataParallel(torch.nn.Module):
