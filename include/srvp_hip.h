@@ -130,6 +130,8 @@ typedef struct {
     const void* da; int32_t da_mode, da_cstride, da_coff, da_border; int32_t da_is_f32;
     const void* da2; const int32_t* da2_idx;                /* da2: compact [B][H][W][C]; da2_idx[n] = row or -1 */
     int32_t N, H, W, C;
+    void* tsum; int32_t tsum_T;                             /* apply only: bf16 [N/T][H+2b][W+2b][C] = sum over the T time steps (frames
+                                                             * ordered t*B + b) of the written gradient, or NULL */
 } srvp_bnbwd_desc;
 int srvp_bn_bwd_reduce(const srvp_bnbwd_desc* d, double* red, void* stream);
 /* red -> dgamma, dbeta (accumulated into fp32 grads when non-NULL) and the per-channel coefficients used by apply */

@@ -52,7 +52,7 @@ class BnBwdDesc(C.Structure):
                 ('da', c_vp), ('da_mode', c_i32), ('da_cstride', c_i32), ('da_coff', c_i32), ('da_border', c_i32),
                 ('da_is_f32', c_i32),
                 ('da2', c_vp), ('da2_idx', c_vp),
-                ('N', c_i32), ('H', c_i32), ('W', c_i32), ('C', c_i32)]
+                ('N', c_i32), ('H', c_i32), ('W', c_i32), ('C', c_i32), ('tsum', c_vp), ('tsum_T', c_i32)]
 
 
 class PackDesc(C.Structure):

@@ -650,6 +650,8 @@ class ConvNetBase:
                    L.ptr(grads[bk + '.weight']), L.ptr(grads[bk + '.bias']), L.ptr(blk.bcoef), blk.cout, blk.cout_r, 1, st)
         else:
             L.call('srvp_bn_bwd_finalize', None, 1.0, None, None, None, None, None, L.ptr(blk.bcoef), blk.cout, blk.cout_r, 0, st)
+        if blk.split and blk.draw_b == 1:
+            d.tsum, d.tsum_T = L.ptr(blk.draw_sum), blk.N // blk.B      # time-summed gradient for the hoisted skip half
         L.call('srvp_bn_bwd_apply', C.byref(d), L.ptr(blk.bcoef), L.ptr(blk.draw), blk.draw_b, st)
 
     @staticmethod
@@ -658,11 +660,7 @@ class ConvNetBase:
             L.call('srvp_wgrad_mfma', C.byref(d), st)
 
     def _mfma_backward(self, blk, grads, st, need_dgrad=True, wgrad=True):
-        if blk.split:
-            # time-summed output gradient per sample (feeds the skip half's weight and data gradients)
-            T = blk.N // blk.B
-            L.call('srvp_skip_grad_reduce', L.ptr(blk.draw), blk.cout, 0, blk.cout, (blk.OH + 2) * (blk.OW + 2), T, blk.B,
-                   L.ptr(blk.draw_sum), st)
+        # (split blocks: the time-summed output gradient draw_sum was written by srvp_bn_bwd_apply alongside draw)
         if wgrad:
             self._wgrad(blk, st)
         if need_dgrad:

@@ -130,6 +130,7 @@ struct BnBwdK {
     const void* da; int da_mode, da_cstride, da_coff, da_border, da_is_f32;
     const bf16_t* da2; const int* da2_idx;
     int N, H, W, C;
+    bf16_t* tsum; int tsum_T;        // apply: also write the sum over the T time steps of each sample (frames are t*B + b)
 };
 
 // g[8] = dA * f'(pre) for pixel (n,y,x), channel group cg; also returns raw values
@@ -383,6 +384,31 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK a, const
         }
         return;
     }
+    if (a.tsum) {
+        // hoisted-skip blocks also need sum_t draw (weight / data gradient of the per-sample skip half): walk the pixels of
+        // the B samples and loop over time inside, so the sum costs one extra store instead of re-reading draw
+        const int Bs = a.N / a.tsum_T;
+        const unsigned P = (unsigned)Bs * a.H * a.W, stride = gridDim.x * PPB;
+        PixWalk w;
+        w.init(blockIdx.x * PPB + pl, stride, a.H, a.W);
+        for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            for (int t = 0; t < a.tsum_T; ++t) {
+                const int n = t * Bs + w.n;
+                float g[8], rawf[8], o[8];
+                bn_bwd_g<MODE>(a, n, w.y, w.x, cg, sc, sh, g, rawf);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { o[e] = k1[e] * g[e] + k2[e] + k3[e] * rawf[e]; acc[e] += o[e]; }
+                size_t off = (((size_t)n * (a.H + 2 * db) + w.y + db) * (a.W + 2 * db) + w.x + db) * a.C + cg * 8;
+                *reinterpret_cast<u32x4_t*>(draw + off) = pack8(o);
+            }
+            size_t soff = (((size_t)w.n * (a.H + 2 * db) + w.y + db) * (a.W + 2 * db) + w.x + db) * a.C + cg * 8;
+            *reinterpret_cast<u32x4_t*>(a.tsum + soff) = pack8(acc);
+        }
+        return;
+    }
     const unsigned P = (unsigned)a.N * a.H * a.W, stride = gridDim.x * PPB;
     PixWalk w;
     w.init(blockIdx.x * PPB + pl, stride, a.H, a.W);
@@ -408,6 +434,8 @@ int fill_k(const srvp_bnbwd_desc* d, BnBwdK& k) {
     k.da = d->da; k.da_mode = d->da_mode; k.da_cstride = d->da_cstride; k.da_coff = d->da_coff;
     k.da_border = d->da_border; k.da_is_f32 = d->da_is_f32; k.da2 = (const bf16_t*)d->da2; k.da2_idx = d->da2_idx;
     k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C;
+    k.tsum = (bf16_t*)d->tsum; k.tsum_T = d->tsum_T;
+    SRVP_REQUIRE(!d->tsum || (d->tsum_T > 0 && d->N % d->tsum_T == 0 && d->da_mode != 2), "srvp_bn_bwd: tsum needs N %% T == 0 and a non-pooled consumer");
     return SRVP_OK;
 }
 
@@ -496,7 +524,8 @@ extern "C" int srvp_bn_bwd_apply(const srvp_bnbwd_desc* d, const float* coef, vo
     long long P = (long long)k.N * k.H * k.W;
     SRVP_REQUIRE(P < (1ll << 31), "srvp_bn_bwd_apply: too many pixels");
     if (k.da_mode == 2) P /= 4;
-    const dim3 g(grid_for(P, PPB * (k.da_mode == 2 ? 1 : 4)));
+    if (k.tsum) P /= k.tsum_T;
+    const dim3 g(grid_for(P, PPB * ((k.da_mode == 2 || k.tsum) ? 1 : 4)));
     if (k.da_mode == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, g, dim3(256), 0, (hipStream_t)stream, k, coef, (bf16_t*)draw, dst_border);
     else if (k.da_mode == 1) hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, g, dim3(256), 0, (hipStream_t)stream, k, coef, (bf16_t*)draw, dst_border);
     else hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, g, dim3(256), 0, (hipStream_t)stream, k, coef, (bf16_t*)draw, dst_border);
