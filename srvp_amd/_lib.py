@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsrvp_hip.so')
+LIB_PATH = os.environ.get('SRVP_LIB') or os.path.join(_HERE, 'libsrvp_hip.so')      # SRVP_LIB: A/B a second build in one run
 MAX_TAPS = 16
 
 ACT_NONE, ACT_LRELU, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3, 4
