@@ -504,6 +504,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     const int NC = C / BK;
     unsigned soff = step_off(0);
     issue_b(soff, 0, bq[0]);
+    issue_b(soff, 1, bq[1]);
     stage_a(0);
     int s = 0;
     for (int cc = 0; cc < NC; ++cc) {
@@ -536,11 +537,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 // weights two slices ahead (slot (kk+2)&3 was consumed two slices ago)
-                if (kk < 3) issue_b(soff, kk + 1, bq[kk + 1]); else issue_b(soff_n, 0, bq[0]);
+                if (kk < 2) issue_b(soff, kk + 2, bq[kk + 2]); else issue_b(soff_n, kk - 2, bq[kk - 2]);
                 if (kk + 1 < 4) load_a(kk + 1, af[(kk + 1) & 1]);
                 // slice kk has landed when only the 2 younger slices (2*TN loads) are outstanding
-                if constexpr (TN == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(bq[kk][0]), "+v"(bq[kk][1])::"memory");
-                else asm volatile("s_waitcnt vmcnt(1)" : "+v"(bq[kk][0])::"memory");
+                if constexpr (TN == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(bq[kk][0]), "+v"(bq[kk][1])::"memory");
+                else asm volatile("s_waitcnt vmcnt(2)" : "+v"(bq[kk][0])::"memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
