@@ -124,6 +124,43 @@ def evaluate(forward_fn, val_loader, device, opt):
     return -global_psnr / n
 
 
+def write_config(opt, path):
+    """The run's options as JSON (the file reference test.py:177 loads to rebuild the model)."""
+    import json
+    cfg = {k: v for k, v in dict(opt).items() if isinstance(v, (int, float, str, bool, list, tuple, type(None)))}
+    with open(path, 'w') as f:
+        json.dump(cfg, f, indent=1, sort_keys=True)
+
+
+def save_train_state(path, model, optimizer, lr_scheduler, itr, best_val_metric):
+    """Everything needed to continue a run bit-for-bit on the same hardware: weights + BN buffers, Adam moments and step,
+    LR schedule, iteration counter, best validation metric, RNG states (python / numpy / torch CPU and device)."""
+    state = dict(model=model.state_dict(), optimizer=optimizer.state_dict(), lr_scheduler=lr_scheduler.state_dict(), itr=itr,
+                 best_val_metric=best_val_metric,
+                 rng=dict(python=random.getstate(), numpy=np.random.get_state(), torch=torch.get_rng_state(),
+                          cuda=torch.cuda.get_rng_state() if torch.cuda.is_available() else None))
+    tmp = path + '.tmp'
+    torch.save(state, tmp)
+    os.replace(tmp, path)
+
+
+def load_train_state(path, model, optimizer, lr_scheduler, device):
+    state = torch.load(path, map_location=device, weights_only=False)
+    model.load_state_dict(state['model'])
+    optimizer.load_state_dict(state['optimizer'])
+    lr_scheduler.load_state_dict(state['lr_scheduler'])
+    rng = state.get('rng') or {}
+    if rng.get('python') is not None:
+        random.setstate(rng['python'])
+    if rng.get('numpy') is not None:
+        np.random.set_state(rng['numpy'])
+    if rng.get('torch') is not None:
+        torch.set_rng_state(rng['torch'].cpu())
+    if rng.get('cuda') is not None and torch.cuda.is_available():
+        torch.cuda.set_rng_state(rng['cuda'].cpu())
+    return state['itr'], state['best_val_metric']
+
+
 def main(opt):
     """Trains SRVP and saves the resulting model (reference train.py:192-384); same flags (srvp_amd/args.py)."""
     from . import data as sdata
@@ -170,6 +207,15 @@ def main(opt):
     os.makedirs(opt.save_path, exist_ok=True)
     itr, finished, status_code = 0, False, 0
     val_metric = best_val_metric = None
+    # what the reference lacks.  config.json (test.py:177 expects it next to the weights) and a resumable
+    # training state (optimizer moments, LR schedule, iteration, best validation metric, RNG) beside the reference-compatible
+    # model*.pt state dicts.  Resume: opt.resume / SRVP_RESUME = directory holding train_state.pt (no new CLI flag).
+    if local_rank == 0:
+        write_config(opt, os.path.join(opt.save_path, 'config.json'))
+    resume_dir = getattr(opt, 'resume', None) or os.environ.get('SRVP_RESUME')
+    if resume_dir:
+        itr, best_val_metric = load_train_state(os.path.join(resume_dir, 'train_state.pt'), model, optimizer, lr_scheduler, device)
+        print(f'Resumed from {resume_dir} at iteration {itr}')
     try:
         while not finished:
             if sampler is not None:
@@ -192,6 +238,8 @@ def main(opt):
                             torch.save(model.state_dict(), os.path.join(opt.save_path, 'model_best.pt'))
                     if opt.chkpt_interval is not None and itr % opt.chkpt_interval == 0:
                         torch.save(model.state_dict(), os.path.join(opt.save_path, f'model_{itr}.pt'))
+                        save_train_state(os.path.join(opt.save_path, 'train_state.pt'), model, optimizer, lr_scheduler, itr,
+                                         best_val_metric)
                     if itr % 50 == 0 or itr == 1:
                         print(f'itr {itr}: loss {loss:.3f} nll {nll:.3f} kl_y_0 {kl_y_0:.4f} kl_z {kl_z:.4f} '
                               f'val {val_metric} best {best_val_metric}', flush=True)
@@ -200,6 +248,7 @@ def main(opt):
     print('Saving...')
     if local_rank == 0:
         torch.save(model.state_dict(), os.path.join(opt.save_path, 'model.pt'))
+        save_train_state(os.path.join(opt.save_path, 'train_state.pt'), model, optimizer, lr_scheduler, itr, best_val_metric)
     print('Done')
     return status_code
 

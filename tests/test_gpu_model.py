@@ -378,3 +378,44 @@ def test_single_rank_collectives(tmp_path):
     l1 = json.loads(dist.stdout.strip().splitlines()[-1])['loss']
     # (not bit-equal: the fp64 statistics atomics retire in a different order from run to run)
     assert abs(l0 - l1) <= 1e-4 * abs(l0), (l0, l1)
+
+
+def test_resume_train_state(tmp_path):
+    """save_train_state / load_train_state continue a run -- same losses as the uninterrupted run (up to the
+    order of the fp64 statistics atomics), optimizer moments and LR schedule included; config.json is written as JSON."""
+    import json
+    import srvp_amd
+    from srvp_amd.train import train, save_train_state, load_train_state, write_config
+    dev = torch.device('cuda')
+    ctor = (64, 1, 8, 16, 4, 4, True, 2, 16, 3, 32, 4, 'vgg')
+    opt = srvp_amd.DotDict(dict(n_euler_steps=2, obs_scale=1.0, beta_y=1.0, beta_z=1.0, l2_res=1.0, lr=1e-3))
+
+    def make():
+        torch.manual_seed(3)
+        m = srvp_amd.StochasticLatentResidualVideoPredictor(*ctor)
+        m.init(1.41)
+        m.to(dev).train()
+        o = srvp_amd.FusedAdam(m, lr=opt.lr)
+        sch = torch.optim.lr_scheduler.LambdaLR(o, lr_lambda=lambda i: max(0, (10 - i) / 10))
+        return m, o, sch
+    x = torch.rand(4, 3, 1, 64, 64, generator=torch.Generator().manual_seed(5)).to(dev)
+    m, o, sch = make()
+    torch.manual_seed(11)
+    for _ in range(2):
+        train(m, o, None, x, dev, opt); sch.step()
+    path = str(tmp_path / 'train_state.pt')
+    save_train_state(path, m, o, sch, 2, -12.5)
+    ref = []
+    for _ in range(2):
+        ref.append(train(m, o, None, x, dev, opt)[0]); sch.step()
+    m2, o2, sch2 = make()
+    itr, best = load_train_state(path, m2, o2, sch2, dev)
+    assert (itr, best) == (2, -12.5)
+    assert sch2.get_last_lr() == pytest.approx(torch.optim.lr_scheduler.LambdaLR.get_last_lr(sch2)) and o2.step_count == 2
+    got = []
+    for _ in range(2):
+        got.append(train(m2, o2, None, x, dev, opt)[0]); sch2.step()
+    for a, b in zip(ref, got):
+        assert abs(a - b) <= 1e-4 * abs(a), (ref, got)
+    write_config(srvp_amd.DotDict(dict(nx=64, archi='vgg', device=[0], lr=3e-4, skipco=True)), str(tmp_path / 'config.json'))
+    assert json.load(open(tmp_path / 'config.json'))['archi'] == 'vgg'
