@@ -272,6 +272,9 @@ int srvp_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr,
 
 /* misc */
 int srvp_fill_f64(double* p, int64_t n, double v, void* stream);
+/* input pipeline (replaces the CPU collate of data/base.py:54-84): uint8 videos stacked [B][T][H][W][C]
+ * (C = 1 for grey-scale arrays without channel axis) -> float32 frames (T, B, C, H, W) in [0, 1] = value / 255 */
+int srvp_frames_u8_to_f32(const void* in_u8, float* out, int B, int T, int H, int W, int C, void* stream);
 int srvp_cast_f32_bf16(const float* src, void* dst, int64_t rows, int cols, int dst_cols, void* stream);
 /* dsel[b][hw][c] = sum_t dcat[t*B+b][hw][coff+c]  (gradient of the skip expand over time, srvp.py:222-223; the
  * gather of srvp.py:187 is undone by srvp_bn_bwd_* through da2_idx) */

@@ -33,6 +33,28 @@ extern "C" int srvp_fill_f64(double* p, int64_t n, double v, void* stream) {
     SRVP_CHECK_LAUNCH("srvp_fill_f64");
     return SRVP_OK;
 }
+// uint8 videos [B][T][H][W][C] (the per-video arrays of reference data/base.py:71-84 stacked) -> float32 frames (T, B, C, H, W) / 255
+namespace {
+__global__ void frames_u8_kernel(const unsigned char* __restrict__ in, float* __restrict__ out, int B, int T, int H, int W, int C) {
+    const long long n = (long long)T * B * C * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W); long long q = i / W;
+        const int y = (int)(q % H); q /= H;
+        const int c = (int)(q % C); q /= C;
+        const int b = (int)(q % B); const int t = (int)(q / B);
+        out[i] = (float)in[((((size_t)b * T + t) * H + y) * W + x) * C + c] / 255.f;
+    }
+}
+}  // namespace
+extern "C" int srvp_frames_u8_to_f32(const void* in, float* out, int B, int T, int H, int W, int C, void* stream) {
+    SRVP_REQUIRE(in && out && B > 0 && T > 0 && H > 0 && W > 0 && C > 0, "srvp_frames_u8_to_f32: bad args");
+    const long long n = (long long)T * B * C * H * W;
+    long long blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(frames_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)in, out, B, T, H, W, C);
+    SRVP_CHECK_LAUNCH("srvp_frames_u8_to_f32");
+    return SRVP_OK;
+}
+
 extern "C" int srvp_cast_f32_bf16(const float* src, void* dst, int64_t rows, int cols, int dst_cols, void* stream) {
     long long n = (long long)rows * dst_cols;
     if (n <= 0) return SRVP_OK;

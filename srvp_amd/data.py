@@ -32,6 +32,26 @@ def collate_fn(videos):
     return torch.stack(videos, 1)
 
 
+def collate_u8(videos):
+    """Device-side variant of reference data/base.py:54-84: stack the per-video uint8 arrays -- (T, H, W) or
+    (T, H, W, 3) each -- into one pinned uint8 tensor [B][T][H][W][C]; `frames_from_u8` finishes the job on the GPU (one
+    quarter of the PCIe bytes of the float32 batch, no CPU transpose / divide)."""
+    arrs = [torch.as_tensor(v) for v in videos]
+    u8 = torch.stack([a if a.ndim == 4 else a.unsqueeze(-1) for a in arrs], 0).contiguous()
+    assert u8.dtype == torch.uint8
+    return u8.pin_memory() if torch.cuda.is_available() else u8
+
+
+def frames_from_u8(u8, device):
+    """uint8 [B][T][H][W][C] (host or device) -> float32 (T, B, C, H, W) in [0, 1] on `device` (srvp_frames_u8_to_f32)."""
+    from . import _lib as L
+    u8 = u8.to(device, non_blocking=True)
+    B, T, H, W, C_ = u8.shape
+    out = torch.empty(T, B, C_, H, W, dtype=torch.float32, device=device)
+    L.call('srvp_frames_u8_to_f32', L.ptr(u8), L.ptr(out), B, T, H, W, C_, L.stream())
+    return out
+
+
 def make_loaders(opt, local_rank):
     if opt.dataset != 'synthetic':
         raise NotImplementedError(

@@ -83,7 +83,11 @@ def train(forward_fn, optimizer, scaler, batch, device, opt):
         raise TypeError('srvp_amd.train.train needs the srvp_amd StochasticLatentResidualVideoPredictor (or a wrapper '
                         'exposing it as .module)')
     optimizer.zero_grad()
-    x = batch.to(device, non_blocking=True)
+    if batch.dtype == torch.uint8:                     # stacked uint8 videos (data.collate_u8): finish the collate on the GPU
+        from .data import frames_from_u8
+        x = frames_from_u8(batch, device)
+    else:
+        x = batch.to(device, non_blocking=True)
     n = x.shape[1]
     acc = fused_step(model, x, opt)
     optimizer.step()

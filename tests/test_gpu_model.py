@@ -419,3 +419,22 @@ def test_resume_train_state(tmp_path):
         assert abs(a - b) <= 1e-4 * abs(a), (ref, got)
     write_config(srvp_amd.DotDict(dict(nx=64, archi='vgg', device=[0], lr=3e-4, skipco=True)), str(tmp_path / 'config.json'))
     assert json.load(open(tmp_path / 'config.json'))['archi'] == 'vgg'
+
+
+@pytest.mark.parametrize('nc', [1, 3])
+def test_u8_collate_matches_reference_collate(nc):
+    """collate_u8 + srvp_frames_u8_to_f32 == the reference's CPU collate_fn (data/base.py:54-84), bit for bit."""
+    import numpy as np
+    from srvp_amd.data import collate_u8, frames_from_u8
+    rng = np.random.RandomState(7)
+    T, B = 5, 3
+    videos = [rng.randint(0, 256, size=(T, 64, 64) if nc == 1 else (T, 64, 64, 3)).astype(np.uint8) for _ in range(B)]
+    ref = torch.zeros((T, B, nc, 64, 64), dtype=torch.uint8)            # restatement of the reference collate
+    for i, v in enumerate(videos):
+        if nc == 1:
+            ref[:, i, 0] += torch.from_numpy(v)
+        else:
+            ref[:, i] += torch.from_numpy(np.moveaxis(v, 3, 1))
+    ref = ref.float() / 255
+    got = frames_from_u8(collate_u8(videos), torch.device('cuda'))
+    assert got.shape == ref.shape and torch.equal(got.cpu(), ref)
