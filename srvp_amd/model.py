@@ -202,17 +202,20 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
                 p.grad = g
         return {k: p.grad for k, p in self.named_parameters()}
 
-    def _plan(self, T, B, nt, n_euler, training):
-        key = (T, B, nt, n_euler, training, str(self._device()))
+    def _plan(self, T, B, nt, n_euler, training, S=1):
+        """S > 1 (inference only): the conditioning frames are encoded once for B videos, the latent path and the decoder run
+        on B*S (video, sample) rows -- row s*B + b -- sharing the B skip tensors / hoisted skip halves through the image maps."""
+        key = (T, B, nt, n_euler, training, str(self._device())) + ((S,) if S > 1 else ())
         pl = self._plans.get(key)
         if pl is None:
+            assert S == 1 or not training
             dev = self._device()
             enc = EncoderNet(self._enc_blocks, T * B, dev, training) if T > 0 else None
-            skip_map = torch.zeros(nt * B, dtype=torch.int32, device=dev) if self.skipco else None
+            skip_map = torch.zeros(nt * B * S, dtype=torch.int32, device=dev) if self.skipco else None
             skip_sel = torch.zeros(B, dtype=torch.int32, device=dev) if self.skipco else None
-            dec = DecoderNet(self._dec_blocks, nt * B, dev, training, enc.skips if (self.skipco and enc) else None, skip_map,
+            dec = DecoderNet(self._dec_blocks, nt * B * S, dev, training, enc.skips if (self.skipco and enc) else None, skip_map,
                              skip_sel)
-            lat = LatentNet(self._cfg(), T, B, nt, n_euler, dev, training)
+            lat = LatentNet(self._cfg(), T, B * S, nt, n_euler, dev, training)
             pl = dict(enc=enc, dec=dec, lat=lat, skip_map=skip_map, skip_sel_t=skip_sel)
             # keep at most two training plans alive (they own all activation memory)
             if training:
@@ -281,6 +284,39 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         pl['hx'], pl['x'] = hx, x
         self._last_plan = pl
         return x_, y, z, w, q_y0, qz, pz, res
+
+    @torch.no_grad()
+    def sample(self, x, nt, n_samples, dt=1.0, tape=None):
+        """n_samples stochastic futures of every video from ONE encoding of the conditioning frames x (T, B, C,
+        64, 64) -- what train.evaluate (train.py:170-174) / test.py:237-246 obtain from n_samples forward passes, each of
+        which re-encodes the same frames.  Inference mode only.  Returns x_ (nt, n_samples, B, C, 64, 64).
+        tape (optional): eps_y0 (n_samples*B, ny), eps_z (nt-1, n_samples*B, nz), row s*B + b."""
+        assert not self.training, 'sample() is an inference entry point (model.eval())'
+        dev = self._require_gpu()
+        n_euler = int(round(1 / dt))
+        T, B, S = x.shape[0], x.shape[1], int(n_samples)
+        st = L.stream()
+        pl = self._plan(T, B, nt, n_euler, False, S=S)
+        params = self._named_tensors()
+        self._pack(pl, params, st)
+        if tape is None:
+            tape = self._draw_tape(T, B * S, nt, False, dev)
+        tape = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in tape.items()}
+        enc, dec, lat = pl['enc'], pl['dec'], pl['lat']
+        x = x.contiguous().float()
+        hx = enc.forward(x.view(T * B, *x.shape[2:]), params, st, None).contiguous().view(T, B, self.nhx)
+        if self.skipco:
+            sel = (T - 1) * B + torch.arange(B, device=dev, dtype=torch.int32)
+            pl['skip_map'].copy_(sel.repeat(nt * S))
+            pl['skip_sel_t'].copy_(sel)
+        hx_s = hx.repeat(1, S, 1).contiguous()                          # (T, S*B, nhx): row s*B + b
+        w = lat.infer_w(hx_s, params, None, st)
+        y0, _ = lat.infer_y(hx_s[:self.nt_inf], params, tape['eps_y0'], st)
+        lat.posterior(hx_s, params, st)
+        y = lat.generate(y0, T, params, tape['eps_z'], st)[0]
+        z_in = torch.cat([w.repeat(nt, 1), y.reshape(nt * B * S, self.ny)], 1)
+        x_flat = dec.forward(z_in, params, st, None)
+        return x_flat.view(nt, S, B, *x_flat.shape[1:]).clone()
 
     def _backward_impl(self, d_x, d_y, d_w, d_qy0, d_qz, d_pz, d_res):
         pl = self._last_plan

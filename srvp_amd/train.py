@@ -112,8 +112,18 @@ def evaluate(forward_fn, val_loader, device, opt):
             nt, n_b = x.shape[0], x.shape[1]
             n += n_b
             best_psnr, best_x = None, None
-            for _ in range(opt.n_samples_test):
-                x_s = forward_fn(x_inf, nt, dt=1 / opt.n_euler_steps)[0]
+            model = _unwrap(forward_fn)
+            if model is not None and opt.n_samples_test > 1 and hasattr(model, 'sample') and not model.training:
+                # one encoding of the conditioning frames, samples fanned out inside the latent path / decoder,
+                # in chunks that keep the decoder batch at the size of a training step
+                chunk = max(1, min(opt.n_samples_test, 2304 // max(1, nt * n_b)))
+                samples = []
+                for s0 in range(0, opt.n_samples_test, chunk):
+                    xs = model.sample(x_inf, nt, min(chunk, opt.n_samples_test - s0), dt=1 / opt.n_euler_steps)
+                    samples.extend(xs[:, i] for i in range(xs.shape[1]))
+            else:
+                samples = (forward_fn(x_inf, nt, dt=1 / opt.n_euler_steps)[0] for _ in range(opt.n_samples_test))
+            for x_s in samples:
                 mse = torch.mean((x_s - x) ** 2, dim=[3, 4])              # (nt, B, C)
                 psnr = torch.mean(10 * torch.log10(1 / mse), dim=[0, 2])  # (B,)
                 if best_psnr is None:

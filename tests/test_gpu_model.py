@@ -438,3 +438,31 @@ def test_u8_collate_matches_reference_collate(nc):
     ref = ref.float() / 255
     got = frames_from_u8(collate_u8(videos), torch.device('cuda'))
     assert got.shape == ref.shape and torch.equal(got.cpu(), ref)
+
+
+@pytest.mark.parametrize('archi,nc,skipco', [('vgg', 3, True), ('dcgan', 1, False)])
+def test_batched_samples_match_per_sample_forward(archi, nc, skipco):
+    """model.sample (one encoding, S futures fanned into the batch dimension of the latent path and the
+    decoder) == S separate inference forward passes (reference train.py:170-174 / test.py:237-246) fed the same draws."""
+    import srvp_amd
+    dev = torch.device('cuda')
+    torch.manual_seed(2)
+    m = srvp_amd.StochasticLatentResidualVideoPredictor(64, nc, 16, 32, 8, 8, skipco, 2, 32, 2, 32, 2, archi)
+    m.init(1.41)
+    m.to(dev).train()
+    T, B, nt, S = 3, 4, 7, 3
+    x = torch.rand(T, B, nc, 64, 64, generator=torch.Generator().manual_seed(4)).to(dev)
+    with torch.no_grad():                                       # settle the BN running statistics, so that in eval mode the
+        for _ in range(25):                                     # frames really depend on the latent draws
+            m(x, T, 0.5)
+    m.eval()
+    g = torch.Generator().manual_seed(9)
+    eps_y0 = torch.randn(S * B, 8, generator=g).to(dev)
+    eps_z = torch.randn(nt - 1, S * B, 8, generator=g).to(dev)
+    xs = m.sample(x, nt, S, dt=0.5, tape=dict(eps_y0=eps_y0, eps_z=eps_z))
+    assert xs.shape == (nt, S, B, nc, 64, 64)
+    for s in range(S):
+        tape = dict(eps_y0=eps_y0[s * B:(s + 1) * B].contiguous(), eps_z=eps_z[:, s * B:(s + 1) * B].contiguous())
+        ref = m(x, nt, 0.5, tape=tape)[0]
+        assert torch.allclose(xs[:, s], ref, atol=2e-3, rtol=0), (s, (xs[:, s] - ref).abs().max().item())
+    assert (xs[:, 0] - xs[:, 1]).abs().max() > 2e-2             # the samples do differ
