@@ -115,8 +115,9 @@ def evaluate(forward_fn, val_loader, device, opt):
             model = _unwrap(forward_fn)
             if model is not None and opt.n_samples_test > 1 and hasattr(model, 'sample') and not model.training:
                 # one encoding of the conditioning frames, samples fanned out inside the latent path / decoder,
-                # in chunks that keep the decoder batch at the size of a training step
-                chunk = max(1, min(opt.n_samples_test, 2304 // max(1, nt * n_b)))
+                # in chunks of <= SRVP_EVAL_FRAMES decoded frames (9216 frames of VGG-64 keep ~31 GB of the 288 GB resident)
+                lim = int(os.environ.get('SRVP_EVAL_FRAMES', 9216))
+                chunk = max(1, min(opt.n_samples_test, lim // max(1, nt * n_b)))
                 samples = []
                 for s0 in range(0, opt.n_samples_test, chunk):
                     xs = model.sample(x_inf, nt, min(chunk, opt.n_samples_test - s0), dt=1 / opt.n_euler_steps)
