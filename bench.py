@@ -124,12 +124,17 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}'
+    # SRVP_DIST_BACKEND=gloo: diagnostic only -- lets the N>1 control flow be exercised on a box with fewer GPUs than ranks
+    # (ranks then share devices, which RCCL refuses); the measured configuration is always RCCL, one rank per GPU
+    backend = os.environ.get('SRVP_DIST_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     sync = None
     if world > 1 or os.environ.get('SRVP_FORCE_COLLECTIVES') == '1':
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        sync = sdist.init_process_group('nccl')
+        sync = sdist.init_process_group(backend)
 
     cfg = CONFIGS[args.config]
     T = cfg['T']
@@ -180,6 +185,7 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = tmax.item()
     if rank != 0:
+        torch.distributed.destroy_process_group()
         return
     frames = B * T * world
     ms_step = dt / args.steps * 1e3
@@ -225,6 +231,8 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(cfg)
     print(json.dumps(line))
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':
