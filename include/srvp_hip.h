@@ -276,6 +276,12 @@ int srvp_fill_f64(double* p, int64_t n, double v, void* stream);
  * (C = 1 for grey-scale arrays without channel axis) -> float32 frames (T, B, C, H, W) in [0, 1] = value / 255 */
 int srvp_frames_u8_to_f32(const void* in_u8, float* out, int B, int T, int H, int W, int C, void* stream);
 int srvp_cast_f32_bf16(const float* src, void* dst, int64_t rows, int cols, int dst_cols, void* stream);
+/* evaluation metrics: x, y = `planes` float32 planes of H x W (<= 64 x 64; (nt*B*C) planes of NCHW frames).
+ * mse[p] = mean((x-y)^2) (test.py:249; PSNR = 10 log10(1/mse), test.py:251, train.py:175-176);
+ * ssim[p] = mean over the (H-F+1) x (W-F+1) window positions of the SSIM map of metrics/ssim.py:92-110 (gaussian window
+ * F = filter_size, sigma; constants (k1 max_val)^2, (k2 max_val)^2) = test.py:56-57.  Either output may be NULL. */
+int srvp_frame_metrics(const float* x, const float* y, int64_t planes, int H, int W, float max_val, int filter_size,
+                       float sigma, float k1, float k2, float* mse, float* ssim, void* stream);
 /* dsel[b][hw][c] = sum_t dcat[t*B+b][hw][coff+c]  (gradient of the skip expand over time, srvp.py:222-223; the
  * gather of srvp.py:187 is undone by srvp_bn_bwd_* through da2_idx) */
 int srvp_skip_grad_reduce(const void* dcat, int cstride, int coff, int C, int HW, int T, int B, void* dsel, void* stream);

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from . import metrics as _metrics
 from .model import StochasticLatentResidualVideoPredictor
 from .optim import FusedAdam
 
@@ -125,7 +126,7 @@ def evaluate(forward_fn, val_loader, device, opt):
             else:
                 samples = (forward_fn(x_inf, nt, dt=1 / opt.n_euler_steps)[0] for _ in range(opt.n_samples_test))
             for x_s in samples:
-                mse = torch.mean((x_s - x) ** 2, dim=[3, 4])              # (nt, B, C)
+                mse = _metrics.mse(x_s, x)                                # (nt, B, C), one pass on the device (§8f-4)
                 psnr = torch.mean(10 * torch.log10(1 / mse), dim=[0, 2])  # (B,)
                 if best_psnr is None:
                     best_psnr, best_x = psnr, x_s.clone()
@@ -133,8 +134,7 @@ def evaluate(forward_fn, val_loader, device, opt):
                     better = psnr > best_psnr
                     best_psnr = torch.where(better, psnr, best_psnr)
                     best_x[:, better] = x_s[:, better]
-            mse = torch.mean((best_x - x) ** 2, dim=[3, 4])
-            psnr = 10 * torch.log10(1 / mse)
+            psnr = _metrics.psnr(best_x, x)
             global_psnr += psnr[inf_len:].mean().item() * n_b
     return -global_psnr / n
 

@@ -266,6 +266,42 @@ def gen_known_answers():
     np.savez_compressed(os.path.join(GOLDEN, 'known_answers.npz'), **out)
 
 
+def metric_videos():
+    """Seeded (prediction, ground truth) video pairs for the metric fixtures: (nt=3, B=2, C, 64, 64) in [0, 1] -- smooth
+    structured frames (sums of random sinusoids) plus noise of three strengths, so that SSIM covers ~0.1 .. ~1."""
+    out = {}
+    for C, seed in ((1, 21), (3, 22)):
+        g = torch.Generator().manual_seed(seed)
+        yy, xx = torch.meshgrid(torch.arange(64.), torch.arange(64.), indexing='ij')
+        gt = torch.zeros(3, 2, C, 64, 64)
+        for _ in range(6):
+            f = torch.rand(3, 2, C, 2, generator=g) * 0.5
+            ph = torch.rand(3, 2, C, 1, 1, generator=g) * 6.28
+            gt += torch.sin(f[..., 0, None, None] * yy + f[..., 1, None, None] * xx + ph) / 6
+        gt = (gt * 0.5 + 0.5).clamp(0, 1)
+        noise = torch.randn(3, 2, C, 64, 64, generator=g) * torch.tensor([0.005, 0.05, 0.3]).view(3, 1, 1, 1, 1)
+        pred = (gt + noise).clamp(0, 1)
+        out[C] = (pred.contiguous(), gt.contiguous())
+    return out
+
+
+def gen_metrics():
+    """PSNR / SSIM of the reference (test.py:249-253 through metrics/ssim.py) on seeded videos."""
+    from metrics.ssim import ssim_loss
+    out = {}
+    for C, (pred, gt) in metric_videos().items():
+        nt, bsz = pred.shape[:2]
+        img = pred.shape[2:]
+        ssim = ssim_loss(pred.view(nt * bsz, *img), gt.view(nt * bsz, *img), max_val=1., reduction='none')   # test.py:56
+        ssim = ssim.mean(dim=[2, 3]).view(nt, bsz, img[0])                                                   # test.py:57
+        mse = torch.mean((pred - gt) ** 2, dim=[3, 4])                                                       # test.py:249
+        out[f'c{C}.pred'], out[f'c{C}.gt'] = pred.numpy(), gt.numpy()
+        out[f'c{C}.ssim'], out[f'c{C}.mse'] = ssim.numpy(), mse.numpy()
+        out[f'c{C}.psnr'] = (10 * torch.log10(1 / mse)).numpy()                                              # test.py:251
+        print(f'metrics C={C}: ssim', ssim.mean(dim=(1, 2)).tolist())
+    np.savez_compressed(os.path.join(GOLDEN, 'metrics.npz'), **out)
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     srvp, ref_train, helper = import_reference()
@@ -273,6 +309,7 @@ def main():
         loss = gen_one(name, spec, srvp, ref_train, helper)
         print(f'{name}: loss {loss:.6f}')
     gen_known_answers()
+    gen_metrics()
     print('done')
 
 

@@ -466,3 +466,36 @@ def test_batched_samples_match_per_sample_forward(archi, nc, skipco):
         ref = m(x, nt, 0.5, tape=tape)[0]
         assert torch.allclose(xs[:, s], ref, atol=2e-3, rtol=0), (s, (xs[:, s] - ref).abs().max().item())
     assert (xs[:, 0] - xs[:, 1]).abs().max() > 2e-2             # the samples do differ
+
+
+def test_evaluate_best_of_n_psnr():
+    """train.evaluate (reference train.py:132-189): best-of-n_samples_test PSNR per video over the predicted frames, with the
+    samples drawn by model.sample and the PSNR by the device metrics kernel -- against the same selection done with the
+    float64 oracle metrics on the same samples."""
+    import srvp_amd
+    from oracle import srvp_oracle as O
+    from srvp_amd.train import evaluate
+    dev = torch.device('cuda')
+    torch.manual_seed(2)
+    m = srvp_amd.StochasticLatentResidualVideoPredictor(64, 1, 16, 32, 8, 8, True, 2, 32, 2, 32, 2, 'vgg')
+    m.init(1.41)
+    m.to(dev).train()
+    g = torch.Generator().manual_seed(4)
+    batches = [torch.rand(6, 3, 1, 64, 64, generator=g) for _ in range(2)]
+    with torch.no_grad():
+        for _ in range(25):
+            m(batches[0].to(dev), 6, 0.5)
+    m.eval()
+    opt = srvp_amd.DotDict(dict(nt_cond=2, n_iter_test=2, n_samples_test=3, n_euler_steps=2))
+    torch.manual_seed(77)
+    got = evaluate(m, batches, dev, opt)
+    torch.manual_seed(77)
+    tot = 0.0
+    for x in batches:
+        xs = m.sample(x[:2].to(dev), 6, 3, dt=0.5).cpu()                      # (nt, S, B, C, H, W)
+        ps = torch.stack([O.video_psnr(xs[:, s], x).mean(dim=(0, 2)) for s in range(3)])      # (S, B)
+        best = ps.argmax(0)
+        bx = torch.stack([xs[:, best[b], b] for b in range(3)], 1)
+        tot += O.video_psnr(bx, x)[2:].mean().item() * 3
+    want = -tot / 6
+    assert abs(got - want) <= 1e-4 * abs(want), (got, want)

@@ -105,3 +105,16 @@ def test_known_answers():
             mine = np.array([(f, int(new), int(keep)) for f, new, keep in O.euler_schedule(nt, n)])
             assert (ref == mine).all(), (n, nt)
     assert np.allclose([O.lr_lambda(i, 1000) for i in range(0, 1200, 100)], z['ka.lr_lambda'])
+
+
+def test_metrics_vs_reference_fixture():
+    """the oracle's SSIM / MSE / PSNR restatement against the reference's own metrics/ssim.py + test.py:249-253
+    outputs (fixture made by tests/make_golden.py:gen_metrics; the reference computes in float32)."""
+    z = np.load(GOLDEN + '/metrics.npz')
+    for C in (1, 3):
+        pred, gt = torch.from_numpy(z[f'c{C}.pred']), torch.from_numpy(z[f'c{C}.gt'])
+        close(O.video_ssim(pred, gt), z[f'c{C}.ssim'], 2e-5, 2e-6, 'ssim')
+        close(O.video_mse(pred, gt), z[f'c{C}.mse'], 1e-5, 1e-9, 'mse')
+        close(O.video_psnr(pred, gt), z[f'c{C}.psnr'], 1e-5, 1e-5, 'psnr')
+    w = O.gaussian_window(11, 1.5)
+    assert abs(w.sum().item() - 1) < 1e-12 and torch.allclose(w, w.t()) and w.argmax().item() == 60
