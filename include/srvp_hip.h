@@ -275,6 +275,12 @@ int srvp_fill_f64(double* p, int64_t n, double v, void* stream);
 /* input pipeline (replaces the CPU collate of data/base.py:54-84): uint8 videos stacked [B][T][H][W][C]
  * (C = 1 for grey-scale arrays without channel axis) -> float32 frames (T, B, C, H, W) in [0, 1] = value / 255 */
 int srvp_frames_u8_to_f32(const void* in_u8, float* out, int B, int T, int H, int W, int C, void* stream);
+/* Stochastic Moving-MNIST batch rasteriser (data/mmnist.py:116-124 + data/base.py:71-84): digits_u8
+ * [n_digits][dh][dw]; idx int32 [B][num_digits] digit of each object; pos int32 [B][num_digits][T][2] = (row, column) offset of
+ * the object at frame t (the rounded trajectory of mmnist.py:165).  out float32 (T, B, 1, nx, nx) = min(255, sum) / 255 and/or
+ * out_u8 uint8 [B][T][nx][nx] (the reference's per-video arrays); either may be NULL. */
+int srvp_mmnist_render(const void* digits_u8, int n_digits, int dh, int dw, const int* idx, const int* pos, int B, int T,
+                       int num_digits, int nx, float* out, void* out_u8, void* stream);
 int srvp_cast_f32_bf16(const float* src, void* dst, int64_t rows, int cols, int dst_cols, void* stream);
 /* evaluation metrics: x, y = `planes` float32 planes of H x W (<= 64 x 64; (nt*B*C) planes of NCHW frames).
  * mse[p] = mean((x-y)^2) (test.py:249; PSNR = 10 log10(1/mse), test.py:251, train.py:175-176);

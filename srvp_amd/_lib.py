@@ -119,6 +119,7 @@ _SIGS = {
     'srvp_adam': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_vp], c_i32),
     'srvp_fill_f64': ([c_vp, c_i64, c_f64, c_vp], c_i32),
     'srvp_frames_u8_to_f32': ([c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
+    'srvp_mmnist_render': ([c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp], c_i32),
     'srvp_cast_f32_bf16': ([c_vp, c_vp, c_i64, c_i32, c_i32, c_vp], c_i32),
     'srvp_frame_metrics': ([c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp], c_i32),
     'srvp_skip_grad_reduce': ([c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp], c_i32),

@@ -55,6 +55,43 @@ extern "C" int srvp_frames_u8_to_f32(const void* in, float* out, int B, int T, i
     return SRVP_OK;
 }
 
+// Stochastic Moving-MNIST rasteriser (the frame assembly of reference data/mmnist.py:116-124 + the collate of
+// data/base.py:71-84): every video b of the batch is the clamped sum of its digits stamped at the trajectory positions,
+// out (T, B, 1, nx, nx) float32 = min(255, sum) / 255.  pos[b][n][t] = (row offset, column offset) of digit n at frame t.
+namespace {
+__global__ void mmnist_render_kernel(const unsigned char* __restrict__ digits, const int* __restrict__ idx,
+                                     const int* __restrict__ pos, float* __restrict__ out, unsigned char* __restrict__ out_u8,
+                                     int B, int T, int nd, int dh, int dw, int nx) {
+    const long long n = (long long)T * B * nx * nx;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nx); long long q = i / nx;
+        const int r = (int)(q % nx); q /= nx;
+        const int b = (int)(q % B); const int t = (int)(q / B);
+        int s = 0;
+        for (int d = 0; d < nd; ++d) {
+            const int* pp = pos + (((size_t)b * nd + d) * T + t) * 2;
+            const int rr = r - pp[0], cc = c - pp[1];
+            if (rr >= 0 && rr < dh && cc >= 0 && cc < dw) s += digits[((size_t)idx[b * nd + d] * dh + rr) * dw + cc];
+        }
+        s = s > 255 ? 255 : s;
+        if (out) out[i] = (float)s / 255.f;
+        if (out_u8) out_u8[((size_t)b * T + t) * nx * nx + (size_t)r * nx + c] = (unsigned char)s;
+    }
+}
+}  // namespace
+extern "C" int srvp_mmnist_render(const void* digits_u8, int n_digits, int dh, int dw, const int* idx, const int* pos, int B, int T,
+                                  int num_digits, int nx, float* out, void* out_u8, void* stream) {
+    SRVP_REQUIRE(digits_u8 && idx && pos && (out || out_u8), "srvp_mmnist_render: null pointer");
+    SRVP_REQUIRE(n_digits > 0 && dh > 0 && dw > 0 && B > 0 && T > 0 && num_digits > 0 && nx >= dh && nx >= dw,
+                 "srvp_mmnist_render: bad sizes");
+    const long long n = (long long)T * B * nx * nx;
+    long long blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(mmnist_render_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned char*)digits_u8, idx, pos, out, (unsigned char*)out_u8, B, T, num_digits, dh, dw, nx);
+    SRVP_CHECK_LAUNCH("srvp_mmnist_render");
+    return SRVP_OK;
+}
+
 extern "C" int srvp_cast_f32_bf16(const float* src, void* dst, int64_t rows, int cols, int dst_cols, void* stream) {
     long long n = (long long)rows * dst_cols;
     if (n <= 0) return SRVP_OK;

@@ -1,7 +1,8 @@
 """
-Input side of the hot path.  The reference's dataset readers / generators (data/*.py) are out of scope for this
-round; what the training loop needs is the batch contract of data/base.py:54-84 --
-float32 (T, B, C, H, W) in [0, 1], time-major -- which `SyntheticVideos` produces from seeded procedural blobs.
+Input side of the hot path.  The batch contract is data/base.py:54-84 -- float32 (T, B, C, H, W) in [0, 1], time-major.
+Built here: the device-side uint8 collate (`collate_u8` / `frames_from_u8`) and the Stochastic Moving-MNIST
+training generator (`srvp_amd.mmnist`, `--dataset smmnist`); `SyntheticVideos` (seeded procedural blobs) serves bench / smoke.
+The KTH / Human3.6M / BAIR file readers of the reference (data/{kth,human,bair}.py) stay out of scope.
 """
 import numpy as np
 import torch
@@ -52,7 +53,61 @@ def frames_from_u8(u8, device):
     return out
 
 
+def mnist_digits(data_dir):
+    """The 60000 training digits (n, 28, 28) uint8 that reference data/mmnist.py:337-340 takes from torchvision's MNIST,
+    read from the raw IDX file torchvision stores under <data_dir>/MNIST/raw (no torchvision, no download here)."""
+    import gzip
+    import os
+    for name in ('MNIST/raw/train-images-idx3-ubyte', 'MNIST/raw/train-images-idx3-ubyte.gz', 'train-images-idx3-ubyte',
+                 'train-images-idx3-ubyte.gz'):
+        path = os.path.join(data_dir, name)
+        if os.path.exists(path):
+            with (gzip.open(path, 'rb') if path.endswith('.gz') else open(path, 'rb')) as f:
+                raw = f.read()
+            magic, n, h, w = np.frombuffer(raw[:16], dtype='>i4')
+            assert magic == 2051, f'{path}: not an IDX image file'
+            return np.frombuffer(raw, dtype=np.uint8, offset=16).reshape(n, h, w)
+    raise FileNotFoundError(f'MNIST training images (train-images-idx3-ubyte[.gz]) not found under {data_dir}[/MNIST/raw]')
+
+
+def fold_ids(n, fold):
+    """reference data/base.py:115-127: 95 % / 5 % split of the training items under the fixed RandomState(42) shuffle."""
+    ids = list(range(n))
+    np.random.RandomState(42).shuffle(ids)
+    n_train = int(0.95 * n)
+    keep = set(ids[:n_train] if fold == 'train' else ids[n_train:])
+    return [i for i in range(n) if i in keep]
+
+
+class MovingMNISTLoader:
+    """Iterable of device-resident (T, B, 1, nx, nx) training batches (srvp_amd.mmnist.MovingMNISTBatches); the length mirrors
+    the reference's arbitrary 500000-item epoch (data/mmnist.py:107-111)."""
+
+    def __init__(self, gen, batch_size, n_items=500000):
+        self.gen, self.batch_size, self.n = gen, batch_size, n_items // batch_size
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        for _ in range(self.n):
+            yield self.gen.batch(self.batch_size)
+
+
 def make_loaders(opt, local_rank):
+    if opt.dataset == 'smmnist':
+        # SURVEY §8f-2: trajectories on the host in the reference's np.random order, frames assembled on the device
+        from .mmnist import MovingMNISTBatches
+        digits = mnist_digits(opt.data_dir)
+        dev = torch.device('cuda', torch.cuda.current_device())
+        mk = lambda fold, T: MovingMNISTBatches(digits[fold_ids(len(digits), fold)], opt.nx, T, opt.max_speed, opt.deterministic,
+                                                opt.ndigits, device=dev)
+        train_loader = MovingMNISTLoader(mk('train', opt.seq_len), opt.batch_size)
+        val_loader = None
+        if local_rank == 0:
+            val_loader = MovingMNISTLoader(mk('val', opt.seq_len_test or opt.seq_len), opt.batch_size_test,
+                                           n_items=max(opt.batch_size_test * opt.n_iter_test, 1))
+        return train_loader, val_loader, None
     if opt.dataset != 'synthetic':
         raise NotImplementedError(
             f"dataset '{opt.dataset}': the reference's dataset readers are outside the hot path rebuilt here "

@@ -302,6 +302,48 @@ def gen_metrics():
     np.savez_compressed(os.path.join(GOLDEN, 'metrics.npz'), **out)
 
 
+def synthetic_digits(n=6, seed=31):
+    """28x28 uint8 'digits' (no MNIST download in the container): bright random strokes on black, values up to 255 so that
+    overlapping objects exercise the clamp of mmnist.py:123."""
+    rng = np.random.RandomState(seed)
+    d = np.zeros((n, 28, 28), np.uint8)
+    for i in range(n):
+        for _ in range(3):
+            r0, c0 = rng.randint(2, 20, 2)
+            h, w = rng.randint(3, 9, 2)
+            d[i, r0:r0 + h, c0:c0 + w] = np.maximum(d[i, r0:r0 + h, c0:c0 + w], rng.randint(100, 256, (h, w)).astype(np.uint8))
+    return d
+
+
+def gen_mmnist():
+    """Videos and trajectories of the reference's stochastic / deterministic Moving-MNIST training generator
+    (data/mmnist.py) under np.random.seed, on synthetic digits."""
+    import data.mmnist as rmm
+    digits = synthetic_digits()
+    out = {'digits': digits}
+    cases = {'s15': (15, 4, False, 2, 123, 8), 's30': (30, 4, False, 2, 7, 6), 'd20': (20, 4, True, 2, 11, 6),
+             'fast3': (25, 9, False, 3, 5, 6)}
+    for name, (T, ms, det, nd, seed, B) in cases.items():
+        ds = rmm.MovingMNIST(list(digits), 64, T, ms, det, nd, True)
+        np.random.seed(seed)
+        out[f'{name}.videos'] = np.stack([ds[i] for i in range(B)], 0)
+        out[f'{name}.cfg'] = np.array([T, ms, int(det), nd, seed, B])
+        np.random.seed(seed + 1000)
+        out[f'{name}.traj'] = np.array([ds._compute_trajectory(28, 28) for _ in range(20)], dtype=np.int64)
+        out[f'{name}.traj_init'] = np.array(ds._compute_trajectory(28, 28, init_cond=(30, 3, -ms, 3)), dtype=np.int64)
+    # the collated float batch of data/base.py:71-84 for the first case
+    from data.base import collate_fn as ref_collate
+    ds = rmm.MovingMNIST(list(digits), 64, 15, 4, False, 2, True)
+    np.random.seed(123)
+    out['s15.batch'] = ref_collate([ds[i] for i in range(8)]).numpy()
+    # the 95 % / 5 % item split of data/base.py:96-132 on 1000 (scalar) items
+    ds = rmm.MovingMNIST(list(range(1000)), 64, 15, 4, False, 2, True)
+    out['fold.val_1000'] = np.array(ds.get_fold('val').data)
+    out['fold.train_1000_head'] = np.array(ds.get_fold('train').data[:50])
+    np.savez_compressed(os.path.join(GOLDEN, 'mmnist.npz'), **out)
+    print('mmnist fixture:', {k: v.shape for k, v in out.items() if k.endswith('videos')})
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     srvp, ref_train, helper = import_reference()
@@ -310,6 +352,7 @@ def main():
         print(f'{name}: loss {loss:.6f}')
     gen_known_answers()
     gen_metrics()
+    gen_mmnist()
     print('done')
 
 

@@ -57,3 +57,23 @@ def test_metrics_errors_and_identity():
         metrics.frame_metrics(torch.rand(1, 1, 1, 65, 64).cuda(), torch.rand(1, 1, 1, 65, 64).cuda())
     with pytest.raises(RuntimeError):
         metrics.frame_metrics(x, x, filter_size=10)
+
+
+@pytest.mark.parametrize('case', ['s15', 's30', 'd20', 'fast3'])
+def test_mmnist_batches_vs_reference_fixture(case):
+    """srvp_mmnist_render (whole batch assembled on the device) under the reference's np.random stream == the
+    reference generator's uint8 videos, and the float batch == its collate_fn output, bit for bit."""
+    from srvp_amd import mmnist as MM
+    z = np.load(GOLDEN + '/mmnist.npz')
+    T, ms, det, nd, seed, B = [int(v) for v in z[f'{case}.cfg']]
+    gen = MM.MovingMNISTBatches(list(z['digits']), 64, T, ms, bool(det), nd)
+    np.random.seed(seed)
+    u8 = gen.videos_u8(B)
+    assert u8.dtype == torch.uint8 and (u8.cpu().numpy() == z[f'{case}.videos']).all()
+    np.random.seed(seed)
+    x = gen.batch(B)
+    assert x.shape == (T, B, 1, 64, 64)
+    ref = torch.from_numpy(z[f'{case}.videos']).float().div(255).permute(1, 0, 2, 3).unsqueeze(2)
+    assert torch.equal(x.cpu(), ref)
+    if case == 's15':
+        assert torch.equal(x.cpu(), torch.from_numpy(z['s15.batch']))

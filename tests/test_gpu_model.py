@@ -499,3 +499,38 @@ def test_evaluate_best_of_n_psnr():
         tot += O.video_psnr(bx, x)[2:].mean().item() * 3
     want = -tot / 6
     assert abs(got - want) <= 1e-4 * abs(want), (got, want)
+
+
+def test_cli_trains_on_smmnist(tmp_path):
+    """`python -m srvp_amd.train` (the reference's train.py CLI) end to end on the device-side Stochastic Moving-MNIST
+    generator: fake MNIST IDX file -> batches -> train steps -> validation (model.sample + device PSNR) ->
+    model.pt / model_best.pt / model_<itr>.pt / config.json / train_state.pt, exit status 0."""
+    import gzip
+    import json
+    import struct
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.RandomState(0)
+    imgs = np.zeros((200, 28, 28), np.uint8)
+    for i in range(200):
+        r, c = rng.randint(4, 16, 2)
+        imgs[i, r:r + 8, c:c + 6] = rng.randint(120, 256)
+    os.makedirs(tmp_path / 'MNIST' / 'raw')
+    with gzip.open(tmp_path / 'MNIST' / 'raw' / 'train-images-idx3-ubyte.gz', 'wb') as f:
+        f.write(struct.pack('>iiii', 2051, 200, 28, 28) + imgs.tobytes())
+    save = tmp_path / 'run'
+    cmd = [sys.executable, '-m', 'srvp_amd.train', '--device', '0', '--seed', '3', '--dataset', 'smmnist', '--data_dir', str(tmp_path),
+           '--save_path', str(save), '--nc', '1', '--seq_len', '6', '--nt_cond', '3', '--nt_inf', '3', '--ny', '8', '--nz', '8',
+           '--archi', 'dcgan', '--nf', '16', '--nhx', '32', '--nh_inf', '32', '--nh_res', '32', '--nlayers_inf', '2', '--nlayers_res', '2',
+           '--batch_size', '8', '--batch_size_test', '4', '--n_iter_test', '2', '--n_samples_test', '3', '--seq_len_test', '9',
+           '--lr_scheduling_burnin', '6', '--lr_scheduling_n_iter', '4', '--val_interval', '5', '--chkpt_interval', '5',
+           '--n_euler_steps', '2', '--beta_z', '2']
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for name in ('model.pt', 'model_best.pt', 'model_5.pt', 'model_10.pt', 'config.json', 'train_state.pt'):
+        assert (save / name).exists(), (name, os.listdir(save))
+    assert json.load(open(save / 'config.json'))['dataset'] == 'smmnist'
+    sd = torch.load(save / 'model.pt', map_location='cpu')
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())

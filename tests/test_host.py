@@ -145,3 +145,47 @@ def test_dotdict_and_lr_lambda():
     assert d.a == 1 and d.missing is None
     d.b = 2
     assert d['b'] == 2
+
+
+MM_CASES = ['s15', 's30', 'd20', 'fast3']
+
+
+@pytest.mark.parametrize('case', MM_CASES)
+def test_mmnist_trajectories_and_videos_vs_reference_fixture(case):
+    """the host trajectory code of srvp_amd.mmnist consumes np.random exactly as the reference generator does
+    (data/mmnist.py:116-237) -- same trajectories, and (with the oracle's numpy frame assembly) the same uint8 videos, bit for
+    bit, as tests/golden/mmnist.npz (made from the reference under np.random.seed)."""
+    import numpy as np
+    from oracle import srvp_oracle as O
+    from srvp_amd import mmnist as MM
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mmnist.npz'))
+    T, ms, det, nd, seed, B = [int(v) for v in z[f'{case}.cfg']]
+    gen = MM.MovingMNISTBatches(list(z['digits']), 64, T, ms, bool(det), nd, device='cpu')
+    np.random.seed(seed)
+    idx, pos = gen.draw(B)
+    assert (O.mmnist_render(z['digits'], idx, pos, 64) == z[f'{case}.videos']).all()
+    np.random.seed(seed + 1000)
+    tr = np.array([MM.trajectory(28, 28, 64, T, ms, bool(det)) for _ in range(20)], dtype=np.int64)
+    assert (tr == z[f'{case}.traj']).all()
+    tri = np.array(MM.trajectory(28, 28, 64, T, ms, bool(det), init_cond=(30, 3, -ms, 3)), dtype=np.int64)
+    assert (tri == z[f'{case}.traj_init']).all()
+    assert pos.min() >= 0 and pos.max() <= 64 - 28
+
+
+def test_mnist_idx_reader_and_folds(tmp_path):
+    """data.mnist_digits reads torchvision's raw IDX file; data.fold_ids == the reference's 95/5 split (data/base.py:96-132,
+    fixture values from the reference)."""
+    import gzip
+    import struct
+    import numpy as np
+    from srvp_amd import data as D
+    imgs = np.random.RandomState(0).randint(0, 256, (37, 28, 28)).astype(np.uint8)
+    os.makedirs(tmp_path / 'MNIST' / 'raw')
+    with gzip.open(tmp_path / 'MNIST' / 'raw' / 'train-images-idx3-ubyte.gz', 'wb') as f:
+        f.write(struct.pack('>iiii', 2051, 37, 28, 28) + imgs.tobytes())
+    assert (D.mnist_digits(str(tmp_path)) == imgs).all()
+    with pytest.raises(FileNotFoundError):
+        D.mnist_digits(str(tmp_path / 'MNIST'))
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mmnist.npz'))
+    assert D.fold_ids(1000, 'val') == list(z['fold.val_1000'])
+    assert D.fold_ids(1000, 'train')[:50] == list(z['fold.train_1000_head'])
