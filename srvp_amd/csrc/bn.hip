@@ -61,11 +61,15 @@ struct PixWalk {
     }
 };
 
-template <bool POOL>
+// ACT >= 0: the activation is a compile-time constant (LeakyReLU, all but two layers of each network); ACT < 0: run-time
+// `act` -- a per-element switch over five activations with exp / division bodies that the compiler cannot hoist out of the
+// pixel loops, which made these HBM-streaming kernels instruction-bound.
+template <bool POOL, int ACT>
 __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ raw, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, int act, int N, int H, int W, int C,
                                                      bf16_t* __restrict__ dst, int db, bf16_t* __restrict__ dpool, int pb,
                                                      float* __restrict__ dst_f32) {
+    if (ACT >= 0) act = ACT;
     const int CG = C / 8;
     const int PPB = blockDim.x / CG;             // (pooled) pixels handled in parallel by one workgroup
     const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
@@ -134,7 +138,7 @@ struct BnBwdK {
 };
 
 // g[8] = dA * f'(pre) for pixel (n,y,x), channel group cg; also returns raw values
-template <int MODE>
+template <int MODE, int ACT>
 __device__ __forceinline__ void bn_bwd_g(const BnBwdK& a, int n, int y, int x, int cg, const float* sc, const float* sh,
                                          float* g, float* rawf) {
     const int C = a.C, H = a.H, W = a.W;
@@ -203,11 +207,12 @@ __device__ __forceinline__ void bn_bwd_g(const BnBwdK& a, int n, int y, int x, i
         }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) g[e] = d[e] * act_bwd(rawf[e] * sc[e] + sh[e], a.act_kind);
+    for (int e = 0; e < 8; ++e) g[e] = d[e] * act_bwd(rawf[e] * sc[e] + sh[e], ACT >= 0 ? ACT : a.act_kind);
 }
 
 // Pooled consumer (da_mode 2), whole 2x2 window (py, px) of image n at once: g[q][8] / raw[q][8] for the window pixels
 // q = 2*i + j.  Arg-max routing with torch's first-max tie rule (scan order (0,0),(0,1),(1,0),(1,1)).
+template <int ACT>
 __device__ __forceinline__ void bn_bwd_g_window(const BnBwdK& a, int n, int py, int px, int cg, const float* sc, const float* sh,
                                                 float (*g)[8], float (*rawf)[8]) {
     const int C = a.C, H = a.H, W = a.W, db = a.da_border, ab = a.act_border;
@@ -246,10 +251,10 @@ __device__ __forceinline__ void bn_bwd_g_window(const BnBwdK& a, int n, int py, 
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) g[q][e] = d[q][e] * act_bwd(rawf[q][e] * sc[e] + sh[e], a.act_kind);
+        for (int e = 0; e < 8; ++e) g[q][e] = d[q][e] * act_bwd(rawf[q][e] * sc[e] + sh[e], ACT >= 0 ? ACT : a.act_kind);
 }
 
-template <int MODE>
+template <int MODE, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdK a, double* red) {
     const int CG = a.C / 8;
     const int PPB = blockDim.x / CG;             // pixels handled in parallel by one workgroup
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdK a, doub
             w.init(blockIdx.x * PPB + pl, stride, a.H / 2, a.W / 2);
             for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
                 float g[4][8], rawf[4][8];
-                bn_bwd_g_window(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
+                bn_bwd_g_window<ACT>(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdK a, doub
                         const float m = ok[u] ? 1.f : 0.f;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            const float g = m * d[e] * act_bwd(rawf[e] * sc[e] + sh[e], a.act_kind);
+                            const float g = m * d[e] * act_bwd(rawf[e] * sc[e] + sh[e], ACT >= 0 ? ACT : a.act_kind);
                             s1[e] += g; s2[e] += g * (rawf[e] - mu[e]) * is[e];
                         }
                     }
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdK a, doub
 #pragma unroll 2
                 for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
                     float g[8], rawf[8];
-                    bn_bwd_g<MODE>(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
+                    bn_bwd_g<MODE, ACT>(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { s1[e] += g[e]; s2[e] += g[e] * (rawf[e] - mu[e]) * is[e]; }
                 }
@@ -353,7 +358,7 @@ __global__ void bn_bwd_finalize_kernel(const double* red, double count, const fl
     coef[c] = (float)k1; coef[C + c] = (float)k2; coef[2 * C + c] = (float)k3;
 }
 
-template <int MODE>
+template <int MODE, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK a, const float* __restrict__ coef,
                                                            bf16_t* __restrict__ draw, int db) {
     const int CG = a.C / 8;
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK a, const
         w.init(blockIdx.x * PPB + pl, stride, a.H / 2, a.W / 2);
         for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
             float g[4][8], rawf[4][8];
-            bn_bwd_g_window(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
+            bn_bwd_g_window<ACT>(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float o[8];
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK a, const
             for (int t = 0; t < a.tsum_T; ++t) {
                 const int n = t * Bs + w.n;
                 float g[8], rawf[8], o[8];
-                bn_bwd_g<MODE>(a, n, w.y, w.x, cg, sc, sh, g, rawf);
+                bn_bwd_g<MODE, ACT>(a, n, w.y, w.x, cg, sc, sh, g, rawf);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { o[e] = k1[e] * g[e] + k2[e] + k3[e] * rawf[e]; acc[e] += o[e]; }
                 size_t off = (((size_t)n * (a.H + 2 * db) + w.y + db) * (a.W + 2 * db) + w.x + db) * a.C + cg * 8;
@@ -416,7 +421,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK a, const
     for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
         const int n = w.n, y = w.y, x = w.x;
         float g[8], rawf[8], o[8];
-        bn_bwd_g<MODE>(a, n, y, x, cg, sc, sh, g, rawf);
+        bn_bwd_g<MODE, ACT>(a, n, y, x, cg, sc, sh, g, rawf);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = k1[e] * g[e] + k2[e] + k3[e] * rawf[e];
         size_t off = (((size_t)n * (a.H + 2 * db) + y + db) * (a.W + 2 * db) + x + db) * a.C + cg * 8;
@@ -476,12 +481,14 @@ extern "C" int srvp_bn_act(const void* raw, const float* scale, const float* shi
         SRVP_REQUIRE(H % 2 == 0 && W % 2 == 0, "srvp_bn_act: pooling needs even H, W");
         long long total = (long long)N * (H / 2) * (W / 2);
         SRVP_REQUIRE(C / 8 <= 256 && (long long)N * H * W < (1ll << 31), "srvp_bn_act: C=%d / size unsupported", C);
-        hipLaunchKernelGGL(bn_act_kernel<true>, dim3(grid_for(total, (256 / (C / 8)) * 2)), dim3(256), 0, st, (const bf16_t*)raw, scale, shift,
+        auto kern = act == ACT_LRELU ? bn_act_kernel<true, ACT_LRELU> : bn_act_kernel<true, -1>;
+        hipLaunchKernelGGL(kern, dim3(grid_for(total, (256 / (C / 8)) * 2)), dim3(256), 0, st, (const bf16_t*)raw, scale, shift,
                            act, N, H, W, C, (bf16_t*)dst, dst_border, (bf16_t*)dst_pool, pool_border, dst_f32);
     } else {
         long long total = (long long)N * H * W;
         SRVP_REQUIRE(C / 8 <= 256 && total < (1ll << 31), "srvp_bn_act: C=%d / size unsupported", C);
-        hipLaunchKernelGGL(bn_act_kernel<false>, dim3(grid_for(total, (256 / (C / 8)) * 4)), dim3(256), 0, st, (const bf16_t*)raw, scale, shift,
+        auto kern = act == ACT_LRELU ? bn_act_kernel<false, ACT_LRELU> : bn_act_kernel<false, -1>;
+        hipLaunchKernelGGL(kern, dim3(grid_for(total, (256 / (C / 8)) * 4)), dim3(256), 0, st, (const bf16_t*)raw, scale, shift,
                            act, N, H, W, C, (bf16_t*)dst, dst_border, (bf16_t*)nullptr, 0, dst_f32);
     }
     SRVP_CHECK_LAUNCH("srvp_bn_act");
@@ -498,9 +505,11 @@ extern "C" int srvp_bn_bwd_reduce(const srvp_bnbwd_desc* d, double* red, void* s
     SRVP_REQUIRE(P < (1ll << 31), "srvp_bn_bwd_reduce: too many pixels");
     if (k.da_mode == 2) P /= 4;
     const dim3 g(grid_for(P, PPB * (k.da_mode == 2 ? 2 : 8)));
-    if (k.da_mode == 0) hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, g, dim3(256), 0, (hipStream_t)stream, k, red);
-    else if (k.da_mode == 1) hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, g, dim3(256), 0, (hipStream_t)stream, k, red);
-    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, g, dim3(256), 0, (hipStream_t)stream, k, red);
+    const bool lr = k.act_kind == ACT_LRELU;
+    auto kern = k.da_mode == 0 ? (lr ? bn_bwd_reduce_kernel<0, ACT_LRELU> : bn_bwd_reduce_kernel<0, -1>)
+              : k.da_mode == 1 ? (lr ? bn_bwd_reduce_kernel<1, ACT_LRELU> : bn_bwd_reduce_kernel<1, -1>)
+                               : (lr ? bn_bwd_reduce_kernel<2, ACT_LRELU> : bn_bwd_reduce_kernel<2, -1>);
+    hipLaunchKernelGGL(kern, g, dim3(256), 0, (hipStream_t)stream, k, red);
     SRVP_CHECK_LAUNCH("srvp_bn_bwd_reduce");
     return SRVP_OK;
 }
@@ -526,9 +535,11 @@ extern "C" int srvp_bn_bwd_apply(const srvp_bnbwd_desc* d, const float* coef, vo
     if (k.da_mode == 2) P /= 4;
     if (k.tsum) P /= k.tsum_T;
     const dim3 g(grid_for(P, PPB * ((k.da_mode == 2 || k.tsum) ? 1 : 4)));
-    if (k.da_mode == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, g, dim3(256), 0, (hipStream_t)stream, k, coef, (bf16_t*)draw, dst_border);
-    else if (k.da_mode == 1) hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, g, dim3(256), 0, (hipStream_t)stream, k, coef, (bf16_t*)draw, dst_border);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, g, dim3(256), 0, (hipStream_t)stream, k, coef, (bf16_t*)draw, dst_border);
+    const bool lr = k.act_kind == ACT_LRELU;
+    auto kern = k.da_mode == 0 ? (lr ? bn_bwd_apply_kernel<0, ACT_LRELU> : bn_bwd_apply_kernel<0, -1>)
+              : k.da_mode == 1 ? (lr ? bn_bwd_apply_kernel<1, ACT_LRELU> : bn_bwd_apply_kernel<1, -1>)
+                               : (lr ? bn_bwd_apply_kernel<2, ACT_LRELU> : bn_bwd_apply_kernel<2, -1>);
+    hipLaunchKernelGGL(kern, g, dim3(256), 0, (hipStream_t)stream, k, coef, (bf16_t*)draw, dst_border);
     SRVP_CHECK_LAUNCH("srvp_bn_bwd_apply");
     return SRVP_OK;
 }

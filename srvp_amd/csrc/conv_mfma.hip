@@ -387,15 +387,17 @@ struct HaloK {
 // ONE grid: blockIdx.y selects the descriptor.
 struct HaloKN { HaloK k[4]; };
 
+// BN = 256 (wave tile 128 x 128, 256 accumulator registers -> AGPRs, one workgroup per CU): every A fragment read from LDS
+// and every B fragment read from L2 feeds four MFMAs instead of two / four -- half the LDS and L1 bytes per flop.
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_halo_kernel(const HaloKN pk) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 256 ? 1 : 2))) void conv_halo_kernel(const HaloKN pk) {
     const HaloK& p = pk.k[blockIdx.y];
     constexpr int BK = 64, NT = 256, CPR = 8;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     // patch pieces per thread: 256-pixel tiles 11 * 256 16-byte pieces = 352 pixels >= 334 (13 = 416 pixels for the
     // 128-column variant, whose epilogue staging is larger than the patch anyway: sixteen 4x4 images + borders = 406);
     // 128-pixel tiles: 192 >= 180
-    constexpr int NA_MAX = BM == 256 ? (BN == 128 ? 13 : 11) : 6;
+    constexpr int NA_MAX = BM == 256 ? (BN >= 128 ? 13 : 11) : 6;
     constexpr int A_BYTES = NA_MAX * NT * 16;
     constexpr int LDC = BN + 8;
     constexpr int C_BYTES = BM * LDC * 2;
@@ -499,8 +501,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     auto issue_b = [&](unsigned soff, int kk, u32x4_t (&dst)[TN]) {
         const char* sb = wbase + (soff + (unsigned)kk * slice_b);     // scalar base of slice kk; column tile j at +j KiB
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst[0]) : "v"(lane_b), "s"(sb) : "memory");
-        if constexpr (TN == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"(dst[1]) : "v"(lane_b), "s"(sb) : "memory");
+        if constexpr (TN >= 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"(dst[1]) : "v"(lane_b), "s"(sb) : "memory");
+        if constexpr (TN == 4) {
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=&v"(dst[2]) : "v"(lane_b), "s"(sb) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=&v"(dst[3]) : "v"(lane_b), "s"(sb) : "memory");
+        }
     };
+    static_assert(TN == 1 || TN == 2 || TN == 4, "B ring: 1, 2 or 4 column tiles per wave");
     const int NC = C / BK;
     unsigned soff = step_off(0);
     issue_b(soff, 0, bq[0]);
@@ -540,7 +547,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
                 if (kk < 2) issue_b(soff, kk + 2, bq[kk + 2]); else issue_b(soff_n, kk - 2, bq[kk - 2]);
                 if (kk + 1 < 4) load_a(kk + 1, af[(kk + 1) & 1]);
                 // slice kk has landed when only the 2 younger slices (2*TN loads) are outstanding
-                if constexpr (TN == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(bq[kk][0]), "+v"(bq[kk][1])::"memory");
+                if constexpr (TN == 4) asm volatile("s_waitcnt vmcnt(8)" : "+v"(bq[kk][0]), "+v"(bq[kk][1]), "+v"(bq[kk][2]), "+v"(bq[kk][3])::"memory");
+                else if constexpr (TN == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(bq[kk][0]), "+v"(bq[kk][1])::"memory");
                 else asm volatile("s_waitcnt vmcnt(2)" : "+v"(bq[kk][0])::"memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -636,10 +644,14 @@ static int halo_variant(const srvp_conv_desc* d) {
     static int bm128 = -1;      // A/B switch: 128-pixel tiles for the narrow (Cout < 128) layers
     if (bm128 < 0) { const char* e = getenv("SRVP_HALO_BM128"); bm128 = e ? atoi(e) : 0; }
     if (bm128 && d->Cout % 128 != 0 && halo_geometry(d, h, 128)) return (bm128 & 2) ? 129 : 128;
-    return halo_geometry(d, h, 256) ? 256 : 0;
+    static int bn256 = -1;      // A/B switch: 256 x 256 tiles (one workgroup per CU) for the wide layers
+    if (bn256 < 0) { const char* e = getenv("SRVP_HALO_BN256"); bn256 = e ? atoi(e) : 0; }
+    if (!halo_geometry(d, h, 256)) return 0;
+    return (bn256 && d->Cout % 256 == 0) ? 257 : 256;
 }
 
 static int launch_halo_any(const srvp_conv_desc* d, int n, int variant, hipStream_t st) {
+    if (variant == 257) return launch_halo_n<256, 256, 2, 2>(d, n, 256, st);
     if (variant == 256) {
         if (d->Cout % 128 == 0) return launch_halo_n<256, 128, 2, 2>(d, n, 256, st);
         if (d->Cout % 64 == 0) return launch_halo_n<256, 64, 4, 1>(d, n, 256, st);
