@@ -228,6 +228,25 @@ def main():
             full = {name: sum(a.elapsed_time(b) for a, b in evs) / 2 for name, evs in table.items()}
             line['kernel_ms_per_step'] = {k: round(v, 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1])}
             line['kernel_ms_total'] = round(sum(full.values()), 3)
+    if prof:
+        # context for `frac`: what the vendor GEMM library (hipBLASLt through torch.matmul) sustains on this very device for
+        # a large bf16 GEMM -- clocks and power limit included.  A measuring stick only; nothing in the product calls it.
+        try:
+            ga = torch.randn(16384, 4608, device=dev, dtype=torch.bfloat16)
+            gb = torch.randn(4608, 8192, device=dev, dtype=torch.bfloat16)
+            for _ in range(3):
+                ga @ gb
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                ga @ gb
+            e1.record()
+            torch.cuda.synchronize()
+            line['roofline']['vendor_gemm_tflops'] = 10 * 2 * 16384 * 8192 * 4608 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+            line['roofline']['vendor_gemm'] = 'hipBLASLt bf16 16384x8192x4608 via torch.matmul, same device, same run'
+        except Exception as exc:   # the measuring stick must never take the bench line down
+            line['roofline']['vendor_gemm_tflops'] = None
+            line['roofline']['vendor_gemm'] = f'unavailable: {exc}'
     if world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(cfg)
     print(json.dumps(line))
