@@ -534,3 +534,42 @@ def test_cli_trains_on_smmnist(tmp_path):
     assert json.load(open(save / 'config.json'))['dataset'] == 'smmnist'
     sd = torch.load(save / 'model.pt', map_location='cpu')
     assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
+
+
+@pytest.mark.parametrize('label,nc,nt_cond,nt,nt_inf,ne', [('kth', 1, 10, 20, 3, 2), ('human', 3, 8, 53, 3, 2)])
+def test_full_width_eval_rollout_vs_oracle(label, nc, nt_cond, nt, nt_inf, ne):
+    """SURVEY §8 C3 / C5 shapes, inference: conditioning frames -> posterior steps -> prior rollout far past the data (53 frames =
+    104 Euler steps for Human3.6M) at full layer widths, BN running statistics settled by a few training-mode passes first;
+    frames and latent states against the CPU oracle (fp32 reference arithmetic) on the same draws, and model.sample on the same
+    draws against forward."""
+    import srvp_amd
+    from oracle import srvp_oracle as O
+    torch.manual_seed(1)
+    ctor = (64, nc, 64, 128, 50, 50, True, nt_inf, 256, 3, 512, 4, 'vgg')
+    model = srvp_amd.StochasticLatentResidualVideoPredictor(*ctor)
+    # contractive residual function: with the training-time gain (1.2) an UNTRAINED dynamics MLP grows |y| ~1.3x per frame
+    # (1e6 by frame 53), the pre-sigmoid logits become differences of huge terms and bf16 rounding alone flips saturated pixels --
+    # the fp32 and the bf16-model oracles then disagree with each other just as much (tools/eval_shape_probe.py)
+    model.init(0.6)
+    model.cuda().train()
+    g = torch.Generator().manual_seed(321)
+    B = 2
+    xw = torch.rand(nt_cond, 6, nc, 64, 64, generator=g)
+    with torch.no_grad():
+        for _ in range(12):
+            model(xw.cuda(), nt_cond, 1 / ne)
+    model.eval()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    x = xw[:, :B].contiguous()
+    tape = dict(eps_y0=torch.randn(B, 50, generator=g), eps_z=torch.randn(nt - 1, B, 50, generator=g))
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        ref = O.forward(sd, O.make_cfg(*ctor), x, nt, ne, tape, training=False)
+        out = model(x.cuda(), nt, 1 / ne, tape=tape)
+    e = dict(x=max_abs(out[0], ref[0]), y=rel_l2(out[1], ref[1]), z=rel_l2(out[2], ref[2]), w=rel_l2(out[3], ref[3]),
+             res=rel_l2(out[7], ref[7]))
+    report(test='full_width_eval_rollout', label=label, errs=e)
+    assert out[0].shape == (nt, B, nc, 64, 64) and out[7].shape[0] == ne * (nt - 1)
+    assert e['x'] < 3e-2 and e['y'] < 2e-2 and e['w'] < 2e-2 and e['res'] < 5e-2, e
+    xs = model.sample(x.cuda(), nt, 1, dt=1 / ne, tape=tape)
+    assert max_abs(xs[:, 0], out[0]) < 2e-3
