@@ -619,13 +619,14 @@ class ConvNetBase:
         elif blk.subpix:
             # [conv_s(skip) when split], then the four output phases as one grid
             for d in blk._fwd[:-4]:
-                L.call('srvp_conv_mfma', C.byref(d), st)
+                if not getattr(self, '_skips_done', False):
+                    L.call('srvp_conv_mfma', C.byref(d), st)
             arr = blk.__dict__.get('_fwd_arr')
             if arr is None:
                 arr = blk._fwd_arr = (L.ConvDesc * 4)(*blk._fwd[-4:])
             L.call('srvp_conv_mfma_multi', arr, 4, st)
         else:
-            for d in blk._fwd:
+            for d in (blk._fwd[1:] if (blk.split and getattr(self, '_skips_done', False)) else blk._fwd):
                 L.call('srvp_conv_mfma', C.byref(d), st)
         self._bn_forward(blk, params, st, sync)
 
@@ -811,6 +812,15 @@ class DecoderNet(ConvNetBase):
         self.nc = ob.cout_r
         self.x_out = ob.x_out
 
+    def precompute_skips(self, st):
+        """conv_s(skip) of every hoisted-skip block (the first descriptor of its forward): it depends on the encoder's skip
+        tensors only, so the caller may run it on a second stream under the latency-bound latent forward; the next forward()
+        then skips those launches."""
+        for blk in self.blocks:
+            if blk.split:
+                L.call('srvp_conv_mfma', C.byref(blk._fwd[0]), st)
+        self._skips_done = True
+
     def forward(self, z_f32, params, st, sync=None):
         """z_f32: fp32 [N][nz_real]"""
         L.call('srvp_cast_f32_bf16', L.ptr(z_f32), L.ptr(self.z.t), self.N, z_f32.shape[1], self.z.C, st)
@@ -818,6 +828,7 @@ class DecoderNet(ConvNetBase):
             self.zero_forward_accumulators()
         for blk in self.blocks[:-1]:
             self._block_forward(blk, params, st, sync)
+        self._skips_done = False
         # image-side output layer: MFMA conv with Cout padded to 32, sigmoid + fp32 frame store in the epilogue
         for d in self.blocks[-1]._fwd:
             L.call('srvp_conv_mfma', C.byref(d), st)

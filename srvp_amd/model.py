@@ -42,6 +42,7 @@ def _set_module(root, path, module):
 
 
 OVERLAP_WGRAD = os.environ.get('SRVP_OVERLAP_WGRAD', '1') != '0'
+OVERLAP_SKIP = os.environ.get('SRVP_OVERLAP_SKIP', '1') == '1'
 
 
 class _Holder(nn.Module):
@@ -274,11 +275,26 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             pl['skip_map'].copy_(sel.repeat(nt))
             pl['skip_sel_t'].copy_(sel)
             pl['skip_sel'] = sel
+        s_done = None
+        if self.skipco and OVERLAP_SKIP and any(b.split for b in dec.blocks):
+            # the hoisted skip halves of the decoder need the encoder only: second stream, under the latent forward (a chain of
+            # small dependent kernels that leaves the GPU mostly idle)
+            if getattr(self, '_side_stream', None) is None:
+                self._side_stream = torch.cuda.Stream()
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self._side_stream):
+                self._side_stream.wait_event(ev)
+                dec.precompute_skips(L.stream())
+                s_done = torch.cuda.Event()
+                s_done.record()
         w = lat.infer_w(hx, params, tape.get('t_w') if training else None, st)
         y0, q_y0 = lat.infer_y(hx[:self.nt_inf], params, tape['eps_y0'], st)
         lat.posterior(hx, params, st)
         y, z, qz, pz, res = lat.generate(y0, T, params, tape['eps_z'], st)
         z_in = torch.cat([w.repeat(nt, 1), y.reshape(nt * B, self.ny)], 1)
+        if s_done is not None:
+            torch.cuda.current_stream().wait_event(s_done)
         x_flat = dec.forward(z_in, params, st, self.sync if training else None)
         x_ = x_flat.view(nt, B, *x_flat.shape[1:])
         pl['hx'], pl['x'] = hx, x
