@@ -114,6 +114,12 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner through C stdio at
+    # communicator creation): everything that goes to file descriptor 1 during the run is sent to stderr, and the JSON line is
+    # written to the real stdout at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import srvp_amd
     from srvp_amd import _lib as L
@@ -249,9 +255,10 @@ def main():
             line['roofline']['vendor_gemm'] = f'unavailable: {exc}'
     if world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(cfg)
-    print(json.dumps(line))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(line) + '\n').encode())
 
 
 if __name__ == '__main__':
