@@ -72,7 +72,7 @@ __device__ __forceinline__ void conv_acc_init(f32x16_t (&acc)[TM][TN], const Con
 // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 template <int BM, int BN, int WM, int WN, int TM, int TN, class RowMap>
 __device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[TM][TN], const ConvK& a, unsigned char* smem, float* red, int n0,
-                                              const RowMap& rowmap) {
+                                              const RowMap& rowmap, bool all_valid = false) {
     constexpr int NT = WM * WN * 64;
     constexpr int LDC = BN + 8;
     const int tid = threadIdx.x;
@@ -95,7 +95,24 @@ __device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[TM][TN], const Con
             }
         return;
     }
-    if (a.stats) {
+    if (a.stats && all_valid) {
+        // every row of the tile is a real output pixel (workgroup-uniform): no per-row masks
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; s1 += v; s2 += v * v; }
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (lhalf == 0) {
+                int col = wn * (TN * 32) + j * 32 + lcol;
+                red[(wm * BN + col) * 2 + 0] = s1;
+                red[(wm * BN + col) * 2 + 1] = s2;
+            }
+        }
+    } else if (a.stats) {
         bool ok[TM][16];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -569,7 +586,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 256 ?
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // run-off prefetches
     __syncthreads();
 
-    conv_epilogue<BM, BN, WM, WN, TM, TN>(acc, a, smem, red, n0, rowmap);
+    conv_epilogue<BM, BN, WM, WN, TM, TN>(acc, a, smem, red, n0, rowmap, nb0 + p.IMG <= a.N);
 }
 
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
