@@ -177,14 +177,34 @@ __device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[TM][TN], const Con
         atomicAdd(a.stats + ch, s1);
         atomicAdd(a.stats + a.stat_mod + ch, s2);
     }
+    // copy-out: thread -> (16-byte channel chunk ch, rows row0 + k * RSTEP).  Unrolled in groups of four with the LDS reads
+    // of a group issued before its stores and the descriptor fields hoisted (as a rolled loop hipcc re-loaded them from the
+    // kernel arguments and serialised LDS read -> store every iteration: ~500 cycles x 16 iterations per tile, more than
+    // the MFMA time of a K = 576 tile)
     constexpr int CCH = BN / 8;
-    bf16_t* dst = a.dst;
-    for (int q = tid; q < BM * CCH; q += NT) {
-        int row = q / CCH, ch = q % CCH;
-        int n, oy, ox;
-        if (!rowmap(row, n, oy, ox)) continue;
-        size_t off = (((size_t)n * a.DHp + oy * a.so + a.ooy) * a.DWp + ox * a.so + a.oox) * a.Cdst + a.cdst_off + n0 + ch * 8;
-        *reinterpret_cast<u32x4_t*>(dst + off) = *reinterpret_cast<const u32x4_t*>(Cs + row * LDC + ch * 8);
+    static_assert(NT % CCH == 0 && (BM * CCH) % NT == 0, "copy-out tiling");
+    constexpr int RSTEP = NT / CCH, ITER = BM * CCH / NT, G = ITER % 4 == 0 ? 4 : (ITER % 2 == 0 ? 2 : 1);
+    const int ch = tid % CCH, row0 = tid / CCH;
+    const int so = a.so, ooy = a.ooy, oox = a.oox, DWp = a.DWp, Cdst = a.Cdst;
+    const size_t img = (size_t)a.DHp * DWp * Cdst;
+    bf16_t* dbase = a.dst + a.cdst_off + n0 + ch * 8;
+    const bf16_t* cbase = Cs + row0 * LDC + ch * 8;
+#pragma unroll
+    for (int g = 0; g < ITER; g += G) {
+        u32x4_t v[G];
+        size_t off[G];
+        bool ok[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int row = row0 + (g + u) * RSTEP;
+            int n, oy, ox;
+            ok[u] = rowmap(row, n, oy, ox);
+            off[u] = (size_t)n * img + (size_t)(unsigned)(((oy * so + ooy) * DWp + ox * so + oox) * Cdst);
+            v[u] = *reinterpret_cast<const u32x4_t*>(cbase + (g + u) * RSTEP * LDC);
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+            if (ok[u]) *reinterpret_cast<u32x4_t*>(dbase + off[u]) = v[u];
     }
 }
 
