@@ -41,6 +41,14 @@ def _set_module(root, path, module):
     cur.add_module(parts[-1], module)
 
 
+def _to_dev(v, dev):
+    if v.device == dev:
+        return v
+    if v.device.type == 'cpu' and dev.type == 'cuda':
+        return v.pin_memory().to(dev, non_blocking=True)
+    return v.to(dev)
+
+
 OVERLAP_WGRAD = os.environ.get('SRVP_OVERLAP_WGRAD', '1') != '0'
 OVERLAP_SKIP = os.environ.get('SRVP_OVERLAP_SKIP', '1') == '1'
 
@@ -258,14 +266,18 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         pl = self._plan(T, B, nt, n_euler, training)
         params = self._named_tensors()
         self._pack(pl, params, st)
-        if tape is None:
-            tape = self._draw_tape(T, B, nt, training, dev)
-        tape = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in tape.items()}
-        self.last_tape = tape
         enc, dec, lat = pl['enc'], pl['dec'], pl['lat']
         x = x.contiguous().float()
         hx = enc.forward(x.view(T * B, *x.shape[2:]), params, st, self.sync if training else None)
         hx = hx.contiguous().view(T, B, self.nhx)
+        # the draws come AFTER the encoder launches (same order within the CPU and the device generator as the reference, which
+        # draws them inside encode / infer_w / infer_y / generate): the per-sample randperm calls cost ~0.3 ms of host time that
+        # the GPU now spends in the encoder instead of idling; the small index tensors travel through pinned memory so that the
+        # copy does not block the host behind the work queued so far
+        if tape is None:
+            tape = self._draw_tape(T, B, nt, training, dev)
+        tape = {k: (_to_dev(v, dev) if torch.is_tensor(v) else v) for k, v in tape.items()}
+        self.last_tape = tape
         if self.skipco:
             ar = torch.arange(B, device=dev, dtype=torch.int32)
             if training:
