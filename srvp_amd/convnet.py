@@ -699,20 +699,34 @@ class ConvNetBase:
         c = self._job_table(jobs, self.dev, self.__dict__.setdefault('_unpack_cache', {}), True)
         L.call('srvp_unpack_wgrad_multi', L.ptr(c['table']), c['n'], c['mx'], st)
 
+    def _pool_accumulators(self):
+        """Re-homes the per-step accumulators of all blocks (BN statistics, BN-backward sums, weight-gradient tiles) in three flat
+        buffers, so that clearing them is three fills per network instead of one per tensor (torch._foreach_zero_ on a list of
+        mixed dtypes falls back to one launch per tensor: ~65 tiny dependent launches per step).  Called between block
+        construction and descriptor construction (descriptors capture the pointers)."""
+        def pool(names, dtype):
+            ts = [(b, n) for b in self.blocks for n in names if getattr(b, n, None) is not None]
+            if not ts:
+                return None
+            sizes = [((getattr(b, n).numel() + 31) // 32) * 32 for b, n in ts]
+            flat = torch.zeros(sum(sizes), dtype=dtype, device=self.dev)
+            off = 0
+            for (b, n), sz in zip(ts, sizes):
+                t = getattr(b, n)
+                assert t.dtype == dtype
+                setattr(b, n, flat[off:off + t.numel()].view(t.shape))
+                off += sz
+            return flat
+        self._acc_fwd = pool(('stats',), torch.float64)
+        self._acc_bwd = [t for t in (pool(('red',), torch.float64), pool(('dw', 'dw_s'), torch.float32)) if t is not None]
+
     def zero_forward_accumulators(self):
-        z = self.__dict__.get('_z_fwd')
-        if z is None:
-            z = self._z_fwd = [b.stats for b in self.blocks if hasattr(b, 'stats')]
-        if z:
-            torch._foreach_zero_(z)
+        if self._acc_fwd is not None:
+            self._acc_fwd.zero_()
 
     def zero_backward_accumulators(self):
-        z = self.__dict__.get('_z_bwd')
-        if z is None:
-            z = self._z_bwd = [t for b in self.blocks for t in (getattr(b, 'red', None), getattr(b, 'dw', None), getattr(b, 'dw_s', None))
-                               if t is not None]
-        if z:
-            torch._foreach_zero_(z)
+        for t in self._acc_bwd:
+            t.zero_()
 
 
 class EncoderNet(ConvNetBase):
@@ -739,6 +753,7 @@ class EncoderNet(ConvNetBase):
                 else:
                     cur = blk.out
             self.blocks.append(blk)
+        self._pool_accumulators()
         for blk in self.blocks:
             if blk.role == 'mfma':
                 blk._fwd = blk.fwd_descs()
@@ -803,6 +818,7 @@ class DecoderNet(ConvNetBase):
                 blk.out = Feat(N, blk.OH, blk.OW, blk.cout_r, device)
                 cur, ups = blk.out, sp['post_up']
             self.blocks.append(blk)
+        self._pool_accumulators()
         for blk in self.blocks:
             blk._fwd = blk.fwd_descs()
             if training:
