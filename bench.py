@@ -40,7 +40,7 @@ CONFIGS = {
 
 def conv_flops(model, N_enc, N_dec):
     """Algorithmic FLOPs (2*MACs of the reference layer definitions) per step, split by kernel class."""
-    out = dict(fwd_mfma=0.0, dgrad_mfma=0.0, wgrad_mfma=0.0, fwd_all=0.0)
+    out = dict(fwd_mfma=0.0, dgrad_mfma=0.0, wgrad_mfma=0.0, fwd_all=0.0, bytes_mfma=0.0)
     for blocks, N, enc in ((model._enc_blocks, N_enc, True), (model._dec_blocks, N_dec, False)):
         h = 64 if enc else 1
         for i, b in enumerate(blocks):
@@ -61,6 +61,10 @@ def conv_flops(model, N_enc, N_dec):
                 out['fwd_mfma'] += f
                 out['dgrad_mfma'] += f
                 out['wgrad_mfma'] += f
+                # ideal bf16 traffic of the forward + the data-gradient launch of the layer: input read once, output written
+                # once (each way), weights once per launch
+                hi = hin * (2 if (not enc and i > 0 and blocks[i - 1].get('post_up')) else 1)
+                out['bytes_mfma'] += 2 * 2.0 * (N * (hi * hi * b['cin'] + ho * ho * b['cout']) + b['cout'] * b['cin'] * b['k'] ** 2)
     return out
 
 
@@ -231,6 +235,7 @@ def main():
                             'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
                             'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC pass, profiles/r01_hbm_traffic.json)',
                             'algorithmic_flops_per_launch': (fl['fwd_mfma'] + fl['dgrad_mfma']) / max(1, nlaunch),
+                            'algorithmic_bytes_per_launch': fl['bytes_mfma'] / max(1, nlaunch),
                             'launches_per_step': nlaunch, 'ms_per_step': per[dom],
                             'timed_with_events': f'{n_prof_steps} of the {args.steps} timed steps (every {EVENT_EVERY}th)'}
         wg = fl['wgrad_mfma'] / (per['srvp_wgrad_mfma'] * 1e-3) / 1e12
