@@ -143,17 +143,29 @@ __device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[TM][TN], const Con
     if (a.out_f32) {
         // image-side output layer: the first out_nc columns are the frame channels; sigmoid (reference
         // conv.py:273-274) and a store into the fp32 (N, C, H, W) frame tensor of module/srvp.py:226.
-        if (lcol < a.out_nc && wn == 0) {
+        // Only out_nc (<= 4) of the 32 columns are real: the few lanes that hold them park their values in LDS [row][4], then
+        // EVERY thread finishes whole pixels (one row decode, out_nc sigmoids and stores, consecutive threads on consecutive
+        // pixels) -- instead of three lanes per half-wave walking 16 * TM rows each with the rest of the wave idle.
+        float* Os = reinterpret_cast<float*>(smem);
+        if (lcol < 4 && wn == 0) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int n, oy, ox;
-                    if (!rowmap(wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf, n, oy, ox)) continue;
-                    float v = acc[i][0][r];
-                    if (a.out_sigmoid) v = 1.f / (1.f + __expf(-v));
-                    a.out_f32[(((size_t)n * a.out_nc + lcol) * a.DHp + oy * a.so + a.ooy) * a.DWp + ox * a.so + a.oox] = v;
-                }
+                for (int r = 0; r < 16; ++r)
+                    Os[(wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * 4 + lcol] = acc[i][0][r];
+        }
+        __syncthreads();
+        for (int row = tid; row < BM; row += NT) {
+            int n, oy, ox;
+            if (!rowmap(row, n, oy, ox)) continue;
+            const f32x4_t o4 = *reinterpret_cast<const f32x4_t*>(Os + row * 4);
+            float* op = a.out_f32 + ((size_t)n * a.out_nc * a.DHp + oy * a.so + a.ooy) * a.DWp + ox * a.so + a.oox;
+            const size_t cs = (size_t)a.DHp * a.DWp;
+            for (int c = 0; c < a.out_nc; ++c) {
+                float v = o4[c];
+                if (a.out_sigmoid) v = 1.f / (1.f + __expf(-v));
+                op[c * cs] = v;
+            }
         }
         return;
     }
