@@ -152,6 +152,7 @@ int srvp_conv_in_wgrad(const float* x, const void* draw, float* dw,
                        int N, int Cin, int H, int W, int Cout, int Cout_real, int k, int s, int p, void* stream);
 /* sigmoid backward of the last decoder layer (conv.py:273-274): dpre = dx_ * x_ * (1 - x_) from the fp32
  * (N, nc, H, W) frame tensors into a bf16 NHWC tensor [N][H+2][W+2][C] (zero border, channels >= nc zero) */
+/* draw == NULL: only the fp32 copy is produced (the caller runs both gradients of the layer on srvp_conv_in_fwd / _wgrad) */
 int srvp_out_dpre(const float* x_out, const float* dx_out, void* draw, float* dpre_f32 /* optional fp32 (N, nc, H, W) copy */,
                   int N, int nc, int H, int W, int C, int apply_sigmoid, void* stream);
 

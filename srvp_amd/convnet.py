@@ -693,7 +693,9 @@ class ConvNetBase:
         L.call('srvp_pack_weight_multi', L.ptr(c['table']), c['n'], c['mx'], st)
 
     def unpack_wgrads(self, grads, st):
-        jobs = [j for blk in self.blocks if blk.role in ('mfma', 'out') for j in blk.unpack_jobs(grads[blk.spec['key'] + '.weight'])]
+        f32_out = getattr(self, '_f32_out', lambda: False)()       # (decoder) the image-side layer accumulates into grads directly
+        jobs = [j for blk in self.blocks if blk.role in ('mfma', 'out') and not (f32_out and blk is self.blocks[-1])
+                for j in blk.unpack_jobs(grads[blk.spec['key'] + '.weight'])]
         if not jobs:
             return
         c = self._job_table(jobs, self.dev, self.__dict__.setdefault('_unpack_cache', {}), True)
@@ -854,8 +856,26 @@ class DecoderNet(ConvNetBase):
         """The weight gradients of a backward(..., defer_wgrad=True): nothing downstream but the optimizer needs them, so the
         caller runs them on a second stream, concurrently with the latency-bound latent backward that follows."""
         for blk in self.blocks:
-            self._wgrad(blk, st)
+            if blk is self.blocks[-1] and self._f32_out():
+                self._out_wgrad_f32(grads, st)
+            else:
+                self._wgrad(blk, st)
         self.unpack_wgrads(grads, st)
+
+    def _f32_out(self):
+        """The image-side layer's gradients run on the exact-fp32 MFMA first-layer kernels (see backward)."""
+        ob = self.blocks[-1]
+        return self.training and (ob.k, ob.s, ob.p) in ((3, 1, 1), (4, 2, 1)) and ob.ctot in (32, 64) and len(ob.srcs) == 1 \
+            and ob.cout_r in (1, 3) and ob.OH == 64
+
+    def _out_wgrad_f32(self, grads, st):
+        """dW[ci][o][kh][kw] = sum_q act[ci][q] dpre[o][q - p + k]: the first-layer weight-gradient kernel with the gradient frames
+        as the image and the layer's (bordered NHWC) input activations as the output gradient -- accumulated straight into the
+        ConvTranspose weight's (Cin, nc, k, k) gradient, in fp32."""
+        ob = self.blocks[-1]
+        f0 = ob.srcs[0]
+        L.call('srvp_conv_in_wgrad', L.ptr(self.dpre_f32), L.ptr(f0.t), L.ptr(grads[ob.spec['key'] + '.weight']),
+               self.N, ob.cout_r, 64, 64, f0.C, ob.cin_r[0], ob.k, ob.s, ob.p, st)
 
     def backward(self, d_x, params, grads, st, sync=None, defer_wgrad=False):
         """d_x: fp32 (N, C, 64, 64).  Returns dz bf16 [N][nz_padded]; skip gradients are left in the blocks' dcat."""
@@ -864,16 +884,20 @@ class DecoderNet(ConvNetBase):
         # The data-gradient of the image-side layer contracts over nc*k*k <= 48 values per pixel: as an MFMA conv on the
         # padded bf16 gradient it wastes 10x the work.  It IS the first-layer forward kernel with the gradient frames as
         # the "image" and the ConvTranspose weight (Cin, nc, k, k) read as (O, I, k, k): exact fp32 on the matrix cores.
-        f32_dgrad = (ob.k, ob.s, ob.p) in ((3, 1, 1), (4, 2, 1)) and ob.ctot in (32, 64) and len(ob.srcs) == 1 and ob.cout_r in (1, 3) \
-            and ob.OH == 64
-        if f32_dgrad and not hasattr(self, 'dpre_f32'):
+        # The weight gradient is the first-layer weight-gradient kernel in the same way (_out_wgrad_f32), so the padded bf16 copy
+        # of the gradient frames (600 MB at the headline config) is never written.
+        f32_out = self._f32_out()
+        if f32_out and not hasattr(self, 'dpre_f32'):
             self.dpre_f32 = torch.empty(self.N, ob.cout_r, ob.OH, ob.OW, dtype=torch.float32, device=self.dev)
-        L.call('srvp_out_dpre', L.ptr(self.x_out), L.ptr(d_x), L.ptr(ob.draw), L.ptr(self.dpre_f32) if f32_dgrad else None,
-               self.N, ob.cout_r, ob.OH, ob.OW, ob.cout, 1, st)
-        self._mfma_backward(ob, grads, st, need_dgrad=not f32_dgrad, wgrad=not defer_wgrad)
-        if f32_dgrad:
+        L.call('srvp_out_dpre', L.ptr(self.x_out), L.ptr(d_x), None if f32_out else L.ptr(ob.draw),
+               L.ptr(self.dpre_f32) if f32_out else None, self.N, ob.cout_r, ob.OH, ob.OW, ob.cout, 1, st)
+        if f32_out:
+            if not defer_wgrad:
+                self._out_wgrad_f32(grads, st)
             L.call('srvp_conv_in_fwd', L.ptr(self.dpre_f32), L.ptr(params[ob.spec['key'] + '.weight']), L.ptr(ob.dcat), None,
                    self.N, ob.cout_r, 64, 64, ob.ctot, ob.cin_r[0], ob.k, ob.s, ob.p, st)
+        else:
+            self._mfma_backward(ob, grads, st, wgrad=not defer_wgrad)
         nxt = ob
         for i in range(len(self.blocks) - 2, -1, -1):
             blk = self.blocks[i]

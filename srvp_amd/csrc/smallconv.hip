@@ -472,9 +472,33 @@ __global__ __launch_bounds__(256) void out_dpre_kernel(const float* __restrict__
 }
 }  // namespace
 
+namespace {
+// fp32 frames only (the image-side layer's gradients then run on the exact-fp32 MFMA first-layer kernels: no padded bf16 copy)
+__global__ __launch_bounds__(256) void out_dpre_f32_kernel(const float* __restrict__ xo, const float* __restrict__ dxo,
+                                                           float* __restrict__ dpre, long long n, int sigmoid) {
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+        if (i + 4 <= n) {
+            f32x4_t d = *reinterpret_cast<const f32x4_t*>(dxo + i);
+            if (sigmoid) { const f32x4_t s = *reinterpret_cast<const f32x4_t*>(xo + i); d = d * s * (1.f - s); }
+            *reinterpret_cast<f32x4_t*>(dpre + i) = d;
+        } else {
+            for (long long j = i; j < n; ++j) { float v = dxo[j]; if (sigmoid) { const float s = xo[j]; v *= s * (1.f - s); } dpre[j] = v; }
+        }
+    }
+}
+}  // namespace
+
 extern "C" int srvp_out_dpre(const float* x_out, const float* dx_out, void* draw, float* dpre_f32, int N, int nc, int H, int W,
                              int C, int apply_sigmoid, void* stream) {
-    SRVP_REQUIRE(x_out && dx_out && draw && C % 8 == 0 && nc <= C, "srvp_out_dpre: bad args");
+    SRVP_REQUIRE(x_out && dx_out && (draw || dpre_f32) && C % 8 == 0 && nc <= C, "srvp_out_dpre: bad args");
+    if (!draw) {
+        const long long n = (long long)N * nc * H * W;
+        long long blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(out_dpre_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_out, dx_out, dpre_f32, n,
+                           apply_sigmoid);
+        SRVP_CHECK_LAUNCH("srvp_out_dpre");
+        return SRVP_OK;
+    }
     long long total = (long long)N * H * W * (C / 8);
     long long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(out_dpre_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_out, dx_out, (bf16_t*)draw,
