@@ -348,6 +348,106 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_mfma_kernel(const float* __
     }
 }
 
+// The same weight gradient with the fp32 operand SPLIT INTO THREE bf16 TERMS (x = x1 + x2 + x3, 3 x 8 significant bits = the
+// fp32 mantissa) against the bf16 output gradient on the bf16 matrix cores: every product bf16 x bf16 is exact in fp32 and the
+// accumulation is fp32, so the result has the accuracy of the fp32 kernel above, but 16 pixels per MFMA at twice the issue rate
+// instead of 2 (v_mfma_f32_32x32x2_f32 made this HBM-sized layer MFMA-bound: 0.60 ms against 1.2 GB of traffic).
+// A = draw^T: the draw tile is staged TRANSPOSED in LDS, [cout][pixel], 16-byte pixel chunks XOR-swizzled by
+// (cout & 7) ^ (cout >> 3 & 7) -- conflict-free for the transposing 2-byte stores and for the ds_read_b128 fragment reads.
+template <int KS, int S, int CIN, int NTL>
+__global__ __launch_bounds__(256) void conv_in_wgrad_mfma3_kernel(const float* __restrict__ x, const bf16_t* __restrict__ draw,
+                                                                  float* dw, int N, int Cout, int Cout_real, int tiles_per_wg) {
+    typedef InGeom<KS, S, CIN> Gm;
+    static_assert(Gm::OW % 8 == 0, "eight consecutive pixels of a K group lie in one output row");
+    constexpr int KT = (Gm::K + 31) / 32;
+    constexpr int XS_BYTES = ((CIN * Gm::PH * Gm::PWp * 4 + 15) / 16) * 16, GS_BYTES = 64 * 128 * 2;
+    constexpr int PART_BYTES = 4 * 64 * (KT * 32 + 1) * 4;
+    constexpr int SM = (XS_BYTES + GS_BYTES) > PART_BYTES ? (XS_BYTES + GS_BYTES) : PART_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char sm[SM];
+    float* xs = reinterpret_cast<float*>(sm);
+    bf16_t* gsT = reinterpret_cast<bf16_t*>(sm + XS_BYTES);                          // draw tile transposed [cout][128 px]
+    float (*part)[64][KT * 32 + 1] = reinterpret_cast<float (*)[64][KT * 32 + 1]>(sm);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lcol = lane & 31, lhalf = lane >> 5;
+    int boff[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const int kidx = kt * 32 + lcol;
+        boff[kt] = kidx >= Gm::K ? -1 : ((kidx / (KS * KS)) * Gm::PH + (kidx / KS) % KS) * Gm::PWp + kidx % KS;
+    }
+    f32x16v acc[NTL][KT];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][kt][r] = 0.f;
+    const long long ntiles = (long long)N * Gm::TPI;
+    const long long t0 = (long long)blockIdx.x * tiles_per_wg;
+    const int cch = Cout / 8;
+    for (int it = 0; it < tiles_per_wg; ++it) {
+        const long long tile = t0 + it;
+        if (tile >= ntiles) break;
+        const int n = (int)(tile / Gm::TPI), tin = (int)(tile % Gm::TPI);
+        __syncthreads();
+        in_load_patch<KS, S, CIN>(x, xs, n, tin);
+        for (int q = tid; q < 128 * cch; q += 256) {
+            const int row = q / cch, ch = q % cch;
+            const int oy = tin * Gm::TR + row / Gm::OW, ox = row % Gm::OW;
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(draw + (((size_t)n * (Gm::OH + 2) + oy + 1) * (Gm::OW + 2) + ox + 1) * Cout + ch * 8);
+            const unsigned short* h = reinterpret_cast<const unsigned short*>(&v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int co = ch * 8 + e;
+                gsT[co * 128 + ((((row >> 3) ^ ((co & 7) ^ ((co >> 3) & 7))) & 15) << 3) + (row & 7)] = h[e];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g16 = 0; g16 < 2; ++g16) {               // this wave's 32 pixels, sixteen per MFMA (this half-wave: eight of them)
+            const int p0 = wid * 32 + g16 * 16 + lhalf * 8;
+            const int pb = ((p0 / Gm::OW) * S) * Gm::PWp + (p0 % Gm::OW) * S;
+            bf16x8_t bt[3][KT];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = boff[kt] >= 0 ? xs[pb + boff[kt] + i * S] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const __bf16 h1 = (__bf16)v[i];
+                    const float r1 = v[i] - (float)h1;
+                    const __bf16 h2 = (__bf16)r1;
+                    const __bf16 h3 = (__bf16)(r1 - (float)h2);
+                    bt[0][kt][i] = h1; bt[1][kt][i] = h2; bt[2][kt][i] = h3;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const int co = j * 32 + lcol;
+                const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(gsT + co * 128 + ((((p0 >> 3) ^ ((co & 7) ^ ((co >> 3) & 7))) & 15) << 3));
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) acc[j][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bt[t][kt], acc[j][kt], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                part[wid][j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf][kt * 32 + lcol] = acc[j][kt][r];
+    __syncthreads();
+    for (int q = tid; q < Cout_real * Gm::K; q += 256) {
+        const int co = q / Gm::K, k = q % Gm::K;
+        atomicAdd(dw + (size_t)co * Gm::K + k, part[0][co][k] + part[1][co][k] + part[2][co][k] + part[3][co][k]);
+    }
+}
+
 template <int KS, int S, int CIN>
 static void launch_in_fwd(const float* x, const float* w, bf16_t* raw, double* stats, int N, int Cout, int Cout_real, hipStream_t st) {
     const long long ntiles = (long long)N * InGeom<KS, S, CIN>::TPI;
@@ -363,12 +463,16 @@ template <int KS, int S, int CIN>
 static void launch_in_wgrad(const float* x, const bf16_t* draw, float* dw, int N, int Cout, int Cout_real, hipStream_t st) {
     const long long ntiles = (long long)N * InGeom<KS, S, CIN>::TPI;
     const int tpw = ntiles >= 32768 ? 16 : (ntiles >= 16 ? 2 : 1);
-    if (Cout == 64)
-        hipLaunchKernelGGL((conv_in_wgrad_mfma_kernel<KS, S, CIN, 2>), dim3((unsigned)((ntiles + tpw - 1) / tpw)), dim3(256), 0, st, x, draw, dw, N,
-                           Cout, Cout_real, tpw);
+    static int split3 = -1;     // A/B switch: 1 = three-term bf16 split on the bf16 matrix cores, 0 = fp32 MFMA
+    if (split3 < 0) { const char* e = getenv("SRVP_IN_WGRAD_SPLIT3"); split3 = e ? atoi(e) : 1; }
+    const dim3 grid((unsigned)((ntiles + tpw - 1) / tpw));
+    if (split3) {
+        if (Cout == 64) hipLaunchKernelGGL((conv_in_wgrad_mfma3_kernel<KS, S, CIN, 2>), grid, dim3(256), 0, st, x, draw, dw, N, Cout, Cout_real, tpw);
+        else hipLaunchKernelGGL((conv_in_wgrad_mfma3_kernel<KS, S, CIN, 1>), grid, dim3(256), 0, st, x, draw, dw, N, Cout, Cout_real, tpw);
+    } else if (Cout == 64)
+        hipLaunchKernelGGL((conv_in_wgrad_mfma_kernel<KS, S, CIN, 2>), grid, dim3(256), 0, st, x, draw, dw, N, Cout, Cout_real, tpw);
     else
-        hipLaunchKernelGGL((conv_in_wgrad_mfma_kernel<KS, S, CIN, 1>), dim3((unsigned)((ntiles + tpw - 1) / tpw)), dim3(256), 0, st, x, draw, dw, N,
-                           Cout, Cout_real, tpw);
+        hipLaunchKernelGGL((conv_in_wgrad_mfma_kernel<KS, S, CIN, 1>), grid, dim3(256), 0, st, x, draw, dw, N, Cout, Cout_real, tpw);
 }
 static bool in_mfma_ok(int Cin, int H, int W, int Cout, int k, int s, int p) {
     static int on = -1;
