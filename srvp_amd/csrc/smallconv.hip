@@ -175,6 +175,32 @@ template <int KS, int S, int CIN> struct InGeom {
     }
 };
 
+// the same patch in two halves, so that the global loads of tile i+1 are in flight while tile i is computed: fetch into registers
+// (element e of this thread is patch element threadIdx.x + 256 e) ...
+template <int KS, int S, int CIN, int NP>
+__device__ __forceinline__ void in_fetch_patch(const float* __restrict__ x, float (&pv)[NP], int n, int tile_in_img) {
+    typedef InGeom<KS, S, CIN> Gm;
+    const int iy0 = tile_in_img * Gm::TR * S - 1;
+#pragma unroll
+    for (int e = 0; e < NP; ++e) {
+        const int i = threadIdx.x + e * 256;
+        const int c = i % Gm::PWp, r = (i / Gm::PWp) % Gm::PH, ci = i / (Gm::PWp * Gm::PH);
+        const int iy = iy0 + r, ix = c - 1;
+        const bool ok = i < CIN * Gm::PH * Gm::PWp && iy >= 0 && iy < Gm::H && ix >= 0 && ix < Gm::W;
+        pv[e] = ok ? x[(((size_t)n * CIN + ci) * Gm::H + iy) * Gm::W + ix] : 0.f;
+    }
+}
+// ... and store into the LDS patch
+template <int KS, int S, int CIN, int NP>
+__device__ __forceinline__ void in_commit_patch(const float (&pv)[NP], float* xs) {
+    typedef InGeom<KS, S, CIN> Gm;
+#pragma unroll
+    for (int e = 0; e < NP; ++e) {
+        const int i = threadIdx.x + e * 256;
+        if (i < CIN * Gm::PH * Gm::PWp) xs[i] = pv[e];
+    }
+}
+
 template <int KS, int S, int CIN>
 __device__ __forceinline__ void in_load_patch(const float* __restrict__ x, float* xs, int n, int tile_in_img) {
     typedef InGeom<KS, S, CIN> Gm;
@@ -210,13 +236,18 @@ __global__ __launch_bounds__(256) void conv_in_fwd_mfma_kernel(const float* __re
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
     const long long ntiles = (long long)N * Gm::TPI;
     const long long t0 = (long long)blockIdx.x * tiles_per_wg;
+    constexpr int NP = (CIN * Gm::PH * Gm::PWp + 255) / 256;
+    float pv[NP];
+    if (t0 < ntiles) in_fetch_patch<KS, S, CIN, NP>(x, pv, (int)(t0 / Gm::TPI), (int)(t0 % Gm::TPI));
     for (int it = 0; it < tiles_per_wg; ++it) {
         const long long tile = t0 + it;
         if (tile >= ntiles) break;
-        const int n = (int)(tile / Gm::TPI), tin = (int)(tile % Gm::TPI);
         __syncthreads();                                  // previous tile's patch / staging are no longer read
-        in_load_patch<KS, S, CIN>(x, xs, n, tin);
+        in_commit_patch<KS, S, CIN, NP>(pv, xs);
         __syncthreads();
+        // next tile's patch: global loads in flight under this tile's MFMAs and epilogue
+        if (it + 1 < tiles_per_wg && tile + 1 < ntiles)
+            in_fetch_patch<KS, S, CIN, NP>(x, pv, (int)((tile + 1) / Gm::TPI), (int)((tile + 1) % Gm::TPI));
         f32x16v acc[NTL];
 #pragma unroll
         for (int j = 0; j < NTL; ++j)
@@ -385,17 +416,33 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_mfma3_kernel(const float* _
     const long long ntiles = (long long)N * Gm::TPI;
     const long long t0 = (long long)blockIdx.x * tiles_per_wg;
     const int cch = Cout / 8;
+    // both operands of tile i+1 are fetched into registers while tile i is computed
+    constexpr int NP = (CIN * Gm::PH * Gm::PWp + 255) / 256, ND = 128 * 8 / 256;      // ND: 16-byte draw pieces per thread (Cout <= 64)
+    float pv[NP];
+    u32x4_t dv[ND];
+    auto fetch_draw = [&](long long tile) {
+        const int n = (int)(tile / Gm::TPI), tin = (int)(tile % Gm::TPI);
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const int q = tid + u * 256;
+            if (q >= 128 * cch) continue;
+            const int row = q / cch, ch = q % cch;
+            const int oy = tin * Gm::TR + row / Gm::OW, ox = row % Gm::OW;
+            dv[u] = *reinterpret_cast<const u32x4_t*>(draw + (((size_t)n * (Gm::OH + 2) + oy + 1) * (Gm::OW + 2) + ox + 1) * Cout + ch * 8);
+        }
+    };
+    if (t0 < ntiles) { in_fetch_patch<KS, S, CIN, NP>(x, pv, (int)(t0 / Gm::TPI), (int)(t0 % Gm::TPI)); fetch_draw(t0); }
     for (int it = 0; it < tiles_per_wg; ++it) {
         const long long tile = t0 + it;
         if (tile >= ntiles) break;
-        const int n = (int)(tile / Gm::TPI), tin = (int)(tile % Gm::TPI);
         __syncthreads();
-        in_load_patch<KS, S, CIN>(x, xs, n, tin);
-        for (int q = tid; q < 128 * cch; q += 256) {
+        in_commit_patch<KS, S, CIN, NP>(pv, xs);
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const int q = tid + u * 256;
+            if (q >= 128 * cch) continue;
             const int row = q / cch, ch = q % cch;
-            const int oy = tin * Gm::TR + row / Gm::OW, ox = row % Gm::OW;
-            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(draw + (((size_t)n * (Gm::OH + 2) + oy + 1) * (Gm::OW + 2) + ox + 1) * Cout + ch * 8);
-            const unsigned short* h = reinterpret_cast<const unsigned short*>(&v);
+            const unsigned short* h = reinterpret_cast<const unsigned short*>(&dv[u]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int co = ch * 8 + e;
@@ -403,6 +450,10 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_mfma3_kernel(const float* _
             }
         }
         __syncthreads();
+        if (it + 1 < tiles_per_wg && tile + 1 < ntiles) {
+            in_fetch_patch<KS, S, CIN, NP>(x, pv, (int)((tile + 1) / Gm::TPI), (int)((tile + 1) % Gm::TPI));
+            fetch_draw(tile + 1);
+        }
 #pragma unroll
         for (int g16 = 0; g16 < 2; ++g16) {               // this wave's 32 pixels, sixteen per MFMA (this half-wave: eight of them)
             const int p0 = wid * 32 + g16 * 16 + lhalf * 8;
