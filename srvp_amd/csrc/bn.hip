@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ 
                 float f[8];
                 unpack8(v[i * R + j], f);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = act_fwd(f[e] * sc[e] + sh[e], act);
+                for (int e = 0; e < 8; ++e) f[e] = act_fwd(__builtin_fmaf(f[e], sc[e], sh[e]), act);   // (explicit fma: bn_bwd_g_window recomputes it)
                 u32x4_t o = pack8(f);
                 if (dst) {
                     size_t doff = (((size_t)n * (H + 2 * db) + yy + db) * (W + 2 * db) + xx + db) * C + cg * 8;
@@ -220,11 +220,17 @@ __device__ __forceinline__ void bn_bwd_g_window(const BnBwdK& a, int n, int py, 
     float t[8], w4[4][8];
     unpack8(*reinterpret_cast<const u32x4_t*>((const bf16_t*)a.da + (((size_t)n * (Hh + 2 * db) + py + db) * (Wh + 2 * db) + px + db) * a.da_cstride +
                                               a.da_coff + cg * 8), t);
+    // The activations the forward max-pooled over are RECOMPUTED from raw (same fma, same activation, same bf16 rounding as
+    // bn_act_kernel stored them) instead of being read back: one full-size tensor read less in both BN-backward passes of the
+    // four pooled layers.
+    (void)ab;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int y = 2 * py + (q >> 1), x = 2 * px + (q & 1);
-        unpack8(*reinterpret_cast<const u32x4_t*>(a.act + (((size_t)n * (H + 2 * ab) + y + ab) * (W + 2 * ab) + x + ab) * C + cg * 8), w4[q]);
         unpack8(*reinterpret_cast<const u32x4_t*>(a.raw + (((size_t)n * H + y) * W + x) * C + cg * 8), rawf[q]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            w4[q][e] = bf2f(f2bf(act_fwd(__builtin_fmaf(rawf[q][e], sc[e], sh[e]), ACT >= 0 ? ACT : a.act_kind)));
     }
     float d[4][8];
 #pragma unroll
