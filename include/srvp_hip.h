@@ -117,6 +117,12 @@ int srvp_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
 int srvp_bn_act(const void* raw, const float* scale, const float* shift, int act,
                 int N, int H, int W, int C,
                 void* dst, int dst_border, void* dst_pool, int pool_border, float* dst_f32, void* stream);
+/* the same; keep_frames (int32 [N], may be NULL) applies to launches with dst_pool: frames n with keep_frames[n] == 0 get only
+ * their pooled output -- the full-resolution activation of a pooled layer is read by nothing but the skip connections */
+int srvp_bn_act_keep(const void* raw, const float* scale, const float* shift, int act,
+                     int N, int H, int W, int C,
+                     void* dst, int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep_frames,
+                     void* stream);
 
 /* backward of activation+BN.  dA comes from one or two places:
  *   main: tensor `da` with channel stride da_cstride / offset da_coff, mode 0 = same resolution,

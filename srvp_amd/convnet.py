@@ -587,7 +587,7 @@ class Block:
 class ConvNetBase:
     """Shared launch helpers."""
 
-    def _bn_forward(self, blk, params, st, sync):
+    def _bn_forward(self, blk, params, st, sync, keep=None):
         N, C_ = blk.N, blk.cout
         scale, shift, mean, invstd = (blk.coef[i] for i in range(4))
         if blk.has_bn:
@@ -605,12 +605,12 @@ class ConvNetBase:
                 L.call('srvp_bn_eval_coeffs', L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(scale), L.ptr(shift), C_,
                        blk.cout_r, BN_EPS, st)
         out, pool = blk.out, blk.pool
-        L.call('srvp_bn_act', L.ptr(blk.raw), L.ptr(scale), L.ptr(shift), blk.act, N, blk.OH, blk.OW, C_,
+        L.call('srvp_bn_act_keep', L.ptr(blk.raw), L.ptr(scale), L.ptr(shift), blk.act, N, blk.OH, blk.OW, C_,
                L.ptr(out.t) if out is not None else None, out.b if out is not None else 0,
                L.ptr(pool.t) if pool is not None else None, pool.b if pool is not None else 0,
-               L.ptr(blk.out_f32), st)
+               L.ptr(blk.out_f32), L.ptr(keep) if pool is not None else None, st)
 
-    def _block_forward(self, blk, params, st, sync, x=None):
+    def _block_forward(self, blk, params, st, sync, x=None, keep=None):
         if blk.role == 'in':
             w = params[blk.spec['key'] + '.weight']
             L.call('srvp_conv_in_fwd', L.ptr(x), L.ptr(w), L.ptr(blk.raw),
@@ -628,7 +628,7 @@ class ConvNetBase:
         else:
             for d in (blk._fwd[1:] if (blk.split and getattr(self, '_skips_done', False)) else blk._fwd):
                 L.call('srvp_conv_mfma', C.byref(d), st)
-        self._bn_forward(blk, params, st, sync)
+        self._bn_forward(blk, params, st, sync, keep)
 
     def _bn_backward(self, blk, params, grads, da, st, sync):
         """da: dict(t, mode, cstride, coff, border, f32, da2, da2_idx).  Produces blk.draw (and BN param grads)."""
@@ -766,11 +766,15 @@ class EncoderNet(ConvNetBase):
         self.skips = {3 - sp['skip_out']: b.out for sp, b in zip(specs, self.blocks) if sp['skip_out'] is not None}
         self.nh_r = specs[-1]['cout']
 
-    def forward(self, x, params, st, sync=None):
+    def forward(self, x, params, st, sync=None, keep=None):
+        """keep: int32 [N] or None.  The full-resolution activation of a POOLED block is read by nothing but the skip connections
+        (the next layer reads the pooled tensor, BN backward recomputes it from the raw output), i.e. for one frame per sample:
+        with `keep` given, pooled blocks store it only for the frames with keep[n] != 0 (saves ~2 GB of writes per step at the
+        headline config)."""
         if self.training:
             self.zero_forward_accumulators()
         for blk in self.blocks:
-            self._block_forward(blk, params, st, sync, x=x)
+            self._block_forward(blk, params, st, sync, x=x, keep=keep)
         return self.blocks[-1].out_f32[:, :self.nh_r]
 
     def backward(self, x, d_hx, skip_grads, params, grads, st, sync=None):

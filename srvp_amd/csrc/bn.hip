@@ -68,7 +68,7 @@ template <bool POOL, int ACT>
 __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ raw, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, int act, int N, int H, int W, int C,
                                                      bf16_t* __restrict__ dst, int db, bf16_t* __restrict__ dpool, int pb,
-                                                     float* __restrict__ dst_f32) {
+                                                     float* __restrict__ dst_f32, const int* __restrict__ keep) {
     if (ACT >= 0) act = ACT;
     const int CG = C / 8;
     const int PPB = blockDim.x / CG;             // (pooled) pixels handled in parallel by one workgroup
@@ -101,7 +101,9 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = act_fwd(__builtin_fmaf(f[e], sc[e], sh[e]), act);   // (explicit fma: bn_bwd_g_window recomputes it)
                 u32x4_t o = pack8(f);
-                if (dst) {
+                // keep (pooled layers): the full-resolution activation is only ever read for the frames that feed a skip
+                // connection (one per sample); the pooled tensor carries everything else forward
+                if (dst && (!keep || keep[n])) {
                     size_t doff = (((size_t)n * (H + 2 * db) + yy + db) * (W + 2 * db) + xx + db) * C + cg * 8;
                     __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t*>(dst + doff));
                 }
@@ -479,8 +481,9 @@ extern "C" int srvp_bn_eval_coeffs(const float* gamma, const float* beta, const 
     return SRVP_OK;
 }
 
-extern "C" int srvp_bn_act(const void* raw, const float* scale, const float* shift, int act, int N, int H, int W, int C,
-                           void* dst, int dst_border, void* dst_pool, int pool_border, float* dst_f32, void* stream) {
+extern "C" int srvp_bn_act_keep(const void* raw, const float* scale, const float* shift, int act, int N, int H, int W, int C,
+                                void* dst, int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep,
+                                void* stream) {
     SRVP_REQUIRE(raw && scale && shift && C % 8 == 0, "srvp_bn_act: bad args");
     hipStream_t st = (hipStream_t)stream;
     if (dst_pool) {
@@ -489,16 +492,21 @@ extern "C" int srvp_bn_act(const void* raw, const float* scale, const float* shi
         SRVP_REQUIRE(C / 8 <= 256 && (long long)N * H * W < (1ll << 31), "srvp_bn_act: C=%d / size unsupported", C);
         auto kern = act == ACT_LRELU ? bn_act_kernel<true, ACT_LRELU> : bn_act_kernel<true, -1>;
         hipLaunchKernelGGL(kern, dim3(grid_for(total, (256 / (C / 8)) * 2)), dim3(256), 0, st, (const bf16_t*)raw, scale, shift,
-                           act, N, H, W, C, (bf16_t*)dst, dst_border, (bf16_t*)dst_pool, pool_border, dst_f32);
+                           act, N, H, W, C, (bf16_t*)dst, dst_border, (bf16_t*)dst_pool, pool_border, dst_f32, (const int*)keep);
     } else {
         long long total = (long long)N * H * W;
         SRVP_REQUIRE(C / 8 <= 256 && total < (1ll << 31), "srvp_bn_act: C=%d / size unsupported", C);
         auto kern = act == ACT_LRELU ? bn_act_kernel<false, ACT_LRELU> : bn_act_kernel<false, -1>;
         hipLaunchKernelGGL(kern, dim3(grid_for(total, (256 / (C / 8)) * 4)), dim3(256), 0, st, (const bf16_t*)raw, scale, shift,
-                           act, N, H, W, C, (bf16_t*)dst, dst_border, (bf16_t*)nullptr, 0, dst_f32);
+                           act, N, H, W, C, (bf16_t*)dst, dst_border, (bf16_t*)nullptr, 0, dst_f32, (const int*)nullptr);
     }
     SRVP_CHECK_LAUNCH("srvp_bn_act");
     return SRVP_OK;
+}
+
+extern "C" int srvp_bn_act(const void* raw, const float* scale, const float* shift, int act, int N, int H, int W, int C,
+                           void* dst, int dst_border, void* dst_pool, int pool_border, float* dst_f32, void* stream) {
+    return srvp_bn_act_keep(raw, scale, shift, act, N, H, W, C, dst, dst_border, dst_pool, pool_border, dst_f32, nullptr, stream);
 }
 
 extern "C" int srvp_bn_bwd_reduce(const srvp_bnbwd_desc* d, double* red, void* stream) {

@@ -243,13 +243,13 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         pl['dec'].pack_weights(params, st)
         self._pack_version = ver
 
-    def _draw_tape(self, T, B, nt, training, dev):
+    def _draw_tape(self, T, B, nt, training, dev, t_skip=None):
         """Random draws in the reference's order: CPU generator for the frame indices, device
         generator for the normals."""
         tape = {}
         if training:
             if self.skipco:
-                tape['t_skip'] = torch.randint(T, size=(B,))
+                tape['t_skip'] = t_skip if t_skip is not None else torch.randint(T, size=(B,))
             tape['t_w'] = torch.stack([torch.randperm(T)[:self.nt_inf] for _ in range(B)], 1)
         tape['eps_y0'] = torch.randn(B, self.ny, device=dev)
         tape['eps_z'] = torch.randn(max(nt - 1, 1), B, self.nz, device=dev)
@@ -268,22 +268,31 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         self._pack(pl, params, st)
         enc, dec, lat = pl['enc'], pl['dec'], pl['lat']
         x = x.contiguous().float()
-        hx = enc.forward(x.view(T * B, *x.shape[2:]), params, st, self.sync if training else None)
+        # frames whose encoder activations feed the skip connections (srvp.py:185-190): drawn first (the reference draws t_skip
+        # before the t_w permutations too), because the pooled encoder blocks keep their full-resolution output for these only
+        t_skip = None
+        if self.skipco and training:
+            t_skip = tape['t_skip'] if tape is not None else torch.randint(T, size=(B,))
+        keep = pl.get('keep')
+        if keep is None:
+            keep = pl['keep'] = torch.zeros(T * B, dtype=torch.int32, device=dev)
+        sel = None
+        if self.skipco:
+            ar = torch.arange(B, device=dev, dtype=torch.int32)
+            sel = (_to_dev(t_skip, dev).to(torch.int32) * B + ar) if training else ((T - 1) * B + ar)
+            keep.zero_()
+            keep[sel.long()] = 1
+        hx = enc.forward(x.view(T * B, *x.shape[2:]), params, st, self.sync if training else None, keep=keep)
         hx = hx.contiguous().view(T, B, self.nhx)
         # the draws come AFTER the encoder launches (same order within the CPU and the device generator as the reference, which
         # draws them inside encode / infer_w / infer_y / generate): the per-sample randperm calls cost ~0.3 ms of host time that
         # the GPU now spends in the encoder instead of idling; the small index tensors travel through pinned memory so that the
         # copy does not block the host behind the work queued so far
         if tape is None:
-            tape = self._draw_tape(T, B, nt, training, dev)
+            tape = self._draw_tape(T, B, nt, training, dev, t_skip=t_skip)
         tape = {k: (_to_dev(v, dev) if torch.is_tensor(v) else v) for k, v in tape.items()}
         self.last_tape = tape
         if self.skipco:
-            ar = torch.arange(B, device=dev, dtype=torch.int32)
-            if training:
-                sel = tape['t_skip'].to(torch.int32) * B + ar
-            else:
-                sel = (T - 1) * B + ar
             pl['skip_map'].copy_(sel.repeat(nt))
             pl['skip_sel_t'].copy_(sel)
             pl['skip_sel'] = sel
