@@ -188,10 +188,12 @@ int srvp_pack_weight(const float* src, void* dst, const srvp_pack_desc* d, void*
 /* fp32 gradient: w_grad[ jr*sj + kr*sk + tap_off[t] ] += packed_grad[t][j][k]  (inverse mapping, for dW) */
 int srvp_unpack_wgrad(const float* src, float* dst, const srvp_pack_desc* d, void* stream);
 /* every layer of a network in one launch: `jobs_dev` is a DEVICE-resident array of njobs jobs (the caller builds it once per
- * plan -- buffers are static), max_total = max over jobs of ntaps*J*K.  Same per-element semantics as the calls above. */
+ * plan -- buffers are static), total_wgs = sum over jobs of srvp_pack_job_wgs(ntaps*J*K).  Same per-element semantics as the calls above. */
 typedef struct { const void* src; void* dst; srvp_pack_desc d; } srvp_pack_job;
-int srvp_pack_weight_multi(const srvp_pack_job* jobs_dev, int njobs, int64_t max_total, void* stream);
-int srvp_unpack_wgrad_multi(const srvp_pack_job* jobs_dev, int njobs, int64_t max_total, void* stream);
+int srvp_pack_weight_multi(const srvp_pack_job* jobs_dev, int njobs, int64_t total_wgs, void* stream);
+int srvp_unpack_wgrad_multi(const srvp_pack_job* jobs_dev, int njobs, int64_t total_wgs, void* stream);
+/* workgroups the multi launches give a job of `total` = ntaps*J*K elements; total_wgs above = the sum over the jobs */
+int srvp_pack_job_wgs(int64_t total);
 
 /* ------------------------------------------------------------------------------------------------
  * Latent path: Linear / MLP / LSTM / residual Euler rollout (module/mlp.py, module/srvp.py:229-413), fp32.

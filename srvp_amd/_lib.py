@@ -103,6 +103,7 @@ _SIGS = {
     'srvp_pack_weight': ([c_vp, c_vp, C.POINTER(PackDesc), c_vp], c_i32),
     'srvp_pack_weight_multi': ([c_vp, c_i32, c_i64, c_vp], c_i32),
     'srvp_unpack_wgrad_multi': ([c_vp, c_i32, c_i64, c_vp], c_i32),
+    'srvp_pack_job_wgs': ([c_i64], c_i32),
     'srvp_unpack_wgrad': ([c_vp, c_vp, C.POINTER(PackDesc), c_vp], c_i32),
     'srvp_gemm_f32': ([c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_axpby_f32': ([c_vp, c_f32, c_vp, c_f32, c_vp, c_i64, c_vp], c_i32),

@@ -680,7 +680,7 @@ class ConvNetBase:
                 arr[i].src = s.data_ptr() if src_is_tensor else s
                 arr[i].dst = d if src_is_tensor else d.data_ptr()
                 arr[i].d = pd
-                mx = max(mx, pd.ntaps * pd.J * pd.K)
+                mx += L.load().srvp_pack_job_wgs(pd.ntaps * pd.J * pd.K)      # total workgroups of the multi launch
             raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             cache.update(key=key, table=raw.to(dev), n=len(jobs), mx=mx, keep=[t for j in jobs for t in j[:2] if torch.is_tensor(t)])
         return cache

@@ -87,22 +87,44 @@ __device__ __forceinline__ bool vec_ok(const srvp_pack_desc& d) {
         if (d.tap_set[t] == 0 ? (d.tap_off[t] < 0 || d.tap_off[t] >= 16) : (d.tap_set[t] >> 16) != 0) return false;
     return true;
 }
-__global__ __launch_bounds__(256) void pack_multi_kernel(const srvp_pack_job* __restrict__ jobs) {
-    const srvp_pack_job& j = jobs[blockIdx.y];
+// Workgroups of a job: one per 512 vector items, at most 256 -- the jobs of a network span three orders of magnitude in size,
+// and a uniform 2-D grid (every job x the largest job's workgroups) spent most of the launch on workgroups with nothing to do.
+__host__ __device__ inline int pack_job_wgs(long long total) {
+    long long w = (total / 8 + 511) / 512;
+    return (int)(w < 1 ? 1 : (w > 256 ? 256 : w));
+}
+// blockIdx.x -> (job, workgroup within the job, workgroups of the job)
+__device__ __forceinline__ const srvp_pack_job* locate_job(const srvp_pack_job* jobs, int njobs, unsigned& wg, unsigned& nwg) {
+    wg = blockIdx.x;
+    for (int i = 0; i < njobs; ++i) {
+        nwg = (unsigned)pack_job_wgs((long long)jobs[i].d.ntaps * jobs[i].d.J * jobs[i].d.K);
+        if (wg < nwg) return jobs + i;
+        wg -= nwg;
+    }
+    return nullptr;
+}
+
+__global__ __launch_bounds__(256) void pack_multi_kernel(const srvp_pack_job* __restrict__ jobs, int njobs) {
+    unsigned wg, nwg;
+    const srvp_pack_job* jp = locate_job(jobs, njobs, wg, nwg);
+    if (!jp) return;
+    const srvp_pack_job& j = *jp;
     const srvp_pack_desc& d = j.d;
     if (!vec_ok(d)) {
         PackArgs a;
         job_args(j, a);
         const long long total = (long long)a.ntaps * a.J * a.K;
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        for (long long i = (long long)wg * blockDim.x + threadIdx.x; i < total; i += (long long)nwg * blockDim.x)
             pack_one((const float*)j.src, (bf16_t*)j.dst, a, i);
         return;
     }
     const float* __restrict__ src = (const float*)j.src;
     bf16_t* __restrict__ dst = (bf16_t*)j.dst;
     const int J = d.J, K = d.K, K8 = K >> 3, ntaps = d.ntaps;
+    unsigned need = 0;                                   // source taps any packed tap reads
+    for (int t = 0; t < ntaps; ++t) need |= d.tap_set[t] ? (unsigned)d.tap_set[t] : 1u << d.tap_off[t];
     const long long items = (long long)J * K8;
-    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < items; q += (long long)gridDim.x * blockDim.x) {
+    for (long long q = (long long)wg * blockDim.x + threadIdx.x; q < items; q += (long long)nwg * blockDim.x) {
         const int jj = (int)(q % J), k8 = (int)(q / J);
         const int jr = real_index(jj, d.J0, d.J0r, d.J1r);
         long long base[8];
@@ -111,16 +133,26 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const srvp_pack_job* __
             const int kr = real_index(k8 * 8 + e, d.K0, d.K0r, d.K1r);
             base[e] = (jr >= 0 && kr >= 0) ? (long long)jr * d.sj + (long long)kr * d.sk : -1;
         }
+        // every source element this item needs (the taps lie within 16 elements of each base) is loaded up front -- up to 128
+        // independent loads in flight instead of one dependent (tap-table load -> element loads -> store) chain per tap
+        float w[8][16];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int sidx = 0; sidx < 16; ++sidx) w[e][sidx] = (base[e] >= 0 && ((need >> sidx) & 1)) ? src[base[e] + sidx] : 0.f;
         for (int t = 0; t < ntaps; ++t) {
             const int off = d.tap_off[t], set = d.tap_set[t];
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 v[e] = 0.f;
-                if (base[e] < 0) continue;
-                if (set == 0) v[e] = src[base[e] + off];
-                else
-                    for (int sidx = 0; sidx < 16; ++sidx) if ((set >> sidx) & 1) v[e] += src[base[e] + sidx];   // fp32 sum, one rounding
+                if (set == 0) {
+#pragma unroll
+                    for (int sidx = 0; sidx < 16; ++sidx) if (sidx == off) v[e] = w[e][sidx];
+                } else {
+#pragma unroll
+                    for (int sidx = 0; sidx < 16; ++sidx) if ((set >> sidx) & 1) v[e] += w[e][sidx];   // fp32 sum, one rounding, fixed order
+                }
             }
             long long o;
             const int k = k8 * 8;
@@ -134,14 +166,17 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const srvp_pack_job* __
         }
     }
 }
-__global__ __launch_bounds__(256) void unpack_multi_kernel(const srvp_pack_job* __restrict__ jobs) {
-    const srvp_pack_job& j = jobs[blockIdx.y];
+__global__ __launch_bounds__(256) void unpack_multi_kernel(const srvp_pack_job* __restrict__ jobs, int njobs) {
+    unsigned wg, nwg;
+    const srvp_pack_job* jp = locate_job(jobs, njobs, wg, nwg);
+    if (!jp) return;
+    const srvp_pack_job& j = *jp;
     const srvp_pack_desc& d = j.d;
     if (!vec_ok(d)) {
         PackArgs a;
         job_args(j, a);
         const long long total = (long long)a.ntaps * a.J * a.K;
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        for (long long i = (long long)wg * blockDim.x + threadIdx.x; i < total; i += (long long)nwg * blockDim.x)
             unpack_one((const float*)j.src, (float*)j.dst, a, i);
         return;
     }
@@ -154,7 +189,7 @@ __global__ __launch_bounds__(256) void unpack_multi_kernel(const srvp_pack_job* 
         shared |= need & m; need |= m;
     }
     const long long items = (long long)J * K8;
-    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < items; q += (long long)gridDim.x * blockDim.x) {
+    for (long long q = (long long)wg * blockDim.x + threadIdx.x; q < items; q += (long long)nwg * blockDim.x) {
         const int jj = (int)(q % J), k8 = (int)(q / J);
         const int jr = real_index(jj, d.J0, d.J0r, d.J1r);
         if (jr < 0) continue;
@@ -371,21 +406,21 @@ extern "C" int srvp_unpack_wgrad(const float* src, float* dst, const srvp_pack_d
     return SRVP_OK;
 }
 
-extern "C" int srvp_pack_weight_multi(const srvp_pack_job* jobs_dev, int njobs, int64_t max_total, void* stream) {
-    SRVP_REQUIRE(jobs_dev && njobs > 0 && max_total > 0, "srvp_pack_weight_multi: bad args");
-    long long bx = (max_total / 8 + 255) / 256; if (bx > 1024) bx = 1024; if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)bx, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+extern "C" int srvp_pack_weight_multi(const srvp_pack_job* jobs_dev, int njobs, int64_t total_wgs, void* stream) {
+    SRVP_REQUIRE(jobs_dev && njobs > 0 && total_wgs > 0 && total_wgs < (1ll << 31), "srvp_pack_weight_multi: bad args");
+    hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)total_wgs), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
     SRVP_CHECK_LAUNCH("srvp_pack_weight_multi");
     return SRVP_OK;
 }
 
-extern "C" int srvp_unpack_wgrad_multi(const srvp_pack_job* jobs_dev, int njobs, int64_t max_total, void* stream) {
-    SRVP_REQUIRE(jobs_dev && njobs > 0 && max_total > 0, "srvp_unpack_wgrad_multi: bad args");
-    long long bx = (max_total / 8 + 255) / 256; if (bx > 1024) bx = 1024; if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(unpack_multi_kernel, dim3((unsigned)bx, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+extern "C" int srvp_unpack_wgrad_multi(const srvp_pack_job* jobs_dev, int njobs, int64_t total_wgs, void* stream) {
+    SRVP_REQUIRE(jobs_dev && njobs > 0 && total_wgs > 0 && total_wgs < (1ll << 31), "srvp_unpack_wgrad_multi: bad args");
+    hipLaunchKernelGGL(unpack_multi_kernel, dim3((unsigned)total_wgs), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
     SRVP_CHECK_LAUNCH("srvp_unpack_wgrad_multi");
     return SRVP_OK;
 }
+
+extern "C" int srvp_pack_job_wgs(int64_t total) { return pack_job_wgs(total); }
 
 extern "C" int srvp_skip_grad_reduce(const void* dcat, int cstride, int coff, int C, int HW, int T, int B, void* dsel,
                                      void* stream) {
