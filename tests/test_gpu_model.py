@@ -599,3 +599,28 @@ def test_training_reduces_the_elbo(archi, nc, skipco):
     const = 6 * nc * 64 * 64 * 0.9189385332
     first, last = sum(losses[:5]) / 5 - const, sum(losses[-5:]) / 5 - const
     assert last < 0.5 * first, (first, last)
+
+
+def test_bench_contract():
+    """bench.py prints exactly ONE line on stdout, a JSON object with the driver's fields plus `roofline` (and, without
+    --no-cpu-baseline, `cpu_baseline`); everything else (library banners included) goes to stderr."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '4', '--warmup', '1', '--batch', '8', '--no-cpu-baseline'],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline'):
+        assert k in d, k
+    assert d['unit'] == 'frames/s' and d['n_gpus'] == 1 and d['steps'] == 4 and d['higher_is_better'] is True and d['vs_baseline'] is None
+    assert abs(d['value'] - 8 * 12 * 4 / (d['ms_per_step'] * 4 / 1e3)) < 1e-6 * d['value']
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    rf = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in rf, k
+    assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
