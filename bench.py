@@ -222,7 +222,8 @@ def main():
         dom = 'srvp_conv_mfma'
         # (srvp_conv_mfma_multi = the same kernels, four sub-pixel phase launches issued as one grid)
         per[dom] = per.get(dom, 0.0) + per.pop('srvp_conv_mfma_multi', 0.0)
-        nlaunch = (len(prof.get(dom, [])) + 4 * len(prof.get('srvp_conv_mfma_multi', []))) // n_prof_steps
+        # kernel launches per step as rocprofv3 counts them (the four sub-pixel phases of a multi call are ONE grid)
+        nlaunch = (len(prof.get(dom, [])) + len(prof.get('srvp_conv_mfma_multi', []))) // n_prof_steps
         ach = (fl['fwd_mfma'] + fl['dgrad_mfma']) / (per[dom] * 1e-3) / 1e12
         # HBM bytes per launch of the same kernel class: PMC counters cannot be collected from inside this process, so the
         # number comes from the committed summary of a separate `rocprofv3 --pmc` pass of this very command
@@ -236,7 +237,7 @@ def main():
                             'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC pass, profiles/r01_hbm_traffic.json)',
                             'algorithmic_flops_per_launch': (fl['fwd_mfma'] + fl['dgrad_mfma']) / max(1, nlaunch),
                             'algorithmic_bytes_per_launch': fl['bytes_mfma'] / max(1, nlaunch),
-                            'launches_per_step': nlaunch, 'ms_per_step': per[dom],
+                            'launches_per_step': nlaunch, 'ms_per_step': per[dom], 'avg_launch_us': per[dom] / max(1, nlaunch) * 1e3,
                             'timed_with_events': f'{n_prof_steps} of the {args.steps} timed steps (every {EVENT_EVERY}th)'}
         wg = fl['wgrad_mfma'] / (per['srvp_wgrad_mfma'] * 1e-3) / 1e12
         line['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'wgrad_halo_kernel / wgrad_mfma_kernel', 'achieved': wg, 'peak': PEAK_BF16_TFLOPS,
