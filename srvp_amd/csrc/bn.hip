@@ -518,7 +518,7 @@ extern "C" int srvp_bn_bwd_reduce(const srvp_bnbwd_desc* d, double* red, void* s
     long long P = (long long)k.N * k.H * k.W;
     SRVP_REQUIRE(P < (1ll << 31), "srvp_bn_bwd_reduce: too many pixels");
     if (k.da_mode == 2) P /= 4;
-    const dim3 g(grid_for(P, PPB * (k.da_mode == 2 ? 2 : 8)));
+    const dim3 g(grid_for(P, PPB * (k.da_mode == 2 ? 16 : 64)));   // >= 64 pixel rows per thread slot: the 2C fp64 atomics per workgroup must stay small beside its streaming work
     const bool lr = k.act_kind == ACT_LRELU;
     auto kern = k.da_mode == 0 ? (lr ? bn_bwd_reduce_kernel<0, ACT_LRELU> : bn_bwd_reduce_kernel<0, -1>)
               : k.da_mode == 1 ? (lr ? bn_bwd_reduce_kernel<1, ACT_LRELU> : bn_bwd_reduce_kernel<1, -1>)
