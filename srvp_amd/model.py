@@ -89,11 +89,18 @@ class _SrvpForward(torch.autograd.Function):
     def forward(ctx, model, x, nt, n_euler, tape, *params):
         outs = model._forward_impl(x, nt, n_euler, tape, training=True)
         ctx.model = model
+        ctx.gen = model._fwd_gen
+        # fresh tensors, like the reference's outputs: the plan-owned buffers are overwritten by the next forward
+        outs = tuple(o.clone() if o is not None else None for o in outs)
         ctx.mark_non_differentiable(outs[2])      # z is a sample: gradient flows through q_z / p_z params
         return outs
 
     @staticmethod
     def backward(ctx, d_x, d_y, d_z, d_w, d_qy0, d_qz, d_pz, d_res):
+        if ctx.gen != ctx.model._fwd_gen:
+            raise RuntimeError('srvp_amd: backward() of a forward pass whose saved activations were overwritten by a later '
+                               'training-mode forward of the same model (activation buffers are preallocated per problem '
+                               'size and shared between calls): run backward before the next forward')
         ctx.model._backward_impl(d_x, d_y, d_w, d_qy0, d_qz, d_pz, d_res)
         return (None,) * (5 + len(list(ctx.model.parameters())))
 
@@ -128,6 +135,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         self._pack_version = None
         self.sync = None            # set by srvp_amd.distributed for multi-GPU (SyncBN statistics + gradient all-reduce)
         self.last_tape = None
+        self._fwd_gen = 0           # training forwards so far (guards backward against overwritten activations)
 
     # ------------------------------------------------------------------------------------------------ init
     def init(self, res_gain=1.41):
@@ -262,6 +270,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         if training:
             assert nt == T, 'training mode requires observations for every generated frame (srvp.py:391)'
             self.flatten_parameters_()
+            self._fwd_gen += 1
         st = L.stream()
         pl = self._plan(T, B, nt, n_euler, training)
         params = self._named_tensors()
@@ -422,7 +431,14 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         if self.training and torch.is_grad_enabled():
             return _SrvpForward.apply(self, x, nt, n_euler, tape, *self.parameters())
         with torch.no_grad():
-            return self._forward_impl(x, nt, n_euler, tape, training=self.training)
+            outs = self._forward_impl(x, nt, n_euler, tape, training=self.training)
+            # fresh tensors, like the reference's outputs (the plan-owned buffers are overwritten by the next call)
+            return tuple(o.clone() if o is not None else None for o in outs)
+
+    def drop_sample_plans(self):
+        """Frees the S > 1 inference plans of sample() (activation buffers for S futures per video)."""
+        for k in [k for k in self._plans if isinstance(k[0], int) and len(k) > 6]:
+            del self._plans[k]
 
     def _infer_plan(self, T, B, nt, n_euler=1):
         return self._plan(T, B, nt, n_euler, False)

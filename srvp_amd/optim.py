@@ -37,9 +37,7 @@ class FusedAdam(torch.optim.Optimizer):
         L.call('srvp_adam', L.ptr(flat_p), L.ptr(flat_g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), flat_p.numel(),
                float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), self.step_count,
                float(grad_scale), L.stream())
-        # parameters changed behind autograd's back: bump versions so packed bf16 weights are refreshed
-        for p in self.model.parameters():
-            p._version  # noqa: B018 (read only; see model._pack which keys on a step counter as well)
+        # parameters changed behind autograd's back: the packed bf16 weights must be refreshed
         self.model._pack_version = None
         return None
 

@@ -131,8 +131,10 @@ def evaluate(forward_fn, val_loader, device, opt):
                 chunk = max(1, min(opt.n_samples_test, lim // max(1, nt * n_b)))
                 samples = []
                 for s0 in range(0, opt.n_samples_test, chunk):
-                    xs = model.sample(x_inf, nt, min(chunk, opt.n_samples_test - s0), dt=1 / opt.n_euler_steps)
-                    samples.extend(xs[:, i] for i in range(xs.shape[1]))
+                    # the last chunk is drawn at the common chunk size and the surplus samples are discarded: one inference
+                    # plan (activation buffers) per evaluation shape instead of one per distinct chunk size
+                    xs = model.sample(x_inf, nt, chunk, dt=1 / opt.n_euler_steps)
+                    samples.extend(xs[:, i] for i in range(min(chunk, opt.n_samples_test - s0)))
             else:
                 samples = (forward_fn(x_inf, nt, dt=1 / opt.n_euler_steps)[0] for _ in range(opt.n_samples_test))
             for x_s in samples:
@@ -146,6 +148,9 @@ def evaluate(forward_fn, val_loader, device, opt):
                     best_x[:, better] = x_s[:, better]
             psnr = _metrics.psnr(best_x, x)
             global_psnr += psnr[inf_len:].mean().item() * n_b
+    model = _unwrap(forward_fn)
+    if model is not None:
+        model.drop_sample_plans()          # tens of GB of S > 1 activation buffers must not stay resident during training
     return -global_psnr / n
 
 
@@ -157,24 +162,48 @@ def write_config(opt, path):
         json.dump(cfg, f, indent=1, sort_keys=True)
 
 
+def _rng_state():
+    return dict(python=random.getstate(), numpy=np.random.get_state(), torch=torch.get_rng_state(),
+                cuda=torch.cuda.get_rng_state() if torch.cuda.is_available() else None)
+
+
+def rank_rng_path(path, rank):
+    """RNG streams differ per rank (numpy is seeded seed + local_rank, train.py:226-228): each rank keeps its own file."""
+    return f'{path}.rng{rank}'
+
+
+def save_rank_rng(path, rank):
+    tmp = rank_rng_path(path, rank) + '.tmp'
+    torch.save(_rng_state(), tmp)
+    os.replace(tmp, rank_rng_path(path, rank))
+
+
 def save_train_state(path, model, optimizer, lr_scheduler, itr, best_val_metric):
     """Everything needed to continue a run bit-for-bit on the same hardware: weights + BN buffers, Adam moments and step,
-    LR schedule, iteration counter, best validation metric, RNG states (python / numpy / torch CPU and device)."""
+    LR schedule, iteration counter, best validation metric, RNG states (python / numpy / torch CPU and device) of the
+    writing rank (rank 0); the other ranks of a data-parallel run save theirs with save_rank_rng."""
     state = dict(model=model.state_dict(), optimizer=optimizer.state_dict(), lr_scheduler=lr_scheduler.state_dict(), itr=itr,
-                 best_val_metric=best_val_metric,
-                 rng=dict(python=random.getstate(), numpy=np.random.get_state(), torch=torch.get_rng_state(),
-                          cuda=torch.cuda.get_rng_state() if torch.cuda.is_available() else None))
+                 best_val_metric=best_val_metric, rng=_rng_state())
     tmp = path + '.tmp'
     torch.save(state, tmp)
     os.replace(tmp, path)
 
 
-def load_train_state(path, model, optimizer, lr_scheduler, device):
+def load_train_state(path, model, optimizer, lr_scheduler, device, rank=0, seed=None):
+    """rank > 0 restores ITS OWN RNG streams (train_state.pt.rng<rank>, written by save_rank_rng); if that file is missing the
+    numpy stream is re-derived from (seed, rank, iteration) so that the ranks never share one data stream after a resume."""
     state = torch.load(path, map_location=device, weights_only=False)
     model.load_state_dict(state['model'])
     optimizer.load_state_dict(state['optimizer'])
     lr_scheduler.load_state_dict(state['lr_scheduler'])
     rng = state.get('rng') or {}
+    if rank > 0:
+        rp = rank_rng_path(path, rank)
+        if os.path.exists(rp):
+            rng = torch.load(rp, map_location='cpu', weights_only=False)
+        else:
+            rng = dict(rng, numpy=None)
+            np.random.seed(((seed or 0) + rank + 7919 * int(state['itr'])) % (2 ** 32))
     if rng.get('python') is not None:
         random.setstate(rng['python'])
     if rng.get('numpy') is not None:
@@ -195,14 +224,16 @@ def main(opt):
     opt.n_gpu = len(opt.device)
     local_rank = int(os.environ.get('LOCAL_RANK', opt.local_rank or 0))
     opt.local_rank = local_rank
-    os.environ.setdefault('HIP_VISIBLE_DEVICES', str(opt.device[local_rank]))
-    device = torch.device('cuda:0')
-    torch.cuda.set_device(0)
+    # train.py:210-212 overwrites CUDA_VISIBLE_DEVICES per process; here --device indexes the devices this process can
+    # already see (an exported HIP_VISIBLE_DEVICES list stays valid, and every rank lands on its own GPU)
+    device = torch.device('cuda', int(opt.device[local_rank]))
+    torch.cuda.set_device(device)
     sync = None
     if opt.n_gpu > 1 or local_rank > 0:
         sync = sdist.init_process_group()
         assert opt.seed is not None
         assert opt.batch_size % opt.n_gpu == 0
+        opt.global_batch_size = opt.batch_size          # what the user passed (and what config.json records)
         opt.batch_size = opt.batch_size // opt.n_gpu
     if opt.seed is None:
         opt.seed = random.randint(1, 10000)
@@ -236,10 +267,13 @@ def main(opt):
     # training state (optimizer moments, LR schedule, iteration, best validation metric, RNG) beside the reference-compatible
     # model*.pt state dicts.  Resume: opt.resume / SRVP_RESUME = directory holding train_state.pt (no new CLI flag).
     if local_rank == 0:
-        write_config(opt, os.path.join(opt.save_path, 'config.json'))
+        cfg_out = dict(opt)
+        cfg_out['batch_size'] = getattr(opt, 'global_batch_size', None) or opt.batch_size
+        write_config(cfg_out, os.path.join(opt.save_path, 'config.json'))
     resume_dir = getattr(opt, 'resume', None) or os.environ.get('SRVP_RESUME')
     if resume_dir:
-        itr, best_val_metric = load_train_state(os.path.join(resume_dir, 'train_state.pt'), model, optimizer, lr_scheduler, device)
+        itr, best_val_metric = load_train_state(os.path.join(resume_dir, 'train_state.pt'), model, optimizer, lr_scheduler, device,
+                                                rank=local_rank, seed=opt.seed)
         print(f'Resumed from {resume_dir} at iteration {itr}')
     try:
         while not finished:
@@ -254,6 +288,8 @@ def main(opt):
                 loss, nll, kl_y_0, kl_z = train(forward_fn, optimizer, None, batch, device, opt)
                 if itr >= opt.lr_scheduling_burnin:
                     lr_scheduler.step()
+                if local_rank > 0 and opt.chkpt_interval is not None and itr % opt.chkpt_interval == 0:
+                    save_rank_rng(os.path.join(opt.save_path, 'train_state.pt'), local_rank)
                 if local_rank == 0:
                     if itr % opt.val_interval == 0 and val_loader is not None:
                         model.eval()
@@ -271,6 +307,8 @@ def main(opt):
     except KeyboardInterrupt:
         status_code = 130
     print('Saving...')
+    if local_rank > 0:
+        save_rank_rng(os.path.join(opt.save_path, 'train_state.pt'), local_rank)
     if local_rank == 0:
         torch.save(model.state_dict(), os.path.join(opt.save_path, 'model.pt'))
         save_train_state(os.path.join(opt.save_path, 'train_state.pt'), model, optimizer, lr_scheduler, itr, best_val_metric)

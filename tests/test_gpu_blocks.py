@@ -50,6 +50,19 @@ CASES = [
     ('conv', 4, 1, 0, 64, 0, False, 4, 128, 5),        # encoder last_conv ("full")
     ('convT', 4, 2, 1, 64, 64, False, 8, 64, 2),       # DCGAN decoder (4 phases) with skip
     ('convT', 4, 1, 0, 50, 0, False, 1, 64, 6),        # decoder first_upconv ("expand"), odd K padded to 64
+    # ---- the widths that carry the FLOPs of VGG-64 (reference module/conv.py:210-223, 335-346), halo kernels at real K
+    ('conv', 3, 1, 1, 512, 0, False, 8, 512, 6),       # encoder.conv.3.2/3.3, decoder.conv.0.1: K = 4608
+    ('conv', 3, 1, 1, 512, 0, False, 8, 256, 5),       # decoder.conv.0.2 (512 -> 256 @ 8x8)
+    ('conv', 3, 1, 1, 256, 0, False, 16, 256, 3),      # encoder.conv.2.2/2.3, decoder.conv.1.1
+    ('conv', 3, 1, 1, 256, 0, False, 16, 512, 2),      # encoder.conv.3.1 geometry (after the pool): 256 -> 512
+    ('conv', 3, 1, 1, 128, 0, False, 32, 64, 2),       # decoder.conv.2.1: wgrad_halo<*,64> at K = 1152
+    ('conv', 3, 1, 1, 64, 0, False, 64, 64, 2),        # encoder.conv.0.1: 64 -> 64 @ 64x64
+    ('conv', 3, 1, 1, 512, 512, True, 4, 512, 4),      # decoder.conv.0.0 as ONE two-source launch (generic kernel, K = 9216)
+    ('conv', 3, 1, 1, 256, 256, True, 8, 256, 3),      # decoder.conv.1.0 likewise
+    ('conv', 4, 2, 1, 256, 0, False, 8, 512, 4),       # DCGAN encoder.conv.3 (K = 4096)
+    ('convT', 4, 2, 1, 512, 0, False, 4, 256, 4),      # DCGAN decoder.conv.0
+    ('conv', 4, 1, 0, 512, 0, False, 4, 128, 7),       # encoder.last_conv at full width (K = 8192)
+    ('convT', 4, 1, 0, 306, 0, False, 1, 512, 5),      # decoder.first_upconv at full width (nh_inf + ny = 306)
 ]
 
 
@@ -231,6 +244,81 @@ def test_conv_halo_split_skip():
     xin = torch.cat([x0, feat_nchw(f1)[smap.cpu().long()]], 1)
     ref = F.conv2d(xin, bf(w.cpu()), None, 1, 1)
     assert rel_err(blk.raw.permute(0, 3, 1, 2).float().cpu(), ref) < 2 ** -7
+
+
+SPLIT_CASES = [
+    # c0r (low-res main input, upsampled x2), c1r (skip), Hs, cout, T, B
+    (512, 512, 4, 512, 3, 2),       # decoder.conv.0.0: 1024 -> 512 @ 8x8 (split skip half + sub-pixel main half)
+    (256, 256, 8, 256, 3, 2),       # decoder.conv.1.0: 512 -> 256 @ 16x16
+    (128, 128, 16, 128, 2, 2),      # decoder.conv.2.0: 256 -> 128 @ 32x32
+    (64, 64, 32, 64, 2, 1),         # decoder.conv.3.0: 128 -> 64 @ 64x64
+]
+
+
+@pytest.mark.parametrize('case', SPLIT_CASES, ids=[f'{c[0]}+{c[1]}to{c[3]}_{2 * c[2]}' for c in SPLIT_CASES])
+def test_split_skip_subpixel_block_full_width(case):
+    """The decoder stage-entry convolutions exactly as the training step runs them (reference module/conv.py:270,331-349 +
+    module/srvp.py:222-223): hoisted skip half conv_s(skip) once per sample + sub-pixel main half on the low-resolution
+    tensor, forward, data-gradients (wrt the low-resolution main input and wrt each sample's skip tensor) and both weight
+    gradients, against torch autograd on cat([upsample(h_t), skip]) with bf16-rounded operands."""
+    from srvp_amd import _lib as L
+    from srvp_amd.convnet import Block
+    c0r, c1r, Hs, cout, T, B = case
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(21)
+    N = T * B
+    f0 = make_feat(N, Hs, Hs, c0r, dev, g)
+    f1 = make_feat(B + 3, 2 * Hs, 2 * Hs, c1r, dev, g)
+    sel = torch.tensor([(3 * b + 1) % (B + 3) for b in range(B)], dtype=torch.int32, device=dev)
+    smap = sel.repeat(T)
+    spec = dict(kind='conv', key='w', bnkey='bn', cin=c0r + c1r, cout=cout, k=3, s=1, p=1, act='leaky_relu')
+    blk = Block(spec, 'mfma', [f0, f1], True, N, dev, True, skip_map=smap, skip_sel=sel)
+    assert blk.split and blk.subpix
+    blk._fwd, blk._dg, blk._wg = blk.fwd_descs(), blk.dgrad_descs(), blk.wgrad_desc()
+    w = (torch.randn(cout, c0r + c1r, 3, 3, generator=g) * 0.05).to(dev)
+    st = L.stream()
+    blk.pack(w, st)
+    blk.stats.zero_()
+    L.call('srvp_conv_mfma', C.byref(blk._fwd[0]), st)
+    L.call('srvp_conv_mfma_multi', (L.ConvDesc * 4)(*blk._fwd[-4:]), 4, st)
+    torch.cuda.synchronize()
+    x0 = F.interpolate(feat_nchw(f0), scale_factor=2, mode='nearest')
+    x1 = feat_nchw(f1)
+    x0 = x0.clone().requires_grad_(True)
+    x1 = x1.clone().requires_grad_(True)
+    xin = torch.cat([x0, x1[smap.cpu().long()]], 1)
+    wr = bf(w.cpu()).clone().requires_grad_(True)
+    ref = F.conv2d(xin, wr, None, 1, 1)
+    raw = blk.raw[..., :cout].permute(0, 3, 1, 2).float().cpu()
+    assert rel_err(raw, ref) < 2 ** -7, rel_err(raw, ref)
+    s1, s2 = ref.sum(dim=(0, 2, 3)).double(), (ref.double() ** 2).sum(dim=(0, 2, 3))
+    assert rel_err(blk.stats[0, :cout], s1) < 4e-3 * max(1.0, (s2.sqrt().max() / (s1.abs().max() + 1e-9)).item())
+    assert rel_err(blk.stats[1, :cout], s2) < 4e-3
+    # ---- backward: draw (per frame) and its sum over time (what srvp_bn_bwd_apply writes beside it)
+    OH = 2 * Hs
+    dr = torch.randn(N, OH, OH, cout, generator=g) * 0.5
+    blk.draw.zero_()
+    blk.draw[:, 1:-1, 1:-1, :cout].copy_(dr)
+    drf = blk.draw[:, 1:-1, 1:-1, :cout].float()
+    blk.draw_sum.zero_()
+    blk.draw_sum[:, 1:-1, 1:-1, :cout].copy_(drf.view(T, B, OH, OH, cout).sum(0))
+    ref.backward(drf.permute(0, 3, 1, 2).cpu())
+    gw = torch.zeros_like(w)
+    blk.dw.zero_(); blk.dw_s.zero_()
+    for d in blk._wg:
+        L.call('srvp_wgrad_mfma', C.byref(d), st)
+    for src, dst, pd in blk.unpack_jobs(gw):
+        L.call('srvp_unpack_wgrad', L.ptr(src), dst, C.byref(pd), st)
+    for d in blk._dg:
+        L.call('srvp_conv_mfma', C.byref(d), st)
+    torch.cuda.synchronize()
+    # main half: exact up to the fp32 summation order; skip half: the time-summed gradient is rounded to bf16 once more
+    assert rel_err(gw[:, :c0r], wr.grad[:, :c0r]) < 2e-3, rel_err(gw[:, :c0r], wr.grad[:, :c0r])
+    assert rel_err(gw[:, c0r:], wr.grad[:, c0r:]) < 6e-3, rel_err(gw[:, c0r:], wr.grad[:, c0r:])
+    d0 = blk.dcat[..., :c0r].permute(0, 3, 1, 2).float().cpu()
+    assert rel_err(d0, F.avg_pool2d(x0.grad, 2) * 4) < 2 ** -7
+    dsel = blk.dsel[..., :c1r].permute(0, 3, 1, 2).float().cpu()
+    assert rel_err(dsel, x1.grad[sel.cpu().long()]) < 2 ** -6
 
 
 @pytest.mark.parametrize('mode', ['plain', 'ups', 'pool', 'skip'])

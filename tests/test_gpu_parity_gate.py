@@ -1,0 +1,171 @@
+"""
+The north_star parity gate at the headline architecture (BASELINE.json: "ELBO within 1e-4 relative of the CPU reference"):
+BAIR shape -- VGG-64, nc=3, skip connections, T=12, n_euler=2 -- at full layer widths on 384 frames (B=32), HIP path in
+its production precision (bf16 MFMA operands / bf16 activation storage) against the fp32 CPU oracle (= the reference's
+arithmetic, oracle pinned by tests/golden/*.npz), forward AND gradients.  Plus SURVEY §8f-1 against the oracle: the
+batched multi-sample rollout `model.sample` and `train.evaluate`'s best-of-N selection vs per-sample oracle forwards.
+"""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'parity_report.jsonl')
+
+
+def report(**kw):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, 'a') as f:
+        f.write(json.dumps(kw) + '\n')
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def cosine(a, b):
+    a, b = a.double().cpu().flatten(), b.double().cpu().flatten()
+    return (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+
+
+def _train_tape(T, B, nt_inf, ny, nz, skipco, g):
+    tape = dict(t_w=torch.stack([torch.randperm(T, generator=g)[:nt_inf] for _ in range(B)], 1),
+                eps_y0=torch.randn(B, ny, generator=g), eps_z=torch.randn(T - 1, B, nz, generator=g))
+    if skipco:
+        tape['t_skip'] = torch.randint(T, (B,), generator=g)
+    return tape
+
+
+def test_bf16_elbo_gate_bair_384_frames():
+    """ELBO <= 1e-4 relative, decoded frames, and per-tensor gradient quality vs the fp32 oracle at 384 frames."""
+    import srvp_amd
+    from oracle import srvp_oracle as O
+    from srvp_amd.train import elbo_terms_and_grads
+    T, B, ne = 12, 32, 2
+    ctor = (64, 3, 64, 128, 50, 50, True, 2, 256, 3, 512, 4, 'vgg')
+    torch.manual_seed(1)
+    model = srvp_amd.StochasticLatentResidualVideoPredictor(*ctor)
+    model.init(1.41)                                   # BAIR recipe (README.md:124-128: default res_gain)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(123)
+    x = torch.rand(T, B, 3, 64, 64, generator=g)
+    tape = _train_tape(T, B, 2, 50, 50, True, g)
+    hp = dict(obs_scale=0.71, beta_y=1.0, beta_z=1.0, l2_res=1.0)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 8
+    torch.set_num_threads(max(1, min(cores, 16)))
+    scal, outs_ref, grads_ref = O.train_step({k: v.clone() for k, v in sd.items()}, O.make_cfg(*ctor), x, ne, tape, hp)
+    model = model.cuda().train()
+    opt = srvp_amd.DotDict(dict(n_euler_steps=ne, **hp))
+    model.flatten_parameters_()
+    model._grads()
+    model._flat[1].zero_()
+    xg = x.cuda()
+    outs = model._forward_impl(xg, T, ne, tape, training=True)
+    x_ = outs[0].clone()
+    acc, gr = elbo_terms_and_grads(model, xg, outs, opt)
+    model._backward_impl(gr[0], None, None, gr[1], gr[2], gr[3], gr[4])
+    nll, kl_y0, kl_z, l2 = acc.cpu().tolist()
+    loss = (nll + kl_y0 + kl_z + l2) / B
+    e_loss = abs(loss - scal['loss']) / abs(scal['loss'])
+    e_nll = abs(nll / B - scal['nll']) / abs(scal['nll'])
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    gerr = {k: rel_l2(grads[k], grads_ref[k]) for k in grads}
+    gcos = {k: cosine(grads[k], grads_ref[k]) for k in grads}
+    flat = torch.cat([grads[k].flatten().double().cpu() for k in grads])
+    flat_ref = torch.cat([grads_ref[k].flatten().double() for k in grads])
+    med = sorted(gerr.values())[len(gerr) // 2]
+    worst = sorted(gerr.items(), key=lambda kv: -kv[1])[:6]
+    wcos = sorted(gcos.items(), key=lambda kv: kv[1])[:6]
+    x_err = (x_.double().cpu() - outs_ref[0].double()).abs().max().item()
+    report(test='bf16_gate_384', frames=T * B, loss=loss, loss_ref=scal['loss'], e_loss=e_loss, e_nll=e_nll, x_maxabs=x_err,
+           median_grad=med, worst_grads=worst, worst_cos=wcos, flat_rel=rel_l2(flat, flat_ref), flat_cos=cosine(flat, flat_ref))
+    assert e_loss <= 1e-4, (loss, scal['loss'], e_loss)            # BASELINE.json north_star
+    assert e_nll <= 1e-4, e_nll
+    assert x_err < 3e-2, x_err
+    # gradients of the whole step in bf16 storage against the fp32 reference arithmetic
+    assert cosine(flat, flat_ref) >= 0.99, cosine(flat, flat_ref)
+    assert min(gcos.values()) >= 0.99, wcos
+    assert med <= 0.05, (med, worst)
+
+
+def _settled_full_width_model(nc, nt_inf, gain, seed, x_warm, ne):
+    import srvp_amd
+    torch.manual_seed(seed)
+    ctor = (64, nc, 64, 128, 50, 50, True, nt_inf, 256, 3, 512, 4, 'vgg')
+    model = srvp_amd.StochasticLatentResidualVideoPredictor(*ctor)
+    model.init(gain)
+    model.cuda().train()
+    with torch.no_grad():                     # settle the BN running statistics (eval mode uses them)
+        for _ in range(12):
+            model(x_warm.cuda(), x_warm.shape[0], 1 / ne)
+    model.eval()
+    return model, ctor
+
+
+def test_batched_samples_vs_oracle_full_width():
+    """SURVEY §8f-1 against the ORACLE: model.sample(x, nt, S=3) on a given tape == three oracle inference forwards
+    (reference train.py:170-174 / test.py:237-246: one forward per sample, each re-encoding the conditioning frames)."""
+    from oracle import srvp_oracle as O
+    nc, nt_cond, nt, ne, S, B = 3, 4, 10, 2, 3, 2
+    g = torch.Generator().manual_seed(99)
+    xw = torch.rand(nt_cond, 6, nc, 64, 64, generator=g)
+    model, ctor = _settled_full_width_model(nc, 2, 1.2, 5, xw, ne)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    x = xw[:, :B].contiguous()
+    eps_y0 = torch.randn(S * B, 50, generator=g)
+    eps_z = torch.randn(nt - 1, S * B, 50, generator=g)
+    xs = model.sample(x.cuda(), nt, S, dt=1 / ne, tape=dict(eps_y0=eps_y0, eps_z=eps_z)).cpu()
+    assert xs.shape == (nt, S, B, nc, 64, 64)
+    torch.set_num_threads(8)
+    errs = []
+    with torch.no_grad():
+        for s in range(S):
+            tape = dict(eps_y0=eps_y0[s * B:(s + 1) * B], eps_z=eps_z[:, s * B:(s + 1) * B])
+            ref = O.forward({k: v.clone() for k, v in sd.items()}, O.make_cfg(*ctor), x, nt, ne, tape, training=False)[0]
+            errs.append((xs[:, s] - ref).abs().max().item())
+    report(test='sample_vs_oracle', errs=errs)
+    assert max(errs) < 3e-2, errs
+    assert (xs[:, 0] - xs[:, 1]).abs().max() > 1e-3                 # the futures do differ
+
+
+def test_evaluate_best_of_n_vs_oracle_full_width():
+    """train.evaluate (reference train.py:132-189) at full width: best-of-N PSNR selection from model.sample + the device
+    metrics kernel, against the same protocol done entirely by the oracle (per-sample inference forwards on the same
+    draws, float64 PSNR, arg-max per video)."""
+    import srvp_amd
+    from oracle import srvp_oracle as O
+    from srvp_amd.train import evaluate
+    nc, nt_cond, nt, ne, S, B = 1, 3, 8, 2, 3, 2
+    g = torch.Generator().manual_seed(17)
+    xw = torch.rand(nt, 6, nc, 64, 64, generator=g)
+    model, ctor = _settled_full_width_model(nc, 2, 1.2, 6, xw[:nt_cond], ne)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    x = xw[:, :B].contiguous()
+    dev = torch.device('cuda')
+    opt = srvp_amd.DotDict(dict(nt_cond=nt_cond, n_iter_test=1, n_samples_test=S, n_euler_steps=ne))
+    torch.manual_seed(77)
+    got = evaluate(model, [x], dev, opt)
+    # the draws evaluate() made: model.sample draws eps_y0 then eps_z from the device generator (model._draw_tape)
+    torch.manual_seed(77)
+    eps_y0 = torch.randn(B * S, 50, device=dev).cpu()
+    eps_z = torch.randn(nt - 1, B * S, 50, device=dev).cpu()
+    torch.set_num_threads(8)
+    ps, xs = [], []
+    with torch.no_grad():
+        for s in range(S):
+            tape = dict(eps_y0=eps_y0[s * B:(s + 1) * B], eps_z=eps_z[:, s * B:(s + 1) * B])
+            x_s = O.forward({k: v.clone() for k, v in sd.items()}, O.make_cfg(*ctor), x[:nt_cond], nt, ne, tape, training=False)[0]
+            xs.append(x_s)
+            ps.append(O.video_psnr(x_s, x).mean(dim=(0, 2)))                      # (B,)  train.py:175-176
+    best = torch.stack(ps).argmax(0)
+    bx = torch.stack([xs[best[b]][:, b] for b in range(B)], 1)
+    want = -O.video_psnr(bx, x)[nt_cond:].mean().item()
+    report(test='evaluate_vs_oracle', got=got, want=want)
+    # PSNR of bf16-path frames (<= 3e-2 max-abs, ~1e-3 typical) against fp32-path frames on noise-like targets
+    assert abs(got - want) <= 2e-3 * abs(want), (got, want)
