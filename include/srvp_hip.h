@@ -65,6 +65,9 @@ typedef struct {
     const int32_t* map0; int32_t dst_is_f32; const float* add_f32; int32_t add_mod;
     int32_t wt_fragmajor;         /* wt is packed MFMA-fragment-major (srvp_pack_desc.layout 1): required by, and only valid
                                    * for, launches that srvp_conv_wants_fragmajor() accepts */
+    int32_t elem_f32;             /* 1: precision = 'fp32' parity mode -- src0 / src1 / dst / wt are FP32 tensors of the same NHWC
+                                   * shapes (wt tap-major, srvp_pack_desc.dst_f32) and the contraction runs in exact fp32 on the
+                                   * matrix cores (v_mfma_f32_32x32x2_f32 = a k-ordered fmaf chain), csrc/conv_f32.hip */
 } srvp_conv_desc;
 int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
 /* 1 (default): 3x3 stride-1 single-source convolutions run on the halo-tiled kernel (input patch staged in LDS once
@@ -92,6 +95,7 @@ typedef struct {
     float* dw;                    /* fp32 [ntaps][Cout][C0+C1], accumulated into */
     int32_t splitk;
     const int32_t* map0;          /* image indirection for src0 (NULL = identity) */
+    int32_t elem_f32;             /* 1: src0 / src1 / dout are fp32 tensors (fp32 parity mode, exact-fp32 MFMA) */
 } srvp_wgrad_desc;
 int srvp_wgrad_mfma(const srvp_wgrad_desc* d, void* stream);
 /* 1: fragments through ds_read_b64_tr_b16 (default), 0: 16-bit LDS reads (conservative fallback) */
@@ -124,6 +128,12 @@ int srvp_bn_act_keep(const void* raw, const float* scale, const float* shift, in
                      void* dst, int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep_frames,
                      void* stream);
 
+/* fp32 parity mode: raw / dst / dst_pool are fp32 tensors of the same shapes */
+int srvp_bn_act_keep_f32(const void* raw, const float* scale, const float* shift, int act,
+                         int N, int H, int W, int C,
+                         void* dst, int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep_frames,
+                         void* stream);
+
 /* backward of activation+BN.  dA comes from one or two places:
  *   main: tensor `da` with channel stride da_cstride / offset da_coff, mode 0 = same resolution,
  *         mode 1 = gradient of the nearest-x2-upsampled tensor (sum the 2x2 block),
@@ -138,6 +148,7 @@ typedef struct {
     int32_t N, H, W, C;
     void* tsum; int32_t tsum_T;                             /* apply only: bf16 [N/T][H+2b][W+2b][C] = sum over the T time steps (frames
                                                              * ordered t*B + b) of the written gradient, or NULL */
+    int32_t elem_f32;                                       /* 1: raw / act / da / da2 / tsum / draw are fp32 tensors (fp32 parity mode) */
 } srvp_bnbwd_desc;
 int srvp_bn_bwd_reduce(const srvp_bnbwd_desc* d, double* red, void* stream);
 /* red -> dgamma, dbeta (accumulated into fp32 grads when non-NULL) and the per-channel coefficients used by apply */
@@ -156,6 +167,13 @@ int srvp_conv_in_fwd(const float* x, const float* w, void* raw, double* stats,
 /* dW[Cout_real][Cin][k][k] += sum draw * x   (draw: bf16 padded(border 1) [N][OH+2][OW+2][Cout]) */
 int srvp_conv_in_wgrad(const float* x, const void* draw, float* dw,
                        int N, int Cin, int H, int W, int Cout, int Cout_real, int k, int s, int p, void* stream);
+/* fp32 parity mode: raw / draw are fp32 NHWC tensors (direct fp32 kernels: an fmaf chain in (ci, kh, kw) order) */
+int srvp_conv_in_fwd_f32(const float* x, const float* w, void* raw, double* stats,
+                         int N, int Cin, int H, int W, int Cout, int Cout_real, int k, int s, int p, void* stream);
+int srvp_conv_in_wgrad_f32(const float* x, const void* draw, float* dw,
+                           int N, int Cin, int H, int W, int Cout, int Cout_real, int k, int s, int p, void* stream);
+int srvp_out_dpre_f32(const float* x_out, const float* dx_out, void* draw, float* dpre_f32,
+                      int N, int nc, int H, int W, int C, int apply_sigmoid, void* stream);
 /* sigmoid backward of the last decoder layer (conv.py:273-274): dpre = dx_ * x_ * (1 - x_) from the fp32
  * (N, nc, H, W) frame tensors into a bf16 NHWC tensor [N][H+2][W+2][C] (zero border, channels >= nc zero) */
 /* draw == NULL: only the fp32 copy is produced (the caller runs both gradients of the layer on srvp_conv_in_fwd / _wgrad) */
@@ -183,6 +201,7 @@ typedef struct {
      * v_mfma_f32_32x32x16_bf16 is then ONE contiguous 1 KiB load (the halo-tiled convolution reads its weights straight
      * from L2 into registers in this order).  Needs J % 32 == 0 and K % 64 == 0. */
     int32_t layout;
+    int32_t dst_f32;              /* 1: the packed tensor is fp32 instead of bf16 (fp32 parity mode; layout 0 only) */
 } srvp_pack_desc;
 int srvp_pack_weight(const float* src, void* dst, const srvp_pack_desc* d, void* stream);
 /* fp32 gradient: w_grad[ jr*sj + kr*sk + tap_off[t] ] += packed_grad[t][j][k]  (inverse mapping, for dW) */
@@ -291,6 +310,8 @@ int srvp_frames_u8_to_f32(const void* in_u8, float* out, int B, int T, int H, in
 int srvp_mmnist_render(const void* digits_u8, int n_digits, int dh, int dw, const int* idx, const int* pos, int B, int T,
                        int num_digits, int nx, float* out, void* out_u8, void* stream);
 int srvp_cast_f32_bf16(const float* src, void* dst, int64_t rows, int cols, int dst_cols, void* stream);
+/* fp32 parity mode: the same zero-padding row copy into an fp32 [rows][dst_cols] tensor */
+int srvp_pad_f32(const float* src, float* dst, int64_t rows, int cols, int dst_cols, void* stream);
 /* evaluation metrics: x, y = `planes` float32 planes of H x W (<= 64 x 64; (nt*B*C) planes of NCHW frames).
  * mse[p] = mean((x-y)^2) (test.py:249; PSNR = 10 log10(1/mse), test.py:251, train.py:175-176);
  * ssim[p] = mean over the (H-F+1) x (W-F+1) window positions of the SSIM map of metrics/ssim.py:92-110 (gaussian window
@@ -300,6 +321,7 @@ int srvp_frame_metrics(const float* x, const float* y, int64_t planes, int H, in
 /* dsel[b][hw][c] = sum_t dcat[t*B+b][hw][coff+c]  (gradient of the skip expand over time, srvp.py:222-223; the
  * gather of srvp.py:187 is undone by srvp_bn_bwd_* through da2_idx) */
 int srvp_skip_grad_reduce(const void* dcat, int cstride, int coff, int C, int HW, int T, int B, void* dsel, void* stream);
+int srvp_skip_grad_reduce_f32(const void* dcat, int cstride, int coff, int C, int HW, int T, int B, void* dsel, void* stream);
 
 #ifdef __cplusplus
 }

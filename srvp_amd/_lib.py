@@ -32,7 +32,8 @@ class ConvDesc(C.Structure):
                 ('Cdst', c_i32), ('cdst_off', c_i32),
                 ('stats', c_vp), ('stat_mod', c_i32),
                 ('out_f32', c_vp), ('out_nc', c_i32), ('out_sigmoid', c_i32),
-                ('map0', c_vp), ('dst_is_f32', c_i32), ('add_f32', c_vp), ('add_mod', c_i32), ('wt_fragmajor', c_i32)]
+                ('map0', c_vp), ('dst_is_f32', c_i32), ('add_f32', c_vp), ('add_mod', c_i32), ('wt_fragmajor', c_i32),
+                ('elem_f32', c_i32)]
 
 
 class WgradDesc(C.Structure):
@@ -43,7 +44,7 @@ class WgradDesc(C.Structure):
                 ('ntaps', c_i32), ('dy', TAPS), ('dx', TAPS),
                 ('dout', c_vp), ('DHp', c_i32), ('DWp', c_i32), ('so', c_i32), ('ooy', TAPS), ('oox', TAPS),
                 ('Cout', c_i32), ('N', c_i32), ('OH', c_i32), ('OW', c_i32),
-                ('dw', c_vp), ('splitk', c_i32), ('map0', c_vp)]
+                ('dw', c_vp), ('splitk', c_i32), ('map0', c_vp), ('elem_f32', c_i32)]
 
 
 class BnBwdDesc(C.Structure):
@@ -52,13 +53,13 @@ class BnBwdDesc(C.Structure):
                 ('da', c_vp), ('da_mode', c_i32), ('da_cstride', c_i32), ('da_coff', c_i32), ('da_border', c_i32),
                 ('da_is_f32', c_i32),
                 ('da2', c_vp), ('da2_idx', c_vp),
-                ('N', c_i32), ('H', c_i32), ('W', c_i32), ('C', c_i32), ('tsum', c_vp), ('tsum_T', c_i32)]
+                ('N', c_i32), ('H', c_i32), ('W', c_i32), ('C', c_i32), ('tsum', c_vp), ('tsum_T', c_i32), ('elem_f32', c_i32)]
 
 
 class PackDesc(C.Structure):
     _fields_ = [('ntaps', c_i32), ('tap_off', TAPS), ('J', c_i32), ('K', c_i32),
                 ('J0', c_i32), ('J0r', c_i32), ('J1r', c_i32), ('K0', c_i32), ('K0r', c_i32), ('K1r', c_i32),
-                ('sj', c_i64), ('sk', c_i64), ('tap_set', TAPS), ('layout', c_i32)]
+                ('sj', c_i64), ('sk', c_i64), ('tap_set', TAPS), ('layout', c_i32), ('dst_f32', c_i32)]
 
 
 class PackJob(C.Structure):
@@ -94,11 +95,15 @@ _SIGS = {
     'srvp_bn_eval_coeffs': ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp], c_i32),
     'srvp_bn_act': ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp], c_i32),
     'srvp_bn_act_keep': ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp], c_i32),
+    'srvp_bn_act_keep_f32': ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp], c_i32),
     'srvp_bn_bwd_reduce': ([C.POINTER(BnBwdDesc), c_vp, c_vp], c_i32),
     'srvp_bn_bwd_finalize': ([c_vp, c_f64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_bn_bwd_apply': ([C.POINTER(BnBwdDesc), c_vp, c_vp, c_i32, c_vp], c_i32),
     'srvp_conv_in_fwd': ([c_vp, c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp], c_i32),
     'srvp_conv_in_wgrad': ([c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp], c_i32),
+    'srvp_conv_in_fwd_f32': ([c_vp, c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp], c_i32),
+    'srvp_conv_in_wgrad_f32': ([c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp], c_i32),
+    'srvp_out_dpre_f32': ([c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_out_dpre': ([c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_pack_weight': ([c_vp, c_vp, C.POINTER(PackDesc), c_vp], c_i32),
     'srvp_pack_weight_multi': ([c_vp, c_i32, c_i64, c_vp], c_i32),
@@ -123,6 +128,8 @@ _SIGS = {
     'srvp_frames_u8_to_f32': ([c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_mmnist_render': ([c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp], c_i32),
     'srvp_cast_f32_bf16': ([c_vp, c_vp, c_i64, c_i32, c_i32, c_vp], c_i32),
+    'srvp_pad_f32': ([c_vp, c_vp, c_i64, c_i32, c_i32, c_vp], c_i32),
+    'srvp_skip_grad_reduce_f32': ([c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp], c_i32),
     'srvp_frame_metrics': ([c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp], c_i32),
     'srvp_skip_grad_reduce': ([c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp], c_i32),
 }

@@ -46,10 +46,11 @@ def cpad(c):
 class Feat:
     """NHWC bf16 tensor [N][H+2b][W+2b][C] with zero border b; Cr = number of real channels."""
 
-    def __init__(self, N, H, W, Cr, device, b=1, C=None):
+    def __init__(self, N, H, W, Cr, device, b=1, C=None, dtype=torch.bfloat16):
+        """dtype: torch.bfloat16 (production) or torch.float32 (precision = 'fp32' parity mode)."""
         self.N, self.H, self.W, self.Cr, self.b = N, H, W, Cr, b
         self.C = cpad(Cr) if C is None else C
-        self.t = torch.zeros(N, H + 2 * b, W + 2 * b, self.C, dtype=torch.bfloat16, device=device)
+        self.t = torch.zeros(N, H + 2 * b, W + 2 * b, self.C, dtype=dtype, device=device)
 
     @property
     def Hp(self):
@@ -86,13 +87,17 @@ def _pack_desc(taps_off, J, K, Jsegs, Ksegs, sj, sk, tap_sets=None):
 class Block:
     """One conv block (conv -> [BN] -> act) of the encoder or decoder: buffers + launch descriptors."""
 
-    def __init__(self, spec, role, srcs, ups, N, device, training, skip_map=None, skip_sel=None):
+    def __init__(self, spec, role, srcs, ups, N, device, training, skip_map=None, skip_sel=None, f32=False):
         """
         role: 'in' (fp32 frames in), 'mfma', 'out' (fp32 frames out)
         srcs: list of source Feat (1 or 2) -- for role 'in' empty;  ups: nearest-x2 applied to srcs[0] by the gather
+        f32: precision = 'fp32' parity mode -- every activation / gradient / packed-weight tensor of the block is fp32 and the
+             launches carry elem_f32 = 1 (exact-fp32 MFMA kernels, csrc/conv_f32.hip)
         """
         self.spec, self.role, self.srcs, self.ups, self.N, self.dev = spec, role, srcs, ups, N, device
         self.training = training
+        self.f32 = bool(f32)
+        self.adt = torch.float32 if f32 else torch.bfloat16
         self.skip_map = skip_map                      # int32 [N] image index into srcs[1]
         self.skip_sel = skip_sel                      # int32 [B] sample -> image index into srcs[1] (hoisted skip half)
         k, s, p = spec['k'], spec['s'], spec['p']
@@ -145,7 +150,7 @@ class Block:
         self.ctot = sum(f.C for f in srcs) if srcs else 0
         self.dcat_c = srcs[0].C if self.split else self.ctot     # channels of the input-gradient tensor `dcat`
         if role != 'out':
-            self.raw = torch.empty(N, self.OH, self.OW, self.cout, dtype=torch.bfloat16, device=device)
+            self.raw = torch.empty(N, self.OH, self.OW, self.cout, dtype=self.adt, device=device)
             C_ = self.cout
             self.coef = torch.zeros(4, C_, dtype=torch.float32, device=device)      # scale, shift, mean, invstd
             if not self.has_bn:
@@ -164,11 +169,11 @@ class Block:
             # gradient wrt the (virtual, concatenated) input of this block: [N][Hin][Win][ctot] bf16, unpadded
             # (sub-pixel blocks: gradient wrt the LOW-resolution source, i.e. already summed over each 2x2 upsample cell)
             dh, dw_ = (srcs[0].H, srcs[0].W) if self.subpix else (self.Hin, self.Win)
-            self.dcat = torch.empty(N, dh, dw_, self.dcat_c, dtype=torch.bfloat16, device=device)
+            self.dcat = torch.empty(N, dh, dw_, self.dcat_c, dtype=self.adt, device=device)
         if training:
             self.draw_b = 0 if (role == 'mfma' and self.geom in ('full', 'expand')) else 1
             bd = self.draw_b
-            self.draw = torch.zeros(N, self.OH + 2 * bd, self.OW + 2 * bd, self.cout, dtype=torch.bfloat16, device=device)
+            self.draw = torch.zeros(N, self.OH + 2 * bd, self.OW + 2 * bd, self.cout, dtype=self.adt, device=device)
         if training and role != 'out':
             self.red = torch.zeros(2, self.cout, dtype=torch.float64, device=device)
             self.bcoef = torch.zeros(3, self.cout, dtype=torch.float32, device=device)
@@ -179,12 +184,19 @@ class Block:
             f1 = srcs[1]
             self.S = torch.empty(self.B, self.OH, self.OW, self.cout, dtype=torch.float32, device=device)
             if training:
-                self.draw_sum = torch.zeros(self.B, self.OH + 2, self.OW + 2, self.cout, dtype=torch.bfloat16, device=device)
-                self.dsel = torch.empty(self.B, self.Hin, self.Win, f1.C, dtype=torch.bfloat16, device=device)
+                self.draw_sum = torch.zeros(self.B, self.OH + 2, self.OW + 2, self.cout, dtype=self.adt, device=device)
+                self.dsel = torch.empty(self.B, self.Hin, self.Win, f1.C, dtype=self.adt, device=device)
                 self.dw_s = torch.zeros(self.k * self.k, self.cout, f1.C, dtype=torch.float32, device=device)
 
     # ------------------------------------------------------------------ weights
     def _alloc_weights(self):
+        self._alloc_weights_impl()
+        for name in ('pf', 'pd', 'pu', 'pf_s', 'pd_s'):          # fp32 parity mode: every packed weight tensor is fp32
+            pd = getattr(self, name, None)
+            if pd is not None:
+                pd.dst_f32 = 1 if self.f32 else 0
+
+    def _alloc_weights_impl(self):
         k, kk = self.k, self.k * self.k
         dev = self.dev
         co_p, co_r = self.cout, self.cout_r
@@ -227,23 +239,23 @@ class Block:
             self.pd_s = _pack_desc(nat, c1p, co_p, sg, osegs, sk_f, sj_f)
             self.s_off = c0r * sk_f                  # element offset of the skip half inside the fp32 weight
             kh_ = 16 if self.subpix else kk
-            self.wt_f = torch.empty(kh_, co_p, c0p, dtype=torch.bfloat16, device=dev)
-            self.wt_f_s = torch.empty(kk, co_p, c1p, dtype=torch.bfloat16, device=dev)
-            self.wt_d = torch.empty(kh_, c0p, co_p, dtype=torch.bfloat16, device=dev) if self.training else None
-            self.wt_d_s = torch.empty(kk, c1p, co_p, dtype=torch.bfloat16, device=dev) if self.training else None
+            self.wt_f = torch.empty(kh_, co_p, c0p, dtype=self.adt, device=dev)
+            self.wt_f_s = torch.empty(kk, co_p, c1p, dtype=self.adt, device=dev)
+            self.wt_d = torch.empty(kh_, c0p, co_p, dtype=self.adt, device=dev) if self.training else None
+            self.wt_d_s = torch.empty(kk, c1p, co_p, dtype=self.adt, device=dev) if self.training else None
             return
         if self.subpix:
             self.pf = _pack_desc(z16, co_p, c0p, osegs, h, sj_f, sk_f, fsets)
             self.pd = _pack_desc(z16, c0p, co_p, h, osegs, sk_f, sj_f, dsets)
             self.pu = self.pf
-            self.wt_f = torch.empty(16, co_p, c0p, dtype=torch.bfloat16, device=dev)
-            self.wt_d = torch.empty(16, c0p, co_p, dtype=torch.bfloat16, device=dev) if self.training else None
+            self.wt_f = torch.empty(16, co_p, c0p, dtype=self.adt, device=dev)
+            self.wt_d = torch.empty(16, c0p, co_p, dtype=self.adt, device=dev) if self.training else None
             return
         self.pf = _pack_desc(order_f, co_p, self.ctot, osegs, isegs, sj_f, sk_f)
         self.pd = _pack_desc(order_d, self.ctot, co_p, isegs, osegs, sk_f, sj_f)
         self.pu = _pack_desc(nat, co_p, self.ctot, osegs, isegs, sj_f, sk_f)
-        self.wt_f = torch.empty(kk, co_p, self.ctot, dtype=torch.bfloat16, device=dev)
-        self.wt_d = torch.empty(kk, self.ctot, co_p, dtype=torch.bfloat16, device=dev) if self.training else None
+        self.wt_f = torch.empty(kk, co_p, self.ctot, dtype=self.adt, device=dev)
+        self.wt_d = torch.empty(kk, self.ctot, co_p, dtype=self.adt, device=dev) if self.training else None
 
     def pack_jobs(self, w):
         """[(fp32 source pointer, packed destination tensor, pack descriptor)] of this block's weight buffers."""
@@ -291,12 +303,13 @@ class Block:
         else:
             d.src1, d.C1, d.H1p, d.W1p, d.ups1, d.map1 = None, 0, 1, 1, 0, None
 
-    @staticmethod
-    def _set_layout(descs, pack_desc):
+    def _set_layout(self, descs, pack_desc):
         """Launches that run on the halo-tiled kernel read their weights MFMA-fragment-major: ask the library, mark the
         descriptors and the pack descriptor of that weight buffer (all launches sharing a buffer agree by construction)."""
         if not descs:
             return
+        for d in descs:
+            d.elem_f32 = 1 if self.f32 else 0
         want = [int(L.load().srvp_conv_wants_fragmajor(C.byref(d))) for d in descs]
         assert len(set(want)) == 1, want
         if sum(d.ntaps for d in descs) != pack_desc.ntaps:
@@ -387,7 +400,7 @@ class Block:
                 self._src_fields(d)
                 self._set_taps(d, [(dy, dx) for _, dy in PHASE[py] for _, dx in PHASE[px]])
                 d.si, d.Cout = 1, self.cout
-                d.wt = L.ptr(self.wt_f) + ph * 4 * self.cout * self.ctot * 2
+                d.wt = L.ptr(self.wt_f) + ph * 4 * self.cout * self.ctot * self.wt_f.element_size()
                 d.N, d.OH, d.OW = N, self.Hin, self.Win
                 d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox, d.Cdst, d.cdst_off = dst_ptr, self.OH, self.OW, 2, py, px, self.cout, 0
                 d.stats, d.stat_mod = (L.ptr(self.stats) if use_stats else None), self.cout
@@ -414,7 +427,7 @@ class Block:
             d.src1, d.C1, d.H1p, d.W1p, d.ups1, d.map1 = None, 0, 1, 1, 0, None
             self._set_taps(d, [(a + u, b + v) for u in (0, 1) for v in (0, 1)])
             d.si, d.Cout = 1, self.cout
-            d.wt = L.ptr(self.wt_f) + ph * 4 * self.cout * f0.C * 2
+            d.wt = L.ptr(self.wt_f) + ph * 4 * self.cout * f0.C * self.wt_f.element_size()
             d.N, d.OH, d.OW = self.N, f0.H, f0.W
             d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox, d.Cdst, d.cdst_off = dst_ptr, self.OH, self.OW, 2, a, b, self.cout, 0
             d.stats, d.stat_mod = (L.ptr(self.stats) if use_stats else None), self.cout
@@ -488,7 +501,7 @@ class Block:
                 d = base()
                 self._set_taps(d, [(dy, dx) for _, dy in PHASE[py] for _, dx in PHASE[px]])
                 d.si = 1
-                d.wt = L.ptr(self.wt_d) + ph * 4 * self.ctot * self.cout * 2
+                d.wt = L.ptr(self.wt_d) + ph * 4 * self.ctot * self.cout * self.wt_d.element_size()
                 d.N, d.OH, d.OW = N, self.OH, self.OW
                 d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox = L.ptr(self.dcat), self.Hin, self.Win, 2, py, px
                 out.append(d)
@@ -526,6 +539,7 @@ class Block:
     def _wgrad_one(self, which):
         k, N, bd = self.k, self.N, self.draw_b
         d = L.WgradDesc()
+        d.elem_f32 = 1 if self.f32 else 0
         self._src_fields(d, which)
         b_in = self.srcs[0].b
         nat = [(kh, kw) for kh in range(k) for kw in range(k)]
@@ -605,7 +619,7 @@ class ConvNetBase:
                 L.call('srvp_bn_eval_coeffs', L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(scale), L.ptr(shift), C_,
                        blk.cout_r, BN_EPS, st)
         out, pool = blk.out, blk.pool
-        L.call('srvp_bn_act_keep', L.ptr(blk.raw), L.ptr(scale), L.ptr(shift), blk.act, N, blk.OH, blk.OW, C_,
+        L.call('srvp_bn_act_keep_f32' if blk.f32 else 'srvp_bn_act_keep', L.ptr(blk.raw), L.ptr(scale), L.ptr(shift), blk.act, N, blk.OH, blk.OW, C_,
                L.ptr(out.t) if out is not None else None, out.b if out is not None else 0,
                L.ptr(pool.t) if pool is not None else None, pool.b if pool is not None else 0,
                L.ptr(blk.out_f32), L.ptr(keep) if pool is not None else None, st)
@@ -613,7 +627,7 @@ class ConvNetBase:
     def _block_forward(self, blk, params, st, sync, x=None, keep=None):
         if blk.role == 'in':
             w = params[blk.spec['key'] + '.weight']
-            L.call('srvp_conv_in_fwd', L.ptr(x), L.ptr(w), L.ptr(blk.raw),
+            L.call('srvp_conv_in_fwd_f32' if blk.f32 else 'srvp_conv_in_fwd', L.ptr(x), L.ptr(w), L.ptr(blk.raw),
                    L.ptr(blk.stats) if (blk.has_bn and blk.training) else None,
                    blk.N, blk.cin_r[0], 64, 64, blk.cout, blk.cout_r, blk.k, blk.s, blk.p, st)
         elif blk.subpix:
@@ -633,6 +647,7 @@ class ConvNetBase:
     def _bn_backward(self, blk, params, grads, da, st, sync):
         """da: dict(t, mode, cstride, coff, border, f32, da2, da2_idx).  Produces blk.draw (and BN param grads)."""
         d = L.BnBwdDesc()
+        d.elem_f32 = 1 if blk.f32 else 0
         d.raw = L.ptr(blk.raw)
         d.act, d.act_border = (L.ptr(blk.out.t), blk.out.b) if blk.out is not None else (None, 0)
         d.scale, d.shift, d.mean, d.invstd = (L.ptr(blk.coef[i]) for i in range(4))
@@ -734,13 +749,14 @@ class ConvNetBase:
 class EncoderNet(ConvNetBase):
     """conv.py:129-154 on N = T*B frames: x fp32 (N, C, 64, 64) -> hx fp32 (N, nh) and the stage outputs (skips)."""
 
-    def __init__(self, specs, N, device, training):
-        self.N, self.dev, self.training = N, device, training
+    def __init__(self, specs, N, device, training, f32=False):
+        self.N, self.dev, self.training, self.f32 = N, device, training, bool(f32)
+        adt = torch.float32 if f32 else torch.bfloat16
         self.blocks = []
         cur = None
         for i, sp in enumerate(specs):
             role = 'in' if i == 0 else 'mfma'
-            blk = Block(sp, role, [] if role == 'in' else [cur], False, N, device, training)
+            blk = Block(sp, role, [] if role == 'in' else [cur], False, N, device, training, f32=f32)
             last = i == len(specs) - 1
             nxt_pool = (not last) and specs[i + 1]['pre'] == 'pool'
             if last:
@@ -748,9 +764,9 @@ class EncoderNet(ConvNetBase):
                 cur = None
             else:
                 need_full = (sp['skip_out'] is not None) or not nxt_pool or training
-                blk.out = Feat(N, blk.OH, blk.OW, blk.cout_r, device) if need_full else None
+                blk.out = Feat(N, blk.OH, blk.OW, blk.cout_r, device, dtype=adt) if need_full else None
                 if nxt_pool:
-                    blk.pool = Feat(N, blk.OH // 2, blk.OW // 2, blk.cout_r, device)
+                    blk.pool = Feat(N, blk.OH // 2, blk.OW // 2, blk.cout_r, device, dtype=adt)
                     cur = blk.pool
                 else:
                     cur = blk.out
@@ -792,7 +808,7 @@ class EncoderNet(ConvNetBase):
             self._bn_backward(blk, params, grads, da, st, sync)
             if blk.role == 'in':
                 w = blk.spec['key'] + '.weight'
-                L.call('srvp_conv_in_wgrad', L.ptr(x), L.ptr(blk.draw), L.ptr(grads[w]), blk.N, blk.cin_r[0], 64, 64,
+                L.call('srvp_conv_in_wgrad_f32' if blk.f32 else 'srvp_conv_in_wgrad', L.ptr(x), L.ptr(blk.draw), L.ptr(grads[w]), blk.N, blk.cin_r[0], 64, 64,
                        blk.cout, blk.cout_r, blk.k, blk.s, blk.p, st)
             else:
                 self._mfma_backward(blk, grads, st)
@@ -804,13 +820,14 @@ class EncoderNet(ConvNetBase):
 class DecoderNet(ConvNetBase):
     """conv.py:249-275 on N = nt*B latent rows: z (N, nz) -> x_ fp32 (N, C, 64, 64); skips come from an EncoderNet."""
 
-    def __init__(self, specs, N, device, training, skip_feats=None, skip_map=None, skip_sel=None):
+    def __init__(self, specs, N, device, training, skip_feats=None, skip_map=None, skip_sel=None, f32=False):
         """skip_map: int32 [N] frame -> image of the skip tensors; skip_sel: int32 [B] sample -> image (enables the
         hoisted skip half; frames are ordered t*B + b)."""
-        self.N, self.dev, self.training = N, device, training
+        self.N, self.dev, self.training, self.f32 = N, device, training, bool(f32)
+        adt = torch.float32 if f32 else torch.bfloat16
         self.blocks = []
         z_r = specs[0]['cin']
-        self.z = Feat(N, 1, 1, z_r, device, b=0)
+        self.z = Feat(N, 1, 1, z_r, device, b=0, dtype=adt)
         cur, ups = self.z, False
         for i, sp in enumerate(specs):
             last = i == len(specs) - 1
@@ -819,9 +836,9 @@ class DecoderNet(ConvNetBase):
                 srcs.append(skip_feats[sp['cat']])
             blk = Block(sp, 'out' if last else 'mfma', srcs, ups, N, device, training,
                         skip_map=skip_map if sp['cat'] is not None else None,
-                        skip_sel=skip_sel if sp['cat'] is not None else None)
+                        skip_sel=skip_sel if sp['cat'] is not None else None, f32=f32)
             if not last:
-                blk.out = Feat(N, blk.OH, blk.OW, blk.cout_r, device)
+                blk.out = Feat(N, blk.OH, blk.OW, blk.cout_r, device, dtype=adt)
                 cur, ups = blk.out, sp['post_up']
             self.blocks.append(blk)
         self._pool_accumulators()
@@ -845,7 +862,7 @@ class DecoderNet(ConvNetBase):
 
     def forward(self, z_f32, params, st, sync=None):
         """z_f32: fp32 [N][nz_real]"""
-        L.call('srvp_cast_f32_bf16', L.ptr(z_f32), L.ptr(self.z.t), self.N, z_f32.shape[1], self.z.C, st)
+        L.call('srvp_pad_f32' if self.f32 else 'srvp_cast_f32_bf16', L.ptr(z_f32), L.ptr(self.z.t), self.N, z_f32.shape[1], self.z.C, st)
         if self.training:
             self.zero_forward_accumulators()
         for blk in self.blocks[:-1]:
@@ -878,7 +895,7 @@ class DecoderNet(ConvNetBase):
         ConvTranspose weight's (Cin, nc, k, k) gradient, in fp32."""
         ob = self.blocks[-1]
         f0 = ob.srcs[0]
-        L.call('srvp_conv_in_wgrad', L.ptr(self.dpre_f32), L.ptr(f0.t), L.ptr(grads[ob.spec['key'] + '.weight']),
+        L.call('srvp_conv_in_wgrad_f32' if self.f32 else 'srvp_conv_in_wgrad', L.ptr(self.dpre_f32), L.ptr(f0.t), L.ptr(grads[ob.spec['key'] + '.weight']),
                self.N, ob.cout_r, 64, 64, f0.C, ob.cin_r[0], ob.k, ob.s, ob.p, st)
 
     def backward(self, d_x, params, grads, st, sync=None, defer_wgrad=False):
@@ -893,12 +910,12 @@ class DecoderNet(ConvNetBase):
         f32_out = self._f32_out()
         if f32_out and not hasattr(self, 'dpre_f32'):
             self.dpre_f32 = torch.empty(self.N, ob.cout_r, ob.OH, ob.OW, dtype=torch.float32, device=self.dev)
-        L.call('srvp_out_dpre', L.ptr(self.x_out), L.ptr(d_x), None if f32_out else L.ptr(ob.draw),
+        L.call('srvp_out_dpre_f32' if (self.f32 and not f32_out) else 'srvp_out_dpre', L.ptr(self.x_out), L.ptr(d_x), None if f32_out else L.ptr(ob.draw),
                L.ptr(self.dpre_f32) if f32_out else None, self.N, ob.cout_r, ob.OH, ob.OW, ob.cout, 1, st)
         if f32_out:
             if not defer_wgrad:
                 self._out_wgrad_f32(grads, st)
-            L.call('srvp_conv_in_fwd', L.ptr(self.dpre_f32), L.ptr(params[ob.spec['key'] + '.weight']), L.ptr(ob.dcat), None,
+            L.call('srvp_conv_in_fwd_f32' if self.f32 else 'srvp_conv_in_fwd', L.ptr(self.dpre_f32), L.ptr(params[ob.spec['key'] + '.weight']), L.ptr(ob.dcat), None,
                    self.N, ob.cout_r, 64, 64, ob.ctot, ob.cin_r[0], ob.k, ob.s, ob.p, st)
         else:
             self._mfma_backward(ob, grads, st, wgrad=not defer_wgrad)
@@ -926,7 +943,7 @@ class DecoderNet(ConvNetBase):
                 out[blk.spec['cat']] = blk.dsel.view(B, f1.H * f1.W, f1.C)
             else:
                 if not hasattr(blk, 'dsel'):
-                    blk.dsel = torch.empty(B, f1.H * f1.W, f1.C, dtype=torch.bfloat16, device=self.dev)
-                L.call('srvp_skip_grad_reduce', L.ptr(blk.dcat), blk.ctot, blk.srcs[0].C, f1.C, f1.H * f1.W, T, B, L.ptr(blk.dsel), st)
+                    blk.dsel = torch.empty(B, f1.H * f1.W, f1.C, dtype=blk.adt, device=self.dev)
+                L.call('srvp_skip_grad_reduce_f32' if blk.f32 else 'srvp_skip_grad_reduce', L.ptr(blk.dcat), blk.ctot, blk.srcs[0].C, f1.C, f1.H * f1.W, T, B, L.ptr(blk.dsel), st)
                 out[blk.spec['cat']] = blk.dsel
         return out

@@ -64,10 +64,10 @@ struct PixWalk {
 // ACT >= 0: the activation is a compile-time constant (LeakyReLU, all but two layers of each network); ACT < 0: run-time
 // `act` -- a per-element switch over five activations with exp / division bodies that the compiler cannot hoist out of the
 // pixel loops, which made these HBM-streaming kernels instruction-bound.
-template <bool POOL, int ACT>
-__global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ raw, const float* __restrict__ scale,
+template <class E, bool POOL, int ACT>
+__global__ __launch_bounds__(256) void bn_act_kernel(const E* __restrict__ raw, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, int act, int N, int H, int W, int C,
-                                                     bf16_t* __restrict__ dst, int db, bf16_t* __restrict__ dpool, int pb,
+                                                     E* __restrict__ dst, int db, E* __restrict__ dpool, int pb,
                                                      float* __restrict__ dst_f32, const int* __restrict__ keep) {
     if (ACT >= 0) act = ACT;
     const int CG = C / 8;
@@ -84,12 +84,12 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ 
     constexpr int R = POOL ? 2 : 1;
     for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
         const int n = w.n, y = w.y, x = w.x;
-        u32x4_t v[R * R];
+        float v[R * R][8];
 #pragma unroll
         for (int i = 0; i < R; ++i)
 #pragma unroll
             for (int j = 0; j < R; ++j)
-                v[i * R + j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(raw + (((size_t)n * H + y * R + i) * W + x * R + j) * C + cg * 8));
+                El<E>::ld8_nt(raw + (((size_t)n * H + y * R + i) * W + x * R + j) * C + cg * 8, v[i * R + j]);
         float mx[8];
 #pragma unroll
         for (int i = 0; i < R; ++i)
@@ -97,15 +97,13 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ 
             for (int j = 0; j < R; ++j) {
                 const int yy = y * R + i, xx = x * R + j;
                 float f[8];
-                unpack8(v[i * R + j], f);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = act_fwd(__builtin_fmaf(f[e], sc[e], sh[e]), act);   // (explicit fma: bn_bwd_g_window recomputes it)
-                u32x4_t o = pack8(f);
+                for (int e = 0; e < 8; ++e) f[e] = act_fwd(__builtin_fmaf(v[i * R + j][e], sc[e], sh[e]), act);   // (explicit fma: bn_bwd_g_window recomputes it)
                 // keep (pooled layers): the full-resolution activation is only ever read for the frames that feed a skip
                 // connection (one per sample); the pooled tensor carries everything else forward
                 if (dst && (!keep || keep[n])) {
                     size_t doff = (((size_t)n * (H + 2 * db) + yy + db) * (W + 2 * db) + xx + db) * C + cg * 8;
-                    __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t*>(dst + doff));
+                    El<E>::st8_nt(dst + doff, f);
                 }
                 if (dst_f32) {
                     const size_t off = (((size_t)n * H + yy) * W + xx) * C + cg * 8;
@@ -113,16 +111,14 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ 
                     for (int e = 0; e < 8; ++e) dst_f32[off + e] = f[e];
                 }
                 if (POOL) {
-                    // pooled values are taken from the bf16-rounded activations (what the consumer of `dst` sees)
-                    float fr[8];
-                    unpack8(o, fr);
+                    // pooled values are taken from the activations as stored (bf16-rounded: what the consumer of `dst` sees)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) mx[e] = (i == 0 && j == 0) ? fr[e] : fmaxf(mx[e], fr[e]);
+                    for (int e = 0; e < 8; ++e) { const float fr = El<E>::rnd(f[e]); mx[e] = (i == 0 && j == 0) ? fr : fmaxf(mx[e], fr); }
                 }
             }
         if (POOL) {
             size_t poff = (((size_t)n * (OH + 2 * pb) + y + pb) * (OW + 2 * pb) + x + pb) * C + cg * 8;
-            *reinterpret_cast<u32x4_t*>(dpool + poff) = pack8(mx);
+            El<E>::st8(dpool + poff, mx);
         }
     }
 }
@@ -131,21 +127,21 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t* __restrict__ 
 // backward
 // ---------------------------------------------------------------------------------------------------------
 struct BnBwdK {
-    const bf16_t* raw; const bf16_t* act; int act_border;
+    const void* raw; const void* act; int act_border;
     const float* scale; const float* shift; const float* mean; const float* invstd; int act_kind;
     const void* da; int da_mode, da_cstride, da_coff, da_border, da_is_f32;
-    const bf16_t* da2; const int* da2_idx;
+    const void* da2; const int* da2_idx;
     int N, H, W, C;
-    bf16_t* tsum; int tsum_T;        // apply: also write the sum over the T time steps of each sample (frames are t*B + b)
+    void* tsum; int tsum_T;        // apply: also write the sum over the T time steps of each sample (frames are t*B + b)
 };
 
 // g[8] = dA * f'(pre) for pixel (n,y,x), channel group cg; also returns raw values
-template <int MODE, int ACT>
+template <class E, int MODE, int ACT>
 __device__ __forceinline__ void bn_bwd_g(const BnBwdK& a, int n, int y, int x, int cg, const float* sc, const float* sh,
                                          float* g, float* rawf) {
     const int C = a.C, H = a.H, W = a.W;
     size_t roff = (((size_t)n * H + y) * W + x) * C + cg * 8;
-    unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(a.raw + roff)), rawf);
+    El<E>::ld8_nt((const E*)a.raw + roff, rawf);
     float d[8];
     const int db = a.da_border, cs = a.da_cstride, co = a.da_coff + cg * 8;
     if (a.da_is_f32) {
@@ -154,10 +150,10 @@ __device__ __forceinline__ void bn_bwd_g(const BnBwdK& a, int n, int y, int x, i
 #pragma unroll
         for (int e = 0; e < 8; ++e) d[e] = da[off + e];
     } else {
-        const bf16_t* da = (const bf16_t*)a.da;
+        const E* da = (const E*)a.da;
         if constexpr (MODE == 0) {
             size_t off = (((size_t)n * (H + 2 * db) + y + db) * (W + 2 * db) + x + db) * cs + co;
-            unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(da + off)), d);
+            El<E>::ld8_nt(da + off, d);
         } else if constexpr (MODE == 1) {
             const int H2 = 2 * H, W2 = 2 * W;
 #pragma unroll
@@ -168,7 +164,7 @@ __device__ __forceinline__ void bn_bwd_g(const BnBwdK& a, int n, int y, int x, i
                 for (int j = 0; j < 2; ++j) {
                     size_t off = (((size_t)n * (H2 + 2 * db) + 2 * y + i + db) * (W2 + 2 * db) + 2 * x + j + db) * cs + co;
                     float t[8];
-                    unpack8(*reinterpret_cast<const u32x4_t*>(da + off), t);
+                    El<E>::ld8(da + off, t);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) d[e] += t[e];
                 }
@@ -176,7 +172,7 @@ __device__ __forceinline__ void bn_bwd_g(const BnBwdK& a, int n, int y, int x, i
             const int Hh = H / 2, Wh = W / 2;
             size_t off = (((size_t)n * (Hh + 2 * db) + (y >> 1) + db) * (Wh + 2 * db) + (x >> 1) + db) * cs + co;
             float t[8];
-            unpack8(*reinterpret_cast<const u32x4_t*>(da + off), t);
+            El<E>::ld8(da + off, t);
             // arg-max routing with torch's first-max tie rule (scan order (0,0),(0,1),(1,0),(1,1) of the window)
             const int ab = a.act_border;
             const int y0 = y & ~1, x0 = x & ~1;
@@ -187,7 +183,7 @@ __device__ __forceinline__ void bn_bwd_g(const BnBwdK& a, int n, int y, int x, i
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     size_t aoff = (((size_t)n * (H + 2 * ab) + y0 + i + ab) * (W + 2 * ab) + x0 + j + ab) * C + cg * 8;
-                    unpack8(*reinterpret_cast<const u32x4_t*>(a.act + aoff), w4[i * 2 + j]);
+                    El<E>::ld8((const E*)a.act + aoff, w4[i * 2 + j]);
                 }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -203,7 +199,7 @@ __device__ __forceinline__ void bn_bwd_g(const BnBwdK& a, int n, int y, int x, i
         if (idx >= 0) {
             size_t off = (((size_t)idx * H + y) * W + x) * C + cg * 8;
             float t[8];
-            unpack8(*reinterpret_cast<const u32x4_t*>(a.da2 + off), t);
+            El<E>::ld8((const E*)a.da2 + off, t);
 #pragma unroll
             for (int e = 0; e < 8; ++e) d[e] += t[e];
         }
@@ -214,14 +210,13 @@ __device__ __forceinline__ void bn_bwd_g(const BnBwdK& a, int n, int y, int x, i
 
 // Pooled consumer (da_mode 2), whole 2x2 window (py, px) of image n at once: g[q][8] / raw[q][8] for the window pixels
 // q = 2*i + j.  Arg-max routing with torch's first-max tie rule (scan order (0,0),(0,1),(1,0),(1,1)).
-template <int ACT>
+template <class E, int ACT>
 __device__ __forceinline__ void bn_bwd_g_window(const BnBwdK& a, int n, int py, int px, int cg, const float* sc, const float* sh,
                                                 float (*g)[8], float (*rawf)[8]) {
     const int C = a.C, H = a.H, W = a.W, db = a.da_border, ab = a.act_border;
     const int Hh = H / 2, Wh = W / 2;
     float t[8], w4[4][8];
-    unpack8(*reinterpret_cast<const u32x4_t*>((const bf16_t*)a.da + (((size_t)n * (Hh + 2 * db) + py + db) * (Wh + 2 * db) + px + db) * a.da_cstride +
-                                              a.da_coff + cg * 8), t);
+    El<E>::ld8((const E*)a.da + (((size_t)n * (Hh + 2 * db) + py + db) * (Wh + 2 * db) + px + db) * a.da_cstride + a.da_coff + cg * 8, t);
     // The activations the forward max-pooled over are RECOMPUTED from raw (same fma, same activation, same bf16 rounding as
     // bn_act_kernel stored them) instead of being read back: one full-size tensor read less in both BN-backward passes of the
     // four pooled layers.
@@ -229,10 +224,10 @@ __device__ __forceinline__ void bn_bwd_g_window(const BnBwdK& a, int n, int py, 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int y = 2 * py + (q >> 1), x = 2 * px + (q & 1);
-        unpack8(*reinterpret_cast<const u32x4_t*>(a.raw + (((size_t)n * H + y) * W + x) * C + cg * 8), rawf[q]);
+        El<E>::ld8((const E*)a.raw + (((size_t)n * H + y) * W + x) * C + cg * 8, rawf[q]);
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            w4[q][e] = bf2f(f2bf(act_fwd(__builtin_fmaf(rawf[q][e], sc[e], sh[e]), ACT >= 0 ? ACT : a.act_kind)));
+            w4[q][e] = El<E>::rnd(act_fwd(__builtin_fmaf(rawf[q][e], sc[e], sh[e]), ACT >= 0 ? ACT : a.act_kind));
     }
     float d[4][8];
 #pragma unroll
@@ -250,7 +245,7 @@ __device__ __forceinline__ void bn_bwd_g_window(const BnBwdK& a, int n, int py, 
             for (int q = 0; q < 4; ++q) {
                 const int y = 2 * py + (q >> 1), x = 2 * px + (q & 1);
                 float u[8];
-                unpack8(*reinterpret_cast<const u32x4_t*>(a.da2 + (((size_t)idx * H + y) * W + x) * C + cg * 8), u);
+                El<E>::ld8((const E*)a.da2 + (((size_t)idx * H + y) * W + x) * C + cg * 8, u);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) d[q][e] += u[e];
             }
@@ -262,7 +257,7 @@ __device__ __forceinline__ void bn_bwd_g_window(const BnBwdK& a, int n, int py, 
         for (int e = 0; e < 8; ++e) g[q][e] = d[q][e] * act_bwd(rawf[q][e] * sc[e] + sh[e], ACT >= 0 ? ACT : a.act_kind);
 }
 
-template <int MODE, int ACT>
+template <class E, int MODE, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdK a, double* red) {
     const int CG = a.C / 8;
     const int PPB = blockDim.x / CG;             // pixels handled in parallel by one workgroup
@@ -285,7 +280,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdK a, doub
             w.init(blockIdx.x * PPB + pl, stride, a.H / 2, a.W / 2);
             for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
                 float g[4][8], rawf[4][8];
-                bn_bwd_g_window<ACT>(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
+                bn_bwd_g_window<E, ACT>(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -298,23 +293,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdK a, doub
                 // iteration with all eight 16-byte loads issued up front (memory-level parallelism; the generic loop
                 // below has one pixel in flight per thread because its loads sit behind the loop-exit test)
                 constexpr int U = 4;
-                const bf16_t* da = (const bf16_t*)a.da;
+                const E* da = (const E*)a.da;
                 const unsigned p0 = blockIdx.x * PPB + pl;
                 for (unsigned p = p0; p < P; p += U * stride) {
-                    u32x4_t rv[U], dv[U];
+                    float rv[U][8], dv[U][8];
                     bool ok[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const unsigned pu = p + u * stride;
                         ok[u] = pu < P;
                         const size_t pc = ok[u] ? pu : p0;
-                        rv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(a.raw + pc * a.C + cg * 8));
-                        dv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(da + pc * a.da_cstride + a.da_coff + cg * 8));
+                        El<E>::ld8_nt((const E*)a.raw + pc * a.C + cg * 8, rv[u]);
+                        El<E>::ld8_nt(da + pc * a.da_cstride + a.da_coff + cg * 8, dv[u]);
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        float rawf[8], d[8];
-                        unpack8(rv[u], rawf); unpack8(dv[u], d);
+                        const float* rawf = rv[u];
+                        const float* d = dv[u];
                         const float m = ok[u] ? 1.f : 0.f;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
@@ -329,7 +324,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdK a, doub
 #pragma unroll 2
                 for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
                     float g[8], rawf[8];
-                    bn_bwd_g<MODE, ACT>(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
+                    bn_bwd_g<E, MODE, ACT>(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { s1[e] += g[e]; s2[e] += g[e] * (rawf[e] - mu[e]) * is[e]; }
                 }
@@ -366,9 +361,9 @@ __global__ void bn_bwd_finalize_kernel(const double* red, double count, const fl
     coef[c] = (float)k1; coef[C + c] = (float)k2; coef[2 * C + c] = (float)k3;
 }
 
-template <int MODE, int ACT>
+template <class E, int MODE, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK a, const float* __restrict__ coef,
-                                                           bf16_t* __restrict__ draw, int db) {
+                                                           E* __restrict__ draw, int db) {
     const int CG = a.C / 8;
     const int PPB = blockDim.x / CG;
     const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
@@ -385,14 +380,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK a, const
         w.init(blockIdx.x * PPB + pl, stride, a.H / 2, a.W / 2);
         for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
             float g[4][8], rawf[4][8];
-            bn_bwd_g_window<ACT>(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
+            bn_bwd_g_window<E, ACT>(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float o[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = k1[e] * g[q][e] + k2[e] + k3[e] * rawf[q][e];
                 size_t off = (((size_t)w.n * (a.H + 2 * db) + 2 * w.y + (q >> 1) + db) * (a.W + 2 * db) + 2 * w.x + (q & 1) + db) * a.C + cg * 8;
-                *reinterpret_cast<u32x4_t*>(draw + off) = pack8(o);
+                El<E>::st8(draw + off, o);
             }
         }
         return;
@@ -411,14 +406,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK a, const
             for (int t = 0; t < a.tsum_T; ++t) {
                 const int n = t * Bs + w.n;
                 float g[8], rawf[8], o[8];
-                bn_bwd_g<MODE, ACT>(a, n, w.y, w.x, cg, sc, sh, g, rawf);
+                bn_bwd_g<E, MODE, ACT>(a, n, w.y, w.x, cg, sc, sh, g, rawf);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { o[e] = k1[e] * g[e] + k2[e] + k3[e] * rawf[e]; acc[e] += o[e]; }
                 size_t off = (((size_t)n * (a.H + 2 * db) + w.y + db) * (a.W + 2 * db) + w.x + db) * a.C + cg * 8;
-                *reinterpret_cast<u32x4_t*>(draw + off) = pack8(o);
+                El<E>::st8(draw + off, o);
             }
             size_t soff = (((size_t)w.n * (a.H + 2 * db) + w.y + db) * (a.W + 2 * db) + w.x + db) * a.C + cg * 8;
-            *reinterpret_cast<u32x4_t*>(a.tsum + soff) = pack8(acc);
+            El<E>::st8((E*)a.tsum + soff, acc);
         }
         return;
     }
@@ -429,11 +424,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK a, const
     for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
         const int n = w.n, y = w.y, x = w.x;
         float g[8], rawf[8], o[8];
-        bn_bwd_g<MODE, ACT>(a, n, y, x, cg, sc, sh, g, rawf);
+        bn_bwd_g<E, MODE, ACT>(a, n, y, x, cg, sc, sh, g, rawf);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = k1[e] * g[e] + k2[e] + k3[e] * rawf[e];
         size_t off = (((size_t)n * (a.H + 2 * db) + y + db) * (a.W + 2 * db) + x + db) * a.C + cg * 8;
-        *reinterpret_cast<u32x4_t*>(draw + off) = pack8(o);
+        El<E>::st8(draw + off, o);
     }
 }
 
@@ -442,12 +437,12 @@ int fill_k(const srvp_bnbwd_desc* d, BnBwdK& k) {
     SRVP_REQUIRE(d->C % 8 == 0 && d->C / 8 <= 256, "srvp_bn_bwd: C=%d unsupported", d->C);
     SRVP_REQUIRE(d->da_mode != 2 || d->act, "srvp_bn_bwd: pooled mode needs the activated tensor");
     SRVP_REQUIRE(d->da_mode != 2 || (d->H % 2 == 0 && d->W % 2 == 0), "srvp_bn_bwd: pooled mode needs even H, W");
-    k.raw = (const bf16_t*)d->raw; k.act = (const bf16_t*)d->act; k.act_border = d->act_border;
+    k.raw = d->raw; k.act = d->act; k.act_border = d->act_border;
     k.scale = d->scale; k.shift = d->shift; k.mean = d->mean; k.invstd = d->invstd; k.act_kind = d->act_kind;
     k.da = d->da; k.da_mode = d->da_mode; k.da_cstride = d->da_cstride; k.da_coff = d->da_coff;
-    k.da_border = d->da_border; k.da_is_f32 = d->da_is_f32; k.da2 = (const bf16_t*)d->da2; k.da2_idx = d->da2_idx;
+    k.da_border = d->da_border; k.da_is_f32 = d->da_is_f32; k.da2 = d->da2; k.da2_idx = d->da2_idx;
     k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C;
-    k.tsum = (bf16_t*)d->tsum; k.tsum_T = d->tsum_T;
+    k.tsum = d->tsum; k.tsum_T = d->tsum_T;
     SRVP_REQUIRE(!d->tsum || (d->tsum_T > 0 && d->N % d->tsum_T == 0 && d->da_mode != 2), "srvp_bn_bwd: tsum needs N %% T == 0 and a non-pooled consumer");
     return SRVP_OK;
 }
@@ -481,27 +476,40 @@ extern "C" int srvp_bn_eval_coeffs(const float* gamma, const float* beta, const 
     return SRVP_OK;
 }
 
-extern "C" int srvp_bn_act_keep(const void* raw, const float* scale, const float* shift, int act, int N, int H, int W, int C,
-                                void* dst, int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep,
-                                void* stream) {
+namespace {
+template <class E>
+int bn_act_launch(const void* raw, const float* scale, const float* shift, int act, int N, int H, int W, int C, void* dst,
+                  int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep, void* stream) {
     SRVP_REQUIRE(raw && scale && shift && C % 8 == 0, "srvp_bn_act: bad args");
     hipStream_t st = (hipStream_t)stream;
     if (dst_pool) {
         SRVP_REQUIRE(H % 2 == 0 && W % 2 == 0, "srvp_bn_act: pooling needs even H, W");
         long long total = (long long)N * (H / 2) * (W / 2);
         SRVP_REQUIRE(C / 8 <= 256 && (long long)N * H * W < (1ll << 31), "srvp_bn_act: C=%d / size unsupported", C);
-        auto kern = act == ACT_LRELU ? bn_act_kernel<true, ACT_LRELU> : bn_act_kernel<true, -1>;
-        hipLaunchKernelGGL(kern, dim3(grid_for(total, (256 / (C / 8)) * 2)), dim3(256), 0, st, (const bf16_t*)raw, scale, shift,
-                           act, N, H, W, C, (bf16_t*)dst, dst_border, (bf16_t*)dst_pool, pool_border, dst_f32, (const int*)keep);
+        auto kern = act == ACT_LRELU ? bn_act_kernel<E, true, ACT_LRELU> : bn_act_kernel<E, true, -1>;
+        hipLaunchKernelGGL(kern, dim3(grid_for(total, (256 / (C / 8)) * 2)), dim3(256), 0, st, (const E*)raw, scale, shift,
+                           act, N, H, W, C, (E*)dst, dst_border, (E*)dst_pool, pool_border, dst_f32, (const int*)keep);
     } else {
         long long total = (long long)N * H * W;
         SRVP_REQUIRE(C / 8 <= 256 && total < (1ll << 31), "srvp_bn_act: C=%d / size unsupported", C);
-        auto kern = act == ACT_LRELU ? bn_act_kernel<false, ACT_LRELU> : bn_act_kernel<false, -1>;
-        hipLaunchKernelGGL(kern, dim3(grid_for(total, (256 / (C / 8)) * 4)), dim3(256), 0, st, (const bf16_t*)raw, scale, shift,
-                           act, N, H, W, C, (bf16_t*)dst, dst_border, (bf16_t*)nullptr, 0, dst_f32, (const int*)nullptr);
+        auto kern = act == ACT_LRELU ? bn_act_kernel<E, false, ACT_LRELU> : bn_act_kernel<E, false, -1>;
+        hipLaunchKernelGGL(kern, dim3(grid_for(total, (256 / (C / 8)) * 4)), dim3(256), 0, st, (const E*)raw, scale, shift,
+                           act, N, H, W, C, (E*)dst, dst_border, (E*)nullptr, 0, dst_f32, (const int*)nullptr);
     }
     SRVP_CHECK_LAUNCH("srvp_bn_act");
     return SRVP_OK;
+}
+}  // namespace
+
+extern "C" int srvp_bn_act_keep(const void* raw, const float* scale, const float* shift, int act, int N, int H, int W, int C,
+                                void* dst, int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep,
+                                void* stream) {
+    return bn_act_launch<bf16_t>(raw, scale, shift, act, N, H, W, C, dst, dst_border, dst_pool, pool_border, dst_f32, keep, stream);
+}
+extern "C" int srvp_bn_act_keep_f32(const void* raw, const float* scale, const float* shift, int act, int N, int H, int W, int C,
+                                    void* dst, int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep,
+                                    void* stream) {
+    return bn_act_launch<float>(raw, scale, shift, act, N, H, W, C, dst, dst_border, dst_pool, pool_border, dst_f32, keep, stream);
 }
 
 extern "C" int srvp_bn_act(const void* raw, const float* scale, const float* shift, int act, int N, int H, int W, int C,
@@ -520,9 +528,17 @@ extern "C" int srvp_bn_bwd_reduce(const srvp_bnbwd_desc* d, double* red, void* s
     if (k.da_mode == 2) P /= 4;
     const dim3 g(grid_for(P, PPB * (k.da_mode == 2 ? 16 : 64)));   // >= 64 pixel rows per thread slot: the 2C fp64 atomics per workgroup must stay small beside its streaming work
     const bool lr = k.act_kind == ACT_LRELU;
-    auto kern = k.da_mode == 0 ? (lr ? bn_bwd_reduce_kernel<0, ACT_LRELU> : bn_bwd_reduce_kernel<0, -1>)
-              : k.da_mode == 1 ? (lr ? bn_bwd_reduce_kernel<1, ACT_LRELU> : bn_bwd_reduce_kernel<1, -1>)
-                               : (lr ? bn_bwd_reduce_kernel<2, ACT_LRELU> : bn_bwd_reduce_kernel<2, -1>);
+    if (d->elem_f32) {
+        auto kern = k.da_mode == 0 ? (lr ? bn_bwd_reduce_kernel<float, 0, ACT_LRELU> : bn_bwd_reduce_kernel<float, 0, -1>)
+                  : k.da_mode == 1 ? (lr ? bn_bwd_reduce_kernel<float, 1, ACT_LRELU> : bn_bwd_reduce_kernel<float, 1, -1>)
+                                   : (lr ? bn_bwd_reduce_kernel<float, 2, ACT_LRELU> : bn_bwd_reduce_kernel<float, 2, -1>);
+        hipLaunchKernelGGL(kern, g, dim3(256), 0, (hipStream_t)stream, k, red);
+        SRVP_CHECK_LAUNCH("srvp_bn_bwd_reduce(f32)");
+        return SRVP_OK;
+    }
+    auto kern = k.da_mode == 0 ? (lr ? bn_bwd_reduce_kernel<bf16_t, 0, ACT_LRELU> : bn_bwd_reduce_kernel<bf16_t, 0, -1>)
+              : k.da_mode == 1 ? (lr ? bn_bwd_reduce_kernel<bf16_t, 1, ACT_LRELU> : bn_bwd_reduce_kernel<bf16_t, 1, -1>)
+                               : (lr ? bn_bwd_reduce_kernel<bf16_t, 2, ACT_LRELU> : bn_bwd_reduce_kernel<bf16_t, 2, -1>);
     hipLaunchKernelGGL(kern, g, dim3(256), 0, (hipStream_t)stream, k, red);
     SRVP_CHECK_LAUNCH("srvp_bn_bwd_reduce");
     return SRVP_OK;
@@ -550,9 +566,17 @@ extern "C" int srvp_bn_bwd_apply(const srvp_bnbwd_desc* d, const float* coef, vo
     if (k.tsum) P /= k.tsum_T;
     const dim3 g(grid_for(P, PPB * ((k.da_mode == 2 || k.tsum) ? 1 : 4)));
     const bool lr = k.act_kind == ACT_LRELU;
-    auto kern = k.da_mode == 0 ? (lr ? bn_bwd_apply_kernel<0, ACT_LRELU> : bn_bwd_apply_kernel<0, -1>)
-              : k.da_mode == 1 ? (lr ? bn_bwd_apply_kernel<1, ACT_LRELU> : bn_bwd_apply_kernel<1, -1>)
-                               : (lr ? bn_bwd_apply_kernel<2, ACT_LRELU> : bn_bwd_apply_kernel<2, -1>);
+    if (d->elem_f32) {
+        auto kern = k.da_mode == 0 ? (lr ? bn_bwd_apply_kernel<float, 0, ACT_LRELU> : bn_bwd_apply_kernel<float, 0, -1>)
+                  : k.da_mode == 1 ? (lr ? bn_bwd_apply_kernel<float, 1, ACT_LRELU> : bn_bwd_apply_kernel<float, 1, -1>)
+                                   : (lr ? bn_bwd_apply_kernel<float, 2, ACT_LRELU> : bn_bwd_apply_kernel<float, 2, -1>);
+        hipLaunchKernelGGL(kern, g, dim3(256), 0, (hipStream_t)stream, k, coef, (float*)draw, dst_border);
+        SRVP_CHECK_LAUNCH("srvp_bn_bwd_apply(f32)");
+        return SRVP_OK;
+    }
+    auto kern = k.da_mode == 0 ? (lr ? bn_bwd_apply_kernel<bf16_t, 0, ACT_LRELU> : bn_bwd_apply_kernel<bf16_t, 0, -1>)
+              : k.da_mode == 1 ? (lr ? bn_bwd_apply_kernel<bf16_t, 1, ACT_LRELU> : bn_bwd_apply_kernel<bf16_t, 1, -1>)
+                               : (lr ? bn_bwd_apply_kernel<bf16_t, 2, ACT_LRELU> : bn_bwd_apply_kernel<bf16_t, 2, -1>);
     hipLaunchKernelGGL(kern, g, dim3(256), 0, (hipStream_t)stream, k, coef, (bf16_t*)draw, dst_border);
     SRVP_CHECK_LAUNCH("srvp_bn_bwd_apply");
     return SRVP_OK;

@@ -40,6 +40,36 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
     return v;
 }
 
+// ---- element type of the activation / gradient tensors: bf16_t (production) or float (precision = 'fp32' parity mode).
+// The HBM-streaming kernels are templated on it and move eight consecutive channels per access either way.
+template <class E> struct El;
+template <> struct El<bf16_t> {
+    static constexpr bool is_f32 = false;
+    static __device__ __forceinline__ void ld8(const bf16_t* p, float* f) { unpack8(*reinterpret_cast<const u32x4_t*>(p), f); }
+    static __device__ __forceinline__ void ld8_nt(const bf16_t* p, float* f) { unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)), f); }
+    static __device__ __forceinline__ void st8(bf16_t* p, const float* f) { *reinterpret_cast<u32x4_t*>(p) = pack8(f); }
+    static __device__ __forceinline__ void st8_nt(bf16_t* p, const float* f) { __builtin_nontemporal_store(pack8(f), reinterpret_cast<u32x4_t*>(p)); }
+    static __device__ __forceinline__ float rnd(float v) { return bf2f(f2bf(v)); }        // the value as the tensor stores it
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+template <> struct El<float> {
+    static constexpr bool is_f32 = true;
+    static __device__ __forceinline__ void ld8(const float* p, float* f) {
+        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p), b = *reinterpret_cast<const f32x4_t*>(p + 4);
+        f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+    }
+    static __device__ __forceinline__ void ld8_nt(const float* p, float* f) { ld8(p, f); }
+    static __device__ __forceinline__ void st8(float* p, const float* f) {
+        *reinterpret_cast<f32x4_t*>(p) = f32x4_t{f[0], f[1], f[2], f[3]};
+        *reinterpret_cast<f32x4_t*>(p + 4) = f32x4_t{f[4], f[5], f[6], f[7]};
+    }
+    static __device__ __forceinline__ void st8_nt(float* p, const float* f) { st8(p, f); }
+    static __device__ __forceinline__ float rnd(float v) { return v; }
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+
 // activation ids shared with the host side (srvp_hip.h)
 #define ACT_NONE 0
 #define ACT_LRELU 1   // LeakyReLU(0.2)  (reference utils.py:41)

@@ -14,6 +14,8 @@
 #include "common.h"
 #include "../../include/srvp_hip.h"
 
+int srvp_conv_f32_launch(const srvp_conv_desc* d, hipStream_t st);     // conv_f32.hip (precision = 'fp32' parity mode)
+
 namespace {
 
 struct RowInfo { int n, oy, ox; };
@@ -629,7 +631,7 @@ static int g_halo = -1;      // -1: read SRVP_CONV_HALO on first use; 0 = generi
 // convolution on a 1-pixel-bordered tensor (or its patch does not fit) -- the generic kernel takes it then.
 static bool halo_geometry(const srvp_conv_desc* d, HaloK& h, int BM) {
     if (g_halo < 0) { const char* e = getenv("SRVP_CONV_HALO"); g_halo = e ? atoi(e) : 1; }
-    if (!g_halo) return false;
+    if (!g_halo || d->elem_f32) return false;
     if (d->ntaps > 9 || d->si != 1 || d->C1 != 0 || d->C0 % 64 != 0) return false;
     for (int t = 0; t < d->ntaps; ++t) if (d->dy[t] < 0 || d->dy[t] > 2 || d->dx[t] < 0 || d->dx[t] > 2) return false;
     const int OH = d->OH, OW = d->OW, ups = d->ups0 ? 1 : 0;
@@ -684,7 +686,7 @@ static int generic_mode() {
 static bool generic_wants_fragmajor(const srvp_conv_desc* d) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("SRVP_CONV_BDIRECT"); on = e ? atoi(e) : 1; }
-    return on && generic_mode() == 5 && d->C0 % 64 == 0 && d->C1 % 64 == 0 && d->Cout % 64 == 0;
+    return on && !d->elem_f32 && generic_mode() == 5 && d->C0 % 64 == 0 && d->C1 % 64 == 0 && d->Cout % 64 == 0;
 }
 
 // 0: not a halo launch; else the tile size (128 / 256) the dispatcher picks for this descriptor
@@ -756,6 +758,7 @@ extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
     SRVP_REQUIRE(d->ntaps >= 1 && d->ntaps <= SRVP_MAX_TAPS, "srvp_conv_mfma: ntaps=%d", d->ntaps);
     SRVP_REQUIRE(d->Cdst % 8 == 0 && d->cdst_off % 8 == 0, "srvp_conv_mfma: dst channel slice must be 16-byte aligned");
     SRVP_REQUIRE(d->stats == nullptr || d->stat_mod > 0, "srvp_conv_mfma: stat_mod");
+    if (d->elem_f32) return srvp_conv_f32_launch(d, st);
     SRVP_REQUIRE((long long)d->N * d->H0p * d->W0p * d->C0 < (1ll << 32) && (d->C1 == 0 || d->map1 || (long long)d->N * d->H1p * d->W1p * d->C1 < (1ll << 32)),
                  "srvp_conv_mfma: source tensors must have fewer than 2^32 elements");
     if (const int v = halo_variant(d)) return launch_halo_any(d, 1, v, st);

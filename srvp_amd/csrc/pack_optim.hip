@@ -17,6 +17,7 @@ struct PackArgs {
     long long sj, sk;         // element strides of the real j / k index in the fp32 tensor
     int tap_set[SRVP_MAX_TAPS];   // != 0: packed tap = sum of the source taps in the bit set
     int layout;                   // 0 tap-major, 1 MFMA-fragment-major (see srvp_hip.h)
+    int dst_f32;                  // packed tensor is fp32 (precision = 'fp32' parity mode; tap-major only)
 };
 
 __device__ __forceinline__ int real_index(int i, int seg0_pad, int seg0_real, int seg1_real) {
@@ -43,7 +44,8 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ src, bf16_t* 
         const int cc = k >> 6, kk = (k >> 4) & 3, kh = (k >> 3) & 1;
         o = ((((long long)(t * (a.K >> 6) + cc) * 4 + kk) * (a.J >> 5) + (j >> 5)) * 64 + kh * 32 + (j & 31)) * 8 + (k & 7);
     }
-    dst[o] = f2bf(v);
+    if (a.dst_f32) reinterpret_cast<float*>(dst)[o] = v;
+    else dst[o] = f2bf(v);
 }
 
 __device__ __forceinline__ void unpack_one(const float* __restrict__ src, float* __restrict__ dst, const PackArgs& a, long long i) {
@@ -75,14 +77,14 @@ __device__ __forceinline__ void job_args(const srvp_pack_job& j, PackArgs& a) {
 #pragma unroll
     for (int t = 0; t < SRVP_MAX_TAPS; ++t) { a.tap_off[t] = j.d.tap_off[t]; a.tap_set[t] = j.d.tap_set[t]; }
     a.J = j.d.J; a.K = j.d.K; a.J0 = j.d.J0; a.J0r = j.d.J0r; a.J1r = j.d.J1r; a.K0 = j.d.K0; a.K0r = j.d.K0r; a.K1r = j.d.K1r;
-    a.sj = j.d.sj; a.sk = j.d.sk; a.layout = j.d.layout;
+    a.sj = j.d.sj; a.sk = j.d.sk; a.layout = j.d.layout; a.dst_f32 = j.d.dst_f32;
 }
 // Vector path (K % 8 == 0, source taps within 16 elements of the (j, k) base -- every conv / convT weight): one work item
 // = (j, eight consecutive k), lanes along j.  The fp32 tensor keeps its taps innermost, so an item's reads / read-modify-writes
 // are runs of `source taps` consecutive floats (re-touched over the tap loop: L1/L2 hits) instead of 4-byte accesses 36
 // bytes apart, and the packed side moves as whole 16-byte (pack) / 32-byte (unpack) vectors.
 __device__ __forceinline__ bool vec_ok(const srvp_pack_desc& d) {
-    if (d.K % 8 != 0) return false;
+    if (d.K % 8 != 0 || d.dst_f32) return false;
     for (int t = 0; t < d.ntaps; ++t)
         if (d.tap_set[t] == 0 ? (d.tap_off[t] < 0 || d.tap_off[t] >= 16) : (d.tap_set[t] >> 16) != 0) return false;
     return true;
@@ -230,13 +232,16 @@ int fill_pack(const srvp_pack_desc* d, PackArgs& a) {
     a.J = d->J; a.K = d->K; a.J0 = d->J0; a.J0r = d->J0r; a.J1r = d->J1r; a.K0 = d->K0; a.K0r = d->K0r; a.K1r = d->K1r;
     a.sj = d->sj; a.sk = d->sk;
     a.layout = d->layout;
+    a.dst_f32 = d->dst_f32;
+    SRVP_REQUIRE(!(d->dst_f32 && d->layout), "srvp_pack: fp32 packed weights are tap-major only");
     SRVP_REQUIRE(d->layout == 0 || (d->layout == 1 && d->J % 32 == 0 && d->K % 64 == 0), "srvp_pack: layout %d needs J %% 32 == 0, K %% 64 == 0", d->layout);
     return SRVP_OK;
 }
 
 // dsel[b][hw][c] = sum_t dcat[(t*B+b)][hw][coff + c]
-__global__ void skip_grad_reduce_kernel(const bf16_t* __restrict__ dcat, int cstride, int coff, int C, int HW, int T, int B,
-                                        bf16_t* __restrict__ dsel) {
+template <class E>
+__global__ void skip_grad_reduce_kernel(const E* __restrict__ dcat, int cstride, int coff, int C, int HW, int T, int B,
+                                        E* __restrict__ dsel) {
     const int CG = C / 8;
     long long total = (long long)B * HW * CG;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -248,11 +253,11 @@ __global__ void skip_grad_reduce_kernel(const bf16_t* __restrict__ dcat, int cst
         for (int t = 0; t < T; ++t) {
             size_t off = (((size_t)(t * B + b)) * HW + hw) * cstride + coff + cg * 8;
             float f[8];
-            unpack8(*reinterpret_cast<const u32x4_t*>(dcat + off), f);
+            El<E>::ld8(dcat + off, f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += f[e];
         }
-        *reinterpret_cast<u32x4_t*>(dsel + ((size_t)b * HW + hw) * C + cg * 8) = pack8(acc);
+        El<E>::st8(dsel + ((size_t)b * HW + hw) * C + cg * 8, acc);
     }
 }
 
@@ -426,9 +431,18 @@ extern "C" int srvp_skip_grad_reduce(const void* dcat, int cstride, int coff, in
                                      void* stream) {
     SRVP_REQUIRE(dcat && dsel && C % 8 == 0 && coff % 8 == 0 && cstride % 8 == 0, "srvp_skip_grad_reduce: bad args");
     long long total = (long long)B * HW * (C / 8);
-    hipLaunchKernelGGL(skip_grad_reduce_kernel, dim3(capped_grid(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(skip_grad_reduce_kernel<bf16_t>, dim3(capped_grid(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)dcat, cstride, coff, C, HW, T, B, (bf16_t*)dsel);
     SRVP_CHECK_LAUNCH("srvp_skip_grad_reduce");
+    return SRVP_OK;
+}
+extern "C" int srvp_skip_grad_reduce_f32(const void* dcat, int cstride, int coff, int C, int HW, int T, int B, void* dsel,
+                                         void* stream) {
+    SRVP_REQUIRE(dcat && dsel && C % 8 == 0 && coff % 8 == 0 && cstride % 8 == 0, "srvp_skip_grad_reduce_f32: bad args");
+    long long total = (long long)B * HW * (C / 8);
+    hipLaunchKernelGGL(skip_grad_reduce_kernel<float>, dim3(capped_grid(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)dcat, cstride, coff, C, HW, T, B, (float*)dsel);
+    SRVP_CHECK_LAUNCH("srvp_skip_grad_reduce_f32");
     return SRVP_OK;
 }
 

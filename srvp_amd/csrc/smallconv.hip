@@ -17,8 +17,9 @@ namespace {
 // first layer forward: raw[n][oy][ox][co] = sum_{ci,kh,kw} x[n][ci][oy*s-p+kh][ox*s-p+kw] * w[co][ci][kh][kw]
 // thread = (pixel, group of 8 output channels); per-channel sum / sumsq for BatchNorm in the epilogue.
 // ---------------------------------------------------------------------------------------------------------
+template <class E>
 __global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          bf16_t* __restrict__ raw, double* stats, int N, int Cin, int H,
+                                                          E* __restrict__ raw, double* stats, int N, int Cin, int H,
                                                           int W, int Cout, int Cout_real, int k, int s, int p, int OH,
                                                           int OW) {
     extern __shared__ float wsh[];                 // [Cin*k*k][Cout] (transposed for conflict-free reads)
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restric
                         for (int e = 0; e < 8; ++e) acc[e] += xv * wr[e];
                     }
                 }
-            *reinterpret_cast<u32x4_t*>(raw + (size_t)pix * Cout + cg * 8) = pack8(acc);
+            El<E>::st8(raw + (size_t)pix * Cout + cg * 8, acc);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s1[e] += acc[e]; s2[e] += acc[e] * acc[e]; }
         }
@@ -76,8 +77,8 @@ __global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restric
 // accumulators and walks a contiguous run of pixels; a "stream" of CG*Cin such threads covers the whole dw for its
 // pixels.  Per pixel and thread: one 16-byte gradient load + k*k frame loads (L1 hits) feed 8*k*k FMAs.  Streams of a
 // workgroup are summed through LDS, then one atomic per weight and workgroup.
-template <int K>
-__global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restrict__ x, const bf16_t* __restrict__ draw,
+template <class E, int K>
+__global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restrict__ x, const E* __restrict__ draw,
                                                            float* dw, int N, int Cin, int H, int W, int Cout, int Cout_real,
                                                            int s, int p, int OH, int OW, long long pix_per_stream) {
     constexpr int KK = K * K;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restr
             int oy = (int)(q % OH); int n = (int)(q / OH);
             for (long long pix = beg; pix < end; ++pix) {
                 float g[8];
-                unpack8(*reinterpret_cast<const u32x4_t*>(draw + (((size_t)n * (OH + 2) + oy + 1) * (OW + 2) + ox + 1) * Cout + cg * 8), g);
+                El<E>::ld8(draw + (((size_t)n * (OH + 2) + oy + 1) * (OW + 2) + ox + 1) * Cout + cg * 8, g);
                 const float* xp = x + ((size_t)n * Cin + ci) * H * W;
                 float xv[KK];
 #pragma unroll
@@ -533,6 +534,60 @@ static bool in_mfma_ok(int Cin, int H, int W, int Cout, int k, int s, int p) {
 
 }  // namespace
 
+namespace {
+template <class E>
+int conv_in_fwd_valu(const float* x, const float* w, void* raw, double* stats, int N, int Cin, int H, int W, int Cout, int Cout_real,
+                     int k, int s, int p, void* stream) {
+    int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
+    size_t sh = (size_t)Cin * k * k * Cout * sizeof(float);
+    long long P = (long long)N * OH * OW;
+    int PPB = 256 / (Cout / 8);
+    long long blocks = (P + (long long)PPB * 16 - 1) / ((long long)PPB * 16);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(conv_in_fwd_kernel<E>, dim3((unsigned)blocks), dim3(256), sh, (hipStream_t)stream, x, w, (E*)raw, stats,
+                       N, Cin, H, W, Cout, Cout_real, k, s, p, OH, OW);
+    SRVP_CHECK_LAUNCH("srvp_conv_in_fwd");
+    return SRVP_OK;
+}
+template <class E>
+int conv_in_wgrad_valu(const float* x, const void* draw, float* dw, int N, int Cin, int H, int W, int Cout, int Cout_real, int k, int s,
+                       int p, void* stream) {
+    int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
+    const int G = (Cout / 8) * Cin;
+    SRVP_REQUIRE(G <= 256, "srvp_conv_in_wgrad: Cout*Cin too large");
+    const int SPB = 256 / G;
+    const long long P = (long long)N * OH * OW;
+    long long blocks = 1024;
+    long long pps = (P + blocks * SPB - 1) / (blocks * SPB);
+    if (pps < 16) { pps = 16; blocks = (P + pps * SPB - 1) / (pps * SPB); }
+    const size_t sh = (size_t)(SPB > 1 ? SPB - 1 : 1) * G * 8 * k * k * sizeof(float);
+    SRVP_REQUIRE(sh <= 160 * 1024, "srvp_conv_in_wgrad: LDS budget");
+    if (k == 3)
+        hipLaunchKernelGGL((conv_in_wgrad_kernel<E, 3>), dim3((unsigned)blocks), dim3(256), sh, (hipStream_t)stream, x,
+                           (const E*)draw, dw, N, Cin, H, W, Cout, Cout_real, s, p, OH, OW, pps);
+    else
+        hipLaunchKernelGGL((conv_in_wgrad_kernel<E, 4>), dim3((unsigned)blocks), dim3(256), sh, (hipStream_t)stream, x,
+                           (const E*)draw, dw, N, Cin, H, W, Cout, Cout_real, s, p, OH, OW, pps);
+    SRVP_CHECK_LAUNCH("srvp_conv_in_wgrad");
+    return SRVP_OK;
+}
+}  // namespace
+
+// precision = 'fp32' parity mode: raw / draw are fp32 NHWC tensors; the direct kernels (an fmaf chain in (ci, kh, kw) order)
+extern "C" int srvp_conv_in_fwd_f32(const float* x, const float* w, void* raw, double* stats, int N, int Cin, int H, int W,
+                                    int Cout, int Cout_real, int k, int s, int p, void* stream) {
+    SRVP_REQUIRE(x && w && raw, "srvp_conv_in_fwd_f32: null pointer");
+    SRVP_REQUIRE(Cin >= 1 && Cin <= MAXC && k <= MAXK && Cout % 8 == 0 && Cout / 8 <= 256, "srvp_conv_in_fwd_f32: unsupported shape");
+    return conv_in_fwd_valu<float>(x, w, raw, stats, N, Cin, H, W, Cout, Cout_real, k, s, p, stream);
+}
+extern "C" int srvp_conv_in_wgrad_f32(const float* x, const void* draw, float* dw, int N, int Cin, int H, int W, int Cout,
+                                      int Cout_real, int k, int s, int p, void* stream) {
+    SRVP_REQUIRE(x && draw && dw, "srvp_conv_in_wgrad_f32: null pointer");
+    SRVP_REQUIRE(Cin >= 1 && Cin <= MAXC && (k == 3 || k == 4) && Cout % 8 == 0, "srvp_conv_in_wgrad_f32: unsupported shape");
+    return conv_in_wgrad_valu<float>(x, draw, dw, N, Cin, H, W, Cout, Cout_real, k, s, p, stream);
+}
+
 extern "C" int srvp_conv_in_fwd(const float* x, const float* w, void* raw, double* stats, int N, int Cin, int H, int W,
                                 int Cout, int Cout_real, int k, int s, int p, void* stream) {
     SRVP_REQUIRE(x && w && raw, "srvp_conv_in_fwd: null pointer");
@@ -546,17 +601,7 @@ extern "C" int srvp_conv_in_fwd(const float* x, const float* w, void* raw, doubl
         SRVP_CHECK_LAUNCH("srvp_conv_in_fwd(mfma)");
         return SRVP_OK;
     }
-    int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
-    size_t sh = (size_t)Cin * k * k * Cout * sizeof(float);
-    long long P = (long long)N * OH * OW;
-    int PPB = 256 / (Cout / 8);
-    long long blocks = (P + (long long)PPB * 16 - 1) / ((long long)PPB * 16);
-    if (blocks > 4096) blocks = 4096;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(conv_in_fwd_kernel, dim3((unsigned)blocks), dim3(256), sh, (hipStream_t)stream, x, w, (bf16_t*)raw, stats,
-                       N, Cin, H, W, Cout, Cout_real, k, s, p, OH, OW);
-    SRVP_CHECK_LAUNCH("srvp_conv_in_fwd");
-    return SRVP_OK;
+    return conv_in_fwd_valu<bf16_t>(x, w, raw, stats, N, Cin, H, W, Cout, Cout_real, k, s, p, stream);
 }
 
 extern "C" int srvp_conv_in_wgrad(const float* x, const void* draw, float* dw, int N, int Cin, int H, int W, int Cout,
@@ -574,23 +619,7 @@ extern "C" int srvp_conv_in_wgrad(const float* x, const void* draw, float* dw, i
         SRVP_CHECK_LAUNCH("srvp_conv_in_wgrad(mfma)");
         return SRVP_OK;
     }
-    const int G = (Cout / 8) * Cin;
-    SRVP_REQUIRE(G <= 256, "srvp_conv_in_wgrad: Cout*Cin too large");
-    const int SPB = 256 / G;
-    const long long P = (long long)N * OH * OW;
-    long long blocks = 1024;
-    long long pps = (P + blocks * SPB - 1) / (blocks * SPB);
-    if (pps < 16) { pps = 16; blocks = (P + pps * SPB - 1) / (pps * SPB); }
-    const size_t sh = (size_t)(SPB > 1 ? SPB - 1 : 1) * G * 8 * k * k * sizeof(float);
-    SRVP_REQUIRE(sh <= 160 * 1024, "srvp_conv_in_wgrad: LDS budget");
-    if (k == 3)
-        hipLaunchKernelGGL(conv_in_wgrad_kernel<3>, dim3((unsigned)blocks), dim3(256), sh, (hipStream_t)stream, x,
-                           (const bf16_t*)draw, dw, N, Cin, H, W, Cout, Cout_real, s, p, OH, OW, pps);
-    else
-        hipLaunchKernelGGL(conv_in_wgrad_kernel<4>, dim3((unsigned)blocks), dim3(256), sh, (hipStream_t)stream, x,
-                           (const bf16_t*)draw, dw, N, Cin, H, W, Cout, Cout_real, s, p, OH, OW, pps);
-    SRVP_CHECK_LAUNCH("srvp_conv_in_wgrad");
-    return SRVP_OK;
+    return conv_in_wgrad_valu<bf16_t>(x, draw, dw, N, Cin, H, W, Cout, Cout_real, k, s, p, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -599,8 +628,9 @@ extern "C" int srvp_conv_in_wgrad(const float* x, const void* draw, float* dw, i
 // channels >= nc zero) that the MFMA data-/weight-gradient kernels consume.
 // ---------------------------------------------------------------------------------------------------------
 namespace {
+template <class E>
 __global__ __launch_bounds__(256) void out_dpre_kernel(const float* __restrict__ xo, const float* __restrict__ dxo,
-                                                       bf16_t* __restrict__ draw, float* __restrict__ dpre_f32, int N, int nc,
+                                                       E* __restrict__ draw, float* __restrict__ dpre_f32, int N, int nc,
                                                        int H, int W, int C, int sigmoid) {
     const int CG = C / 8;
     const long long total = (long long)N * H * W * CG;
@@ -622,7 +652,7 @@ __global__ __launch_bounds__(256) void out_dpre_kernel(const float* __restrict__
             f[e] = v;
         }
         size_t off = (((size_t)n * (H + 2) + y + 1) * (W + 2) + x + 1) * C + cg * 8;
-        *reinterpret_cast<u32x4_t*>(draw + off) = pack8(f);
+        El<E>::st8(draw + off, f);
     }
 }
 }  // namespace
@@ -643,6 +673,25 @@ __global__ __launch_bounds__(256) void out_dpre_f32_kernel(const float* __restri
 }
 }  // namespace
 
+namespace {
+template <class E>
+int out_dpre_launch(const float* x_out, const float* dx_out, void* draw, float* dpre_f32, int N, int nc, int H, int W, int C,
+                    int apply_sigmoid, void* stream) {
+    long long total = (long long)N * H * W * (C / 8);
+    long long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(out_dpre_kernel<E>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_out, dx_out, (E*)draw,
+                       dpre_f32, N, nc, H, W, C, apply_sigmoid);
+    SRVP_CHECK_LAUNCH("srvp_out_dpre");
+    return SRVP_OK;
+}
+}  // namespace
+
+extern "C" int srvp_out_dpre_f32(const float* x_out, const float* dx_out, void* draw, float* dpre_f32, int N, int nc, int H, int W,
+                                 int C, int apply_sigmoid, void* stream) {
+    SRVP_REQUIRE(x_out && dx_out && draw && C % 8 == 0 && nc <= C, "srvp_out_dpre_f32: bad args");
+    return out_dpre_launch<float>(x_out, dx_out, draw, dpre_f32, N, nc, H, W, C, apply_sigmoid, stream);
+}
+
 extern "C" int srvp_out_dpre(const float* x_out, const float* dx_out, void* draw, float* dpre_f32, int N, int nc, int H, int W,
                              int C, int apply_sigmoid, void* stream) {
     SRVP_REQUIRE(x_out && dx_out && (draw || dpre_f32) && C % 8 == 0 && nc <= C, "srvp_out_dpre: bad args");
@@ -654,10 +703,5 @@ extern "C" int srvp_out_dpre(const float* x_out, const float* dx_out, void* draw
         SRVP_CHECK_LAUNCH("srvp_out_dpre");
         return SRVP_OK;
     }
-    long long total = (long long)N * H * W * (C / 8);
-    long long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(out_dpre_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_out, dx_out, (bf16_t*)draw,
-                       dpre_f32, N, nc, H, W, C, apply_sigmoid);
-    SRVP_CHECK_LAUNCH("srvp_out_dpre");
-    return SRVP_OK;
+    return out_dpre_launch<bf16_t>(x_out, dx_out, draw, dpre_f32, N, nc, H, W, C, apply_sigmoid, stream);
 }

@@ -18,12 +18,13 @@ __global__ void fill_f64_kernel(double* p, long long n, double v) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
-__global__ void cast_f32_bf16_kernel(const float* src, bf16_t* dst, long long rows, int cols, int dst_cols) {
+template <class E>
+__global__ void cast_f32_kernel(const float* src, E* dst, long long rows, int cols, int dst_cols) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * dst_cols) return;
     long long r = i / dst_cols;
     int c = (int)(i - r * dst_cols);
-    dst[i] = c < cols ? f2bf(src[r * cols + c]) : (bf16_t)0;
+    El<E>::st(dst + i, c < cols ? src[r * cols + c] : 0.f);
 }
 }  // namespace
 
@@ -95,8 +96,17 @@ extern "C" int srvp_mmnist_render(const void* digits_u8, int n_digits, int dh, i
 extern "C" int srvp_cast_f32_bf16(const float* src, void* dst, int64_t rows, int cols, int dst_cols, void* stream) {
     long long n = (long long)rows * dst_cols;
     if (n <= 0) return SRVP_OK;
-    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+    hipLaunchKernelGGL(cast_f32_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
                        (bf16_t*)dst, (long long)rows, cols, dst_cols);
     SRVP_CHECK_LAUNCH("srvp_cast_f32_bf16");
+    return SRVP_OK;
+}
+// fp32 parity mode: the same zero-padding copy into an fp32 tensor
+extern "C" int srvp_pad_f32(const float* src, float* dst, int64_t rows, int cols, int dst_cols, void* stream) {
+    long long n = (long long)rows * dst_cols;
+    if (n <= 0) return SRVP_OK;
+    hipLaunchKernelGGL(cast_f32_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       (long long)rows, cols, dst_cols);
+    SRVP_CHECK_LAUNCH("srvp_pad_f32");
     return SRVP_OK;
 }

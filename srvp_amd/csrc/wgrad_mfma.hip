@@ -12,6 +12,8 @@
 #include "common.h"
 #include "../../include/srvp_hip.h"
 
+int srvp_wgrad_f32_launch(const srvp_wgrad_desc* d, hipStream_t st);   // conv_f32.hip (precision = 'fp32' parity mode)
+
 namespace {
 
 struct WgradK {
@@ -703,6 +705,7 @@ extern "C" int srvp_wgrad_mfma(const srvp_wgrad_desc* d, void* stream) {
     SRVP_REQUIRE(d->C0 % 32 == 0 && d->C1 % 32 == 0 && d->Cout % 32 == 0 && d->C0 > 0,
                  "srvp_wgrad_mfma: channel counts must be padded to 32");
     SRVP_REQUIRE(d->ntaps >= 1 && d->ntaps <= SRVP_MAX_TAPS && d->splitk >= 1, "srvp_wgrad_mfma: ntaps/splitk");
+    if (d->elem_f32) return srvp_wgrad_f32_launch(d, st);
     if (g_use_tr < 0) {
         const char* e = getenv("SRVP_WGRAD_TR");
         g_use_tr = e ? atoi(e) : 1;

@@ -136,6 +136,9 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         self.sync = None            # set by srvp_amd.distributed for multi-GPU (SyncBN statistics + gradient all-reduce)
         self.last_tape = None
         self._fwd_gen = 0           # training forwards so far (guards backward against overwritten activations)
+        # 'bf16' (production: bf16 MFMA operands / activation storage, fp32 accumulation) or 'fp32' (parity mode: every tensor
+        # fp32, contractions in exact fp32 on the matrix cores) -- set_precision()
+        self.precision = os.environ.get('SRVP_PRECISION', 'bf16')
 
     # ------------------------------------------------------------------------------------------------ init
     def init(self, res_gain=1.41):
@@ -154,6 +157,17 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             if isinstance(m, nn.Linear):
                 nn.init.orthogonal_(m.weight.data, gain=res_gain)
                 nn.init.constant_(m.bias.data, 0.0)
+
+    def set_precision(self, precision):
+        """'bf16': the production path.  'fp32': parity mode -- the conv stacks run on fp32 activations / gradients / packed
+        weights with exact-fp32 MFMA contractions (csrc/conv_f32.hip), so that the whole pipeline can be held against the
+        reference's fp32 arithmetic at 1e-5 (tests/test_gpu_fp32_mode.py); ~16x lower matrix throughput by construction."""
+        assert precision in ('bf16', 'fp32'), precision
+        if precision != self.precision:
+            self.precision = precision
+            self._plans = {}
+            self._pack_version = None
+        return self
 
     # ------------------------------------------------------------------------------------------------ plumbing
     def _cfg(self):
@@ -222,16 +236,17 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
     def _plan(self, T, B, nt, n_euler, training, S=1):
         """S > 1 (inference only): the conditioning frames are encoded once for B videos, the latent path and the decoder run
         on B*S (video, sample) rows -- row s*B + b -- sharing the B skip tensors / hoisted skip halves through the image maps."""
-        key = (T, B, nt, n_euler, training, str(self._device())) + ((S,) if S > 1 else ())
+        f32 = self.precision == 'fp32'
+        key = (T, B, nt, n_euler, training, str(self._device()) + ('/fp32' if f32 else '')) + ((S,) if S > 1 else ())
         pl = self._plans.get(key)
         if pl is None:
             assert S == 1 or not training
             dev = self._device()
-            enc = EncoderNet(self._enc_blocks, T * B, dev, training) if T > 0 else None
+            enc = EncoderNet(self._enc_blocks, T * B, dev, training, f32=f32) if T > 0 else None
             skip_map = torch.zeros(nt * B * S, dtype=torch.int32, device=dev) if self.skipco else None
             skip_sel = torch.zeros(B, dtype=torch.int32, device=dev) if self.skipco else None
             dec = DecoderNet(self._dec_blocks, nt * B * S, dev, training, enc.skips if (self.skipco and enc) else None, skip_map,
-                             skip_sel)
+                             skip_sel, f32=f32)
             lat = LatentNet(self._cfg(), T, B * S, nt, n_euler, dev, training)
             pl = dict(enc=enc, dec=dec, lat=lat, skip_map=skip_map, skip_sel_t=skip_sel)
             # keep at most two training plans alive (they own all activation memory)
@@ -475,17 +490,19 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         dev = self._require_gpu()
         nt, B = y.shape[0], y.shape[1]
         assert (skip is None) == (not self.skipco)
-        key = ('decode', nt, B, self.training, str(dev))
+        f32 = self.precision == 'fp32'
+        key = ('decode', nt, B, self.training, str(dev) + ('/fp32' if f32 else ''))
         pl = self._plans.get(key)
         if pl is None:
             from .convnet import Feat
             feats = None
             skip_map = None
             if self.skipco:
-                feats = {i: Feat(B, s.shape[2], s.shape[3], s.shape[1], dev) for i, s in enumerate(skip)}
+                feats = {i: Feat(B, s.shape[2], s.shape[3], s.shape[1], dev, dtype=torch.float32 if f32 else torch.bfloat16)
+                         for i, s in enumerate(skip)}
                 skip_map = torch.arange(B, dtype=torch.int32, device=dev).repeat(nt)
             dec = DecoderNet(self._dec_blocks, nt * B, dev, False, feats, skip_map,
-                             torch.arange(B, dtype=torch.int32, device=dev) if self.skipco else None)
+                             torch.arange(B, dtype=torch.int32, device=dev) if self.skipco else None, f32=f32)
             pl = dict(dec=dec, feats=feats)
             self._plans[key] = pl
         st = L.stream()

