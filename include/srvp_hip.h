@@ -262,8 +262,13 @@ typedef struct {
     int32_t pz_external;                   /* 1: every frame is a posterior frame and the caller evaluates p_z (forward and
                                             * backward) BATCHED over all frames outside the serial chain -- the prior MLP only
                                             * feeds the KL term then (srvp.py:383-390), its input is the stored state */
+    void* fused_ws; int64_t fused_ws_bytes; /* optional workspace of srvp_rollout_fused_ws_bytes(d) bytes: with it, posterior-only
+                                            * training chains (pz_external, hid_dyn) run as ONE persistent kernel forward and ONE
+                                            * backward (csrc/rollout_fused.hip) instead of nl + 1 launches per Euler step */
 } srvp_rollout_desc;
 int srvp_rollout_fwd(const srvp_rollout_desc* d, void* stream);
+/* bytes of fused_ws the persistent kernels need for this chain, 0 if it must run unfused (dimensions / LDS budget / mode) */
+int64_t srvp_rollout_fused_ws_bytes(const srvp_rollout_desc* d);
 typedef struct {
     srvp_rollout_desc f;
     const float* d_y_all;                  /* [nsteps+1][B][ny] gradient wrt every stored state (zeros where unused) */

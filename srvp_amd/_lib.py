@@ -73,7 +73,7 @@ class RolloutDesc(C.Structure):
                 ('y0', c_vp), ('q_z_params', c_vp), ('eps_z', c_vp),
                 ('y_all', c_vp), ('z', c_vp), ('p_z_params', c_vp), ('res', c_vp),
                 ('inp_all', c_vp), ('hid_dyn', c_vp), ('hid_pz', c_vp), ('scratch_hid', c_vp), ('scratch_out', c_vp),
-                ('pz_external', c_i32)]
+                ('pz_external', c_i32), ('fused_ws', c_vp), ('fused_ws_bytes', c_i64)]
 
 
 class RolloutBwdDesc(C.Structure):
@@ -117,6 +117,7 @@ _SIGS = {
     'srvp_lstm_fwd': ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_lstm_bwd': ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_rollout_fwd': ([C.POINTER(RolloutDesc), c_vp], c_i32),
+    'srvp_rollout_fused_ws_bytes': ([C.POINTER(RolloutDesc)], c_i64),
     'srvp_rollout_bwd': ([C.POINTER(RolloutBwdDesc), c_vp], c_i32),
     'srvp_nll': ([c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_vp, c_vp], c_i32),
     'srvp_kl': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp], c_i32),

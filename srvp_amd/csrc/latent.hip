@@ -8,7 +8,16 @@
 #include "common.h"
 #include "../../include/srvp_hip.h"
 
+int srvp_rollout_fused_fwd(const srvp_rollout_desc* d, hipStream_t st);          // rollout_fused.hip
+int srvp_rollout_fused_bwd(const srvp_rollout_bwd_desc* d, hipStream_t st);
+
 namespace {
+
+inline bool use_fused(const srvp_rollout_desc& f) {
+    if (!f.fused_ws) return false;
+    const int64_t need = srvp_rollout_fused_ws_bytes(&f);
+    return need > 0 && f.fused_ws_bytes >= need;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // C[M][N] (+)= epi( A[M][K] * B[K][N] + bias ),  generic element strides.
@@ -472,6 +481,7 @@ extern "C" int srvp_rollout_fwd(const srvp_rollout_desc* d, void* stream) {
         hipLaunchKernelGGL(rsample_fwd_kernel, g1((long long)F * zs), dim3(256), 0, st, d->q_z_params, d->eps_z, d->z, (long long)F * B, nz);
         hipLaunchKernelGGL(fill_inp_kernel, g1((long long)d->nsteps * B * nin), dim3(256), 0, st, d->z, d->y0, d->inp_all, d->nsteps,
                            d->n_euler, B, ny, nz);
+        if (use_fused(*d)) return srvp_rollout_fused_fwd(d, st);          // the whole chain: one persistent kernel
         for (int i = 0; i < d->nsteps; ++i) {
             float* inp = d->inp_all + (size_t)i * B * nin;
             int rc = mlp_fwd(st, d->dyn_w, d->dyn_b, nl, nin, nh, ny, inp, B, d->hid_dyn + (size_t)i * hl, (size_t)d->nsteps * hl, d->scratch_out);
@@ -535,6 +545,13 @@ extern "C" int srvp_rollout_bwd(const srvp_rollout_bwd_desc* d, void* stream) {
         // posterior-only chain: seed of the last step, then per step nl GEMMs + ONE kernel (close step i, seed step i-1); the
         // gradients wrt z and the posterior samples' backward are finished for all frames at once afterwards
         const int S = f.nsteps;
+        if (use_fused(f)) {
+            if (int rc = srvp_rollout_fused_bwd(d, st)) return rc;        // writes every delta, dinp_all and d_y0
+            hipLaunchKernelGGL(dz_finalize_kernel, g1((long long)F * zs), dim3(256), 0, st, d->dinp_all, d->d_z, f.q_z_params, f.eps_z, d->d_qz,
+                               F, S, f.n_euler, B, ny, nz);
+            SRVP_CHECK_LAUNCH("srvp_rollout_bwd(fused)");
+            return SRVP_OK;
+        }
         hipLaunchKernelGGL(euler_bwd_seed_kernel, g1((long long)ys), dim3(256), 0, st, d->d_y_all + ys * S, carry,
                            d->d_res ? d->d_res + ys * (S - 1) : nullptr, f.dt, dy, d->dhid_dyn + (size_t)(S - 1) * B * dwd + (size_t)(nl - 1) * dls_d,
                            B, ny, dwd);

@@ -1,0 +1,569 @@
+// Persistent fused residual rollout (training / posterior chain): ONE launch runs all n_euler * (T - 1) Euler steps of
+//   y_{i+1} = y_i + dt * MLP_dynamics([y_i, z_{frame(i)}])                 (reference module/srvp.py:300-323, 377-405)
+// forward, and ONE launch runs the whole backward-through-time chain, instead of (nl GEMMs + 1 update) launches per step
+// (236 dependent micro-launches per training step at the headline config, ~6 ms that did not shrink with the batch).
+//
+// Decomposition: samples are independent, hidden units are not.  The batch is cut into 32-row tiles; a CLUSTER of
+// G = nh / 32 workgroups owns one row tile, workgroup g of the cluster owns hidden columns [32 g, 32 g + 32) of every
+// layer for the whole kernel, so its weight slices (nh x 32 fp32 per hidden layer: 64 KB at nh = 512) are loaded ONCE into
+// LDS / registers and stay there for all steps -- no weight traffic inside the chain.  Per layer the cluster exchanges the
+// 32 x nh activation tile through global memory (the hid_dyn / dhid_dyn tensors the weight-gradient GEMMs need anyway) and
+// synchronises with a monotonic counter (agent-scope release / acquire); the first-in-cluster layer of a step needs no
+// exchange (every workgroup carries the y / dy state itself) and the last layer is split-K over the cluster with
+// deterministic partial sums.  nl - 1 cluster barriers per Euler step.  Arithmetic: exact fp32 on the matrix cores
+// (v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain), wave tile 16 x 16 with the full K per wave (no cross-wave reduction).
+//
+// All workgroups of a launch must be co-resident (they spin on each other): the launcher keeps the grid <= the number of CUs
+// (one workgroup per CU: > 80 KB of LDS each) and walks larger batches in several launches.
+#include "common.h"
+#include "../../include/srvp_hip.h"
+
+namespace {
+
+constexpr int RT = 32;           // rows per cluster tile
+constexpr int CW = 32;           // hidden columns per workgroup
+constexpr int KP0_MAX = 128;     // padded width of the first-layer input (ny + nz <= 128)
+constexpr int NYP_MAX = 64;      // padded ny (<= 64)
+constexpr int MAX_NL = 8;
+
+struct RollF {
+    int B, ny, nz, nh, nl, S, ne, G, nin, kp0, nyp, ntiles, tile0, cl_per_xcd;
+    float dt;
+    const float* W[MAX_NL]; const float* b[MAX_NL];
+    // forward
+    const float* y0; float* y_all; float* res; float* inp_all; float* hid;
+    // backward
+    const float* d_y_all; const float* d_res; float* dhid; float* dinp_all; float* d_y0; int dwd;
+    float* part; unsigned* cnt;
+    int dbg;     // timing experiments only (SRVP_RF_DEBUG): 1 no barrier wait, 2 no A loads, 4 no partial reads, 8 no big MFMAs
+};
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// B-operand slice [K][32] in LDS: element (k, c) -- two k rows per 64-float line, 16-float groups XOR-swizzled by the
+// line-pair index so that the four k rows {k0 + 4 q} one MFMA reads (lane group q) fall on four disjoint bank groups
+__device__ __forceinline__ int sw(int k, int c) { return (k >> 1) * 64 + ((((k & 1) << 5) | c) ^ (((k >> 2) & 3) << 4)); }
+
+// Everything the workgroups of a cluster exchange inside the kernel is written and read with AGENT-SCOPE accesses (sc1:
+// write-through / miss-always, the code the compiler emits for relaxed agent-scope atomics), so the barrier needs no cache
+// maintenance: a whole-L2 write-back + invalidate per barrier (what an agent-scope release / acquire FENCE costs on this
+// multi-XCD part while other kernels keep the L2 full of dirty lines) measured 27 us per layer.
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ void cluster_barrier(unsigned* cnt, unsigned target, int dbg = 0) {
+    if (!(dbg & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's agent-scope stores have been acknowledged
+    __syncthreads();
+    if (dbg & 1) return;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+}
+
+// workgroup -> (cluster, member): members of a cluster sit on ONE XCD when workgroups are dealt round-robin to the 8 XCDs
+// (speed only: the exchange then stays inside that XCD's L2)
+__device__ __forceinline__ bool locate(const RollF& a, int& cl, int& g) {
+    const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+    cl = x * a.cl_per_xcd + k / a.G;
+    g = k % a.G;
+    return cl < a.ntiles;
+}
+
+// acc(16x16, this wave) += A(rows from global -- written by the other workgroups of the cluster: agent-scope loads, 16 bytes
+// each, counted by hand) x B(LDS slice).  K is walked in 512-wide blocks of four 128-wide chunks, all 32 loads of a block
+// issued before its first MFMA.  The loads are UNCONDITIONAL (addresses clamped into the row) and no in-flight register lives
+// across a loop back-edge or a branch: hipcc places phi copies of such registers BEFORE the hand-written wait.
+__device__ __forceinline__ void ld_chunk(f32x4v (&a4)[8], const float* p, int k0, int K) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + 16 * j < K ? k0 + 16 * j : K - 16;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(a4[j]) : "v"(p + k) : "memory");
+    }
+}
+__device__ __forceinline__ void mm_chunk(f32x4v& acc, f32x4v (&a4)[8], const float* Bs, int k0, int K, int q, int cc) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (k0 + 16 * j >= K) break;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j][e], Bs[sw(k0 + 16 * j + 4 * q + e, cc)], acc, 0, 0, 0);
+    }
+}
+#define WAIT_A4(buf, n) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7]) :: "memory")
+__device__ __forceinline__ void gemm_glob_lds(f32x4v& acc, const float* arow, const float* Bs, int K, int q, int cc, int dbg = 0) {
+    const float* p = arow + 4 * q;
+    if (dbg & 8) return;
+    for (int k0 = 0; k0 < K; k0 += 512) {
+        f32x4v b0[8], b1[8], b2[8], b3[8];
+        if (dbg & 2) { for (int j = 0; j < 8; ++j) { b0[j] = b1[j] = b2[j] = b3[j] = f32x4v{1.f, 1.f, 1.f, 1.f}; } mm_chunk(acc, b0, Bs, k0, K, q, cc); mm_chunk(acc, b1, Bs, k0 + 128, K, q, cc); mm_chunk(acc, b2, Bs, k0 + 256, K, q, cc); mm_chunk(acc, b3, Bs, k0 + 384, K, q, cc); continue; }
+        ld_chunk(b0, p, k0, K); ld_chunk(b1, p, k0 + 128, K); ld_chunk(b2, p, k0 + 256, K); ld_chunk(b3, p, k0 + 384, K);
+        WAIT_A4(b0, 24); mm_chunk(acc, b0, Bs, k0, K, q, cc);
+        WAIT_A4(b1, 16); mm_chunk(acc, b1, Bs, k0 + 128, K, q, cc);
+        WAIT_A4(b2, 8); mm_chunk(acc, b2, Bs, k0 + 256, K, q, cc);
+        WAIT_A4(b3, 0); mm_chunk(acc, b3, Bs, k0 + 384, K, q, cc);
+    }
+}
+
+// Sum of the G split-K slabs for two (row, 4-column) items per thread: all 2 GP 16-byte agent-scope loads in flight at once
+// (a serial per-slab loop of 4-byte loads cost 24-48 us per Euler step: half of the whole kernel), fixed summation order.
+// Unconditional loads (slab index clamped), see gemm_glob_lds.
+#define WAIT8(v, o) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[o]), "+v"(v[o + 1]), "+v"(v[o + 2]), "+v"(v[o + 3]), "+v"(v[o + 4]), "+v"(v[o + 5]), "+v"(v[o + 6]), "+v"(v[o + 7]) :: "memory")
+template <int GP>
+__device__ __forceinline__ void sum_slabs2(f32x4v& sa, f32x4v& sb, const float* pa, const float* pb, int G, size_t slab_stride) {
+    f32x4v va[GP], vb[GP];
+#pragma unroll
+    for (int gg = 0; gg < GP; ++gg) {
+        const size_t o = (size_t)(gg < G ? gg : G - 1) * slab_stride;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(va[gg]) : "v"(pa + o) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(vb[gg]) : "v"(pb + o) : "memory");
+    }
+#pragma unroll
+    for (int o = 0; o < GP; o += 8) { WAIT8(va, o); WAIT8(vb, o); }
+#pragma unroll
+    for (int gg = 0; gg < GP; ++gg)
+        if (gg < G) { sa += va[gg]; sb += vb[gg]; }
+}
+
+// ------------------------------------------------------------------------------------------------------------ forward
+template <int GP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_fused_fwd_kernel(const RollF a) {
+    extern __shared__ float lds[];
+    int cl, g;
+    if (!locate(a, cl, g)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int rh = wid >> 1, ch = wid & 1, q = lane >> 4, c16 = lane & 15;
+    const int cc = 16 * ch + c16;                         // column inside the workgroup's 32-column slice
+    const int row0 = (a.tile0 + cl) * RT;
+    const int colbase = g * CW;
+    const int nl = a.nl, nh = a.nh, ny = a.ny, nin = a.nin, B = a.B;
+    const int nfull = nl - 2;                             // hidden layers with K = nh (LDS-resident slices)
+    // LDS: [nfull][nh][32] slices | Is [32][kp0 + 1] | Ys [32][ny] | Hs [32][33]
+    float* Wl = lds;
+    float* Is = Wl + (size_t)nfull * nh * CW;
+    float* Ys = Is + RT * (a.kp0 + 1);
+    float* Hs = Ys + RT * ny;
+    float* Bl = Hs + RT * 33;                             // bias of the last layer
+    unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;       // one 256-byte line per cluster
+    // split-K partials: a FRESH slab per Euler step (agent-scope loads are served by the reader's L2: a slab address that was
+    // read before would be answered with the old line when the producing workgroup sits on another XCD)
+    float* part = a.part + (size_t)(a.tile0 + cl) * a.S * a.G * RT * KP0_MAX;
+    unsigned target = 0;
+
+    // ---- one-time: weight slices.  hidden layers l = 1 .. nl-2 into LDS (B[k][c] = W_l[colbase + c][k])
+    for (int l = 1; l <= nfull; ++l) {
+        const float* W = a.W[l];
+        float* dst = Wl + (size_t)(l - 1) * nh * CW;
+        for (int idx = tid; idx < nh * CW; idx += 256) {
+            const int c = idx / nh, k = idx - c * nh;     // consecutive threads walk k: coalesced rows of W
+            dst[sw(k, c)] = W[(size_t)(colbase + c) * nh + k];
+        }
+    }
+    // first layer (K = nin) and last layer (split-K: this workgroup's 32 hidden units x ny outputs): B fragments in registers
+    float w0[KP0_MAX / 4];                                // B0[k = 16 j + 4 q + e][cc] = W_0[colbase + cc][k]
+#pragma unroll
+    for (int j = 0; j < KP0_MAX / 16; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 16 * j + 4 * q + e;
+            w0[j * 4 + e] = k < nin ? a.W[0][(size_t)(colbase + cc) * nin + k] : 0.f;
+        }
+    // last-layer tiles of this wave: tile t = wid + 4 u -> (row half t & 1, output column tile t >> 1)
+    float wl[2][8];                                       // BL[k = 4 jj + q][col] = W_last[col][colbase + k]
+    const int ntl = 2 * (a.nyp / 16);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = wid + 4 * u, col = 16 * (t >> 1) + c16;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+            wl[u][jj] = (t < ntl && col < ny) ? a.W[nl - 1][(size_t)col * nh + colbase + 4 * jj + q] : 0.f;
+    }
+    // state
+    for (int idx = tid; idx < RT * ny; idx += 256) {
+        const int r = idx / ny, c = idx - r * ny;
+        const int row = row0 + r < B ? row0 + r : B - 1;
+        Ys[idx] = a.y0[(size_t)row * ny + c];
+    }
+    if (tid < ny) Bl[tid] = a.b[nl - 1][tid];
+    // z part of the first-layer input: this thread's elements of the [32][kp0] staging tile, fetched ONE STEP AHEAD (the
+    // dependent global-load latencies of a step, not its arithmetic, are most of what a step costs)
+    float zr[KP0_MAX * RT / 256];
+    auto fetch_z = [&](int step) {
+#pragma unroll
+        for (int u = 0; u < KP0_MAX * RT / 256; ++u) {
+            const int idx = tid + 256 * u, r = idx / a.kp0, k = idx - r * a.kp0;
+            const int row = row0 + r < B ? row0 + r : B - 1;
+            zr[u] = (idx < RT * a.kp0 && k >= ny && k < nin) ? a.inp_all[((size_t)step * B + row) * nin + k] : 0.f;
+        }
+    };
+    fetch_z(0);
+    __syncthreads();
+    const int arow_l = 16 * rh + c16;                     // A row of this lane inside the tile
+    const int grow = row0 + arow_l < B ? row0 + arow_l : B - 1;
+    const size_t hs = (size_t)a.S * B * nh;               // layer stride of hid
+
+    for (int i = 0; i < a.S; ++i) {
+        // ---- stage [y_i, z] (z part prefilled in inp_all by the caller, constant during the kernel)
+#pragma unroll
+        for (int u = 0; u < KP0_MAX * RT / 256; ++u) {
+            const int idx = tid + 256 * u, r = idx / a.kp0, k = idx - r * a.kp0;
+            if (idx < RT * a.kp0) Is[r * (a.kp0 + 1) + k] = k < ny ? Ys[r * ny + k] : zr[u];
+        }
+        if (i + 1 < a.S) fetch_z(i + 1);
+        __syncthreads();
+        // ---- layer 0: A from LDS, B from registers
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+        float bl = a.b[0][colbase + cc];                  // bias of the layer being finished (loaded ahead of its use)
+        {
+            const float* ar = Is + arow_l * (a.kp0 + 1) + 4 * q;
+#pragma unroll
+            for (int j = 0; j < KP0_MAX / 16; ++j) {
+                if (16 * j >= a.kp0) break;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[16 * j + e], w0[j * 4 + e], acc, 0, 0, 0);
+            }
+        }
+        for (int l = 0; l <= nfull; ++l) {
+            // epilogue of full-output layer l: bias, ReLU, store the saved activation (= the exchange buffer)
+            float* hdst = a.hid + (size_t)l * hs + (size_t)i * B * nh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 16 * rh + 4 * q + e;
+                float v = acc[e] + bl;
+                v = v > 0.f ? v : 0.f;
+                if (row0 + r < B) st_agent(hdst + (size_t)(row0 + r) * nh + colbase + cc, v);
+                if (l == nfull) Hs[r * 33 + cc] = v;
+            }
+            if (l == nfull) break;
+            bl = a.b[l + 1][colbase + cc];
+            cluster_barrier(cnt, target += a.G, a.dbg);
+            // ---- layer l + 1: A = complete hidden tile from global, B = LDS slice
+            acc = f32x4v{0.f, 0.f, 0.f, 0.f};
+            gemm_glob_lds(acc, hdst + (size_t)grow * nh, Wl + (size_t)l * nh * CW, nh, q, cc, a.dbg);
+        }
+        __syncthreads();                                  // Hs complete
+        // ---- last layer, split-K over the cluster: partial[32 x ny] from this workgroup's 32 hidden units
+        float* pdst = part + ((size_t)i * a.G + g) * RT * KP0_MAX;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = wid + 4 * u;
+            if (t >= ntl) break;
+            const int trh = t & 1, ct = t >> 1;
+            f32x4v o = {0.f, 0.f, 0.f, 0.f};
+            const float* hr = Hs + (16 * trh + c16) * 33 + q;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) o = __builtin_amdgcn_mfma_f32_16x16x4f32(hr[4 * jj], wl[u][jj], o, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st_agent(pdst + (16 * trh + 4 * q + e) * NYP_MAX + 16 * ct + c16, o[e]);
+        }
+        cluster_barrier(cnt, target += a.G, a.dbg);
+        // ---- every workgroup: sum the G partials in a fixed order, Euler update of its copy of the state
+        const float* psrc = part + (size_t)i * a.G * RT * KP0_MAX;
+        const int nq = a.nyp / 4;                          // 4-column items per row
+        for (int it = tid; it < RT * nq; it += 512) {
+            const int itb = it + 256 < RT * nq ? it + 256 : it;
+            f32x4v sv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            if (!(a.dbg & 4))
+                sum_slabs2<GP>(sv[0], sv[1], psrc + (it / nq) * NYP_MAX + 4 * (it % nq), psrc + (itb / nq) * NYP_MAX + 4 * (itb % nq), a.G,
+                               (size_t)RT * KP0_MAX);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int item = h ? itb : it;
+                if (h && itb == it) break;
+                const int r = item / nq, c0 = 4 * (item % nq);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = c0 + e;
+                    if (c >= ny) break;
+                    const float rs = a.dt * (sv[h][e] + Bl[c]);
+                    const float yn = Ys[r * ny + c] + rs;
+                    Ys[r * ny + c] = yn;
+                    if (g == 0 && row0 + r < B) {
+                        const size_t o = (size_t)(row0 + r) * ny + c;
+                        a.res[(size_t)i * B * ny + o] = rs;
+                        a.y_all[(size_t)(i + 1) * B * ny + o] = yn;
+                        if (i + 1 < a.S) a.inp_all[((size_t)(i + 1) * B + row0 + r) * nin + c] = yn;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ backward
+// per step (descending): dout = dt (d_res_i + dy);  delta_{nl-2} = (dout W_{nl-1}) relu'(h_{nl-2});  delta_{l-1} =
+// (delta_l W_l) relu'(h_{l-1});  dinp = delta_0 W_0;  dy <- d_y_all[i] + dy + dinp[:, :ny]
+template <int GP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_fused_bwd_kernel(const RollF a) {
+    extern __shared__ float lds[];
+    int cl, g;
+    if (!locate(a, cl, g)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int rh = wid >> 1, ch = wid & 1, q = lane >> 4, c16 = lane & 15;
+    const int cc = 16 * ch + c16;
+    const int row0 = (a.tile0 + cl) * RT;
+    const int colbase = g * CW;
+    const int nl = a.nl, nh = a.nh, ny = a.ny, nin = a.nin, B = a.B, dwd = a.dwd;
+    const int nfull = nl - 2;
+    // LDS: [nfull][nh][32] slices (B[k][c] = W_l[k][colbase + c], l = nl-2 .. 1) | Do [32][nyp + 1] | Dy [32][ny] | Hs [32][33]
+    float* Wl = lds;
+    float* Do = Wl + (size_t)nfull * nh * CW;
+    float* Dy = Do + RT * (a.nyp + 1);
+    float* Hs = Dy + RT * ny;
+    unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;
+    float* part = a.part + (size_t)(a.tile0 + cl) * a.S * a.G * RT * KP0_MAX;       // fresh slab per step (see the forward kernel)
+    unsigned target = 0;
+    for (int l = 1; l <= nfull; ++l) {
+        const float* W = a.W[l];
+        float* dst = Wl + (size_t)(l - 1) * nh * CW;
+        for (int idx = tid; idx < nh * CW; idx += 256) {
+            const int k = idx / CW, c = idx - k * CW;     // consecutive threads walk the 32 columns of row k
+            dst[sw(k, c)] = W[(size_t)k * nh + colbase + c];
+        }
+    }
+    // last layer backward (K = ny): B[k = 16 j + 4 q + e][cc] = W_{nl-1}[k][colbase + cc] in registers
+    float wlb[NYP_MAX / 4];
+#pragma unroll
+    for (int j = 0; j < NYP_MAX / 16; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 16 * j + 4 * q + e;
+            wlb[j * 4 + e] = k < ny ? a.W[nl - 1][(size_t)k * nh + colbase + cc] : 0.f;
+        }
+    // input gradient (split-K: this workgroup's 32 units of delta_0): tiles t = wid + 4 u -> (row half t & 1, column tile t >> 1)
+    // B[k = 4 jj + q][col] = W_0[colbase + k][col]
+    const int ntl = 2 * (a.kp0 / 16);
+    float w0b[KP0_MAX / 16 * 2 / 4][8];
+#pragma unroll
+    for (int u = 0; u < KP0_MAX / 16 * 2 / 4; ++u) {
+        const int t = wid + 4 * u, col = 16 * (t >> 1) + c16;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+            w0b[u][jj] = (t < ntl && col < nin) ? a.W[0][(size_t)(colbase + 4 * jj + q) * nin + col] : 0.f;
+    }
+    for (int idx = tid; idx < RT * ny; idx += 256) {
+        const int r = idx / ny, c = idx - r * ny;
+        const int row = row0 + r < B ? row0 + r : B - 1;
+        Dy[idx] = a.d_y_all[((size_t)a.S * B + row) * ny + c];
+    }
+    __syncthreads();
+    const int arow_l = 16 * rh + c16;
+    const int grow = row0 + arow_l < B ? row0 + arow_l : B - 1;
+    const size_t hs = (size_t)a.S * B * nh;               // layer stride of hid
+    const size_t ds = (size_t)a.S * B * dwd;              // layer stride of dhid
+
+    // global operands that do not depend on the chain are fetched ahead of their use (one step / one layer), so that their
+    // latencies do not add up on the serial path: d_res of the next step to visit, the ReLU masks of the next layer
+    float dres[NYP_MAX * RT / 256];
+    auto fetch_dres = [&](int step) {
+#pragma unroll
+        for (int u = 0; u < NYP_MAX * RT / 256; ++u) {
+            const int idx = tid + 256 * u, r = idx / a.nyp, c = idx - r * a.nyp;
+            const int row = row0 + r < B ? row0 + r : B - 1;
+            dres[u] = (a.d_res && idx < RT * a.nyp && c < ny) ? a.d_res[((size_t)step * B + row) * ny + c] : 0.f;
+        }
+    };
+    float hm[4];                                          // saved activations (ReLU masks) of this lane's 4 output elements
+    auto fetch_mask = [&](int l, int step) {
+        const float* hsrc = a.hid + (size_t)l * hs + (size_t)step * B * nh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 16 * rh + 4 * q + e;
+            const int row = row0 + r < B ? row0 + r : B - 1;
+            hm[e] = hsrc[(size_t)row * nh + colbase + cc];
+        }
+    };
+    fetch_dres(a.S - 1);
+    for (int i = a.S - 1; i >= 0; --i) {
+        // ---- dout = dt (d_res_i + dy): every workgroup from its own state; member 0 stores it (delta of the last layer)
+        fetch_mask(nl - 2, i);
+#pragma unroll
+        for (int u = 0; u < NYP_MAX * RT / 256; ++u) {
+            const int idx = tid + 256 * u, r = idx / a.nyp, c = idx - r * a.nyp;
+            if (idx >= RT * a.nyp) break;
+            float v = 0.f;
+            if (c < ny) {
+                v = a.dt * (dres[u] + Dy[r * ny + c]);
+                if (g == 0 && row0 + r < B) a.dhid[(size_t)(nl - 1) * ds + ((size_t)i * B + row0 + r) * dwd + c] = v;
+            }
+            Do[r * (a.nyp + 1) + c] = v;
+        }
+        if (i > 0) fetch_dres(i - 1);
+        __syncthreads();
+        // ---- delta_{nl-2} slice: A = dout (LDS), B = registers
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+        {
+            const float* ar = Do + arow_l * (a.nyp + 1) + 4 * q;
+#pragma unroll
+            for (int j = 0; j < NYP_MAX / 16; ++j) {
+                if (16 * j >= a.nyp) break;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[16 * j + e], wlb[j * 4 + e], acc, 0, 0, 0);
+            }
+        }
+        for (int l = nl - 2; l >= 0; --l) {
+            // epilogue: delta_l = acc * relu'(h_l) (mask from the saved post-ReLU activation), stored for the weight gradients
+            float* ddst = a.dhid + (size_t)l * ds + (size_t)i * B * dwd;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 16 * rh + 4 * q + e;
+                const float v = hm[e] > 0.f ? acc[e] : 0.f;
+                if (row0 + r < B) st_agent(ddst + (size_t)(row0 + r) * dwd + colbase + cc, v);
+                if (l == 0) Hs[r * 33 + cc] = v;
+            }
+            if (l == 0) break;
+            fetch_mask(l - 1, i);
+            cluster_barrier(cnt, target += a.G, a.dbg);
+            // ---- delta_{l-1} slice: A = complete delta_l tile (global), B = LDS slice of W_l
+            acc = f32x4v{0.f, 0.f, 0.f, 0.f};
+            gemm_glob_lds(acc, ddst + (size_t)grow * dwd, Wl + (size_t)(l - 1) * nh * CW, nh, q, cc, a.dbg);
+        }
+        __syncthreads();
+        // ---- dinp partial (split-K over the cluster)
+        float* pdst = part + ((size_t)i * a.G + g) * RT * KP0_MAX;
+#pragma unroll
+        for (int u = 0; u < KP0_MAX / 16 * 2 / 4; ++u) {
+            const int t = wid + 4 * u;
+            if (t >= ntl) break;
+            const int trh = t & 1, ct = t >> 1;
+            f32x4v o = {0.f, 0.f, 0.f, 0.f};
+            const float* hr = Hs + (16 * trh + c16) * 33 + q;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) o = __builtin_amdgcn_mfma_f32_16x16x4f32(hr[4 * jj], w0b[u][jj], o, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st_agent(pdst + (16 * trh + 4 * q + e) * KP0_MAX + 16 * ct + c16, o[e]);
+        }
+        // d_y_all[i] of this thread's items (c < ny only), fetched before the barrier wait
+        const int nq = a.kp0 / 4;
+        float dyv[KP0_MAX / 4 * RT / 256][4];
+#pragma unroll
+        for (int u = 0; u < KP0_MAX / 4 * RT / 256; ++u) {
+            const int item = tid + 256 * u, r = item / nq, c0 = 4 * (item % nq);
+            const int row = row0 + r < B ? row0 + r : B - 1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                dyv[u][e] = (item < RT * nq && c0 + e < ny) ? a.d_y_all[((size_t)i * B + row) * ny + c0 + e] : 0.f;
+        }
+        cluster_barrier(cnt, target += a.G, a.dbg);
+        const float* psrc = part + (size_t)i * a.G * RT * KP0_MAX;
+#pragma unroll
+        for (int u2 = 0; u2 < KP0_MAX / 4 * RT / 512; ++u2) {
+            const int it = tid + 512 * u2;
+            if (it >= RT * nq) break;
+            const int itb = it + 256 < RT * nq ? it + 256 : it;
+            f32x4v sv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            if (!(a.dbg & 4))
+                sum_slabs2<GP>(sv[0], sv[1], psrc + (it / nq) * KP0_MAX + 4 * (it % nq), psrc + (itb / nq) * KP0_MAX + 4 * (itb % nq), a.G,
+                               (size_t)RT * KP0_MAX);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int item = h ? itb : it;
+                if (h && itb == it) break;
+                const int r = item / nq, c0 = 4 * (item % nq);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = c0 + e;
+                    if (c >= nin) break;
+                    const float sum = sv[h][e];
+                    if (g == 0 && row0 + r < B) a.dinp_all[((size_t)i * B + row0 + r) * nin + c] = sum;
+                    if (c < ny) Dy[r * ny + c] = dyv[2 * u2 + h][e] + Dy[r * ny + c] + sum;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (g == 0)
+        for (int idx = tid; idx < RT * ny; idx += 256) {
+            const int r = idx / ny, c = idx - r * ny;
+            if (row0 + r < B) a.d_y0[(size_t)(row0 + r) * ny + c] = Dy[idx];
+        }
+}
+
+int g_fused = -1, g_ncu = 0;
+
+}  // namespace
+
+// 0 if this chain cannot run fused (the caller keeps the per-layer launch sequence), else the workspace size in bytes
+extern "C" int64_t srvp_rollout_fused_ws_bytes(const srvp_rollout_desc* d) {
+    if (g_fused < 0) { const char* e = getenv("SRVP_ROLLOUT_FUSED"); g_fused = e ? atoi(e) : 1; }
+    if (!g_fused || !d) return 0;
+    const int nin = d->ny + d->nz;
+    if (d->nl < 2 || d->nl > MAX_NL || d->nh % CW != 0 || d->nh / CW > 32 || nin > KP0_MAX || d->ny > NYP_MAX || d->ny > d->nh ||
+        d->nsteps < 1) return 0;
+    if (!d->pz_external || !d->hid_dyn) return 0;
+    const int kp0 = (nin + 15) / 16 * 16, nyp = (d->ny + 15) / 16 * 16;
+    const size_t lds_f = ((size_t)(d->nl - 2) * d->nh * CW + RT * (kp0 + 1) + RT * d->ny + RT * 33 + NYP_MAX) * 4;
+    const size_t lds_b = ((size_t)(d->nl - 2) * d->nh * CW + RT * (nyp + 1) + RT * d->ny + RT * 33) * 4;
+    if (lds_f > 160 * 1024 || lds_b > 160 * 1024) return 0;
+    const int64_t tiles = (d->B + RT - 1) / RT;
+    return tiles * 256 /* counters (padded) */ + tiles * (int64_t)d->nsteps * (d->nh / CW) * RT * KP0_MAX * 4;
+}
+
+static int fused_common(const srvp_rollout_desc& f, RollF& k, void* ws) {
+    if (!g_ncu) {
+        hipDeviceProp_t p; int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) p.multiProcessorCount = 256;
+        g_ncu = p.multiProcessorCount;
+    }
+    k.B = f.B; k.ny = f.ny; k.nz = f.nz; k.nh = f.nh; k.nl = f.nl; k.S = f.nsteps; k.ne = f.n_euler; k.G = f.nh / CW;
+    { const char* e = getenv("SRVP_RF_DEBUG"); k.dbg = e ? atoi(e) : 0; }
+    k.nin = f.ny + f.nz; k.kp0 = (k.nin + 15) / 16 * 16; k.nyp = (f.ny + 15) / 16 * 16; k.dt = f.dt;
+    for (int l = 0; l < MAX_NL; ++l) { k.W[l] = l < f.nl ? f.dyn_w[l] : nullptr; k.b[l] = l < f.nl ? f.dyn_b[l] : nullptr; }
+    const int tiles = (f.B + RT - 1) / RT;
+    k.cnt = (unsigned*)ws;
+    k.part = (float*)((char*)ws + (size_t)tiles * 256);
+    return tiles;
+}
+
+// clusters per launch: all workgroups co-resident (grid <= CUs), whole clusters per XCD
+static int clusters_per_launch(int G, int tiles, int& cl_per_xcd) {
+    int per_xcd = (g_ncu / 8) / G;
+    if (per_xcd < 1) per_xcd = 1;
+    int need = (tiles + 7) / 8;
+    cl_per_xcd = need < per_xcd ? need : per_xcd;
+    return cl_per_xcd * 8;
+}
+
+int srvp_rollout_fused_fwd(const srvp_rollout_desc* d, hipStream_t st) {
+    RollF k{};
+    const int tiles = fused_common(*d, k, d->fused_ws);
+    k.y0 = d->y0; k.y_all = d->y_all; k.res = d->res; k.inp_all = d->inp_all; k.hid = d->hid_dyn;
+    const size_t lds = ((size_t)(k.nl - 2) * k.nh * CW + RT * (k.kp0 + 1) + RT * k.ny + RT * 33 + NYP_MAX) * 4;
+    auto kern = k.G <= 8 ? rollout_fused_fwd_kernel<8> : (k.G <= 16 ? rollout_fused_fwd_kernel<16> : rollout_fused_fwd_kernel<32>);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd(fused): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd(fused): memset failed");
+    int cpx;
+    const int per = clusters_per_launch(k.G, tiles, cpx);
+    for (int t0 = 0; t0 < tiles; t0 += per) {
+        k.tile0 = t0; k.ntiles = tiles - t0 < per ? tiles - t0 : per; k.cl_per_xcd = cpx;
+        hipLaunchKernelGGL(kern, dim3(8 * cpx * k.G), dim3(256), lds, st, k);
+    }
+    SRVP_CHECK_LAUNCH("srvp_rollout_fwd(fused)");
+    return SRVP_OK;
+}
+
+int srvp_rollout_fused_bwd(const srvp_rollout_bwd_desc* d, hipStream_t st) {
+    RollF k{};
+    const srvp_rollout_desc& f = d->f;
+    const int tiles = fused_common(f, k, f.fused_ws);
+    k.hid = f.hid_dyn; k.d_y_all = d->d_y_all; k.d_res = d->d_res; k.dhid = d->dhid_dyn; k.dinp_all = d->dinp_all; k.d_y0 = d->d_y0;
+    k.dwd = f.nh > f.ny ? f.nh : f.ny;
+    const size_t lds = ((size_t)(k.nl - 2) * k.nh * CW + RT * (k.nyp + 1) + RT * k.ny + RT * 33) * 4;
+    auto kern = k.G <= 8 ? rollout_fused_bwd_kernel<8> : (k.G <= 16 ? rollout_fused_bwd_kernel<16> : rollout_fused_bwd_kernel<32>);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_bwd(fused): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_bwd(fused): memset failed");
+    int cpx;
+    const int per = clusters_per_launch(k.G, tiles, cpx);
+    for (int t0 = 0; t0 < tiles; t0 += per) {
+        k.tile0 = t0; k.ntiles = tiles - t0 < per ? tiles - t0 : per; k.cl_per_xcd = cpx;
+        hipLaunchKernelGGL(kern, dim3(8 * cpx * k.G), dim3(256), lds, st, k);
+    }
+    SRVP_CHECK_LAUNCH("srvp_rollout_bwd(fused)");
+    return SRVP_OK;
+}

@@ -184,6 +184,14 @@ class LatentNet:
             # term -- it leaves the serial chain and runs once, batched over all frames, on the stored states
             self.pz_ext = bool(self.training and n_data >= self.nt and PZ_BATCHED and self.dwp == self.cfg['nh_res'])
             self._rd.pz_external = 1 if self.pz_ext else 0
+            if self.pz_ext:
+                # persistent fused chain (csrc/rollout_fused.hip): the library says how much workspace it wants, 0 = not eligible
+                need = int(L.load().srvp_rollout_fused_ws_bytes(C.byref(self._rd)))
+                if need > 0:
+                    ws = self.__dict__.get('_fused_ws')
+                    if ws is None or ws.numel() < need:
+                        ws = self._fused_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
+                    self._rd.fused_ws, self._rd.fused_ws_bytes = L.ptr(ws), need
             L.call('srvp_rollout_fwd', C.byref(self._rd), st)
             if self.pz_ext:
                 B, F, nlr, ny, nz, nhr = self.B, self.F, self.nl_res, self.cfg['ny'], self.cfg['nz'], self.cfg['nh_res']

@@ -114,8 +114,8 @@ def test_bf16_elbo_gate_bair_384_frames():
     assert med <= 1.25 * m_med + 0.01, (med, m_med, worst)
     assert min(gcos.values()) >= min(mcos.values()) - 0.03, (wcos, sorted(mcos.items(), key=lambda kv: kv[1])[:3])
     assert max(gerr.values()) <= 1.25 * max(merr.values()) + 0.02, (worst, max(merr.values()))
-    # decoder + latent tensors (short backward chains) are tight in absolute terms
-    short = [k for k in gerr if not k.startswith('encoder.')]
+    # the decoder tensors (short backward chain, no dependence on the encoder's rounded activations) are tight in absolute terms
+    short = [k for k in gerr if k.startswith('decoder.')]
     assert min(gcos[k] for k in short) >= 0.98, sorted(((k, gcos[k]) for k in short), key=lambda kv: kv[1])[:4]
 
 
