@@ -151,9 +151,14 @@ typedef struct {
     int32_t elem_f32;                                       /* 1: raw / act / da / da2 / tsum / draw are fp32 tensors (fp32 parity mode) */
 } srvp_bnbwd_desc;
 int srvp_bn_bwd_reduce(const srvp_bnbwd_desc* d, double* red, void* stream);
-/* red -> dgamma, dbeta (accumulated into fp32 grads when non-NULL) and the per-channel coefficients used by apply */
+/* red -> dgamma, dbeta (accumulated into fp32 grads when non-NULL, times param_grad_scale) and the per-channel coefficients
+ * used by apply.  Data parallel (SyncBatchNorm, train.py:283): `red` and `count` are the all-reduced GLOBAL sums, and
+ * param_grad_scale = 1 / world -- every rank then holds the global parameter gradient divided by world, so that the DDP
+ * average over ranks of the world-times-too-large per-rank gradients (loss / LOCAL batch, train.py:106) is the single-process
+ * gradient, exactly like torch's SyncBatchNorm, which forms dgamma / dbeta from the local sums. */
 int srvp_bn_bwd_finalize(const double* red, double count, const float* scale, const float* mean, const float* invstd,
-                         float* dgamma, float* dbeta, float* coef, int C, int C_real, int has_bn, void* stream);
+                         float* dgamma, float* dbeta, float* coef, int C, int C_real, int has_bn, float param_grad_scale,
+                         void* stream);
 /* pass 2: draw = scale*(g - mean_g - xhat*mean_gx) -> bf16 tensor with border `dst_border` */
 int srvp_bn_bwd_apply(const srvp_bnbwd_desc* d, const float* coef, void* draw, int dst_border, void* stream);
 

@@ -658,14 +658,17 @@ class ConvNetBase:
         d.N, d.H, d.W, d.C = blk.N, blk.OH, blk.OW, blk.cout
         if blk.has_bn:
             L.call('srvp_bn_bwd_reduce', C.byref(d), L.ptr(blk.red), st)
-            count = float(blk.N * blk.OH * blk.OW)
+            local = float(blk.N * blk.OH * blk.OW)
+            count = local
             if sync is not None:
                 count = sync.allreduce_stats(blk.red, count)
             bk = blk.spec['bnkey']
+            # (count / local = number of ranks whose sums are in `red`: the parameter gradients are formed from the global sums
+            # and must come out world times smaller, see srvp_hip.h)
             L.call('srvp_bn_bwd_finalize', L.ptr(blk.red), count, L.ptr(blk.coef[0]), L.ptr(blk.coef[2]), L.ptr(blk.coef[3]),
-                   L.ptr(grads[bk + '.weight']), L.ptr(grads[bk + '.bias']), L.ptr(blk.bcoef), blk.cout, blk.cout_r, 1, st)
+                   L.ptr(grads[bk + '.weight']), L.ptr(grads[bk + '.bias']), L.ptr(blk.bcoef), blk.cout, blk.cout_r, 1, local / count, st)
         else:
-            L.call('srvp_bn_bwd_finalize', None, 1.0, None, None, None, None, None, L.ptr(blk.bcoef), blk.cout, blk.cout_r, 0, st)
+            L.call('srvp_bn_bwd_finalize', None, 1.0, None, None, None, None, None, L.ptr(blk.bcoef), blk.cout, blk.cout_r, 0, 1.0, st)
         if blk.split and blk.draw_b == 1:
             d.tsum, d.tsum_T = L.ptr(blk.draw_sum), blk.N // blk.B      # time-summed gradient for the hoisted skip half
         L.call('srvp_bn_bwd_apply', C.byref(d), L.ptr(blk.bcoef), L.ptr(blk.draw), blk.draw_b, st)

@@ -346,14 +346,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdK a, doub
 
 __global__ void bn_bwd_finalize_kernel(const double* red, double count, const float* scale, const float* mean,
                                        const float* invstd, float* dgamma, float* dbeta, float* coef, int C, int C_real,
-                                       int has_bn) {
+                                       int has_bn, float pscale) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     if (c >= C_real) { coef[c] = 0.f; coef[C + c] = 0.f; coef[2 * C + c] = 0.f; return; }
     if (!has_bn) { coef[c] = 1.f; coef[C + c] = 0.f; coef[2 * C + c] = 0.f; return; }
     double sg = red[c], sgx = red[C + c];
-    if (dgamma) dgamma[c] += (float)sgx;
-    if (dbeta) dbeta[c] += (float)sg;
+    if (dgamma) dgamma[c] += (float)(sgx * pscale);
+    if (dbeta) dbeta[c] += (float)(sg * pscale);
     double mg = sg / count, mgx = sgx / count;
     double k1 = scale[c];
     double k3 = -k1 * mgx * invstd[c];
@@ -546,10 +546,10 @@ extern "C" int srvp_bn_bwd_reduce(const srvp_bnbwd_desc* d, double* red, void* s
 
 extern "C" int srvp_bn_bwd_finalize(const double* red, double count, const float* scale, const float* mean,
                                     const float* invstd, float* dgamma, float* dbeta, float* coef, int C, int C_real,
-                                    int has_bn, void* stream) {
+                                    int has_bn, float param_grad_scale, void* stream) {
     SRVP_REQUIRE(coef && C > 0 && (!has_bn || (red && scale && mean && invstd)), "srvp_bn_bwd_finalize: bad args");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, red, count, scale,
-                       mean, invstd, dgamma, dbeta, coef, C, C_real, has_bn);
+                       mean, invstd, dgamma, dbeta, coef, C, C_real, has_bn, param_grad_scale);
     SRVP_CHECK_LAUNCH("srvp_bn_bwd_finalize");
     return SRVP_OK;
 }

@@ -402,7 +402,7 @@ def test_bn_act_fwd_bwd(mode, C_):
     draw = torch.zeros(N, H + 2, H + 2, Cp, dtype=torch.bfloat16, device=dev)
     L.call('srvp_bn_bwd_reduce', C.byref(d), L.ptr(red), st)
     L.call('srvp_bn_bwd_finalize', L.ptr(red), cnt, L.ptr(coef[0]), L.ptr(coef[2]), L.ptr(coef[3]), L.ptr(dgamma), L.ptr(dbeta),
-           L.ptr(bcoef), Cp, C_, 1, st)
+           L.ptr(bcoef), Cp, C_, 1, 1.0, st)
     L.call('srvp_bn_bwd_apply', C.byref(d), L.ptr(bcoef), L.ptr(draw), 1, st)
     torch.cuda.synchronize()
     got = draw[:, 1:-1, 1:-1, :C_].permute(0, 3, 1, 2).float().cpu()
