@@ -115,6 +115,10 @@ def main():
     ap.add_argument('--config', default='bair', choices=list(CONFIGS))
     ap.add_argument('--batch', type=int, default=192, help='per-GPU batch (weak scaling) unless --global-batch is given')
     ap.add_argument('--global-batch', type=int, default=None, help='fixed global batch split over the ranks (strong scaling)')
+    ap.add_argument('--no-strong', action='store_true', help='N > 1: skip the extra strong-scaling measurement (global batch 192 split over the ranks)')
+    ap.add_argument('--h2d', choices=['none', 'u8'], default='none',
+                    help="u8: every step starts from a pinned uint8 host batch (H2D copy + device-side /255 collate inside the timed "
+                         "region, as reference train.py:84 pays it); default: batch resident in HBM (the contract's `value`)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
@@ -159,6 +163,10 @@ def main():
     opt = srvp_amd.DotDict(dict(n_euler_steps=cfg['n_euler'], obs_scale=cfg['obs_scale'], beta_y=1.0, beta_z=cfg['beta_z'], l2_res=1.0))
     g = torch.Generator().manual_seed(123 + rank)
     x = torch.rand(T, B, cfg['ctor'][1], 64, 64, generator=g).to(dev)          # synthetic batch, resident in HBM
+    if args.h2d == 'u8':
+        # the reference's loader hands over uint8 videos (data/base.py:71-84): stacked [B][T][H][W][C] in pinned host memory;
+        # srvp_amd.train.train() copies them and finishes the collate (transpose + /255) on the device
+        x = (torch.rand(B, T, 64, 64, cfg['ctor'][1], generator=g) * 255).to(torch.uint8).pin_memory()
 
     def barrier():
         torch.cuda.synchronize()
@@ -199,6 +207,23 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = tmax.item()
+    # ---- N > 1: the same step with the reference's DDP split of ONE global batch (config 4 of BASELINE.json: batch 192 over the
+    # node's GPUs) -- strong scaling, reported beside the headline weak-scaling value
+    strong = None
+    if world > 1 and not args.no_strong and args.global_batch is None and 192 % world == 0:
+        Bs = 192 // world
+        xs = torch.rand(T, Bs, cfg['ctor'][1], 64, 64, generator=g).to(dev)
+        for _ in range(max(2, args.warmup)):
+            train(fwd, optim, None, xs, dev, opt)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            train(fwd, optim, None, xs, dev, opt)
+        barrier()
+        ts = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(ts, op=torch.distributed.ReduceOp.MAX)
+        strong = dict(scaling='strong', global_batch=192, per_gpu_batch=Bs, ms_per_step=ts.item() / args.steps * 1e3,
+                      value=192 * T * args.steps / ts.item(), unit='frames/s')
     if rank != 0:
         torch.distributed.destroy_process_group()
         return
@@ -211,10 +236,14 @@ def main():
         'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': 'bf16',
         'data': 'synthetic (uniform random frames, random-init weights)',
         'config': {'workload': cfg['label'], 'per_gpu_batch': B, 'global_batch': B * world, 'seq_len': T,
-                   'parallelism': f'dp{world}', 'step': 'forward + ELBO + backward + Adam (reference train.py:49-129)'},
+                   'parallelism': f'dp{world}', 'step': 'forward + ELBO + backward + Adam (reference train.py:49-129)',
+                   'input': 'uint8 host batch, H2D + device collate inside the step' if args.h2d == 'u8' else 'float32 batch resident in HBM',
+                   'collectives': sync.transport if sync is not None else None},
         'loss': loss[0] if loss else None,
         'model_flops_frac_of_bf16_peak': (3 * fl['fwd_all'] * world * args.steps / dt) / (PEAK_BF16_TFLOPS * 1e12 * world),
     }
+    if strong is not None:
+        line['strong_scaling'] = strong
     if prof:
         per = {}
         for name, evs in prof.items():

@@ -308,6 +308,20 @@ int srvp_rsample_bwd(const float* params, const float* eps, const float* dout, f
 int srvp_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
               int step, float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Data parallelism over the GPUs of a node: RCCL (xGMI) collectives enqueued on the caller's stream -- the gradient
+ * all-reduce of DistributedDataParallel (train.py:309-314) and the SyncBatchNorm statistics exchange (train.py:278-283).
+ * RCCL is bound at run time (dlopen), so the library has no link-time dependency on it.  One process per GPU; the 128-byte
+ * id made by rank 0 (srvp_comm_unique_id) is handed to the other ranks by the host (e.g. torch.distributed's store).
+ * ------------------------------------------------------------------------------------------------ */
+int srvp_comm_unique_id(void* id128);
+int srvp_comm_init(const void* id128, int rank, int world, void** comm_out);
+int srvp_comm_destroy(void* comm);
+/* in-place sum over ranks */
+int srvp_allreduce_f64(void* comm, double* buf, int64_t n, void* stream);
+int srvp_allreduce_f32(void* comm, float* buf, int64_t n, void* stream);
+int srvp_bcast_bytes(void* comm, void* buf, int64_t nbytes, int root, void* stream);
+
 /* misc */
 int srvp_fill_f64(double* p, int64_t n, double v, void* stream);
 /* input pipeline (replaces the CPU collate of data/base.py:54-84): uint8 videos stacked [B][T][H][W][C]

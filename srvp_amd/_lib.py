@@ -125,6 +125,12 @@ _SIGS = {
     'srvp_rsample_fwd': ([c_vp, c_vp, c_vp, c_i64, c_i32, c_vp], c_i32),
     'srvp_rsample_bwd': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp], c_i32),
     'srvp_adam': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_vp], c_i32),
+    'srvp_comm_unique_id': ([c_vp], c_i32),
+    'srvp_comm_init': ([c_vp, c_i32, c_i32, C.POINTER(c_vp)], c_i32),
+    'srvp_comm_destroy': ([c_vp], c_i32),
+    'srvp_allreduce_f64': ([c_vp, c_vp, c_i64, c_vp], c_i32),
+    'srvp_allreduce_f32': ([c_vp, c_vp, c_i64, c_vp], c_i32),
+    'srvp_bcast_bytes': ([c_vp, c_vp, c_i64, c_i32, c_vp], c_i32),
     'srvp_fill_f64': ([c_vp, c_i64, c_f64, c_vp], c_i32),
     'srvp_frames_u8_to_f32': ([c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_mmnist_render': ([c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp], c_i32),

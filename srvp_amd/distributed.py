@@ -1,21 +1,73 @@
 """
-Data parallelism over the GPUs of one node: one process per GPU, RCCL (torch.distributed backend "nccl" on ROCm)
-over xGMI.  Replaces DistributedDataParallel + SyncBatchNorm of the reference (train.py:205-219, 278-283, 309-314):
+Data parallelism over the GPUs of one node: one process per GPU, RCCL over xGMI.  Replaces DistributedDataParallel +
+SyncBatchNorm of the reference (train.py:205-219, 278-283, 309-314):
 
-  * gradients live in ONE flat fp32 buffer (model.flatten_parameters_), so the exchange is a few large all-reduces
-    of contiguous slices -- the decoder's slice is launched as soon as the decoder backward has been queued, so it
-    overlaps the latent + encoder backward; averaged over ranks like DDP;
-  * BatchNorm statistics (sum, sum of squares; and the two backward sums) are all-reduced per layer in fp64, which
-    makes N-GPU results equal the 1-GPU results on the same global batch up to summation order (SyncBatchNorm).
+  * gradients live in ONE flat fp32 buffer (model.flatten_parameters_), so the exchange is a few large all-reduces of
+    contiguous slices -- the decoder's slice is launched as soon as the decoder backward has been queued, so it overlaps the
+    latent + encoder backward; averaged over ranks like DDP;
+  * BatchNorm statistics (sum, sum of squares; and the two backward sums) are all-reduced per layer in fp64, which makes N-GPU
+    results equal the 1-GPU results on the same global batch up to summation order (SyncBatchNorm) -- checked by
+    tests/test_two_rank_equality.py.  Each of these 42 small all-reduces per step feeds the very next kernel (the layer's
+    normalisation / its gradient), so they cannot be coalesced across layers; what can be removed is their host and stream
+    overhead:
+  * transport: RCCL driven from the C ABI (csrc/comm.hip: ncclAllReduce enqueued on the compute stream -- one kernel in stream
+    order, no hop to a communicator stream, no Python dispatch per collective) on two communicators (statistics / gradients,
+    so that a gradient slice queued behind the weight-gradient kernels on the side stream cannot hold up the statistics of
+    the layers behind it).  `SRVP_COMM=torch`, a non-RCCL backend (gloo: CPU tests, several ranks on one GPU) or a failed
+    self-test fall back to the same collectives through torch.distributed.
 """
+import ctypes as C
 import os
 
 import torch
 import torch.distributed as dist
 
+from . import _lib as L
+
+
+class NativeComm:
+    """One RCCL communicator owned by libsrvp_hip.so (srvp_comm_*), bootstrapped through torch.distributed."""
+
+    def __init__(self, group=None):
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        lib = L.load()
+        ident = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            L.check(lib.srvp_comm_unique_id(buf), 'srvp_comm_unique_id')
+            ident = [bytes(buf.raw)]
+        dist.broadcast_object_list(ident, src=0, group=group)
+        self.handle = C.c_void_p()
+        L.check(lib.srvp_comm_init(ident[0], rank, world, C.byref(self.handle)), 'srvp_comm_init')
+        self.rank, self.world = rank, world
+
+    def allreduce(self, t):
+        assert t.is_cuda and t.is_contiguous()
+        name = {torch.float64: 'srvp_allreduce_f64', torch.float32: 'srvp_allreduce_f32'}[t.dtype]
+        L.call(name, self.handle, L.ptr(t), t.numel(), L.stream())
+
+    def broadcast(self, t, root=0):
+        assert t.is_cuda and t.is_contiguous()
+        L.call('srvp_bcast_bytes', self.handle, L.ptr(t), t.numel() * t.element_size(), root, L.stream())
+
+    def self_test(self):
+        """Every rank contributes rank + 1: the sum must be world (world + 1) / 2 in both dtypes."""
+        want = self.world * (self.world + 1) / 2
+        for dt in (torch.float64, torch.float32):
+            t = torch.full((257,), float(self.rank + 1), dtype=dt, device='cuda')
+            self.allreduce(t)
+            if not bool((t == want).all().item()):
+                return False
+        return True
+
+    def close(self):
+        if self.handle:
+            L.load().srvp_comm_destroy(self.handle)
+            self.handle = C.c_void_p()
+
 
 class Sync:
-    def __init__(self, group=None, stat_group=None):
+    def __init__(self, group=None, stat_group=None, native=None):
         self.group = group
         # BatchNorm statistics travel on their OWN communicator: RCCL executes the collectives of one communicator in issue
         # order, and the decoder's gradient slice (issued from the second stream, behind ~5 ms of weight-gradient kernels)
@@ -27,11 +79,30 @@ class Sync:
         # SRVP_FORCE_COLLECTIVES=1: issue every collective even on a single rank (exercises the RCCL call path on a
         # 1-GPU box: tests/test_gpu_model.py::test_single_rank_collectives)
         self.force = os.environ.get('SRVP_FORCE_COLLECTIVES', '0') == '1'
+        self.native_grads = self.native_stats = None
+        if native is None:
+            native = (dist.get_backend(group) == 'nccl' and os.environ.get('SRVP_COMM', 'rccl') != 'torch'
+                      and torch.cuda.is_available() and (self.world > 1 or self.force))
+        if native:
+            try:
+                g, s = NativeComm(group), NativeComm(group)
+                ok = torch.tensor([1 if (g.self_test() and s.self_test()) else 0], device='cuda')
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)        # every rank takes the same path
+                if int(ok.item()) == 1:
+                    self.native_grads, self.native_stats = g, s
+                else:
+                    g.close(), s.close()
+            except L.SrvpHipError as e:                  # librccl not loadable etc.: same on every rank
+                print(f'srvp_amd.distributed: native RCCL path unavailable ({e}); using torch.distributed')
+        self.transport = 'rccl (C ABI, in-stream)' if self.native_stats is not None else f'torch.distributed ({dist.get_backend(group)})'
 
     def allreduce_stats(self, t, count):
         """In-place sum of a small fp64 statistics tensor over ranks; returns the global element count."""
         if self.sync_bn and (self.world > 1 or self.force):
-            dist.all_reduce(t, group=self.stat_group)
+            if self.native_stats is not None:
+                self.native_stats.allreduce(t)
+            else:
+                dist.all_reduce(t, group=self.stat_group)
             return count * self.world
         return count
 
@@ -51,6 +122,16 @@ class Sync:
             return
         flat_g = model._flat[1]
         enc_end, dec_end, total = self._slices(model)
+        if self.native_grads is not None:
+            # in-stream: the decoder slice on the stream it is called from (the weight-gradient side stream, which the caller
+            # joins before the final call), the rest + the DDP average on the compute stream
+            if what == 'decoder':
+                self.native_grads.allreduce(flat_g[enc_end:dec_end])
+            else:
+                self.native_grads.allreduce(flat_g[:enc_end])
+                self.native_grads.allreduce(flat_g[dec_end:])
+                flat_g.mul_(1.0 / self.world)
+            return
         if what == 'decoder':
             self.handles.append(dist.all_reduce(flat_g[enc_end:dec_end], group=self.group, async_op=True))
         else:
@@ -60,6 +141,12 @@ class Sync:
                 h.wait()
             self.handles = []
             flat_g.mul_(1.0 / self.world)     # DDP averages gradients over ranks
+
+    def broadcast(self, t):
+        if self.native_grads is not None:
+            self.native_grads.broadcast(t, 0)
+        else:
+            dist.broadcast(t, 0, group=self.group)
 
 
 def init_process_group(backend=None):
@@ -81,9 +168,12 @@ class DataParallel(torch.nn.Module):
         # same initial parameters / buffers on every rank (DDP broadcasts from rank 0)
         if sync.world > 1 or sync.force:
             module.flatten_parameters_()
-            dist.broadcast(module._flat[0], 0, group=sync.group)
+            sync.broadcast(module._flat[0])
             for b in module.buffers():
-                dist.broadcast(b, 0, group=sync.group)
+                if b.is_cuda and b.numel() > 0:
+                    sync.broadcast(b)
+                else:
+                    dist.broadcast(b, 0, group=sync.group)
 
     def forward(self, *a, **k):
         return self.module(*a, **k)
