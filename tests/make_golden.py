@@ -228,6 +228,111 @@ def gen_one(name, spec, srvp, ref_train, helper):
     return loss
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# FULL-WIDTH reference runs (nf = 64, nhx = 128, nh_inf = 256, nh_res = 512) of the C2..C5 shapes of
+# BASELINE.json at batch 2.  Full tensors would be tens of MB, so the fixture holds what pins the computation without them:
+# the noise tape, per-tensor weight checksums (weights / inputs are re-created on the target from their seeds), the ELBO
+# scalars, the small latent outputs in full, strided samples of the decoded frames, and for every parameter gradient its norm,
+# its projection on a seeded random direction, and (for tensors of <= 1024 elements) the gradient itself.
+FULL = {
+    'full_c2_smmnist_dcgan': dict(ctor=(64, 1, 64, 128, 20, 20, False, 5, 256, 3, 512, 4, 'dcgan'), T=15, B=2, n_euler=1,
+                                  hp=dict(obs_scale=1.0, beta_y=1.0, beta_z=2.0, l2_res=1.0), res_gain=1.41, lr=3e-4),
+    'full_c3_kth_vgg': dict(ctor=(64, 1, 64, 128, 50, 50, True, 3, 256, 3, 512, 4, 'vgg'), T=20, B=2, n_euler=2,
+                            hp=dict(obs_scale=0.2, beta_y=1.0, beta_z=1.0, l2_res=1.0), res_gain=1.2, lr=3e-4),
+    'full_c4_bair_vgg': dict(ctor=(64, 3, 64, 128, 50, 50, True, 2, 256, 3, 512, 4, 'vgg'), T=12, B=2, n_euler=2,
+                             hp=dict(obs_scale=0.71, beta_y=1.0, beta_z=1.0, l2_res=1.0), res_gain=1.41, lr=3e-4),
+    'full_c5_human_vgg': dict(ctor=(64, 3, 64, 128, 50, 50, True, 3, 256, 3, 512, 4, 'vgg'), T=16, B=2, n_euler=2,
+                              hp=dict(obs_scale=0.2, beta_y=1.0, beta_z=1.0, l2_res=1.0), res_gain=1.2, lr=3e-4,
+                              rollout=dict(nt_cond=8, nt=53)),
+}
+
+
+def frame_samples(x_):
+    """Strided pixel samples of (nt, B, C, 64, 64) frames: every 5th row / column with a per-frame phase."""
+    return x_[:, :, :, 1::5, 2::5].contiguous()
+
+
+def grad_direction(name, shape):
+    g = torch.Generator().manual_seed(abs(hash_name(name)) % (2 ** 31))
+    return torch.randn(shape, generator=g)
+
+
+def hash_name(name):
+    h = 0
+    for ch in name:
+        h = (h * 131 + ord(ch)) % 1000000007
+    return h
+
+
+def gen_full(name, spec, srvp, ref_train, helper):
+    torch.set_num_threads(8)
+    ctor, T, B, n_euler, hp = spec['ctor'], spec['T'], spec['B'], spec['n_euler'], spec['hp']
+    cfg_keys = ['nx', 'nc', 'nf', 'nhx', 'ny', 'nz', 'skipco', 'nt_inf', 'nh_inf', 'nlayers_inf', 'nh_res',
+                'nlayers_res', 'archi']
+    cfg = dict(zip(cfg_keys, ctor))
+    torch.manual_seed(1)
+    model = srvp.StochasticLatentResidualVideoPredictor(*ctor)
+    model.init(res_gain=spec['res_gain'])
+    x = torch.from_numpy(synth_video(T, B, cfg['nc'], seed=321))
+    out = {'x.checksum': np.array([x.double().sum().item(), x.double().abs().max().item()])}
+    out['sd0.checksums'] = np.array([[v.double().sum().item(), v.double().abs().sum().item()] for v in model.state_dict().values()])
+    opt = helper.DotDict(dict(n_euler_steps=n_euler, torch_amp=False, apex_amp=False, **hp))
+    optimizer = torch.optim.Adam(model.parameters(), lr=spec['lr'])
+    model.train()
+    grads = {}
+    orig_step = optimizer.step
+
+    def step_and_capture(*a, **k):
+        for kk, p in model.named_parameters():
+            grads[kk] = p.grad.detach().clone()
+        return orig_step(*a, **k)
+    optimizer.step = step_and_capture
+    fwd_outs = {}
+
+    def forward_fn(xx, nt, dt):
+        o = model(xx, nt, dt=dt)
+        for n_, v in zip(OUT_NAMES, o):
+            fwd_outs[n_] = v.detach().clone()
+        return o
+    with Tape() as tape:
+        loss, nll, kl_y_0, kl_z = ref_train.train(forward_fn, optimizer, None, x, torch.device('cpu'), opt)
+    out.update(tape_arrays(tape, cfg, True))
+    for n_, v in fwd_outs.items():
+        out['train.' + n_] = (frame_samples(v) if n_ == 'x_' else v).numpy()
+    out['train.scalars'] = np.array([loss, nll, kl_y_0, kl_z], np.float64)
+    out['train.l2_res'] = np.array(torch.norm(fwd_outs['res'], p=2, dim=2).sum().item(), np.float64)
+    names = list(grads)
+    out['grad.norm'] = np.array([grads[k].double().norm().item() for k in names])
+    out['grad.dot'] = np.array([(grads[k].double() * grad_direction(k, grads[k].shape).double()).sum().item() for k in names])
+    for k in names:
+        if grads[k].numel() <= 1024:
+            out['grad.' + k] = grads[k].numpy()
+    # BN running statistics after the step (conv.py:104)
+    for k, v in model.state_dict().items():
+        if k.endswith(('running_mean', 'running_var')):
+            out['sd1.' + k] = v.detach().numpy().copy()
+    # ---------------- long-horizon prediction (config 5: test.py / train.evaluate call pattern, seq_len_test = 53) ----------------
+    ro = spec.get('rollout')
+    if ro is not None:
+        # inference weights: the initial ones (BN running statistics at their defaults), so that the target needs no optimizer step
+        torch.manual_seed(1)
+        model = srvp.StochasticLatentResidualVideoPredictor(*ctor)
+        model.init(res_gain=spec['res_gain'])
+        model.eval()
+        xr = torch.from_numpy(synth_video(ro['nt_cond'], B, cfg['nc'], seed=322))
+        with torch.no_grad(), Tape() as tape:
+            o = model(xr, ro['nt'], dt=1 / n_euler)
+        ev = tape_arrays(tape, cfg, False)
+        out.update({k.replace('tape.', 'roll.tape.'): v for k, v in ev.items()})
+        out['roll.y'] = o[1].numpy()
+        out['roll.x_'] = frame_samples(o[0]).numpy()
+        out['roll.cfg'] = np.array([ro['nt_cond'], ro['nt']])
+    meta = dict(ctor=list(ctor), T=T, B=B, n_euler=n_euler, hp=hp, res_gain=spec['res_gain'], lr=spec['lr'], grad_names=names)
+    out['meta'] = np.array(repr(meta))
+    np.savez_compressed(os.path.join(GOLDEN, name + '.npz'), **out)
+    return loss
+
+
 def gen_known_answers():
     """Small known-answer vectors produced by the reference's utils / schedule code."""
     import math
@@ -347,6 +452,11 @@ def gen_mmnist():
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     srvp, ref_train, helper = import_reference()
+    if '--full' in sys.argv:                               # only the full-width fixtures (minutes of CPU time)
+        for name, spec in FULL.items():
+            loss = gen_full(name, spec, srvp, ref_train, helper)
+            print(f'{name}: loss {loss:.6f}', flush=True)
+        return
     for name, spec in TINY.items():
         loss = gen_one(name, spec, srvp, ref_train, helper)
         print(f'{name}: loss {loss:.6f}')

@@ -1,0 +1,161 @@
+"""
+SURVEY §8c item 2: FULL-WIDTH fixtures made by running the real reference (tests/make_golden.py --full; reference
+train.py:49-129 through module/srvp.py:415-470) on the C2..C5 shapes of BASELINE.json at batch 2 -- SM-MNIST DCGAN (T=15,
+nt_inf=5), KTH VGG (T=20, nt_inf=3), BAIR VGG (T=12), Human3.6M VGG (T=16, nt_inf=3) + its 53-frame prediction at the
+recipe's res_gain = 1.2.  Weights and inputs are re-created from their seeds (checked against the fixture's checksums); the
+fixture pins the ELBO scalars, all latent outputs, strided samples of the decoded frames, and for every parameter gradient
+its norm and its projection on a seeded random direction (full tensors for the small ones).
+
+  * CPU: the oracle against these fixtures (pins the oracle at full width, not only at nf in {4, 8}).
+  * GPU: the HIP path in fp32 mode (tight) and in bf16 mode (ELBO band) against the same fixtures.
+Gradient tolerances: the reference's own fp32 autograd on these untrained small-batch BatchNorm networks is reproducible to
+3e-3 .. 1e-2 between summation orders (fp32 oracle vs float64 oracle, tests/test_gpu_fp32_mode.py; the oracle's hand-written
+BatchNorm against the reference's fused one moves the KTH-shape BN gradients by 1.1e-2), hence 3e-2 on norms / projections / tensors.
+"""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import GOLDEN, OUT_NAMES, full_fixture_names
+from make_golden import frame_samples, grad_direction, synth_video
+
+
+class Full:
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+        self.meta = ast.literal_eval(str(self.z['meta']))
+        self.ctor = tuple(self.meta['ctor'])
+
+    def t(self, k):
+        return torch.from_numpy(np.array(self.z[k]))
+
+    def tape(self, prefix='tape.'):
+        return {k[len(prefix):]: self.t(k) for k in self.z.files if k.startswith(prefix)}
+
+    def model_and_input(self):
+        """Re-creates the reference's initial weights (same-seed construction, tests/test_host.py) and input, and checks both
+        against the checksums taken from the reference run."""
+        import srvp_amd
+        torch.manual_seed(1)
+        m = srvp_amd.StochasticLatentResidualVideoPredictor(*self.ctor)
+        m.init(res_gain=self.meta['res_gain'])
+        cs = np.array([[v.double().sum().item(), v.double().abs().sum().item()] for v in m.state_dict().values()])
+        # (orthogonal init runs a LAPACK QR: its rounding differs between host CPUs at the 1e-7 level -- far below what a wrong
+        # RNG order or a wrong initialiser would show)
+        assert np.allclose(cs, self.z['sd0.checksums'], rtol=1e-5, atol=1e-5)
+        x = torch.from_numpy(synth_video(self.meta['T'], self.meta['B'], self.ctor[1], seed=321))
+        assert np.allclose([x.double().sum().item(), x.double().abs().max().item()], self.z['x.checksum'], rtol=1e-9)
+        return m, x
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def check_step(fx, loss_terms, outs, grads, tol_loss, tol_x, tol_out, tol_grad):
+    """loss_terms: (loss, nll/B, kl_y0/B, kl_z/B, l2_res); outs: the 8 forward outputs; grads: name -> tensor."""
+    ref = fx.z['train.scalars']
+    assert abs(loss_terms[0] - ref[0]) <= tol_loss * abs(ref[0]), (loss_terms[0], ref[0])
+    assert abs(loss_terms[1] - ref[1]) <= tol_loss * abs(ref[1])
+    assert abs(loss_terms[4] - float(fx.z['train.l2_res'])) <= max(tol_out, 10 * tol_loss) * abs(float(fx.z['train.l2_res']))
+    for n, o in zip(OUT_NAMES, outs):
+        r = fx.t('train.' + n)
+        if n == 'x_':
+            assert (frame_samples(o.detach().cpu()) - r).abs().max().item() <= tol_x, n
+        else:
+            assert rel_l2(o, r) <= tol_out, (n, rel_l2(o, r))
+    names = fx.meta['grad_names']
+    bad = []
+    for i, k in enumerate(names):
+        g = grads[k].detach().double().cpu()
+        nref, dref = float(fx.z['grad.norm'][i]), float(fx.z['grad.dot'][i])
+        d = (g * grad_direction(k, g.shape).double()).sum().item()
+        if abs(g.norm().item() - nref) > tol_grad * nref or abs(d - dref) > 2 * tol_grad * nref:
+            bad.append((k, g.norm().item() / nref, (d - dref) / nref))
+        if 'grad.' + k in fx.z.files and rel_l2(g, fx.t('grad.' + k)) > tol_grad:
+            bad.append((k, 'full', rel_l2(g, fx.t('grad.' + k))))
+    assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize('name', full_fixture_names())
+def test_oracle_vs_full_width_reference_fixture(name):
+    from oracle import srvp_oracle as O
+    fx = Full(name)
+    m, x = fx.model_and_input()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    torch.set_num_threads(8)
+    scal, outs, grads = O.train_step(sd, O.make_cfg(*fx.ctor), x, fx.meta['n_euler'], fx.tape(), fx.meta['hp'])
+    check_step(fx, (scal['loss'], scal['nll'], scal['kl_y_0'], scal['kl_z'], scal['l2_res']), outs, grads, 2e-6, 1e-5, 1e-4, 3e-2)
+    for k in fx.z.files:
+        if k.startswith('sd1.'):
+            assert (sd[k[4:]] - fx.t(k)).abs().max().item() <= 1e-5 * (1 + fx.t(k).abs().max().item()), k
+    if 'roll.cfg' in fx.z.files:
+        nt_cond, nt = (int(v) for v in fx.z['roll.cfg'])
+        m2, _ = fx.model_and_input()
+        sd2 = {k: v.detach().clone() for k, v in m2.state_dict().items()}
+        xr = torch.from_numpy(synth_video(nt_cond, fx.meta['B'], fx.ctor[1], seed=322))
+        with torch.no_grad():
+            o = O.forward(sd2, O.make_cfg(*fx.ctor), xr, nt, fx.meta['n_euler'], fx.tape('roll.tape.'), training=False)
+        check_rollout(fx, o[1], o[0], 1e-6)
+
+
+def check_rollout(fx, y, x_, eps0):
+    """53-frame prediction at res_gain = 1.2: the untrained residual MLP expands |y| by ~1.3x per frame, and so it expands any
+    arithmetic difference: the fp32 reference run twice with different summation orders agrees to eps0 * 1.35^t at frame t.
+    The latent states are therefore held to a tolerance that grows at that rate, the decoded frames (saturating sigmoid of
+    logits that scale with |y|) to the matching absolute band."""
+    yr, xr = fx.t('roll.y'), fx.t('roll.x_')
+    nt = yr.shape[0]
+    for t in range(nt):
+        tol = min(0.5, eps0 * 1.35 ** t)
+        e = rel_l2(y[t], yr[t])
+        assert e <= tol, (t, e, tol)
+    xs = frame_samples(x_.detach().cpu())
+    for t in range(nt):
+        tol = min(1.0, 20 * eps0 * 1.35 ** t + 1e-5)
+        assert (xs[t] - xr[t]).abs().max().item() <= tol, (t, (xs[t] - xr[t]).abs().max().item(), tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('name', full_fixture_names())
+def test_hip_vs_full_width_reference_fixture(name, precision):
+    import srvp_amd
+    from srvp_amd.train import elbo_terms_and_grads
+    fx = Full(name)
+    m, x = fx.model_and_input()
+    m = m.cuda().train().set_precision(precision)
+    hp, ne = fx.meta['hp'], fx.meta['n_euler']
+    opt = srvp_amd.DotDict(dict(n_euler_steps=ne, **hp))
+    m.flatten_parameters_()
+    m._grads()
+    m._flat[1].zero_()
+    xg = x.cuda()
+    outs = m._forward_impl(xg, x.shape[0], ne, fx.tape(), training=True)
+    outs_c = [o.clone() for o in outs]
+    acc, gr = elbo_terms_and_grads(m, xg, outs, opt)
+    m._backward_impl(gr[0], None, None, gr[1], gr[2], gr[3], gr[4])
+    nll, kl_y0, kl_z, l2 = acc.cpu().tolist()
+    B = x.shape[1]
+    loss = (nll + hp['beta_y'] * kl_y0 + hp['beta_z'] * kl_z + hp['l2_res'] * l2) / B
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    if precision == 'fp32':
+        check_step(fx, (loss, nll / B, kl_y0 / B, kl_z / B, l2), outs_c, grads, 1e-5, 2e-5, 2e-4, 3e-2)
+    else:
+        # bf16 storage on 24-40 frames: the ELBO band of tests/test_gpu_model.py (1e-4 is asserted at 384 frames), frames 3e-2
+        ref = fx.z['train.scalars']
+        assert abs(loss - ref[0]) <= 3e-4 * abs(ref[0]), (loss, ref[0])
+        assert (frame_samples(outs_c[0].cpu()) - fx.t('train.x_')).abs().max().item() <= 3e-2
+        for n, o in zip(OUT_NAMES[1:], outs_c[1:]):
+            assert rel_l2(o, fx.t('train.' + n)) <= 6e-2, n
+    if 'roll.cfg' in fx.z.files and precision == 'fp32':
+        nt_cond, nt = (int(v) for v in fx.z['roll.cfg'])
+        m2, _ = fx.model_and_input()
+        m2 = m2.cuda().eval().set_precision('fp32')
+        xr = torch.from_numpy(synth_video(nt_cond, fx.meta['B'], fx.ctor[1], seed=322)).cuda()
+        o = m2(xr, nt, dt=1 / ne, tape=fx.tape('roll.tape.'))
+        check_rollout(fx, o[1], o[0], 2e-6)
