@@ -30,11 +30,11 @@ PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA, /opt/skills/guides/MI355X_MIC
 CONFIGS = {
     # name: (ctor args in the reference's positional order, T, hyper-parameters)  -- README.md:111-128 recipes
     'bair': dict(ctor=(64, 3, 64, 128, 50, 50, True, 2, 256, 3, 512, 4, 'vgg'), T=12, n_euler=2, obs_scale=0.71, beta_z=1.0,
-                 res_gain=1.41, label='BAIR 64x64x3 vgg+skipco seq_len=12 n_euler=2'),
+                 res_gain=1.41, batch=192, label='BAIR 64x64x3 vgg+skipco seq_len=12 n_euler=2'),
     'kth': dict(ctor=(64, 1, 64, 128, 50, 50, True, 3, 256, 3, 512, 4, 'vgg'), T=20, n_euler=2, obs_scale=0.2, beta_z=1.0,
-                res_gain=1.2, label='KTH 64x64x1 vgg+skipco seq_len=20 n_euler=2'),
+                res_gain=1.2, batch=100, label='KTH 64x64x1 vgg+skipco seq_len=20 n_euler=2'),
     'smmnist': dict(ctor=(64, 1, 64, 128, 20, 20, False, 5, 256, 3, 512, 4, 'dcgan'), T=15, n_euler=1, obs_scale=1.0, beta_z=2.0,
-                    res_gain=1.41, label='SM-MNIST 64x64x1 dcgan seq_len=15'),
+                    res_gain=1.41, batch=128, label='SM-MNIST 64x64x1 dcgan seq_len=15'),
 }
 
 
@@ -113,7 +113,8 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='bair', choices=list(CONFIGS))
-    ap.add_argument('--batch', type=int, default=192, help='per-GPU batch (weak scaling) unless --global-batch is given')
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (weak scaling) unless --global-batch is given; default: the '
+                    "config's recipe batch (bair 192, kth 100, smmnist 128: BASELINE.json configs 4, 3, 2)")
     ap.add_argument('--global-batch', type=int, default=None, help='fixed global batch split over the ranks (strong scaling)')
     ap.add_argument('--no-strong', action='store_true', help='N > 1: skip the extra strong-scaling measurement (global batch 192 split over the ranks)')
     ap.add_argument('--h2d', choices=['none', 'u8'], default='none',
@@ -152,6 +153,8 @@ def main():
 
     cfg = CONFIGS[args.config]
     T = cfg['T']
+    if args.batch is None:
+        args.batch = cfg['batch']
     B = args.batch if args.global_batch is None else args.global_batch // world
     scaling = 'weak' if args.global_batch is None else 'strong'
     torch.manual_seed(1)
@@ -257,13 +260,30 @@ def main():
         # HBM bytes per launch of the same kernel class: PMC counters cannot be collected from inside this process, so the
         # number comes from the committed summary of a separate `rocprofv3 --pmc` pass of this very command
         # (tools/hbm_traffic.py -> profiles/r01_hbm_traffic.json, corrections of MI355X_MICROARCH.md's HBM section)
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')
-        if args.config == 'bair' and B == 192 and os.path.exists(tpath):
+        traffic, tpath = None, None
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_hbm_traffic.json')))
+        if args.config == 'bair' and B == 192 and cands:
+            tpath = cands[-1]                                   # the latest round's PMC pass
             traffic = json.load(open(tpath))['srvp_conv_mfma']['bytes_per_launch']
+        # what the matrix cores actually execute: MACs of the launch descriptors (padded channels, hoisted skip half evaluated
+        # once per sample, sub-pixel upsample convolutions) -- less than the reference's layer definitions ask for
+        pl = model._last_plan
+        ex_macs = 0
+        for net in (pl['enc'], pl['dec']):
+            for blk in net.blocks:
+                if blk.role == 'in' or (blk.role == 'out' and net._f32_out() if hasattr(net, '_f32_out') else False):
+                    continue
+                for d in list(getattr(blk, '_fwd', [])) + list(getattr(blk, '_dg', [])):
+                    ex_macs += d.N * d.OH * d.OW * d.Cout * d.ntaps * (d.C0 + d.C1)
+                if blk.role == 'out':                           # (its data-gradient runs on the fp32 image-side kernel instead)
+                    for d in getattr(blk, '_dg', []):
+                        ex_macs -= d.N * d.OH * d.OW * d.Cout * d.ntaps * (d.C0 + d.C1)
+        ex = 2.0 * ex_macs / (per[dom] * 1e-3) / 1e12
         line['roofline'] = {'bound': 'mfma', 'kernel': 'conv_halo_kernel / conv_mfma_kernel (srvp_conv_mfma: forward + data-gradient implicit GEMMs)',
                             'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
-                            'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC pass, profiles/r01_hbm_traffic.json)',
+                            'executed_flops_per_step': 2.0 * ex_macs, 'executed': ex, 'executed_frac': ex / PEAK_BF16_TFLOPS,
+                            'traffic': traffic, 'traffic_unit': f'HBM bytes per launch (rocprofv3 PMC pass, {os.path.relpath(tpath, ROOT) if tpath else None})',
                             'algorithmic_flops_per_launch': (fl['fwd_mfma'] + fl['dgrad_mfma']) / max(1, nlaunch),
                             'algorithmic_bytes_per_launch': fl['bytes_mfma'] / max(1, nlaunch),
                             'launches_per_step': nlaunch, 'ms_per_step': per[dom], 'avg_launch_us': per[dom] / max(1, nlaunch) * 1e3,

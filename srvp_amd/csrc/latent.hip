@@ -103,10 +103,100 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
     }
 }
 
+// Weight-gradient shape: C[M][N] += A^T B with BOTH operands row-major over the reduction index (A = delta [K][M], B =
+// activations [K][N], K = (steps x batch) rows in the thousands, M, N = layer widths).  The 32x32 kernel above reads such
+// operands 4 bytes per lane per MFMA with nothing staged (4 MAC per L2 byte: 0.3-0.6 ms per GEMM at K = 4224, 1.6 ms per
+// training step on the serial latent-backward path).  Here a workgroup owns a 64x64 tile, stages 32-row chunks of both
+// operands in LDS with 16-byte loads (double-buffered, every LDS value feeds two MFMAs' worth of lanes), and K is split over
+// gridDim.z with fp32 atomics into the (accumulated anyway) gradient.  Exact fp32 MFMA as everywhere in the latent path.
+template <bool VEC>
+__global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B, long long ldb,
+                                                          float* C, long long ldc, int M, int N, int K, int kper) {
+    constexpr int LD = 96;                                 // row stride: the two k rows of an MFMA land on disjoint bank halves
+    __shared__ __attribute__((aligned(16))) float As[2][32 * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][32 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1, r = lane & 31, kh = lane >> 5;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int kb = blockIdx.z * kper;
+    int ke = kb + kper; if (ke > K) ke = K;
+    if (kb >= ke) return;
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // staging: 32 rows x 16 four-column pieces per operand = 512 pieces, two per thread
+    f32x4_t ra[2], rb[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int p = tid + 256 * u, row = p >> 4, c4 = (p & 15) * 4;
+            const int k = k0 + row;
+            f32x4_t va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if (k < ke) {
+                const float* ap = A + (long long)k * lda + m0 + c4;
+                const float* bp = B + (long long)k * ldb + n0 + c4;
+                if (VEC) {
+                    if (m0 + c4 < M) va = *reinterpret_cast<const f32x4_t*>(ap);      // (M, N multiples of 4: a piece is all-in or all-out)
+                    if (n0 + c4 < N) vb = *reinterpret_cast<const f32x4_t*>(bp);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { if (m0 + c4 + e < M) va[e] = ap[e]; if (n0 + c4 + e < N) vb[e] = bp[e]; }
+                }
+            }
+            ra[u] = va; rb[u] = vb;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int p = tid + 256 * u, row = p >> 4, c4 = (p & 15) * 4;
+            *reinterpret_cast<f32x4_t*>(&As[buf][row * LD + c4]) = ra[u];
+            *reinterpret_cast<f32x4_t*>(&Bs[buf][row * LD + c4]) = rb[u];
+        }
+    };
+    fetch(kb);
+    int buf = 0;
+    for (int k0 = kb; k0 < ke; k0 += 32, buf ^= 1) {
+        commit(buf);
+        __syncthreads();
+        if (k0 + 32 < ke) fetch(k0 + 32);                 // next chunk's global loads fly under this chunk's MFMAs
+        const float* ap = &As[buf][kh * LD + wm * 32 + r];
+        const float* bp = &Bs[buf][kh * LD + wn * 32 + r];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk * LD], bp[2 * kk * LD], acc, 0, 0, 0);
+        // (the other buffer is rewritten only after the next barrier: one barrier per chunk suffices with two buffers)
+    }
+    const int n = n0 + wn * 32 + r;
+    if (n >= N) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int m = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+        if (m < M) atomicAdd(C + (long long)m * ldc + n, acc[i]);
+    }
+}
+
 int gemm(hipStream_t st, const float* A, long long a_rs, long long a_cs, const float* B, long long b_rs, long long b_cs,
          const float* bias, float* C, long long c_rs, int M, int N, int K, int act, int accumulate,
          const float* mask = nullptr, long long mask_rs = 0, float alpha = 1.f) {
     if (M <= 0 || N <= 0) return SRVP_OK;
+    static int tn_on = -1;
+    if (tn_on < 0) { const char* e = getenv("SRVP_GEMM_TN"); tn_on = e ? atoi(e) : 1; }
+    if (tn_on && a_rs == 1 && b_cs == 1 && accumulate && !bias && !mask && act == ACT_NONE && alpha == 1.f && K >= 128) {
+        // A^T B, both operands row-major over K (weight gradients)
+        const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);
+        int splits = (int)((768 + tiles - 1) / tiles);
+        const int maxs = (K + 63) / 64;
+        if (splits > maxs) splits = maxs;
+        if (splits < 1) splits = 1;
+        int kper = ((K + splits - 1) / splits + 31) / 32 * 32;
+        splits = (K + kper - 1) / kper;
+        const dim3 grid((N + 63) / 64, (M + 63) / 64, splits);
+        const bool vec = M % 4 == 0 && N % 4 == 0 && a_cs % 4 == 0 && b_rs % 4 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0;
+        if (vec) hipLaunchKernelGGL(gemm_tn_f32_kernel<true>, grid, dim3(256), 0, st, A, a_cs, B, b_rs, C, c_rs, M, N, K, kper);
+        else hipLaunchKernelGGL(gemm_tn_f32_kernel<false>, grid, dim3(256), 0, st, A, a_cs, B, b_rs, C, c_rs, M, N, K, kper);
+        SRVP_CHECK_LAUNCH("srvp_gemm_f32(tn)");
+        return SRVP_OK;
+    }
     GemmArgs g{A, a_rs, a_cs, B, b_rs, b_cs, bias, C, c_rs, mask, mask_rs, M, N, K, act, accumulate, alpha};
     dim3 grid((N + 31) / 32, (M + 31) / 32);
     const bool av = a_cs == 1 && K % 4 == 0 && a_rs % 4 == 0 && ((uintptr_t)A % 16) == 0;
