@@ -65,6 +65,11 @@ typedef struct {
     const int32_t* map0; int32_t dst_is_f32; const float* add_f32; int32_t add_mod;
     int32_t wt_fragmajor;         /* wt is packed MFMA-fragment-major (srvp_pack_desc.layout 1): required by, and only valid
                                    * for, launches that srvp_conv_wants_fragmajor() accepts */
+    int32_t tap_phase_chunks;     /* > 0 (halo kernel only): src0 is a SPACE-TO-DEPTH tensor whose 64-channel chunk cc belongs to
+                                   * phase cc / tap_phase_chunks (0..3) and is convolved with THAT phase's taps only: dy/dx hold
+                                   * 4 x ntaps entries, [phase * ntaps + t].  The data-gradient of a sub-pixel upsample convolution
+                                   * (conv.py:331-349) over the output gradient stored [N][H/2+2][W/2+2][4C] is then one launch with
+                                   * K = 4 C ntaps exactly.  wt: [ntaps][Cout][C0] as usual (chunk -> phase implied) */
     int32_t elem_f32;             /* 1: precision = 'fp32' parity mode -- src0 / src1 / dst / wt are FP32 tensors of the same NHWC
                                    * shapes (wt tap-major, srvp_pack_desc.dst_f32) and the contraction runs in exact fp32 on the
                                    * matrix cores (v_mfma_f32_32x32x2_f32 = a k-ordered fmaf chain), csrc/conv_f32.hip */
@@ -96,6 +101,11 @@ typedef struct {
     int32_t splitk;
     const int32_t* map0;          /* image indirection for src0 (NULL = identity) */
     int32_t elem_f32;             /* 1: src0 / src1 / dout are fp32 tensors (fp32 parity mode, exact-fp32 MFMA) */
+    int32_t dout_cstride, dout_coff; /* dout is a channel slice of a wider tensor: pixel stride dout_cstride channels (0 = Cout),
+                                   * first channel dout_coff (one phase of a space-to-depth gradient) */
+    int32_t dout_phase_taps;      /* > 0 (per-tap kernel): tap t reads the channel slice of phase t / dout_phase_taps, i.e. first
+                                   * channel dout_coff + (t / dout_phase_taps) * Cout -- all 16 (phase, tap) weight gradients of a
+                                   * sub-pixel block in ONE launch over its space-to-depth output gradient */
 } srvp_wgrad_desc;
 int srvp_wgrad_mfma(const srvp_wgrad_desc* d, void* stream);
 /* 1: fragments through ds_read_b64_tr_b16 (default), 0: 16-bit LDS reads (conservative fallback) */
@@ -149,6 +159,9 @@ typedef struct {
     void* tsum; int32_t tsum_T;                             /* apply only: bf16 [N/T][H+2b][W+2b][C] = sum over the T time steps (frames
                                                              * ordered t*B + b) of the written gradient, or NULL */
     int32_t elem_f32;                                       /* 1: raw / act / da / da2 / tsum / draw are fp32 tensors (fp32 parity mode) */
+    int32_t draw_s2d;                                       /* apply only: draw is written SPACE-TO-DEPTH, [N][H/2+2][W/2+2][4C] with a
+                                                             * 1-pixel border: pixel (y, x) -> position (y/2, x/2), channel group
+                                                             * (y&1)*2 + (x&1) (consumed by tap_phase_chunks launches); da_mode 0 / 1 */
 } srvp_bnbwd_desc;
 int srvp_bn_bwd_reduce(const srvp_bnbwd_desc* d, double* red, void* stream);
 /* red -> dgamma, dbeta (accumulated into fp32 grads when non-NULL, times param_grad_scale) and the per-channel coefficients
@@ -207,6 +220,8 @@ typedef struct {
      * from L2 into registers in this order).  Needs J % 32 == 0 and K % 64 == 0. */
     int32_t layout;
     int32_t dst_f32;              /* 1: the packed tensor is fp32 instead of bf16 (fp32 parity mode; layout 0 only) */
+    int32_t kc_total, kc_off;     /* layout 1: this job fills the 64-wide K chunks [kc_off, kc_off + K/64) of a destination that has
+                                   * kc_total chunks per tap (0 = K/64, i.e. the whole tensor): one job per phase of a space-to-depth K axis */
 } srvp_pack_desc;
 int srvp_pack_weight(const float* src, void* dst, const srvp_pack_desc* d, void* stream);
 /* fp32 gradient: w_grad[ jr*sj + kr*sk + tap_off[t] ] += packed_grad[t][j][k]  (inverse mapping, for dW) */

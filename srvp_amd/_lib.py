@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):
                 ('stats', c_vp), ('stat_mod', c_i32),
                 ('out_f32', c_vp), ('out_nc', c_i32), ('out_sigmoid', c_i32),
                 ('map0', c_vp), ('dst_is_f32', c_i32), ('add_f32', c_vp), ('add_mod', c_i32), ('wt_fragmajor', c_i32),
-                ('elem_f32', c_i32)]
+                ('tap_phase_chunks', c_i32), ('elem_f32', c_i32)]
 
 
 class WgradDesc(C.Structure):
@@ -44,7 +44,7 @@ class WgradDesc(C.Structure):
                 ('ntaps', c_i32), ('dy', TAPS), ('dx', TAPS),
                 ('dout', c_vp), ('DHp', c_i32), ('DWp', c_i32), ('so', c_i32), ('ooy', TAPS), ('oox', TAPS),
                 ('Cout', c_i32), ('N', c_i32), ('OH', c_i32), ('OW', c_i32),
-                ('dw', c_vp), ('splitk', c_i32), ('map0', c_vp), ('elem_f32', c_i32)]
+                ('dw', c_vp), ('splitk', c_i32), ('map0', c_vp), ('elem_f32', c_i32), ('dout_cstride', c_i32), ('dout_coff', c_i32), ('dout_phase_taps', c_i32)]
 
 
 class BnBwdDesc(C.Structure):
@@ -53,13 +53,13 @@ class BnBwdDesc(C.Structure):
                 ('da', c_vp), ('da_mode', c_i32), ('da_cstride', c_i32), ('da_coff', c_i32), ('da_border', c_i32),
                 ('da_is_f32', c_i32),
                 ('da2', c_vp), ('da2_idx', c_vp),
-                ('N', c_i32), ('H', c_i32), ('W', c_i32), ('C', c_i32), ('tsum', c_vp), ('tsum_T', c_i32), ('elem_f32', c_i32)]
+                ('N', c_i32), ('H', c_i32), ('W', c_i32), ('C', c_i32), ('tsum', c_vp), ('tsum_T', c_i32), ('elem_f32', c_i32), ('draw_s2d', c_i32)]
 
 
 class PackDesc(C.Structure):
     _fields_ = [('ntaps', c_i32), ('tap_off', TAPS), ('J', c_i32), ('K', c_i32),
                 ('J0', c_i32), ('J0r', c_i32), ('J1r', c_i32), ('K0', c_i32), ('K0r', c_i32), ('K1r', c_i32),
-                ('sj', c_i64), ('sk', c_i64), ('tap_set', TAPS), ('layout', c_i32), ('dst_f32', c_i32)]
+                ('sj', c_i64), ('sk', c_i64), ('tap_set', TAPS), ('layout', c_i32), ('dst_f32', c_i32), ('kc_total', c_i32), ('kc_off', c_i32)]
 
 
 class PackJob(C.Structure):

@@ -18,6 +18,7 @@ from . import _lib as L
 
 CP = 32                      # channel padding granule
 SUBPIX = os.environ.get('SRVP_SUBPIX', '1') != '0'
+S2D = os.environ.get('SRVP_SUBPIX_S2D', '1') != '0'
 # Sub-pixel form of "nearest x2 upsample, then 3x3 conv" (conv.py:331-349): output phase a in {0,1} of a row pair reads
 # two low-resolution rows with SUMS of the original taps -- R[a][u] = kernel rows folded into effective tap u -- and
 # the gradient wrt the low-resolution input is a 4x4 stride-2 conv of the output gradient with D[dy] folded rows.
@@ -149,6 +150,16 @@ class Block:
                            (len(srcs) == 1 or self.split) and self.k == 3)
         self.ctot = sum(f.C for f in srcs) if srcs else 0
         self.dcat_c = srcs[0].C if self.split else self.ctot     # channels of the input-gradient tensor `dcat`
+        # Sub-pixel BACKWARD on the halo kernels (space-to-depth): the output gradient is stored [N][H/2+2][W/2+2][4 cout] (phase
+        # = channel group, written that way by srvp_bn_bwd_apply), the data gradient is ONE halo convolution over it with the four
+        # taps of each chunk's phase (K = 16 cout exactly) and the weight gradient four 4-tap halo launches on the channel slices --
+        # instead of a 16-tap stride-2 gather and 16 per-tap weight gradients on the generic kernels at half the MFMA rate.
+        # Needs what the halo kernels need: 64-multiple channel counts, power-of-two low-resolution grid (>= 8 columns where the
+        # weight gradient runs on the halo kernel too, i.e. cout = 64).
+        self.s2d = bool(S2D and self.subpix and training and not f32 and self.cout % 64 == 0 and srcs[0].C % 64 == 0
+                        and srcs[0].W >= (8 if self.cout == 64 else 4) and srcs[0].H >= 4
+                        and (srcs[0].W & (srcs[0].W - 1)) == 0 and (srcs[0].H & (srcs[0].H - 1)) == 0
+                        and 4 * N * (srcs[0].H + 2) * (srcs[0].W + 2) * self.cout < 2 ** 32)
         if role != 'out':
             self.raw = torch.empty(N, self.OH, self.OW, self.cout, dtype=self.adt, device=device)
             C_ = self.cout
@@ -173,7 +184,10 @@ class Block:
         if training:
             self.draw_b = 0 if (role == 'mfma' and self.geom in ('full', 'expand')) else 1
             bd = self.draw_b
-            self.draw = torch.zeros(N, self.OH + 2 * bd, self.OW + 2 * bd, self.cout, dtype=self.adt, device=device)
+            if self.s2d:
+                self.draw = torch.zeros(N, self.OH // 2 + 2, self.OW // 2 + 2, 4 * self.cout, dtype=self.adt, device=device)
+            else:
+                self.draw = torch.zeros(N, self.OH + 2 * bd, self.OW + 2 * bd, self.cout, dtype=self.adt, device=device)
         if training and role != 'out':
             self.red = torch.zeros(2, self.cout, dtype=torch.float64, device=device)
             self.bcoef = torch.zeros(3, self.cout, dtype=torch.float32, device=device)
@@ -195,6 +209,17 @@ class Block:
             pd = getattr(self, name, None)
             if pd is not None:
                 pd.dst_f32 = 1 if self.f32 else 0
+        if self.s2d and self.wt_d is not None:
+            # data-gradient weights of the space-to-depth form: packed [4 taps (u, v)][cin][K = 4 phases x cout], fragment-major;
+            # phase (a, b) occupies the K chunks [ph cout/64, (ph + 1) cout/64) and holds the folded taps R[a][u] x R[b][v]
+            # transposed -- one pack job per phase (srvp_pack_desc.kc_off)
+            c0p, c0r, co_p, co_r = self.srcs[0].C, self.cin_r[0], self.cout, self.cout_r
+            self.pd_ph = []
+            for ph, (a, b) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+                sets = [_tapset(SUB_R[a][u], SUB_R[b][v]) for u in (0, 1) for v in (0, 1)]
+                d = _pack_desc([0] * 4, c0p, co_p, (c0p, c0r, 0), (co_p, co_r, 0), self.pd.sj, self.pd.sk, sets)
+                d.layout, d.kc_total, d.kc_off = 1, 4 * co_p // 64, ph * co_p // 64
+                self.pd_ph.append(d)
 
     def _alloc_weights_impl(self):
         k, kk = self.k, self.k * self.k
@@ -260,7 +285,9 @@ class Block:
     def pack_jobs(self, w):
         """[(fp32 source pointer, packed destination tensor, pack descriptor)] of this block's weight buffers."""
         jobs = [(L.ptr(w), self.wt_f, self.pf)]
-        if self.wt_d is not None:
+        if self.wt_d is not None and self.s2d:
+            jobs += [(L.ptr(w), self.wt_d, d) for d in self.pd_ph]
+        elif self.wt_d is not None:
             jobs.append((L.ptr(w), self.wt_d, self.pd))
         if self.split:
             ws = L.ptr(w) + 4 * self.s_off
@@ -277,7 +304,10 @@ class Block:
 
     def pack(self, w, st):
         L.call('srvp_pack_weight', L.ptr(w), L.ptr(self.wt_f), C.byref(self.pf), st)
-        if self.wt_d is not None:
+        if self.wt_d is not None and self.s2d:
+            for d in self.pd_ph:
+                L.call('srvp_pack_weight', L.ptr(w), L.ptr(self.wt_d), C.byref(d), st)
+        elif self.wt_d is not None:
             L.call('srvp_pack_weight', L.ptr(w), L.ptr(self.wt_d), C.byref(self.pd), st)
         if self.split:
             ws = L.ptr(w) + 4 * self.s_off
@@ -437,6 +467,13 @@ class Block:
     def dgrad_descs(self):
         """ConvDesc list computing dcat = gradient wrt the block input from draw."""
         out = self._dgrad_descs_raw()
+        if self.s2d:
+            out[0].wt_fragmajor, out[0].elem_f32 = 1, 0
+            want = int(L.load().srvp_conv_wants_fragmajor(C.byref(out[0])))
+            assert want == 1, 'space-to-depth data gradient is not eligible for the halo kernel'
+            if self.split:
+                self._set_layout(out[1:], self.pd_s)
+            return out
         if self.split:
             self._set_layout(out[:1], self.pd)
             self._set_layout(out[1:], self.pd_s)       # gradient wrt the skip tensor
@@ -461,7 +498,21 @@ class Block:
             d = base()
             # dIn[i] = sum_kh dOut[i + p - kh]  -> padded coordinate i + p - kh + bd
             taps = [(self.p - kh + bd, self.p - kw + bd) for kh in range(k) for kw in range(k)]
-            if self.subpix:
+            if self.s2d:
+                # gradient wrt the low-resolution source from the space-to-depth output gradient: phase (a, b), folded tap (u, v) of
+                # the forward reads padded input row i + a + u, so the gradient of input row p collects phase-(a, b) output row
+                # p + 1 - a - u = padded row p + 2 - a - u of the s2d tensor
+                f0 = self.srcs[0]
+                d.src0, d.C0, d.H0p, d.W0p = L.ptr(self.draw), 4 * self.cout, f0.H + 2, f0.W + 2
+                d.ntaps = 4
+                ent = [(2 - a - u, 2 - b - v) for a in (0, 1) for b in (0, 1) for u in (0, 1) for v in (0, 1)]
+                d.dy, d.dx = L.taps([e[0] for e in ent]), L.taps([e[1] for e in ent])
+                d.tap_phase_chunks = self.cout // 64
+                d.si, d.wt = 1, L.ptr(self.wt_d)
+                d.N, d.OH, d.OW = N, f0.H, f0.W
+                d.Cout, d.Cdst = self.dcat_c, self.dcat_c
+                d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox = L.ptr(self.dcat), f0.H, f0.W, 1, 0, 0
+            elif self.subpix:
                 # gradient wrt the low-resolution source: 4x4 stride-2 conv of draw with folded taps (padded row 2 i + dy)
                 assert bd == 1
                 f0 = self.srcs[0]
@@ -532,9 +583,85 @@ class Block:
         return out
 
     def wgrad_desc(self):
+        if self.s2d:
+            main = self._wgrad_s2d()
+            return main + [self._wgrad_one('s')] if self.split else main
         if self.split:
             return [self._wgrad_one('h'), self._wgrad_one('s')]
         return self._wgrad_one(None)
+
+    def _wgrad_s2d(self):
+        """Weight gradient of a sub-pixel block from its space-to-depth output gradient; entries (a*2+b)*4 + u*2+v of dw.
+        cout = 64: four 4-tap HALO launches, one per output phase (dout = the phase's channel slice, taps = that phase's folded
+        offsets).  Wider layers: the halo kernel is LDS-DMA bound with only 4 taps per staged tile (measured 0.55-0.60 vs
+        0.50-0.52 ms), so ONE 16-tap launch of the per-tap kernel, tap t reading the slice of phase t / 4 at unit stride."""
+        f0 = self.srcs[0]
+        out = []
+        if self.cout > 64:
+            ent = [(a, b, u, v) for a in (0, 1) for b in (0, 1) for u in (0, 1) for v in (0, 1)]
+            d = L.WgradDesc()
+            d.src0, d.C0, d.H0p, d.W0p, d.ups0 = L.ptr(f0.t), f0.C, f0.Hp, f0.Wp, 0
+            d.src1, d.C1, d.H1p, d.W1p, d.ups1, d.map1 = None, 0, 1, 1, 0, None
+            d.ntaps = 16
+            d.dy, d.dx = L.taps([a + u for a, b, u, v in ent]), L.taps([b + v for a, b, u, v in ent])
+            d.si, d.so = 1, 1
+            d.ooy, d.oox = L.taps([1] * 16), L.taps([1] * 16)
+            d.dout, d.Cout, d.dout_cstride, d.dout_coff, d.dout_phase_taps = L.ptr(self.draw), self.cout, 4 * self.cout, 0, 4
+            d.DHp, d.DWp = f0.H + 2, f0.W + 2
+            d.N, d.OH, d.OW = self.N, f0.H, f0.W
+            d.dw = L.ptr(self.dw)
+            bj = 128 if self.cout % 128 == 0 else 64
+            bc = 128 if f0.C % 128 == 0 else 64
+            tiles = (self.cout // bj) * (f0.C // bc) * 16
+            chunks = (self.N * f0.H * f0.W + 31) // 32
+            d.splitk = int(max(1, min((1024 + tiles - 1) // tiles, chunks // 4 if chunks >= 4 else 1)))
+            return [d]
+        for ph, (a, b) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+            d = L.WgradDesc()
+            d.src0, d.C0, d.H0p, d.W0p, d.ups0 = L.ptr(f0.t), f0.C, f0.Hp, f0.Wp, 0
+            d.src1, d.C1, d.H1p, d.W1p, d.ups1, d.map1 = None, 0, 1, 1, 0, None
+            d.ntaps = 4
+            d.dy, d.dx = L.taps([a + u for u in (0, 1) for v in (0, 1)]), L.taps([b + v for u in (0, 1) for v in (0, 1)])
+            d.si, d.so = 1, 1
+            d.ooy, d.oox = L.taps([1] * 4), L.taps([1] * 4)
+            d.dout, d.Cout, d.dout_cstride, d.dout_coff = L.ptr(self.draw), self.cout, 4 * self.cout, ph * self.cout
+            d.DHp, d.DWp = f0.H + 2, f0.W + 2
+            d.N, d.OH, d.OW = self.N, f0.H, f0.W
+            d.dw = L.ptr(self.dw) + 4 * ph * 4 * self.cout * self.dcat_c
+            # split-K for the per-tap kernel (the halo kernel picks its own): enough workgroups to fill the chip
+            bj = 128 if self.cout % 128 == 0 else 64
+            bc = 128 if f0.C % 128 == 0 else 64
+            tiles = (self.cout // bj) * (f0.C // bc) * 4
+            chunks = (self.N * f0.H * f0.W + 31) // 32
+            d.splitk = int(max(1, min((1024 + tiles - 1) // tiles, chunks // 4 if chunks >= 4 else 1)))
+            out.append(d)
+        return out
+
+    # (tests / tools) the output gradient in the block's own layout
+    def put_draw(self, dr):
+        """dr: [N][OH][OW][cout_real] -> self.draw (bordered NHWC, or space-to-depth for s2d blocks)."""
+        self.draw.zero_()
+        cr = dr.shape[-1]
+        if self.s2d:
+            v = self.draw.view(self.N, self.OH // 2 + 2, self.OW // 2 + 2, 4, self.cout)
+            for a in (0, 1):
+                for b in (0, 1):
+                    v[:, 1:-1, 1:-1, a * 2 + b, :cr].copy_(dr[:, a::2, b::2])
+        else:
+            bd = self.draw_b
+            self.draw[:, bd:bd + self.OH, bd:bd + self.OW, :cr].copy_(dr)
+
+    def get_draw(self):
+        """[N][OH][OW][cout] view-independent copy of the stored output gradient (rounded as stored)."""
+        if self.s2d:
+            v = self.draw.view(self.N, self.OH // 2 + 2, self.OW // 2 + 2, 4, self.cout)
+            out = torch.empty(self.N, self.OH, self.OW, self.cout, dtype=self.draw.dtype, device=self.draw.device)
+            for a in (0, 1):
+                for b in (0, 1):
+                    out[:, a::2, b::2] = v[:, 1:-1, 1:-1, a * 2 + b]
+            return out
+        bd = self.draw_b
+        return self.draw[:, bd:bd + self.OH, bd:bd + self.OW].clone()
 
     def _wgrad_one(self, which):
         k, N, bd = self.k, self.N, self.draw_b
@@ -648,6 +775,7 @@ class ConvNetBase:
         """da: dict(t, mode, cstride, coff, border, f32, da2, da2_idx).  Produces blk.draw (and BN param grads)."""
         d = L.BnBwdDesc()
         d.elem_f32 = 1 if blk.f32 else 0
+        d.draw_s2d = 1 if getattr(blk, 's2d', False) else 0
         d.raw = L.ptr(blk.raw)
         d.act, d.act_border = (L.ptr(blk.out.t), blk.out.b) if blk.out is not None else (None, 0)
         d.scale, d.shift, d.mean, d.invstd = (L.ptr(blk.coef[i]) for i in range(4))

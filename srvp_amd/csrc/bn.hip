@@ -133,7 +133,15 @@ struct BnBwdK {
     const void* da2; const int* da2_idx;
     int N, H, W, C;
     void* tsum; int tsum_T;        // apply: also write the sum over the T time steps of each sample (frames are t*B + b)
+    int s2d;                         // apply: draw is written space-to-depth [N][H/2+2][W/2+2][4C] (border 1)
 };
+
+// element offset of pixel (n, y, x), channel group cg in the gradient tensor `draw`
+__device__ __forceinline__ size_t draw_off(const BnBwdK& a, int n, int y, int x, int cg, int db) {
+    if (a.s2d)
+        return ((((size_t)n * (a.H / 2 + 2) + (y >> 1) + 1) * (a.W / 2 + 2) + (x >> 1) + 1) * 4 + ((y & 1) * 2 + (x & 1))) * a.C + cg * 8;
+    return (((size_t)n * (a.H + 2 * db) + y + db) * (a.W + 2 * db) + x + db) * a.C + cg * 8;
+}
 
 // g[8] = dA * f'(pre) for pixel (n,y,x), channel group cg; also returns raw values
 template <class E, int MODE, int ACT>
@@ -409,8 +417,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK a, const
                 bn_bwd_g<E, MODE, ACT>(a, n, w.y, w.x, cg, sc, sh, g, rawf);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { o[e] = k1[e] * g[e] + k2[e] + k3[e] * rawf[e]; acc[e] += o[e]; }
-                size_t off = (((size_t)n * (a.H + 2 * db) + w.y + db) * (a.W + 2 * db) + w.x + db) * a.C + cg * 8;
-                El<E>::st8(draw + off, o);
+                El<E>::st8(draw + draw_off(a, n, w.y, w.x, cg, db), o);
             }
             size_t soff = (((size_t)w.n * (a.H + 2 * db) + w.y + db) * (a.W + 2 * db) + w.x + db) * a.C + cg * 8;
             El<E>::st8((E*)a.tsum + soff, acc);
@@ -427,8 +434,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK a, const
         bn_bwd_g<E, MODE, ACT>(a, n, y, x, cg, sc, sh, g, rawf);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = k1[e] * g[e] + k2[e] + k3[e] * rawf[e];
-        size_t off = (((size_t)n * (a.H + 2 * db) + y + db) * (a.W + 2 * db) + x + db) * a.C + cg * 8;
-        El<E>::st8(draw + off, o);
+        El<E>::st8(draw + draw_off(a, n, y, x, cg, db), o);
     }
 }
 
@@ -443,6 +449,8 @@ int fill_k(const srvp_bnbwd_desc* d, BnBwdK& k) {
     k.da_border = d->da_border; k.da_is_f32 = d->da_is_f32; k.da2 = d->da2; k.da2_idx = d->da2_idx;
     k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C;
     k.tsum = d->tsum; k.tsum_T = d->tsum_T;
+    k.s2d = d->draw_s2d;
+    SRVP_REQUIRE(!d->draw_s2d || (d->da_mode != 2 && d->H % 2 == 0 && d->W % 2 == 0), "srvp_bn_bwd: draw_s2d needs even H, W and a non-pooled consumer");
     SRVP_REQUIRE(!d->tsum || (d->tsum_T > 0 && d->N % d->tsum_T == 0 && d->da_mode != 2), "srvp_bn_bwd: tsum needs N %% T == 0 and a non-pooled consumer");
     return SRVP_OK;
 }

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradF a) {
 }  // namespace
 
 int srvp_conv_f32_launch(const srvp_conv_desc* d, hipStream_t st) {
-    SRVP_REQUIRE(d->wt_fragmajor == 0, "srvp_conv_mfma(fp32): weights must be tap-major");
+    SRVP_REQUIRE(d->wt_fragmajor == 0 && d->tap_phase_chunks == 0, "srvp_conv_mfma(fp32): weights must be tap-major, no space-to-depth sources");
     ConvF k;
     k.src0 = (const float*)d->src0; k.src1 = (const float*)d->src1; k.map1 = d->map1; k.map0 = d->map0;
     k.C0 = d->C0; k.C1 = d->C1; k.H0p = d->H0p; k.W0p = d->W0p; k.H1p = d->H1p; k.W1p = d->W1p;
@@ -247,6 +247,7 @@ int srvp_conv_f32_launch(const srvp_conv_desc* d, hipStream_t st) {
 }
 
 int srvp_wgrad_f32_launch(const srvp_wgrad_desc* d, hipStream_t st) {
+    SRVP_REQUIRE(d->dout_cstride == 0 && d->dout_coff == 0 && d->dout_phase_taps == 0, "srvp_wgrad_mfma(fp32): channel-sliced dout is not supported");
     WgradF k;
     k.src0 = (const float*)d->src0; k.src1 = (const float*)d->src1; k.map1 = d->map1; k.map0 = d->map0;
     k.C0 = d->C0; k.C1 = d->C1; k.H0p = d->H0p; k.W0p = d->W0p; k.H1p = d->H1p; k.W1p = d->W1p;

@@ -31,6 +31,7 @@ struct ConvK {
     double* stats; int stat_mod;
     float* out_f32; int out_nc, out_sigmoid;
     const int* map0; int dst_is_f32; const float* add_f32; int add_mod;
+    int phase_chunks;          // > 0: space-to-depth source, taps of chunk cc are entries [(cc / phase_chunks) * ntaps + t]
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -400,11 +401,14 @@ static int fill_convk(const srvp_conv_desc* d, ConvK& k) {
     k.C0 = d->C0; k.C1 = d->C1; k.H0p = d->H0p; k.W0p = d->W0p; k.H1p = d->H1p; k.W1p = d->W1p;
     k.ups0 = d->ups0; k.ups1 = d->ups1; k.si = d->si; k.ntaps = d->ntaps;
     k.dy_bits = 0; k.dx_bits = 0;
-    for (int t = 0; t < d->ntaps; ++t) {
+    const int nent = d->tap_phase_chunks > 0 ? 4 * d->ntaps : d->ntaps;
+    SRVP_REQUIRE(nent <= SRVP_MAX_TAPS, "srvp_conv_mfma: 4 x ntaps tap entries exceed %d", SRVP_MAX_TAPS);
+    for (int t = 0; t < nent; ++t) {
         SRVP_REQUIRE(d->dy[t] >= 0 && d->dy[t] < 16 && d->dx[t] >= 0 && d->dx[t] < 16, "srvp_conv_mfma: tap offset out of [0,15]");
         k.dy_bits |= (unsigned long long)d->dy[t] << (4 * t);
         k.dx_bits |= (unsigned long long)d->dx[t] << (4 * t);
     }
+    k.phase_chunks = d->tap_phase_chunks;
     k.wt = (const bf16_t*)d->wt; k.Cout = d->Cout; k.N = d->N; k.OH = d->OH; k.OW = d->OW;
     k.dst = (bf16_t*)d->dst; k.DHp = d->DHp; k.DWp = d->DWp; k.so = d->so; k.ooy = d->ooy; k.oox = d->oox;
     k.Cdst = d->Cdst; k.cdst_off = d->cdst_off; k.stats = d->stats; k.stat_mod = d->stat_mod;
@@ -572,9 +576,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 256 ?
         __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        const int tph = a.phase_chunks > 0 ? (cc / a.phase_chunks) * ntaps : 0;      // first tap entry of this chunk's phase
         for (int t = 0; t < ntaps; ++t, ++s) {
             const unsigned soff_n = step_off(s + 1);
-            const int dy = (int)((a.dy_bits >> (4 * t)) & 15), dx = (int)((a.dx_bits >> (4 * t)) & 15);
+            const int dy = (int)((a.dy_bits >> (4 * (tph + t))) & 15), dx = (int)((a.dx_bits >> (4 * (tph + t))) & 15);
             int apix[TM], asw[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -633,7 +638,9 @@ static bool halo_geometry(const srvp_conv_desc* d, HaloK& h, int BM) {
     if (g_halo < 0) { const char* e = getenv("SRVP_CONV_HALO"); g_halo = e ? atoi(e) : 1; }
     if (!g_halo || d->elem_f32) return false;
     if (d->ntaps > 9 || d->si != 1 || d->C1 != 0 || d->C0 % 64 != 0) return false;
-    for (int t = 0; t < d->ntaps; ++t) if (d->dy[t] < 0 || d->dy[t] > 2 || d->dx[t] < 0 || d->dx[t] > 2) return false;
+    const int nent = d->tap_phase_chunks > 0 ? 4 * d->ntaps : d->ntaps;
+    if (nent > SRVP_MAX_TAPS || (d->tap_phase_chunks > 0 && (d->C0 / 64) != 4 * d->tap_phase_chunks)) return false;
+    for (int t = 0; t < nent; ++t) if (d->dy[t] < 0 || d->dy[t] > 2 || d->dx[t] < 0 || d->dx[t] > 2) return false;
     const int OH = d->OH, OW = d->OW, ups = d->ups0 ? 1 : 0;
     if (OH < 2 || OW < 2 || (OH & (OH - 1)) || (OW & (OW - 1))) return false;
     if (d->H0p != (OH >> ups) + 2 || d->W0p != (OW >> ups) + 2) return false;
@@ -762,6 +769,7 @@ extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
     SRVP_REQUIRE((long long)d->N * d->H0p * d->W0p * d->C0 < (1ll << 32) && (d->C1 == 0 || d->map1 || (long long)d->N * d->H1p * d->W1p * d->C1 < (1ll << 32)),
                  "srvp_conv_mfma: source tensors must have fewer than 2^32 elements");
     if (const int v = halo_variant(d)) return launch_halo_any(d, 1, v, st);
+    SRVP_REQUIRE(d->tap_phase_chunks == 0, "srvp_conv_mfma: tap_phase_chunks launches run on the halo kernel only, and this descriptor is not eligible for it");
     const bool k64 = (d->C0 % 64 == 0) && (d->C1 % 64 == 0);
     // LDS ring depth / K step (A/B switch SRVP_CONV_MODE): 5 = BK64 single buffer (default: 3 workgroups per CU hide the
     // DMA latency better than a deeper ring at 1-2 workgroups per CU: 39.0 vs 40.9 (x2) / 43 (BK32 x3) / 46 (BK32 x4) /

@@ -18,6 +18,7 @@ struct PackArgs {
     int tap_set[SRVP_MAX_TAPS];   // != 0: packed tap = sum of the source taps in the bit set
     int layout;                   // 0 tap-major, 1 MFMA-fragment-major (see srvp_hip.h)
     int dst_f32;                  // packed tensor is fp32 (precision = 'fp32' parity mode; tap-major only)
+    int kc_total, kc_off;         // layout 1: K chunks per tap of the destination (0 = K/64) and first chunk of this job
 };
 
 __device__ __forceinline__ int real_index(int i, int seg0_pad, int seg0_real, int seg1_real) {
@@ -42,7 +43,8 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ src, bf16_t* 
     long long o = i;
     if (a.layout == 1) {
         const int cc = k >> 6, kk = (k >> 4) & 3, kh = (k >> 3) & 1;
-        o = ((((long long)(t * (a.K >> 6) + cc) * 4 + kk) * (a.J >> 5) + (j >> 5)) * 64 + kh * 32 + (j & 31)) * 8 + (k & 7);
+        const int KC = a.kc_total ? a.kc_total : (a.K >> 6);
+        o = ((((long long)(t * KC + cc + a.kc_off) * 4 + kk) * (a.J >> 5) + (j >> 5)) * 64 + kh * 32 + (j & 31)) * 8 + (k & 7);
     }
     if (a.dst_f32) reinterpret_cast<float*>(dst)[o] = v;
     else dst[o] = f2bf(v);
@@ -77,7 +79,7 @@ __device__ __forceinline__ void job_args(const srvp_pack_job& j, PackArgs& a) {
 #pragma unroll
     for (int t = 0; t < SRVP_MAX_TAPS; ++t) { a.tap_off[t] = j.d.tap_off[t]; a.tap_set[t] = j.d.tap_set[t]; }
     a.J = j.d.J; a.K = j.d.K; a.J0 = j.d.J0; a.J0r = j.d.J0r; a.J1r = j.d.J1r; a.K0 = j.d.K0; a.K0r = j.d.K0r; a.K1r = j.d.K1r;
-    a.sj = j.d.sj; a.sk = j.d.sk; a.layout = j.d.layout; a.dst_f32 = j.d.dst_f32;
+    a.sj = j.d.sj; a.sk = j.d.sk; a.layout = j.d.layout; a.dst_f32 = j.d.dst_f32; a.kc_total = j.d.kc_total; a.kc_off = j.d.kc_off;
 }
 // Vector path (K % 8 == 0, source taps within 16 elements of the (j, k) base -- every conv / convT weight): one work item
 // = (j, eight consecutive k), lanes along j.  The fp32 tensor keeps its taps innermost, so an item's reads / read-modify-writes
@@ -160,7 +162,8 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const srvp_pack_job* __
             const int k = k8 * 8;
             if (d.layout == 1) {
                 const int cc = k >> 6, kk = (k >> 4) & 3, kh = (k >> 3) & 1;
-                o = ((((long long)(t * (K >> 6) + cc) * 4 + kk) * (J >> 5) + (jj >> 5)) * 64 + kh * 32 + (jj & 31)) * 8;
+                const int KC = d.kc_total ? d.kc_total : (K >> 6);
+                o = ((((long long)(t * KC + cc + d.kc_off) * 4 + kk) * (J >> 5) + (jj >> 5)) * 64 + kh * 32 + (jj & 31)) * 8;
             } else {
                 o = ((long long)t * J + jj) * K + k;
             }
@@ -233,6 +236,7 @@ int fill_pack(const srvp_pack_desc* d, PackArgs& a) {
     a.sj = d->sj; a.sk = d->sk;
     a.layout = d->layout;
     a.dst_f32 = d->dst_f32;
+    a.kc_total = d->kc_total; a.kc_off = d->kc_off;
     SRVP_REQUIRE(!(d->dst_f32 && d->layout), "srvp_pack: fp32 packed weights are tap-major only");
     SRVP_REQUIRE(d->layout == 0 || (d->layout == 1 && d->J % 32 == 0 && d->K % 64 == 0), "srvp_pack: layout %d needs J %% 32 == 0, K %% 64 == 0", d->layout);
     return SRVP_OK;

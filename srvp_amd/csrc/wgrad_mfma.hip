@@ -25,6 +25,8 @@ struct WgradK {
     float* dw; int splitk;
     const int* map0;
     int lg_hw, lg_ow;          // log2 of OH*OW and OW when both are powers of two, else -1
+    int dcs, dco;              // dout pixel stride in channels (= Cout unless dout is a channel slice) and first channel
+    int ptaps;                 // > 0: tap t reads the slice of phase t / ptaps (first channel dco + (t / ptaps) * Cout)
 };
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(WJ * WC * 64) void wgrad_regstage_kernel(const Wgra
             const bool valid = m < Mi;
             int n, oy, ox;
             decode(valid ? m : Mi - 1, n, oy, ox);
-            unsigned off = (((unsigned)n * a.DHp + oy * a.so + ooy) * a.DWp + ox * a.so + oox) * a.Cout + j0 + ch * 8;
+            unsigned off = (((unsigned)n * a.DHp + oy * a.so + ooy) * a.DWp + ox * a.so + oox) * a.dcs + a.dco + (a.ptaps ? (t / a.ptaps) * a.Cout : 0) + j0 + ch * 8;
             u32x4_t v = {0u, 0u, 0u, 0u};
             if (q < BP * XCH) v = *reinterpret_cast<const u32x4_t*>(a.dout + off);
             const unsigned keep = valid ? 0xffffffffu : 0u;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(WJ * WC * 64) void wgrad_mfma_kernel(const WgradK a
             const int m = mbase + xrow[i];
             const int n = m >> a.lg_hw, r = m & (hw - 1);
             const int oy = r >> a.lg_ow, ox = r & (a.OW - 1);
-            unsigned off = (((unsigned)n * a.DHp + oy * a.so + ooy) * a.DWp + ox * a.so + oox) * a.Cout + j0 + xch[i] * 8;
+            unsigned off = (((unsigned)n * a.DHp + oy * a.so + ooy) * a.DWp + ox * a.so + oox) * a.dcs + a.dco + (a.ptaps ? (t / a.ptaps) * a.Cout : 0) + j0 + xch[i] * 8;
             const int qb = ((wid * 64 + i * NT) % (BP * XCH)) * 8;        // wave-uniform LDS element offset of this piece
             __builtin_amdgcn_global_load_lds((gptr_t)(a.dout + off), (lptr_t)(Xd + qb), 16, 0, 0);
         }
@@ -423,12 +425,14 @@ struct WgradHaloK {
     int lgTW, RH, PW, Ppix, lg_nxb, lg_nyb, ntiles, oo;   // oo: border offset of dout (ooy = oox)
 };
 
-template <bool UPS, int BJ>
+template <bool UPS, int BJ, int NTAPS = 9>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_halo_kernel(const WgradHaloK p) {
     // BJ = 64: wave = (cout tile, cin tile), all 9 taps.  BJ = 32 (image-side layer, Cout padded to 32): wave = (cin tile,
     // tap group 0-4 / 5-8); the second group computes one duplicate tap that is not written back.
+    // NTAPS = 4 (BJ = 64): one phase of a sub-pixel upsample convolution -- dout is a channel slice of the space-to-depth
+    // gradient, the four taps are that phase's offsets inside the same 3x3 window.
     constexpr int NT = 256, NBUF = 4, BC = 64;
-    constexpr int NTW = BJ == 64 ? 9 : 5;                // taps per wave
+    constexpr int NTW = BJ == 64 ? NTAPS : 5;            // taps per wave
     constexpr int XROW = BJ * 2;                         // bytes per dout pixel row
     constexpr int XBYTES = 32 * XROW;                    // [32 px][BJ ch]
     constexpr int YPIECES = 3 * NT;                      // 96 px * 8 chunks
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         const int xq = BJ == 64 ? tid : (tid & 127);
         const int pk = BJ == 64 ? (xq >> 3) : (xq >> 2), pos = BJ == 64 ? (xq & 7) : (xq & 3);
         const int ty = pk >> p.lgTW, tx = pk & (TW - 1);
-        xlane = (unsigned)((ty * a.DWp + tx) * a.Cout + ((BJ == 64 ? (pos ^ (((pk >> 1) & 1) << 2)) : pos) * 8));
+        xlane = (unsigned)((ty * a.DWp + tx) * a.dcs + ((BJ == 64 ? (pos ^ (((pk >> 1) & 1) << 2)) : pos) * 8));
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int q = tid + i * NT;
@@ -487,7 +491,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         const int n = tau >> (p.lg_nxb + p.lg_nyb);
         const int y0 = yb * p.RH, x0 = xb << p.lgTW;
         const int ns = a.map0 ? maps[n] : n;             // LDS copy: a global load here would sit in the DMA's vmcnt queue
-        const unsigned xbase = (((unsigned)n * a.DHp + y0 + p.oo) * a.DWp + x0 + p.oo) * a.Cout + j0;
+        const unsigned xbase = (((unsigned)n * a.DHp + y0 + p.oo) * a.DWp + x0 + p.oo) * a.dcs + a.dco + j0;
         const unsigned ybase = (((unsigned)ns * a.H0p + (y0 >> ups)) * a.W0p + (x0 >> ups)) * a.C0 + c0;
         unsigned char* sb = lds + (size_t)buf * STAGE;
         __builtin_amdgcn_global_load_lds((gptr_t)(a.dout + xbase + xlane), (lptr_t)(sb + (BJ == 64 ? wid : (wid & 1)) * 1024), 16, 0, 0);
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     unsigned toff[NTW][NAD];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-        const int tg = (tap0 + t) > 8 ? 8 : tap0 + t;
+        const int tg = (tap0 + t) > NTAPS - 1 ? NTAPS - 1 : tap0 + t;
         const int dy = (int)((a.dy_bits >> (4 * tg)) & 15), dx = (int)((a.dx_bits >> (4 * tg)) & 15);
         if constexpr (!UPS) {
             const unsigned P0 = (unsigned)((ty0 + dy) * PW + tx0 + dx) << 7, P1 = (unsigned)((ty1 + dy) * PW + tx0 + dx) << 7;
@@ -618,7 +622,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     const int lcol = lane & 31, lhalf = lane >> 5;
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-        if (tap0 + t > 8) break;
+        if (tap0 + t > NTAPS - 1) break;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int jj = j0 + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
@@ -635,8 +639,15 @@ static int try_launch_halo(const srvp_wgrad_desc* d, const WgradK& k, hipStream_
     done = false;
     if (g_wgrad_halo < 0) { const char* e = getenv("SRVP_WGRAD_HALO"); g_wgrad_halo = e ? atoi(e) : 1; }
     if (!g_wgrad_halo) return SRVP_OK;
-    if (d->ntaps != 9 || d->si != 1 || d->so != 1 || d->C1 != 0 || d->C0 % 64 || (d->Cout % 64 && d->Cout != 32)) return SRVP_OK;
-    for (int t = 0; t < 9; ++t)
+    // one phase of a sub-pixel block (space-to-depth dout): with 4 taps per staged tile the halo kernel is LDS-DMA bound (16 KB staged
+    // per 8 MFMAs per wave); it beats the per-tap kernel only on the 64-channel 64x64 stage (0.65 vs 0.90 ms), wider layers
+    // measured 0.55-0.60 vs 0.50-0.52 ms and stay on the per-tap kernel (which reads the channel slice through dcs / dco as well)
+    static int four_max = -1;
+    if (four_max < 0) { const char* e = getenv("SRVP_WGRAD_HALO4_MAXC"); four_max = e ? atoi(e) : 64; }
+    const bool four = d->ntaps == 4 && d->Cout % 64 == 0 && d->Cout <= four_max && !d->ups0;
+    if ((d->ntaps != 9 && !four) || d->si != 1 || d->so != 1 || d->C1 != 0 || d->C0 % 64 || (d->Cout % 64 && d->Cout != 32)) return SRVP_OK;
+    if ((!four && (d->dout_cstride || d->dout_coff)) || d->dout_phase_taps) return SRVP_OK;
+    for (int t = 0; t < d->ntaps; ++t)
         if (d->dy[t] < 0 || d->dy[t] > 2 || d->dx[t] < 0 || d->dx[t] > 2 || d->ooy[t] != d->ooy[0] || d->oox[t] != d->ooy[0]) return SRVP_OK;
     const int OH = d->OH, OW = d->OW, ups = d->ups0 ? 1 : 0;
     if (OW < 8 || (OW & (OW - 1)) || (OH & (OH - 1))) return SRVP_OK;
@@ -663,6 +674,12 @@ static int try_launch_halo(const srvp_wgrad_desc* d, const WgradK& k, hipStream_
     if (splitk > h.ntiles / 8) splitk = h.ntiles / 8 > 0 ? h.ntiles / 8 : 1;
     h.a.splitk = splitk;
     const long long blocks = (long long)pairs * splitk;
+    if (four) {
+        hipLaunchKernelGGL((wgrad_halo_kernel<false, 64, 4>), dim3((unsigned)blocks), dim3(256), 0, st, h);
+        SRVP_CHECK_LAUNCH("srvp_wgrad_mfma(halo, 4 taps)");
+        done = true;
+        return SRVP_OK;
+    }
     if (bj == 32) {
         if (ups) hipLaunchKernelGGL((wgrad_halo_kernel<true, 32>), dim3((unsigned)blocks), dim3(256), 0, st, h);
         else hipLaunchKernelGGL((wgrad_halo_kernel<false, 32>), dim3((unsigned)blocks), dim3(256), 0, st, h);
@@ -722,14 +739,16 @@ extern "C" int srvp_wgrad_mfma(const srvp_wgrad_desc* d, void* stream) {
         k.ooy_bits |= (unsigned long long)d->ooy[t] << (4 * t); k.oox_bits |= (unsigned long long)d->oox[t] << (4 * t);
     }
     k.dout = (const bf16_t*)d->dout; k.DHp = d->DHp; k.DWp = d->DWp; k.so = d->so; k.Cout = d->Cout;
+    k.dcs = d->dout_cstride ? d->dout_cstride : d->Cout; k.dco = d->dout_coff; k.ptaps = d->dout_phase_taps;
     k.N = d->N; k.OH = d->OH; k.OW = d->OW; k.dw = d->dw; k.splitk = d->splitk;
     SRVP_REQUIRE((long long)d->N * d->OH * d->OW < (1ll << 31), "srvp_wgrad_mfma: too many pixels");
-    SRVP_REQUIRE((long long)d->N * d->DHp * d->DWp * d->Cout < (1ll << 32) && (long long)d->N * d->H0p * d->W0p * d->C0 < (1ll << 32),
+    SRVP_REQUIRE((long long)d->N * d->DHp * d->DWp * k.dcs < (1ll << 32) && (long long)d->N * d->H0p * d->W0p * d->C0 < (1ll << 32),
                  "srvp_wgrad_mfma: operand tensors must have fewer than 2^32 elements");
     auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
     k.lg_ow = lg(d->OW); k.lg_hw = lg(d->OH * d->OW);
     if (k.lg_hw < 0) k.lg_ow = -1;
     const bool tr = (g_use_tr & 1) != 0;
+    // (a channel-sliced 4-tap phase launch exists on the halo kernel only: it is taken whatever the A/B switches say)
     if (tr && !(g_use_tr & 4)) {
         bool done = false;
         if (int rc = try_launch_halo(d, k, st, done)) return rc;

@@ -122,15 +122,14 @@ def test_block_conv_fwd_bwd(case, use_tr):
     assert rel_err(blk.stats[0, :cout], s1) < stol * max(1.0, (s2.sqrt().max() / (s1.abs().max() + 1e-9)).item())
     assert rel_err(blk.stats[1, :cout], s2) < stol
     # ---- backward
-    bd = blk.draw_b
     dr = torch.randn(N, blk.OH, blk.OW, cout, generator=g) * 0.5
-    blk.draw.zero_()
-    blk.draw[:, bd:bd + blk.OH, bd:bd + blk.OW, :cout].copy_(dr)
-    dr_ref = blk.draw[:, bd:bd + blk.OH, bd:bd + blk.OW, :cout].permute(0, 3, 1, 2).float().cpu()
+    blk.put_draw(dr.to(dev))                             # (bordered NHWC, or space-to-depth for the sub-pixel halo backward)
+    dr_ref = blk.get_draw()[..., :cout].permute(0, 3, 1, 2).float().cpu()
     ref.backward(dr_ref)
     grads = {'w.weight': torch.zeros_like(w)}
     blk.dw.zero_()
-    L.call('srvp_wgrad_mfma', C.byref(blk._wg), st)
+    for d in (blk._wg if isinstance(blk._wg, list) else [blk._wg]):
+        L.call('srvp_wgrad_mfma', C.byref(d), st)
     L.call('srvp_unpack_wgrad', L.ptr(blk.dw), L.ptr(grads['w.weight']), C.byref(blk.pu), st)
     for d in blk._dg:
         L.call('srvp_conv_mfma', C.byref(d), st)
@@ -158,11 +157,13 @@ HALO_CASES = [
 
 
 @pytest.mark.parametrize('case', HALO_CASES, ids=[f'{c[0]}to{c[1]}_{c[2]}{"up" if c[3] else ""}_n{c[4]}_{c[5]}' for c in HALO_CASES])
-def test_conv_halo_matches_generic(case):
+def test_conv_halo_matches_generic(case, monkeypatch):
     """The halo-tiled 3x3 kernel and the generic tap-gather kernel accumulate in the same order: bit-identical raw
     outputs / frames / data-gradients; BN statistics equal up to the fp32 per-tile partial sums."""
     from srvp_amd import _lib as L
+    from srvp_amd import convnet
     from srvp_amd.convnet import Block
+    monkeypatch.setattr(convnet, 'S2D', False)           # (the space-to-depth sub-pixel backward has no generic-kernel twin)
     c0r, cout, Hs, ups, N, role = case
     dev = torch.device('cuda')
     g = torch.Generator().manual_seed(11)
@@ -204,10 +205,12 @@ def test_conv_halo_matches_generic(case):
         assert rel_err(res[1][2], res[0][2]) < 1e-6          # per-tile partial sums are fp32, tile shapes differ
 
 
-def test_conv_halo_split_skip():
+def test_conv_halo_split_skip(monkeypatch):
     """Hoisted skip half through the halo kernel (map0 sample indirection, fp32 S output, S added in the epilogue)."""
     from srvp_amd import _lib as L
+    from srvp_amd import convnet
     from srvp_amd.convnet import Block
+    monkeypatch.setattr(convnet, 'S2D', False)
     dev = torch.device('cuda')
     g = torch.Generator().manual_seed(12)
     T, B, Hs = 3, 2, 8
@@ -297,9 +300,8 @@ def test_split_skip_subpixel_block_full_width(case):
     # ---- backward: draw (per frame) and its sum over time (what srvp_bn_bwd_apply writes beside it)
     OH = 2 * Hs
     dr = torch.randn(N, OH, OH, cout, generator=g) * 0.5
-    blk.draw.zero_()
-    blk.draw[:, 1:-1, 1:-1, :cout].copy_(dr)
-    drf = blk.draw[:, 1:-1, 1:-1, :cout].float()
+    blk.put_draw(dr.to(dev))
+    drf = blk.get_draw()[..., :cout].float()
     blk.draw_sum.zero_()
     blk.draw_sum[:, 1:-1, 1:-1, :cout].copy_(drf.view(T, B, OH, OH, cout).sum(0))
     ref.backward(drf.permute(0, 3, 1, 2).cpu())
