@@ -35,7 +35,6 @@ struct RollF {
     // backward
     const float* d_y_all; const float* d_res; float* dhid; float* dinp_all; float* d_y0; int dwd;
     float* part; unsigned* cnt;
-    int dbg;     // timing experiments only (SRVP_RF_DEBUG): 1 no barrier wait, 2 no A loads, 4 no partial reads, 8 no big MFMAs
 };
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -51,10 +50,9 @@ __device__ __forceinline__ int sw(int k, int c) { return (k >> 1) * 64 + ((((k &
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__device__ __forceinline__ void cluster_barrier(unsigned* cnt, unsigned target, int dbg = 0) {
-    if (!(dbg & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's agent-scope stores have been acknowledged
+__device__ __forceinline__ void cluster_barrier(unsigned* cnt, unsigned target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's agent-scope stores have been acknowledged
     __syncthreads();
-    if (dbg & 1) return;
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
@@ -92,12 +90,10 @@ __device__ __forceinline__ void mm_chunk(f32x4v& acc, f32x4v (&a4)[8], const flo
     }
 }
 #define WAIT_A4(buf, n) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7]) :: "memory")
-__device__ __forceinline__ void gemm_glob_lds(f32x4v& acc, const float* arow, const float* Bs, int K, int q, int cc, int dbg = 0) {
+__device__ __forceinline__ void gemm_glob_lds(f32x4v& acc, const float* arow, const float* Bs, int K, int q, int cc) {
     const float* p = arow + 4 * q;
-    if (dbg & 8) return;
     for (int k0 = 0; k0 < K; k0 += 512) {
         f32x4v b0[8], b1[8], b2[8], b3[8];
-        if (dbg & 2) { for (int j = 0; j < 8; ++j) { b0[j] = b1[j] = b2[j] = b3[j] = f32x4v{1.f, 1.f, 1.f, 1.f}; } mm_chunk(acc, b0, Bs, k0, K, q, cc); mm_chunk(acc, b1, Bs, k0 + 128, K, q, cc); mm_chunk(acc, b2, Bs, k0 + 256, K, q, cc); mm_chunk(acc, b3, Bs, k0 + 384, K, q, cc); continue; }
         ld_chunk(b0, p, k0, K); ld_chunk(b1, p, k0 + 128, K); ld_chunk(b2, p, k0 + 256, K); ld_chunk(b3, p, k0 + 384, K);
         WAIT_A4(b0, 24); mm_chunk(acc, b0, Bs, k0, K, q, cc);
         WAIT_A4(b1, 16); mm_chunk(acc, b1, Bs, k0 + 128, K, q, cc);
@@ -237,10 +233,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             if (l == nfull) break;
             bl = a.b[l + 1][colbase + cc];
-            cluster_barrier(cnt, target += a.G, a.dbg);
+            cluster_barrier(cnt, target += a.G);
             // ---- layer l + 1: A = complete hidden tile from global, B = LDS slice
             acc = f32x4v{0.f, 0.f, 0.f, 0.f};
-            gemm_glob_lds(acc, hdst + (size_t)grow * nh, Wl + (size_t)l * nh * CW, nh, q, cc, a.dbg);
+            gemm_glob_lds(acc, hdst + (size_t)grow * nh, Wl + (size_t)l * nh * CW, nh, q, cc);
         }
         __syncthreads();                                  // Hs complete
         // ---- last layer, split-K over the cluster: partial[32 x ny] from this workgroup's 32 hidden units
@@ -257,15 +253,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int e = 0; e < 4; ++e) st_agent(pdst + (16 * trh + 4 * q + e) * NYP_MAX + 16 * ct + c16, o[e]);
         }
-        cluster_barrier(cnt, target += a.G, a.dbg);
+        cluster_barrier(cnt, target += a.G);
         // ---- every workgroup: sum the G partials in a fixed order, Euler update of its copy of the state
         const float* psrc = part + (size_t)i * a.G * RT * KP0_MAX;
         const int nq = a.nyp / 4;                          // 4-column items per row
         for (int it = tid; it < RT * nq; it += 512) {
             const int itb = it + 256 < RT * nq ? it + 256 : it;
             f32x4v sv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            if (!(a.dbg & 4))
-                sum_slabs2<GP>(sv[0], sv[1], psrc + (it / nq) * NYP_MAX + 4 * (it % nq), psrc + (itb / nq) * NYP_MAX + 4 * (itb % nq), a.G,
+            sum_slabs2<GP>(sv[0], sv[1], psrc + (it / nq) * NYP_MAX + 4 * (it % nq), psrc + (itb / nq) * NYP_MAX + 4 * (itb % nq), a.G,
                                (size_t)RT * KP0_MAX);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -415,10 +410,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             if (l == 0) break;
             fetch_mask(l - 1, i);
-            cluster_barrier(cnt, target += a.G, a.dbg);
+            cluster_barrier(cnt, target += a.G);
             // ---- delta_{l-1} slice: A = complete delta_l tile (global), B = LDS slice of W_l
             acc = f32x4v{0.f, 0.f, 0.f, 0.f};
-            gemm_glob_lds(acc, ddst + (size_t)grow * dwd, Wl + (size_t)(l - 1) * nh * CW, nh, q, cc, a.dbg);
+            gemm_glob_lds(acc, ddst + (size_t)grow * dwd, Wl + (size_t)(l - 1) * nh * CW, nh, q, cc);
         }
         __syncthreads();
         // ---- dinp partial (split-K over the cluster)
@@ -446,7 +441,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int e = 0; e < 4; ++e)
                 dyv[u][e] = (item < RT * nq && c0 + e < ny) ? a.d_y_all[((size_t)i * B + row) * ny + c0 + e] : 0.f;
         }
-        cluster_barrier(cnt, target += a.G, a.dbg);
+        cluster_barrier(cnt, target += a.G);
         const float* psrc = part + (size_t)i * a.G * RT * KP0_MAX;
 #pragma unroll
         for (int u2 = 0; u2 < KP0_MAX / 4 * RT / 512; ++u2) {
@@ -454,8 +449,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (it >= RT * nq) break;
             const int itb = it + 256 < RT * nq ? it + 256 : it;
             f32x4v sv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            if (!(a.dbg & 4))
-                sum_slabs2<GP>(sv[0], sv[1], psrc + (it / nq) * KP0_MAX + 4 * (it % nq), psrc + (itb / nq) * KP0_MAX + 4 * (itb % nq), a.G,
+            sum_slabs2<GP>(sv[0], sv[1], psrc + (it / nq) * KP0_MAX + 4 * (it % nq), psrc + (itb / nq) * KP0_MAX + 4 * (itb % nq), a.G,
                                (size_t)RT * KP0_MAX);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -508,7 +502,6 @@ static int fused_common(const srvp_rollout_desc& f, RollF& k, void* ws) {
         g_ncu = p.multiProcessorCount;
     }
     k.B = f.B; k.ny = f.ny; k.nz = f.nz; k.nh = f.nh; k.nl = f.nl; k.S = f.nsteps; k.ne = f.n_euler; k.G = f.nh / CW;
-    { const char* e = getenv("SRVP_RF_DEBUG"); k.dbg = e ? atoi(e) : 0; }
     k.nin = f.ny + f.nz; k.kp0 = (k.nin + 15) / 16 * 16; k.nyp = (f.ny + 15) / 16 * 16; k.dt = f.dt;
     for (int l = 0; l < MAX_NL; ++l) { k.W[l] = l < f.nl ? f.dyn_w[l] : nullptr; k.b[l] = l < f.nl ? f.dyn_b[l] : nullptr; }
     const int tiles = (f.B + RT - 1) / RT;
