@@ -183,9 +183,20 @@ def main():
     # HIP events around the launches of the two dominant kernel classes only (~110 per step), on every EVENT_EVERY-th step of
     # the timed region: each event record is a marker packet in the stream (~1 ms per step if every step carries them; timing
     # all 329 launches costs ~3 ms per step), so the full per-kernel table is taken in an extra untimed pass
-    EVENT_EVERY = 4
+    EVENT_EVERY = int(os.environ.get('SRVP_BENCH_EVENT_EVERY', 4))
     timing = not args.no_kernel_timing
     prof, n_prof_steps = ({} if timing else None), 0
+    if timing:
+        # one instrumented step OUTSIDE the timed region: the first timing event of a process costs ~75-100 ms once (the runtime
+        # switches the queue to profiling mode), which is 7-10 ms per step of a 10-step run of the short-step configs
+        L.PROFILE, L.PROFILE_ONLY = {}, {'srvp_conv_mfma', 'srvp_conv_mfma_multi', 'srvp_wgrad_mfma'}
+        train(fwd, optim, None, x, dev, opt)
+        L.PROFILE, L.PROFILE_ONLY = None, None
+    # no cyclic-GC pause inside the timed region: the ~100 event objects of an instrumented step can trigger a full collection
+    # over the process's (large) object graph -- a 90 ms host stall, i.e. +7 ms per step of a 10-step run of the short-step configs
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -194,8 +205,11 @@ def main():
             n_prof_steps += 1
         loss = train(fwd, optim, None, x, dev, opt)
         L.PROFILE, L.PROFILE_ONLY = None, None
+        if os.environ.get('SRVP_BENCH_TRACE'):
+            print(f'step {i} host t={1e3 * (time.perf_counter() - t0):.2f} ms', file=sys.stderr)
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     table = None
     if prof is not None and rank == 0:
         L.PROFILE = {}                      # untimed extra pass: every launch

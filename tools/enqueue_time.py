@@ -6,13 +6,13 @@ import srvp_amd, bench
 from srvp_amd import _lib as L
 from srvp_amd.train import train, fused_step
 
-cfg = bench.CONFIGS['bair']; B = int(os.environ.get('B', 192)); T = cfg['T']
+cfg = bench.CONFIGS[os.environ.get('CFG', 'bair')]; B = int(os.environ.get('B', cfg['batch'])); T = cfg['T']
 dev = torch.device('cuda', 0)
 torch.manual_seed(1)
 model = srvp_amd.StochasticLatentResidualVideoPredictor(*cfg['ctor']); model.init(res_gain=cfg['res_gain']); model.to(dev).train()
 optim = srvp_amd.FusedAdam(model, lr=3e-4)
 opt = srvp_amd.DotDict(dict(n_euler_steps=cfg['n_euler'], obs_scale=cfg['obs_scale'], beta_y=1.0, beta_z=cfg['beta_z'], l2_res=1.0))
-x = torch.rand(T, B, 3, 64, 64).to(dev)
+x = torch.rand(T, B, cfg['ctor'][1], 64, 64).to(dev)
 for _ in range(3):
     train(model, optim, None, x, dev, opt)
 torch.cuda.synchronize()
