@@ -16,13 +16,16 @@ def rel(a, b):
 
 # (the persistent fused rollout kernels take the chains whose hidden width is a multiple of 32: cases 2 and 4-7 -- headline
 # dimensions, SM-MNIST dimensions on three ragged row tiles, 2- and 3-layer MLPs, one Euler step per frame)
-FUSED = {1: False, 2: True, 3: False, 4: True, 5: True, 6: True, 7: True}
+FUSED = {1: False, 2: True, 3: False, 4: True, 5: True, 6: True, 7: True, 8: True}
 
 
 @pytest.mark.parametrize('case,ne,T,B,dims', [(1, 1, 4, 3, (8, 3, 3, 8, 16, 3, 4, 2)), (2, 2, 5, 6, (128, 50, 50, 256, 512, 3, 4, 2)),
                                                (3, 2, 4, 5, (16, 5, 7, 24, 40, 2, 3, 3)), (4, 1, 6, 70, (32, 20, 20, 64, 512, 2, 4, 3)),
                                                (5, 2, 4, 33, (16, 10, 6, 32, 64, 2, 2, 2)), (6, 2, 4, 40, (16, 12, 9, 32, 96, 2, 3, 2)),
-                                               (7, 4, 3, 192, (32, 50, 50, 64, 512, 2, 4, 2))])
+                                               (7, 4, 3, 192, (32, 50, 50, 64, 512, 2, 4, 2)),
+                                               # 19 row tiles at 16 workgroups per cluster: more clusters than fit on the chip at once,
+                                               # so the chain runs as two co-resident launches (tile0 > 0 in the second)
+                                               (8, 1, 3, 600, (16, 20, 20, 32, 512, 2, 3, 2))])
 def test_latent_forward_backward(case, ne, T, B, dims):
     import srvp_amd
     from oracle import srvp_oracle as O
@@ -147,6 +150,24 @@ def test_fused_rollout_under_load_is_deterministic():
         torch.cuda.synchronize()
         for k, (x, r) in enumerate(zip(got, ref)):
             assert torch.equal(x, r), (rep, k, (x - r).abs().max().item())
+
+
+@pytest.mark.parametrize('M,N,K', [(512, 100, 4224), (50, 512, 2112), (37, 129, 515), (1024, 128, 2304), (6, 7, 130)])
+def test_gemm_tn_weight_gradient_shape(M, N, K):
+    """srvp_gemm_f32 in the weight-gradient form C += A^T B (both operands row-major over K: the LDS-staged split-K kernel),
+    aligned and ragged sizes, against float64."""
+    from srvp_amd import _lib as L
+    g = torch.Generator().manual_seed(M + N + K)
+    dev = torch.device('cuda')
+    lda, ldb = M + (3 if M % 4 else 0), N + (5 if N % 4 else 8)
+    A = torch.randn(K, lda, generator=g).to(dev)
+    B = torch.randn(K, ldb, generator=g).to(dev)
+    C0 = torch.randn(M, N, generator=g).to(dev)
+    Cm = C0.clone()
+    # A element (m, k) at A[m * 1 + k * lda], B element (k, n) at B[k * ldb + n]
+    L.call('srvp_gemm_f32', L.ptr(A), 1, lda, L.ptr(B), ldb, 1, None, L.ptr(Cm), N, M, N, K, L.ACT_NONE, 1, L.stream())
+    ref = C0.double() + A[:, :M].double().t() @ B[:, :N].double()
+    assert rel(Cm, ref) < 2e-6, rel(Cm, ref)
 
 
 def test_elbo_and_adam_kernels():
