@@ -250,7 +250,7 @@ def main():
     line = {
         'metric': 'training frames/sec (BxT) per node, BAIR VGG-64 seq_len=12' if args.config == 'bair' else f'training frames/sec ({cfg["label"]})',
         'value': frames * args.steps / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': 'bf16',
+        'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': model.precision,
         'data': 'synthetic (uniform random frames, random-init weights)',
         'config': {'workload': cfg['label'], 'per_gpu_batch': B, 'global_batch': B * world, 'seq_len': T,
                    'parallelism': f'dp{world}', 'step': 'forward + ELBO + backward + Adam (reference train.py:49-129)',
