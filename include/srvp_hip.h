@@ -241,6 +241,12 @@ int srvp_pack_job_wgs(int64_t total);
 int srvp_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs,
                   const float* bias, float* C, int64_t c_rs, int M, int N, int K, int act, int accumulate,
                   void* stream);
+/* weight + bias gradient of one Linear layer in ONE launch: gw[M][N] += delta[:, :M]^T act[:, :N], gb[M] += column sums of delta
+ * (gb may be NULL); delta [K][ld_delta], act [K][ld_act] row-major over the K = (steps x batch) rows (autograd of mlp.py:21-45) */
+int srvp_linear_wgrad_f32(const float* delta, int64_t ld_delta, const float* act, int64_t ld_act, float* gw, int64_t ld_gw,
+                          float* gb, int M, int N, int K, void* stream);
+/* dst[blk * dst_stride + i] += src[blk * n + i], i < n, blk < nblk (p_z input gradients added onto the frame-start states) */
+int srvp_add_blocks_f32(float* dst, int64_t dst_stride, const float* src, int nblk, int64_t n, void* stream);
 /* out = a*x + b*y (y may be NULL) */
 int srvp_axpby_f32(float* out, float a, const float* x, float b, const float* y, int64_t n, void* stream);
 /* column sums: out[n] (+)= sum_m A[m][n] */

@@ -111,6 +111,8 @@ _SIGS = {
     'srvp_pack_job_wgs': ([c_i64], c_i32),
     'srvp_unpack_wgrad': ([c_vp, c_vp, C.POINTER(PackDesc), c_vp], c_i32),
     'srvp_gemm_f32': ([c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
+    'srvp_linear_wgrad_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
+    'srvp_add_blocks_f32': ([c_vp, c_i64, c_vp, c_i32, c_i64, c_vp], c_i32),
     'srvp_axpby_f32': ([c_vp, c_f32, c_vp, c_f32, c_vp, c_i64, c_vp], c_i32),
     'srvp_colsum_f32': ([c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_act_bwd_f32': ([c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp], c_i32),

@@ -103,6 +103,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
     }
 }
 
+__global__ void colsum_kernel(const float* A, long long a_rs, float* out, int M, int N, int rows_per_block);
+
 // Weight-gradient shape: C[M][N] += A^T B with BOTH operands row-major over the reduction index (A = delta [K][M], B =
 // activations [K][N], K = (steps x batch) rows in the thousands, M, N = layer widths).  The 32x32 kernel above reads such
 // operands 4 bytes per lane per MFMA with nothing staged (4 MAC per L2 byte: 0.3-0.6 ms per GEMM at K = 4224, 1.6 ms per
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
 // gridDim.z with fp32 atomics into the (accumulated anyway) gradient.  Exact fp32 MFMA as everywhere in the latent path.
 template <bool VEC>
 __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B, long long ldb,
-                                                          float* C, long long ldc, int M, int N, int K, int kper) {
+                                                          float* C, long long ldc, int M, int N, int K, int kper, float* colsum) {
     constexpr int LD = 96;                                 // row stride: the two k rows of an MFMA land on disjoint bank halves
     __shared__ __attribute__((aligned(16))) float As[2][32 * LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][32 * LD];
@@ -121,9 +123,12 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float* __restric
     const int kb = blockIdx.z * kper;
     int ke = kb + kper; if (ke > K) ke = K;
     if (kb >= ke) return;
-    f32x16_t acc;
+    f32x16_t acc, accs;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; accs[i] = 0.f; }
+    // bias gradient for free: the column sums of A (= sum over rows of delta) are A^T x ones -- one extra MFMA per k pair in the
+    // waves of the first column tile (the separate column-sum launch per layer was 16 launches per step)
+    const bool do_sum = colsum != nullptr && blockIdx.x == 0 && wn == 0;
     // staging: 32 rows x 16 four-column pieces per operand = 512 pieces, two per thread
     f32x4_t ra[2], rb[2];
     auto fetch = [&](int k0) {
@@ -164,7 +169,18 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float* __restric
         const float* bp = &Bs[buf][kh * LD + wn * 32 + r];
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk * LD], bp[2 * kk * LD], acc, 0, 0, 0);
+        if (do_sum) {
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) accs = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk * LD], 1.f, accs, 0, 0, 0);
+        }
         // (the other buffer is rewritten only after the next barrier: one barrier per chunk suffices with two buffers)
+    }
+    if (do_sum && r == 0) {                               // every column of accs holds the sums: lane column 0 of each half writes them
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+            if (m < M) atomicAdd(colsum + m, accs[i]);
+        }
     }
     const int n = n0 + wn * 32 + r;
     if (n >= N) return;
@@ -177,7 +193,7 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float* __restric
 
 int gemm(hipStream_t st, const float* A, long long a_rs, long long a_cs, const float* B, long long b_rs, long long b_cs,
          const float* bias, float* C, long long c_rs, int M, int N, int K, int act, int accumulate,
-         const float* mask = nullptr, long long mask_rs = 0, float alpha = 1.f) {
+         const float* mask = nullptr, long long mask_rs = 0, float alpha = 1.f, float* colsum = nullptr) {
     if (M <= 0 || N <= 0) return SRVP_OK;
     static int tn_on = -1;
     if (tn_on < 0) { const char* e = getenv("SRVP_GEMM_TN"); tn_on = e ? atoi(e) : 1; }
@@ -192,10 +208,13 @@ int gemm(hipStream_t st, const float* A, long long a_rs, long long a_cs, const f
         splits = (K + kper - 1) / kper;
         const dim3 grid((N + 63) / 64, (M + 63) / 64, splits);
         const bool vec = M % 4 == 0 && N % 4 == 0 && a_cs % 4 == 0 && b_rs % 4 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0;
-        if (vec) hipLaunchKernelGGL(gemm_tn_f32_kernel<true>, grid, dim3(256), 0, st, A, a_cs, B, b_rs, C, c_rs, M, N, K, kper);
-        else hipLaunchKernelGGL(gemm_tn_f32_kernel<false>, grid, dim3(256), 0, st, A, a_cs, B, b_rs, C, c_rs, M, N, K, kper);
+        if (vec) hipLaunchKernelGGL(gemm_tn_f32_kernel<true>, grid, dim3(256), 0, st, A, a_cs, B, b_rs, C, c_rs, M, N, K, kper, colsum);
+        else hipLaunchKernelGGL(gemm_tn_f32_kernel<false>, grid, dim3(256), 0, st, A, a_cs, B, b_rs, C, c_rs, M, N, K, kper, colsum);
         SRVP_CHECK_LAUNCH("srvp_gemm_f32(tn)");
         return SRVP_OK;
+    }
+    if (colsum) {                                          // (small K: the column sums as their own launch)
+        hipLaunchKernelGGL(colsum_kernel, dim3((M + 63) / 64, (K + 127) / 128), dim3(256), 0, st, A, a_cs, colsum, K, M, 128);
     }
     GemmArgs g{A, a_rs, a_cs, B, b_rs, b_cs, bias, C, c_rs, mask, mask_rs, M, N, K, act, accumulate, alpha};
     dim3 grid((N + 31) / 32, (M + 31) / 32);
@@ -463,6 +482,30 @@ extern "C" int srvp_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const f
                              void* stream) {
     SRVP_REQUIRE(A && B && C, "srvp_gemm_f32: null pointer");
     return gemm((hipStream_t)stream, A, a_rs, a_cs, B, b_rs, b_cs, bias, C, c_rs, M, N, K, act, accumulate);
+}
+
+// gw[M][N] += delta[:, :M]^T act[:, :N] ; gb[M] += column sums of delta  (K rows): the weight / bias gradient of one Linear layer
+extern "C" int srvp_linear_wgrad_f32(const float* delta, int64_t ld_delta, const float* act, int64_t ld_act, float* gw, int64_t ld_gw,
+                                     float* gb, int M, int N, int K, void* stream) {
+    SRVP_REQUIRE(delta && act && gw, "srvp_linear_wgrad_f32: null pointer");
+    return gemm((hipStream_t)stream, delta, 1, ld_delta, act, ld_act, 1, nullptr, gw, ld_gw, M, N, K, ACT_NONE, 1, nullptr, 0, 1.f, gb);
+}
+
+namespace {
+// dst[blk * dst_stride + i] += src[blk * n + i]
+__global__ void add_blocks_kernel(float* dst, long long dst_stride, const float* src, int nblk, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nblk * n) return;
+    const long long b = i / n, e = i - b * n;
+    dst[b * dst_stride + e] += src[i];
+}
+}  // namespace
+extern "C" int srvp_add_blocks_f32(float* dst, int64_t dst_stride, const float* src, int nblk, int64_t n, void* stream) {
+    SRVP_REQUIRE(dst && src, "srvp_add_blocks_f32: null pointer");
+    if ((long long)nblk * n <= 0) return SRVP_OK;
+    hipLaunchKernelGGL(add_blocks_kernel, g1((long long)nblk * n), dim3(256), 0, (hipStream_t)stream, dst, (long long)dst_stride, src, nblk, (long long)n);
+    SRVP_CHECK_LAUNCH("srvp_add_blocks_f32");
+    return SRVP_OK;
 }
 
 extern "C" int srvp_axpby_f32(float* out, float a, const float* x, float b, const float* y, int64_t n, void* stream) {

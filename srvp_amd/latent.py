@@ -27,9 +27,7 @@ def linear_bwd(st, x, w, dy, gw, gb, dx=None, dx_acc=0):
     """dy: [M][N] (contiguous).  gw += dy^T x ; gb += colsum(dy) ; dx (+)= dy w"""
     M, K = x.shape
     N = w.shape[0]
-    _gemm(st, dy, 1, N, x, K, 1, None, gw, K, N, K, M, acc=1)
-    if gb is not None:
-        L.call('srvp_colsum_f32', L.ptr(dy), N, L.ptr(gb), M, N, 1, st)
+    L.call('srvp_linear_wgrad_f32', L.ptr(dy), N, L.ptr(x), K, L.ptr(gw), K, L.ptr(gb), N, K, M, st)      # weight + bias gradient
     if dx is not None:
         _gemm(st, dy, N, 1, w, K, 1, None, dx, K, M, K, N, acc=dx_acc)
 
@@ -245,9 +243,7 @@ class LatentNet:
                 _gemm(st, self.dhid_pz[l].view(F * B, dwp), dwp, 1, w, nhr, 1, None, dst, dwp, F * B, nhr, cout)
                 L.call('srvp_act_bwd_f32', L.ptr(self.hid_pz[l - 1]), L.ptr(dst), L.ptr(dst), F * B * nhr, L.ACT_RELU, 1, st)
             _gemm(st, self.dhid_pz[0].view(F * B, dwp), dwp, 1, params[keys[0] + '.weight'], ny, 1, None, self._pz_dx, ny, F * B, ny, nhr)
-            for f in range(F):
-                tgt = self.d_y_all[f * ne]
-                L.call('srvp_axpby_f32', L.ptr(tgt), 1.0, L.ptr(tgt), 1.0, L.ptr(self._pz_dx[f * B:(f + 1) * B]), B * ny, st)
+            L.call('srvp_add_blocks_f32', L.ptr(self.d_y_all), ne * B * ny, L.ptr(self._pz_dx), F, B * ny, st)
         L.call('srvp_rollout_bwd', C.byref(bd), st)
         # weight gradients of dynamics / p_z: one GEMM per layer over all (step, sample) rows
         for name, nrow, width, dh, hid, inp, nin, nout in (
@@ -265,8 +261,8 @@ class LatentNet:
                 if a_prev is None:
                     # p_z input = state at the start of every frame: y_all[f*ne]
                     a_prev = self.y_all[0:S:ne].reshape(nrow, ny)
-                _gemm(st, delta, 1, width, a_prev, cin, 1, None, grads[k + '.weight'], cin, cout, cin, nrow, acc=1)
-                L.call('srvp_colsum_f32', L.ptr(delta), width, L.ptr(grads[k + '.bias']), nrow, cout, 1, st)
+                L.call('srvp_linear_wgrad_f32', L.ptr(delta), width, L.ptr(a_prev), cin, L.ptr(grads[k + '.weight']), cin,
+                       L.ptr(grads[k + '.bias']), cout, cin, nrow, st)
         # ---- q_z + LSTM
         nq = T - 1
         if nq > 0:
