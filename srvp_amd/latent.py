@@ -260,7 +260,8 @@ class LatentNet:
                     a_prev, cin = hid[l - 1].view(nrow, nhr), nhr
                 if a_prev is None:
                     # p_z input = state at the start of every frame: y_all[f*ne]
-                    a_prev = self.y_all[0:S:ne].reshape(nrow, ny)
+                    # (contiguous rows: with B == 1 the strided slice reshapes to a VIEW whose row stride is ne * ny, not ny)
+                    a_prev = self.y_all[0:S:ne].reshape(nrow, ny).contiguous()
                 L.call('srvp_linear_wgrad_f32', L.ptr(delta), width, L.ptr(a_prev), cin, L.ptr(grads[k + '.weight']), cin,
                        L.ptr(grads[k + '.bias']), cout, cin, nrow, st)
         # ---- q_z + LSTM
