@@ -90,3 +90,115 @@ def test_eval_nt_edges(nt, B):
     xs2 = m.sample(x.cuda(), nt, 2, dt=0.5, tape=dict(eps_y0=torch.cat([tape['eps_y0'], e2y]), eps_z=torch.cat([tape['eps_z'], e2z], 1)))
     out2 = m(x.cuda(), nt, 0.5, tape=dict(eps_y0=e2y, eps_z=e2z))
     assert (xs2[:, 0] - out[0]).abs().max().item() <= 1e-5 and (xs2[:, 1] - out2[0]).abs().max().item() <= 1e-5
+
+
+def _one_train_step(m, x, tape, ne, hp):
+    import srvp_amd
+    from srvp_amd.train import elbo_terms_and_grads
+    m.train()
+    m.flatten_parameters_(); m._grads(); m._flat[1].zero_()
+    xg = x.cuda()
+    outs = m._forward_impl(xg, x.shape[0], ne, tape, training=True)
+    opt = srvp_amd.DotDict(dict(n_euler_steps=ne, **hp))
+    acc, gr = elbo_terms_and_grads(m, xg, outs, opt)
+    m._backward_impl(gr[0], None, None, gr[1], gr[2], gr[3], gr[4])
+    torch.cuda.synchronize()
+    return acc.cpu().clone(), m._flat[1].detach().cpu().clone()
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+def test_interleaved_shapes_modes_and_precisions(precision):
+    """Plans, packed weights, descriptor tables and workspaces are cached per problem size: a training step must give the same
+    result whether it is the first thing a model does or comes after other batch sizes, inference passes, multi-sample rollouts
+    and a precision switch (stale-cache bugs show up here)."""
+    ctor = (64, 3, 8, 16, 4, 5, True, 2, 16, 3, 64, 4, 'vgg')
+    hp = dict(obs_scale=0.5, beta_y=1.0, beta_z=1.0, l2_res=1.0)
+    ne = 2
+    g = torch.Generator().manual_seed(21)
+
+    def problem(T, B):
+        x = torch.rand(T, B, 3, 64, 64, generator=g)
+        tape = dict(t_skip=torch.randint(T, (B,), generator=g), t_w=torch.stack([torch.randperm(T, generator=g)[:2] for _ in range(B)], 1),
+                    eps_y0=torch.randn(B, 4, generator=g), eps_z=torch.randn(T - 1, B, 5, generator=g))
+        return x, tape
+    pA, pB = problem(4, 5), problem(3, 34)
+    # reference: a fresh model per problem (BN running statistics do not enter a training-mode step)
+    want = {}
+    for name, (x, tape) in (('A', pA), ('B', pB)):
+        m = _model(ctor).cuda().set_precision(precision)
+        want[name] = _one_train_step(m, x, tape, ne, hp)
+    m = _model(ctor).cuda().set_precision(precision)
+    seq = ['A', 'B', 'eval', 'A', 'sample', 'B', 'switch', 'A', 'B']
+    other = 'fp32' if precision == 'bf16' else 'bf16'
+    for step in seq:
+        if step in ('A', 'B'):
+            x, tape = pA if step == 'A' else pB
+            acc, grad = _one_train_step(m, x, tape, ne, hp)
+            wa, wg = want[step]
+            # (the fp64 BatchNorm atomics retire in a different order from run to run: equal to summation order, not bit for bit)
+            assert torch.allclose(acc, wa, rtol=1e-6, atol=0), (step, acc, wa)
+            e = ((grad.double() - wg.double()).norm() / wg.double().norm()).item()
+            assert e <= (1e-4 if precision == 'fp32' else 0.12), (step, e)
+        elif step == 'eval':
+            m.eval()
+            m(pA[0][:2].cuda(), 6, 1 / ne)
+        elif step == 'sample':
+            m.eval()
+            m.sample(pB[0][:2, :3].cuda(), 5, 3, dt=1 / ne)
+        else:
+            m.set_precision(other)
+            _one_train_step(m, pA[0], pA[1], ne, hp)
+            m.set_precision(precision)
+
+
+SWEEP = [
+    # archi, nc, nf, nhx, ny, nz, skipco, nt_inf, nh_inf, nl_inf, nh_res, nl_res, T, B, ne
+    ('vgg', 3, 16, 20, 6, 3, True, 3, 40, 2, 96, 2, 5, 3, 4),
+    ('vgg', 1, 24, 33, 7, 9, False, 1, 24, 1, 64, 3, 3, 4, 1),
+    ('dcgan', 3, 16, 48, 10, 10, True, 2, 32, 3, 128, 4, 4, 5, 2),
+    ('dcgan', 1, 20, 17, 3, 8, False, 4, 20, 2, 32, 5, 6, 2, 2),
+    ('vgg', 3, 8, 64, 12, 4, True, 2, 16, 4, 160, 3, 3, 7, 1),
+    ('dcgan', 3, 32, 32, 5, 5, False, 2, 64, 3, 64, 2, 3, 9, 4),
+]
+
+
+@pytest.mark.parametrize('cfg', SWEEP, ids=[f'{c[0]}_nc{c[1]}_nf{c[2]}_nhx{c[3]}_y{c[4]}z{c[5]}_s{int(c[6])}_res{c[10]}x{c[11]}_T{c[12]}B{c[13]}e{c[14]}' for c in SWEEP])
+def test_config_sweep_vs_oracle_fp32(cfg):
+    """Unusual widths / depths / paddings the fixtures do not reach (channel counts that are not multiples of 32, odd latent sizes,
+    1..5-layer MLPs, 1..4 Euler sub-steps, nt_inf from 1 to T-...): one fp32-mode training step against the oracle."""
+    import srvp_amd
+    from oracle import srvp_oracle as O
+    from srvp_amd.train import elbo_terms_and_grads
+    archi, nc, nf, nhx, ny, nz, skipco, nt_inf, nh_inf, nl_inf, nh_res, nl_res, T, B, ne = cfg
+    ctor = (64, nc, nf, nhx, ny, nz, skipco, nt_inf, nh_inf, nl_inf, nh_res, nl_res, archi)
+    m = _model(ctor, seed=11)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(T, B, nc, 64, 64, generator=g)
+    tape = dict(t_w=torch.stack([torch.randperm(T, generator=g)[:nt_inf] for _ in range(B)], 1),
+                eps_y0=torch.randn(B, ny, generator=g), eps_z=torch.randn(T - 1, B, nz, generator=g))
+    if skipco:
+        tape['t_skip'] = torch.randint(T, (B,), generator=g)
+    hp = dict(obs_scale=0.6, beta_y=1.0, beta_z=2.0, l2_res=0.5)
+    torch.set_num_threads(8)
+    scal, outs_ref, grads_ref = O.train_step(sd, O.make_cfg(*ctor), x, ne, tape, hp)
+    m = m.cuda().train().set_precision('fp32')
+    m.flatten_parameters_(); m._grads(); m._flat[1].zero_()
+    xg = x.cuda()
+    outs = m._forward_impl(xg, T, ne, tape, training=True)
+    opt = srvp_amd.DotDict(dict(n_euler_steps=ne, **hp))
+    acc, gr = elbo_terms_and_grads(m, xg, outs, opt)
+    m._backward_impl(gr[0], None, None, gr[1], gr[2], gr[3], gr[4])
+    nll, kl_y0, kl_z, l2 = acc.cpu().tolist()
+    loss = (nll + hp['beta_y'] * kl_y0 + hp['beta_z'] * kl_z + hp['l2_res'] * l2) / B
+    assert abs(loss - scal['loss']) <= 1e-5 * abs(scal['loss']), (loss, scal['loss'])
+    for o, r in zip(outs, outs_ref):
+        assert rel_l2(o, r) <= 1e-4
+    norms = sorted(v.double().norm().item() for v in grads_ref.values())
+    floor = 1e-2 * norms[len(norms) // 2]
+    bad = {}
+    for k, p in m.named_parameters():
+        e = (p.grad.double().cpu() - grads_ref[k].double()).norm().item()
+        if e > 1e-2 * max(grads_ref[k].double().norm().item(), floor):
+            bad[k] = e / (grads_ref[k].double().norm().item() + 1e-30)
+    assert not bad, bad
