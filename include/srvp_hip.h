@@ -73,6 +73,12 @@ typedef struct {
     int32_t elem_f32;             /* 1: precision = 'fp32' parity mode -- src0 / src1 / dst / wt are FP32 tensors of the same NHWC
                                    * shapes (wt tap-major, srvp_pack_desc.dst_f32) and the contraction runs in exact fp32 on the
                                    * matrix cores (v_mfma_f32_32x32x2_f32 = a k-ordered fmaf chain), csrc/conv_f32.hip */
+    int32_t splitk;               /* > 1 (generic kernel; dst_is_f32 = 1, no stats / add_f32): the K steps are shared out over `splitk`
+                                   * workgroups per output tile, split z writing its partial sums to the fp32 slab
+                                   * dst + z * N*DHp*DWp*Cdst -- for the tiny-M, long-K launches (the 4x4 -> 1x1 encoder output
+                                   * layer, conv.py:176-179 / 224, and the data gradient of the 1x1 -> 4x4 decoder input layer,
+                                   * conv.py:299-301): K = 8192 is 128 dependent K steps on a handful of workgroups otherwise.
+                                   * srvp_splitk_finish sums the slabs in a fixed order (deterministic) */
 } srvp_conv_desc;
 int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
 /* 1 (default): 3x3 stride-1 single-source convolutions run on the halo-tiled kernel (input patch staged in LDS once
@@ -355,6 +361,11 @@ int srvp_frames_u8_to_f32(const void* in_u8, float* out, int B, int T, int H, in
 int srvp_mmnist_render(const void* digits_u8, int n_digits, int dh, int dw, const int* idx, const int* pos, int B, int T,
                        int num_digits, int nx, float* out, void* out_u8, void* stream);
 int srvp_cast_f32_bf16(const float* src, void* dst, int64_t rows, int cols, int dst_cols, void* stream);
+/* dst bf16 [M][C] = sum_z parts[z * slab_elems + m * C + c] (z ascending), the slabs of an srvp_conv_mfma launch with splitk > 1;
+ * stats (may be NULL): += per-column sum and sum of squares of the fp32 sums (column c -> stats[c % stat_mod], stats[stat_mod + c %
+ * stat_mod]), i.e. what the convolution's own BatchNorm-statistics epilogue computes (conv.py:104) */
+int srvp_splitk_finish(const float* parts, int splitk, int64_t slab_elems, int64_t M, int C, void* dst, double* stats,
+                       int stat_mod, void* stream);
 /* fp32 parity mode: the same zero-padding row copy into an fp32 [rows][dst_cols] tensor */
 int srvp_pad_f32(const float* src, float* dst, int64_t rows, int cols, int dst_cols, void* stream);
 /* evaluation metrics: x, y = `planes` float32 planes of H x W (<= 64 x 64; (nt*B*C) planes of NCHW frames).

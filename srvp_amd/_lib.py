@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):
                 ('stats', c_vp), ('stat_mod', c_i32),
                 ('out_f32', c_vp), ('out_nc', c_i32), ('out_sigmoid', c_i32),
                 ('map0', c_vp), ('dst_is_f32', c_i32), ('add_f32', c_vp), ('add_mod', c_i32), ('wt_fragmajor', c_i32),
-                ('tap_phase_chunks', c_i32), ('elem_f32', c_i32)]
+                ('tap_phase_chunks', c_i32), ('elem_f32', c_i32), ('splitk', c_i32)]
 
 
 class WgradDesc(C.Structure):
@@ -137,6 +137,7 @@ _SIGS = {
     'srvp_frames_u8_to_f32': ([c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_mmnist_render': ([c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp], c_i32),
     'srvp_cast_f32_bf16': ([c_vp, c_vp, c_i64, c_i32, c_i32, c_vp], c_i32),
+    'srvp_splitk_finish': ([c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp], c_i32),
     'srvp_pad_f32': ([c_vp, c_vp, c_i64, c_i32, c_i32, c_vp], c_i32),
     'srvp_skip_grad_reduce_f32': ([c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp], c_i32),
     'srvp_frame_metrics': ([c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp], c_i32),

@@ -19,6 +19,7 @@ from . import _lib as L
 CP = 32                      # channel padding granule
 SUBPIX = os.environ.get('SRVP_SUBPIX', '1') != '0'
 S2D = os.environ.get('SRVP_SUBPIX_S2D', '1') != '0'
+SPLITK = int(os.environ.get('SRVP_CONV_SPLITK', '16'))    # tiny-M long-K launches: K steps shared over this many workgroups
 # Sub-pixel form of "nearest x2 upsample, then 3x3 conv" (conv.py:331-349): output phase a in {0,1} of a row pair reads
 # two low-resolution rows with SUMS of the original taps -- R[a][u] = kernel rows folded into effective tap u -- and
 # the gradient wrt the low-resolution input is a 4x4 stride-2 conv of the output gradient with D[dy] folded rows.
@@ -350,6 +351,35 @@ class Block:
             d.wt_fragmajor = want[0]
         pack_desc.layout = want[0]
 
+    def _split_k(self, d, tag, dst_ptr, stats_ptr):
+        """Tiny-M, long-K launch (4x4 -> 1x1 forward, 1x1 -> 4x4 data gradient: K = 16 * C as 128 dependent K steps on a handful
+        of workgroups): share the K steps out over srvp_conv_desc.splitk workgroups per tile, each into its own fp32 slab, and let
+        srvp_splitk_finish sum the slabs in a fixed order into `dst_ptr` (+ the BatchNorm statistics).  Returns the finish call's
+        arguments, or None when the launch keeps its single pass."""
+        ctot = d.C0 + d.C1
+        if self.f32 or SPLITK <= 1 or ctot % 64 or d.Cout % 4:
+            return None
+        steps = d.ntaps * (ctot // 64)
+        tiles = -(-(d.N * d.OH * d.OW) // 128) * -(-d.Cout // 128)
+        sk = min(SPLITK, steps // 4, max(1, 512 // tiles))
+        if sk <= 1:
+            return None
+        M = d.N * d.OH * d.OW
+        parts = torch.empty(sk * M * d.Cout, dtype=torch.float32, device=self.dev)
+        setattr(self, 'parts_' + tag, parts)
+        d.dst, d.dst_is_f32, d.stats, d.stat_mod, d.splitk = L.ptr(parts), 1, None, 1, sk
+        d.Cdst, d.cdst_off = d.Cout, 0
+        return (L.ptr(parts), sk, M * d.Cout, M, d.Cout, dst_ptr, stats_ptr, self.cout)
+
+    def finish_fwd(self, st):
+        """After the forward launches of this block: sums the split-K slabs (if the forward was split) into raw + statistics."""
+        if getattr(self, '_fwd_fin', None):
+            L.call('srvp_splitk_finish', *self._fwd_fin, st)
+
+    def finish_dgrad(self, st):
+        if getattr(self, '_dg_fin', None):
+            L.call('srvp_splitk_finish', *self._dg_fin, st)
+
     def _set_taps(self, d, taps):
         d.ntaps = len(taps)
         d.dy = L.taps([t[0] for t in taps])
@@ -422,6 +452,9 @@ class Block:
             d.N, d.OH, d.OW = N, self.OH, self.OW
             d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox, d.Cdst, d.cdst_off = dst_ptr, self.OH, self.OW, 1, 0, 0, self.cout, 0
             d.stats, d.stat_mod = (L.ptr(self.stats) if use_stats else None), self.cout
+            self._fwd_fin = None
+            if self.geom == 'full' and not frame_out:
+                self._fwd_fin = self._split_k(d, 'f', dst_ptr, L.ptr(self.stats) if use_stats else None)
             finish(d)
         elif self.geom == 'up':
             assert b_in == 1
@@ -579,6 +612,7 @@ class Block:
             d.si, d.wt = 1, L.ptr(self.wt_d)
             d.N, d.OH, d.OW = N, 1, 1
             d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox = L.ptr(self.dcat), 1, 1, 1, 0, 0
+            self._dg_fin = self._split_k(d, 'd', L.ptr(self.dcat), None)
             out.append(d)
         return out
 
@@ -769,6 +803,7 @@ class ConvNetBase:
         else:
             for d in (blk._fwd[1:] if (blk.split and getattr(self, '_skips_done', False)) else blk._fwd):
                 L.call('srvp_conv_mfma', C.byref(d), st)
+            blk.finish_fwd(st)
         self._bn_forward(blk, params, st, sync, keep)
 
     def _bn_backward(self, blk, params, grads, da, st, sync):
@@ -813,6 +848,7 @@ class ConvNetBase:
         if need_dgrad:
             for d in blk._dg:
                 L.call('srvp_conv_mfma', C.byref(d), st)
+            blk.finish_dgrad(st)
 
     # ---- whole-network launches: every layer's pack / unpack in ONE kernel (device-resident job table, rebuilt only when a
     # pointer or layout changes) and one multi-tensor zero for the accumulators -- ~140 tiny launches per step otherwise

@@ -32,6 +32,8 @@ struct ConvK {
     float* out_f32; int out_nc, out_sigmoid;
     const int* map0; int dst_is_f32; const float* add_f32; int add_mod;
     int phase_chunks;          // > 0: space-to-depth source, taps of chunk cc are entries [(cc / phase_chunks) * ntaps + t]
+    int splitk;                // > 1 (generic kernel, fp32 destination): blockIdx.y walks its share of the K steps into slab blockIdx.y
+    long long slab;            // elements per split-K slab
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -84,7 +86,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[TM][TN], const Con
     const int lcol = lane & 31, lhalf = lane >> 5;
     const int hw = a.OH * a.OW;
     if (a.dst_is_f32) {
-        float* dstf = reinterpret_cast<float*>(a.dst);
+        float* dstf = reinterpret_cast<float*>(a.dst) + (a.splitk > 1 ? (size_t)blockIdx.y * a.slab : (size_t)0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -284,7 +286,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
     // shifted pixel positions, i.e. mostly the same cache lines (reuse distance BM*BK*2 B = 16 KiB per workgroup),
     // instead of coming back to a pixel one whole tap (BM*Ctot*2 B) later (30 % L2 misses measured, profiles/).
     const int kpt = Ctot / BK;                       // channel chunks
-    const int S = a.ntaps * kpt;
+    const int S_all = a.ntaps * kpt;
+    // split-K (tiny-M, long-K launches: the 4x4 -> 1x1 layer and the data-gradient of its mirror image are 128 dependent K steps
+    // on a handful of workgroups otherwise): blockIdx.y owns K steps [s_lo, S) and its own fp32 slab, summed in a fixed order by
+    // srvp_splitk_finish (deterministic)
+    const int s_lo = a.splitk > 1 ? (int)((long long)S_all * blockIdx.y / a.splitk) : 0;
+    const int S = a.splitk > 1 ? (int)((long long)S_all * (blockIdx.y + 1) / a.splitk) : S_all;
 
     auto stage = [&](int s, int buf) {
         const int cc = s / a.ntaps;
@@ -343,8 +350,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvK a) 
     // s_barrier per step (a __syncthreads() would drain the whole DMA queue: vmcnt(0)).
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i)
-        if (i < S) stage(i, i);
-    for (int s = 0; s < S; ++s) {
+        if (s_lo + i < S) stage(s_lo + i, (s_lo + i) % NBUF);
+    for (int s = s_lo; s < S; ++s) {
         const int buf = s % NBUF;
         if constexpr (NBUF == 1) {
             // single buffer, latency hidden by the other workgroups of the CU (3-4 resident at 34 KB of LDS each)
@@ -409,6 +416,7 @@ static int fill_convk(const srvp_conv_desc* d, ConvK& k) {
         k.dx_bits |= (unsigned long long)d->dx[t] << (4 * t);
     }
     k.phase_chunks = d->tap_phase_chunks;
+    k.splitk = 1; k.slab = 0;
     k.wt = (const bf16_t*)d->wt; k.Cout = d->Cout; k.N = d->N; k.OH = d->OH; k.OW = d->OW;
     k.dst = (bf16_t*)d->dst; k.DHp = d->DHp; k.DWp = d->DWp; k.so = d->so; k.ooy = d->ooy; k.oox = d->oox;
     k.Cdst = d->Cdst; k.cdst_off = d->cdst_off; k.stats = d->stats; k.stat_mod = d->stat_mod;
@@ -636,7 +644,7 @@ static int g_halo = -1;      // -1: read SRVP_CONV_HALO on first use; 0 = generi
 // convolution on a 1-pixel-bordered tensor (or its patch does not fit) -- the generic kernel takes it then.
 static bool halo_geometry(const srvp_conv_desc* d, HaloK& h, int BM) {
     if (g_halo < 0) { const char* e = getenv("SRVP_CONV_HALO"); g_halo = e ? atoi(e) : 1; }
-    if (!g_halo || d->elem_f32) return false;
+    if (!g_halo || d->elem_f32 || d->splitk > 1) return false;
     if (d->ntaps > 9 || d->si != 1 || d->C1 != 0 || d->C0 % 64 != 0) return false;
     const int nent = d->tap_phase_chunks > 0 ? 4 * d->ntaps : d->ntaps;
     if (nent > SRVP_MAX_TAPS || (d->tap_phase_chunks > 0 && (d->C0 / 64) != 4 * d->tap_phase_chunks)) return false;
@@ -727,7 +735,14 @@ int launch(const srvp_conv_desc* d, hipStream_t st) {
     SRVP_REQUIRE(blocks > 0 && blocks < (1ll << 31), "srvp_conv_mfma: bad grid %lld", blocks);
     ConvK k;
     if (int rc = fill_convk(d, k)) return rc;
-    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM, WN, NBUF, BDIRECT>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, st, k);
+    if (d->splitk > 1) {
+        const int steps = d->ntaps * ((d->C0 + d->C1) / BK);
+        SRVP_REQUIRE(d->dst_is_f32 && !d->stats && !d->add_f32 && !d->out_f32 && d->splitk <= steps && d->splitk <= 64,
+                     "srvp_conv_mfma: splitk = %d needs an fp32 slab destination without statistics / add_f32 and at most %d (64) splits", d->splitk, steps);
+        k.splitk = d->splitk;
+        k.slab = (long long)d->N * d->DHp * d->DWp * d->Cdst;
+    }
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM, WN, NBUF, BDIRECT>), dim3((unsigned)blocks, (unsigned)k.splitk), dim3(WM * WN * 64), 0, st, k);
     SRVP_CHECK_LAUNCH("srvp_conv_mfma");
     return SRVP_OK;
 }
@@ -765,6 +780,7 @@ extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
     SRVP_REQUIRE(d->ntaps >= 1 && d->ntaps <= SRVP_MAX_TAPS, "srvp_conv_mfma: ntaps=%d", d->ntaps);
     SRVP_REQUIRE(d->Cdst % 8 == 0 && d->cdst_off % 8 == 0, "srvp_conv_mfma: dst channel slice must be 16-byte aligned");
     SRVP_REQUIRE(d->stats == nullptr || d->stat_mod > 0, "srvp_conv_mfma: stat_mod");
+    SRVP_REQUIRE(!(d->elem_f32 && d->splitk > 1), "srvp_conv_mfma: splitk is not available in fp32 parity mode");
     if (d->elem_f32) return srvp_conv_f32_launch(d, st);
     SRVP_REQUIRE((long long)d->N * d->H0p * d->W0p * d->C0 < (1ll << 32) && (d->C1 == 0 || d->map1 || (long long)d->N * d->H1p * d->W1p * d->C1 < (1ll << 32)),
                  "srvp_conv_mfma: source tensors must have fewer than 2^32 elements");

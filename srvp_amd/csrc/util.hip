@@ -110,3 +110,56 @@ extern "C" int srvp_pad_f32(const float* src, float* dst, int64_t rows, int cols
     SRVP_CHECK_LAUNCH("srvp_pad_f32");
     return SRVP_OK;
 }
+
+// Sum of the split-K slabs of srvp_conv_mfma(splitk > 1) in a fixed order -> bf16 rows (+ the BatchNorm batch statistics the
+// convolution epilogue would have formed from its fp32 accumulators: per-column sum / sum of squares, fp64 atomics).
+namespace {
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ parts, int splitk, long long slab, long long M, int C,
+                                                            bf16_t* __restrict__ dst, double* __restrict__ stats, int stat_mod, int rows_per_block) {
+    __shared__ float red[4][64][8];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    const int cg = C >> 2;
+    for (int c4 = tx; c4 < ((cg + 63) / 64) * 64; c4 += 64) {
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c4 < cg)
+            for (long long r = r0 + ty; r < r1; r += 4) {
+                const float* p = parts + r * C + c4 * 4;
+                f32x4_t v = *reinterpret_cast<const f32x4_t*>(p);
+#pragma unroll 8
+                for (int z = 1; z < splitk; ++z) { const f32x4_t u = *reinterpret_cast<const f32x4_t*>(p + z * slab); v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
+                bf16_t o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = f2bf(v[e]); s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+                *reinterpret_cast<unsigned long long*>(dst + r * C + c4 * 4) = *reinterpret_cast<const unsigned long long*>(o);
+            }
+        if (stats) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { red[ty][tx][e] = s1[e]; red[ty][tx][4 + e] = s2[e]; }
+            __syncthreads();
+            if (ty == 0 && c4 < cg) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    double a = 0., b = 0.;
+                    for (int w = 0; w < 4; ++w) { a += red[w][tx][e]; b += red[w][tx][4 + e]; }
+                    const int ch = (c4 * 4 + e) % stat_mod;
+                    atomicAdd(stats + ch, a);
+                    atomicAdd(stats + stat_mod + ch, b);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+}  // namespace
+extern "C" int srvp_splitk_finish(const float* parts, int splitk, int64_t slab_elems, int64_t M, int C, void* dst, double* stats,
+                                  int stat_mod, void* stream) {
+    SRVP_REQUIRE(parts && dst && splitk >= 1 && M > 0 && C > 0 && C % 4 == 0 && slab_elems >= M * C, "srvp_splitk_finish: bad args");
+    SRVP_REQUIRE(!stats || stat_mod > 0, "srvp_splitk_finish: stat_mod");
+    const int rpb = 8;          // 2 rows per thread: the kernel is a chain of dependent slab loads, so many short workgroups
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, parts, splitk,
+                       (long long)slab_elems, (long long)M, C, (bf16_t*)dst, stats, stat_mod, rpb);
+    SRVP_CHECK_LAUNCH("srvp_splitk_finish");
+    return SRVP_OK;
+}

@@ -51,6 +51,7 @@ def _to_dev(v, dev):
 
 OVERLAP_WGRAD = os.environ.get('SRVP_OVERLAP_WGRAD', '1') != '0'
 OVERLAP_SKIP = os.environ.get('SRVP_OVERLAP_SKIP', '1') == '1'
+OVERLAP_PACK = os.environ.get('SRVP_OVERLAP_PACK', '1') == '1'    # decoder weight packing on the second stream, under the encoder
 
 
 class _Holder(nn.Module):
@@ -257,14 +258,29 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             self._pack_version = None
         return pl
 
-    def _pack(self, pl, params, st):
+    def _pack(self, pl, params, st, overlap=False):
+        """bf16 MFMA-layout copies of the conv weights, redone when a parameter changed.  overlap: the decoder's share (60 % of the
+        bytes; nothing reads it before the decoder forward) goes to the second stream, under the encoder forward; returns the event
+        the decoder has to wait for (None: nothing pending)."""
         ver = (id(pl), tuple(p._version for p in self.parameters()))
         if ver == self._pack_version:
-            return
+            return None
+        self._pack_version = ver
         if pl['enc'] is not None:
             pl['enc'].pack_weights(params, st)
-        pl['dec'].pack_weights(params, st)
-        self._pack_version = ver
+        if not (overlap and pl['enc'] is not None):
+            pl['dec'].pack_weights(params, st)
+            return None
+        if getattr(self, '_side_stream', None) is None:
+            self._side_stream = torch.cuda.Stream()
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self._side_stream):
+            self._side_stream.wait_event(ev)
+            pl['dec'].pack_weights(params, L.stream())
+            done = torch.cuda.Event()
+            done.record()
+        return done
 
     def _draw_tape(self, T, B, nt, training, dev, t_skip=None):
         """Random draws in the reference's order: CPU generator for the frame indices, device
@@ -289,7 +305,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         st = L.stream()
         pl = self._plan(T, B, nt, n_euler, training)
         params = self._named_tensors()
-        self._pack(pl, params, st)
+        pack_done = self._pack(pl, params, st, overlap=training and OVERLAP_PACK)
         enc, dec, lat = pl['enc'], pl['dec'], pl['lat']
         x = x.contiguous().float()
         # frames whose encoder activations feed the skip connections (srvp.py:185-190): drawn first (the reference draws t_skip
@@ -340,6 +356,8 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         z_in = torch.cat([w.repeat(nt, 1), y.reshape(nt * B, self.ny)], 1)
         if s_done is not None:
             torch.cuda.current_stream().wait_event(s_done)
+        if pack_done is not None:
+            torch.cuda.current_stream().wait_event(pack_done)
         x_flat = dec.forward(z_in, params, st, self.sync if training else None)
         x_ = x_flat.view(nt, B, *x_flat.shape[1:])
         pl['hx'], pl['x'] = hx, x

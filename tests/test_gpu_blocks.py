@@ -6,6 +6,7 @@ Reference: torch CPU fp32 ops on the same bf16-rounded operands (so only accumul
 rounding differ): tolerance = 2^-7 relative to the tensor's scale for bf16 outputs, 1e-3 for fp32 reductions.
 """
 import ctypes as C
+import zlib
 
 import pytest
 import torch
@@ -73,7 +74,8 @@ def test_block_conv_fwd_bwd(case, use_tr):
     from srvp_amd.convnet import Block, Feat
     kind, k, s, p, c0r, c1r, ups, Hs, cout, N = case
     dev = torch.device('cuda')
-    g = torch.Generator().manual_seed(hash(case) % 1000)
+    # (hash() of a tuple holding strings changes from process to process: a fixed seed per case keeps the run reproducible)
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()) % 1000)
     if kind == 'convT' and Hs == 1:
         f0 = Feat(N, 1, 1, c0r, dev, b=0)
         f0.interior().copy_(torch.randn(N, 1, 1, c0r, generator=g))
@@ -98,6 +100,7 @@ def test_block_conv_fwd_bwd(case, use_tr):
     blk.stats.zero_()
     for d in blk._fwd:
         L.call('srvp_conv_mfma', C.byref(d), st)
+    blk.finish_fwd(st)                                   # (split-K launches: slabs -> raw + statistics)
     torch.cuda.synchronize()
     # ---- reference forward
     x0 = feat_nchw(f0)
@@ -133,6 +136,7 @@ def test_block_conv_fwd_bwd(case, use_tr):
     L.call('srvp_unpack_wgrad', L.ptr(blk.dw), L.ptr(grads['w.weight']), C.byref(blk.pu), st)
     for d in blk._dg:
         L.call('srvp_conv_mfma', C.byref(d), st)
+    blk.finish_dgrad(st)
     torch.cuda.synchronize()
     assert rel_err(grads['w.weight'], wr.grad) < 2e-3, rel_err(grads['w.weight'], wr.grad)
     dcat = blk.dcat.float().cpu()                       # [N][Hin][Win][ctot]
@@ -313,6 +317,7 @@ def test_split_skip_subpixel_block_full_width(case):
         L.call('srvp_unpack_wgrad', L.ptr(src), dst, C.byref(pd), st)
     for d in blk._dg:
         L.call('srvp_conv_mfma', C.byref(d), st)
+    blk.finish_dgrad(st)
     torch.cuda.synchronize()
     # main half: exact up to the fp32 summation order; skip half: the time-summed gradient is rounded to bf16 once more
     assert rel_err(gw[:, :c0r], wr.grad[:, :c0r]) < 2e-3, rel_err(gw[:, :c0r], wr.grad[:, :c0r])
@@ -491,6 +496,7 @@ def test_image_side_layers(nc, k, s, p):
     L.call('srvp_unpack_wgrad', L.ptr(blk.dw), L.ptr(grads['w.weight']), C.byref(blk.pu), st)
     for d in blk._dg:
         L.call('srvp_conv_mfma', C.byref(d), st)
+    blk.finish_dgrad(st)
     torch.cuda.synchronize()
     assert rel_err(grads['w.weight'], wtr.grad) < 1e-2            # dpre is rounded to bf16 before the reduction
     dact = blk.dcat
