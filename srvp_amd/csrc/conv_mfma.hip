@@ -719,6 +719,17 @@ static int halo_variant(const srvp_conv_desc* d) {
 static int launch_halo_any(const srvp_conv_desc* d, int n, int variant, hipStream_t st) {
     if (variant == 257) return launch_halo_n<256, 256, 2, 2>(d, n, 256, st);
     if (variant == 256) {
+        // small grids (few images): 64-column tiles double the number of workgroups of a launch that would not fill the chip with
+        // 128-column ones
+        static int below = -1;
+        if (below < 0) { const char* e = getenv("SRVP_HALO_BN64_BELOW"); below = e ? atoi(e) : 600; }
+        if (d->Cout % 128 == 0 && below > 0) {
+            HaloK h;
+            if (halo_geometry(d, h, 256)) {
+                const long long b = (long long)((d->N + h.IMG - 1) / h.IMG) * h.tiles_x * h.tiles_y * (d->Cout / 128) * n;
+                if (b < below && h.NA <= 11) return launch_halo_n<256, 64, 4, 1>(d, n, 256, st);     // (11 = patch pieces of the 64-column kernel)
+            }
+        }
         if (d->Cout % 128 == 0) return launch_halo_n<256, 128, 2, 2>(d, n, 256, st);
         if (d->Cout % 64 == 0) return launch_halo_n<256, 64, 4, 1>(d, n, 256, st);
         return launch_halo_n<256, 32, 4, 1>(d, n, 256, st);
