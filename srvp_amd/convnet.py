@@ -960,15 +960,25 @@ class EncoderNet(ConvNetBase):
             self._block_forward(blk, params, st, sync, x=x, keep=keep)
         return self.blocks[-1].out_f32[:, :self.nh_r]
 
-    def backward(self, x, d_hx, skip_grads, params, grads, st, sync=None):
+    def backward(self, x, d_hx, skip_grads, params, grads, st, sync=None, side=None):
         """
         d_hx: fp32 [N][nh_padded] gradient of the encoder output; skip_grads: {stage: (dsel bf16 [B][H][W][C], idx int32 [N])}
+        side (a torch stream, optional): the unpacking of the MFMA layers' weight gradients runs there, under the image-side layer's
+        backward (its BatchNorm passes and weight gradient, ~1 ms that needs none of it); the caller joins the stream afterwards.
         """
         nb = len(self.blocks)
         self.zero_backward_accumulators()
         da = dict(t=d_hx, mode=0, cstride=d_hx.shape[1], coff=0, border=0, f32=True)
+        unpacked = False
         for i in range(nb - 1, -1, -1):
             blk = self.blocks[i]
+            if blk.role == 'in' and side is not None and nb > 1:
+                ev = torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    self.unpack_wgrads(grads, L.stream())
+                unpacked = True
             sk = blk.spec['skip_out']
             if sk is not None and skip_grads and (3 - sk) in skip_grads:
                 da['da2'], da['da2_idx'] = skip_grads[3 - sk]
@@ -981,7 +991,8 @@ class EncoderNet(ConvNetBase):
                 self._mfma_backward(blk, grads, st)
                 pooled = blk.spec['pre'] == 'pool'
                 da = dict(t=blk.dcat, mode=2 if pooled else 0, cstride=blk.dcat_c, coff=0, border=0)
-        self.unpack_wgrads(grads, st)
+        if not unpacked:
+            self.unpack_wgrads(grads, st)
 
 
 class DecoderNet(ConvNetBase):

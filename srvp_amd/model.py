@@ -449,9 +449,13 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             d_hx_p[:, :self.nhx] = d_hx
         else:
             d_hx_p = d_hx
-        enc.backward(pl['x'].view(T * B, *pl['x'].shape[2:]), d_hx_p, skip_grads, params, grads, st, self.sync)
+        enc.backward(pl['x'].view(T * B, *pl['x'].shape[2:]), d_hx_p, skip_grads, params, grads, st, self.sync,
+                     side=self._side_stream if overlap else None)
         if overlap:
-            torch.cuda.current_stream().wait_event(wg_done)
+            # (the side stream holds the decoder's weight gradients + unpack and, behind them, the encoder's unpack)
+            side_done = torch.cuda.Event()
+            side_done.record(self._side_stream)
+            torch.cuda.current_stream().wait_event(side_done)
         if self.sync is not None:
             self.sync.grads_ready('all', self)
 
