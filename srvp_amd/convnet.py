@@ -949,14 +949,18 @@ class EncoderNet(ConvNetBase):
         self.skips = {3 - sp['skip_out']: b.out for sp, b in zip(specs, self.blocks) if sp['skip_out'] is not None}
         self.nh_r = specs[-1]['cout']
 
-    def forward(self, x, params, st, sync=None, keep=None):
+    def forward(self, x, params, st, sync=None, keep=None, packed=None):
         """keep: int32 [N] or None.  The full-resolution activation of a POOLED block is read by nothing but the skip connections
         (the next layer reads the pooled tensor, BN backward recomputes it from the raw output), i.e. for one frame per sample:
         with `keep` given, pooled blocks store it only for the frames with keep[n] != 0 (saves ~2 GB of writes per step at the
-        headline config)."""
+        headline config).  packed: event after which the packed MFMA weights are ready (they are packed on another stream while the
+        image-side layer, which reads the fp32 weights, runs)."""
         if self.training:
             self.zero_forward_accumulators()
         for blk in self.blocks:
+            if packed is not None and blk.role != 'in':
+                torch.cuda.current_stream().wait_event(packed)
+                packed = None
             self._block_forward(blk, params, st, sync, x=x, keep=keep)
         return self.blocks[-1].out_f32[:, :self.nh_r]
 

@@ -259,28 +259,31 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         return pl
 
     def _pack(self, pl, params, st, overlap=False):
-        """bf16 MFMA-layout copies of the conv weights, redone when a parameter changed.  overlap: the decoder's share (60 % of the
-        bytes; nothing reads it before the decoder forward) goes to the second stream, under the encoder forward; returns the event
-        the decoder has to wait for (None: nothing pending)."""
+        """bf16 MFMA-layout copies of the conv weights, redone when a parameter changed.  overlap: on the second stream -- the
+        encoder's share under the image-side layer (which reads the fp32 weights), the decoder's (60 % of the bytes; nothing reads
+        it before the decoder forward) under the rest of the encoder; returns the two events to wait for (None: nothing pending)."""
         ver = (id(pl), tuple(p._version for p in self.parameters()))
         if ver == self._pack_version:
-            return None
+            return None, None
         self._pack_version = ver
-        if pl['enc'] is not None:
-            pl['enc'].pack_weights(params, st)
         if not (overlap and pl['enc'] is not None):
+            if pl['enc'] is not None:
+                pl['enc'].pack_weights(params, st)
             pl['dec'].pack_weights(params, st)
-            return None
+            return None, None
         if getattr(self, '_side_stream', None) is None:
             self._side_stream = torch.cuda.Stream()
         ev = torch.cuda.Event()
         ev.record()
         with torch.cuda.stream(self._side_stream):
             self._side_stream.wait_event(ev)
+            pl['enc'].pack_weights(params, L.stream())
+            enc_done = torch.cuda.Event()
+            enc_done.record()
             pl['dec'].pack_weights(params, L.stream())
-            done = torch.cuda.Event()
-            done.record()
-        return done
+            dec_done = torch.cuda.Event()
+            dec_done.record()
+        return enc_done, dec_done
 
     def _draw_tape(self, T, B, nt, training, dev, t_skip=None):
         """Random draws in the reference's order: CPU generator for the frame indices, device
@@ -305,7 +308,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         st = L.stream()
         pl = self._plan(T, B, nt, n_euler, training)
         params = self._named_tensors()
-        pack_done = self._pack(pl, params, st, overlap=training and OVERLAP_PACK)
+        enc_packed, pack_done = self._pack(pl, params, st, overlap=training and OVERLAP_PACK)
         enc, dec, lat = pl['enc'], pl['dec'], pl['lat']
         x = x.contiguous().float()
         # frames whose encoder activations feed the skip connections (srvp.py:185-190): drawn first (the reference draws t_skip
@@ -322,7 +325,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             sel = (_to_dev(t_skip, dev).to(torch.int32) * B + ar) if training else ((T - 1) * B + ar)
             keep.zero_()
             keep[sel.long()] = 1
-        hx = enc.forward(x.view(T * B, *x.shape[2:]), params, st, self.sync if training else None, keep=keep)
+        hx = enc.forward(x.view(T * B, *x.shape[2:]), params, st, self.sync if training else None, keep=keep, packed=enc_packed)
         hx = hx.contiguous().view(T, B, self.nhx)
         # the draws come AFTER the encoder launches (same order within the CPU and the device generator as the reference, which
         # draws them inside encode / infer_w / infer_y / generate): the per-sample randperm calls cost ~0.3 ms of host time that
