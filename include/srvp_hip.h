@@ -79,6 +79,11 @@ typedef struct {
                                    * layer, conv.py:176-179 / 224, and the data gradient of the 1x1 -> 4x4 decoder input layer,
                                    * conv.py:299-301): K = 8192 is 128 dependent K steps on a handful of workgroups otherwise.
                                    * srvp_splitk_finish sums the slabs in a fixed order (deterministic) */
+    int32_t f32_quad;             /* q > 0: the fp32 tensor of the hoisted skip half -- `dst` of the dst_is_f32 launch that writes it,
+                                   * `add_f32` of the launches that read it -- is stored pixel-quad-major for a consumer of output stride q:
+                                   * element (n, Y, X, c) at ((((n DHp + Y) q + X % q) (DWp / q / 4) + (X / q) / 4) C + c) 4 + (X / q) % 4,
+                                   * so that four consecutive output columns of a consumer lane are one 16-byte load.  Consumers need
+                                   * so == q and OW % 4 == 0; same values, another layout */
 } srvp_conv_desc;
 int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
 /* 1 (default): 3x3 stride-1 single-source convolutions run on the halo-tiled kernel (input patch staged in LDS once

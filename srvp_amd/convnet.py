@@ -19,6 +19,7 @@ from . import _lib as L
 CP = 32                      # channel padding granule
 SUBPIX = os.environ.get('SRVP_SUBPIX', '1') != '0'
 S2D = os.environ.get('SRVP_SUBPIX_S2D', '1') != '0'
+S_QUAD = os.environ.get('SRVP_S_QUAD', '1') != '0'        # hoisted skip half stored pixel-quad-major (16-byte loads in the consumers)
 SPLITK = int(os.environ.get('SRVP_CONV_SPLITK', '16'))    # tiny-M long-K launches: K steps shared over this many workgroups
 # Sub-pixel form of "nearest x2 upsample, then 3x3 conv" (conv.py:331-349): output phase a in {0,1} of a row pair reads
 # two low-resolution rows with SUMS of the original taps -- R[a][u] = kernel rows folded into effective tap u -- and
@@ -420,10 +421,16 @@ class Block:
             ds.N, ds.OH, ds.OW = self.B, self.OH, self.OW
             ds.dst, ds.DHp, ds.DWp, ds.so, ds.ooy, ds.oox, ds.Cdst, ds.cdst_off = L.ptr(self.S), self.OH, self.OW, 1, 0, 0, self.cout, 0
             ds.dst_is_f32, ds.stats, ds.stat_mod = 1, None, 1
+            # S pixel-quad-major for its consumers (stride 2 for the sub-pixel phases): one 16-byte load per four accumulators
+            so_c = 2 if self.subpix else 1
+            # (measured per layer, same box: 0.336 -> 0.300, 0.410 -> 0.350, 0.593 -> 0.475 ms on the 512 / 256 / 128-channel stage
+            # entries; the 64-channel one, on the 64-column kernel variant, got slower: 0.875 -> 0.938 ms, so it keeps the plain layout)
+            quad = so_c if (S_QUAD and not self.f32 and (self.OW // so_c) % 4 == 0 and self.cout % 128 == 0) else 0
+            ds.f32_quad = quad
             out.append(ds)
             if self.subpix:
                 for d in self._subpix_fwd(dst_ptr, use_stats):
-                    d.add_f32, d.add_mod = L.ptr(self.S), self.B
+                    d.add_f32, d.add_mod, d.f32_quad = L.ptr(self.S), self.B, quad
                     finish(d)
                 return out
             d = L.ConvDesc()                      # conv_h(h_t) + S[sample]
@@ -433,7 +440,7 @@ class Block:
             d.N, d.OH, d.OW = N, self.OH, self.OW
             d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox, d.Cdst, d.cdst_off = dst_ptr, self.OH, self.OW, 1, 0, 0, self.cout, 0
             d.stats, d.stat_mod = (L.ptr(self.stats) if use_stats else None), self.cout
-            d.add_f32, d.add_mod = L.ptr(self.S), self.B
+            d.add_f32, d.add_mod, d.f32_quad = L.ptr(self.S), self.B, quad
             finish(d)
         elif self.subpix:
             for d in self._subpix_fwd(dst_ptr, use_stats):

@@ -32,6 +32,7 @@ struct ConvK {
     float* out_f32; int out_nc, out_sigmoid;
     const int* map0; int dst_is_f32; const float* add_f32; int add_mod;
     int phase_chunks;          // > 0: space-to-depth source, taps of chunk cc are entries [(cc / phase_chunks) * ntaps + t]
+    int f32_quad;              // > 0: the fp32 tensor (dst of a dst_is_f32 launch / add_f32) is pixel-quad-major for consumer stride f32_quad
     int splitk;                // > 1 (generic kernel, fp32 destination): blockIdx.y walks its share of the K steps into slab blockIdx.y
     long long slab;            // elements per split-K slab
 };
@@ -56,6 +57,29 @@ __device__ __forceinline__ void conv_acc_init(f32x16_t (&acc)[TM][TN], const Con
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        return;
+    }
+    if (a.f32_quad > 0) {
+        // quad-major S (see srvp_conv_desc.f32_quad): the four accumulator registers 4g .. 4g+3 of a lane are four consecutive output
+        // columns of one row -> ONE 16-byte load instead of four 4-byte loads (the S tile is the largest stream of a K = 4 C0
+        // sub-pixel launch: 128 KB per workgroup against 83 KB of patch and 64 KB of output)
+        const int wq = a.DWp / a.f32_quad / 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int n = 0, oy = 0, ox = 0;
+                const bool ok = rowmap(wm * (TM * 32) + i * 32 + 8 * g + 4 * lhalf, n, oy, ox);
+                const float* sp = a.add_f32 + (((((size_t)sample_of(n) * a.DHp + oy * a.so + a.ooy) * a.f32_quad + a.oox) * wq + (ox >> 2)) * a.Cout +
+                                               n0 + wn * (TN * 32) + lcol) * 4;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+                    if (ok) v = *reinterpret_cast<const f32x4_t*>(sp + j * 128);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = v[e];
+                }
+            }
         return;
     }
 #pragma unroll
@@ -93,6 +117,15 @@ __device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[TM][TN], const Con
             for (int r = 0; r < 16; ++r) {
                 int n, oy, ox;
                 if (!rowmap(wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf, n, oy, ox)) continue;
+                if (a.f32_quad > 0) {
+                    // element (n, Y, X, c) at ((((n DHp + Y) q + X % q) (DWp / q / 4) + (X / q) / 4) C + c) 4 + (X / q) % 4
+                    const int Y = oy * a.so + a.ooy, X = ox * a.so + a.oox, xl = X / a.f32_quad, ph = X - xl * a.f32_quad;
+                    float* dq = dstf + (((((size_t)n * a.DHp + Y) * a.f32_quad + ph) * (a.DWp / a.f32_quad / 4) + (xl >> 2)) * a.Cdst + a.cdst_off + n0 +
+                                        wn * (TN * 32) + lcol) * 4 + (xl & 3);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) dq[j * 128] = acc[i][j][r];
+                    continue;
+                }
                 float* dp = dstf + (((size_t)n * a.DHp + oy * a.so + a.ooy) * a.DWp + ox * a.so + a.oox) * a.Cdst + a.cdst_off + n0 +
                             wn * (TN * 32) + lcol;
 #pragma unroll
@@ -417,6 +450,7 @@ static int fill_convk(const srvp_conv_desc* d, ConvK& k) {
     }
     k.phase_chunks = d->tap_phase_chunks;
     k.splitk = 1; k.slab = 0;
+    k.f32_quad = d->f32_quad;
     k.wt = (const bf16_t*)d->wt; k.Cout = d->Cout; k.N = d->N; k.OH = d->OH; k.OW = d->OW;
     k.dst = (bf16_t*)d->dst; k.DHp = d->DHp; k.DWp = d->DWp; k.so = d->so; k.ooy = d->ooy; k.oox = d->oox;
     k.Cdst = d->Cdst; k.cdst_off = d->cdst_off; k.stats = d->stats; k.stat_mod = d->stat_mod;
@@ -791,6 +825,9 @@ extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
     SRVP_REQUIRE(d->ntaps >= 1 && d->ntaps <= SRVP_MAX_TAPS, "srvp_conv_mfma: ntaps=%d", d->ntaps);
     SRVP_REQUIRE(d->Cdst % 8 == 0 && d->cdst_off % 8 == 0, "srvp_conv_mfma: dst channel slice must be 16-byte aligned");
     SRVP_REQUIRE(d->stats == nullptr || d->stat_mod > 0, "srvp_conv_mfma: stat_mod");
+    SRVP_REQUIRE(d->f32_quad == 0 || (!d->elem_f32 && d->splitk <= 1 && (d->dst_is_f32 || d->add_f32) && d->DWp % (4 * d->f32_quad) == 0 &&
+                                      (d->add_f32 == nullptr || (d->so == d->f32_quad && d->OW % 4 == 0)) && d->cdst_off == 0),
+                 "srvp_conv_mfma: f32_quad = %d needs an fp32 S tensor whose width is a multiple of 4 x the consumer stride (and so == f32_quad, OW %% 4 == 0 on the consumer)", d->f32_quad);
     SRVP_REQUIRE(!(d->elem_f32 && d->splitk > 1), "srvp_conv_mfma: splitk is not available in fp32 parity mode");
     if (d->elem_f32) return srvp_conv_f32_launch(d, st);
     SRVP_REQUIRE((long long)d->N * d->H0p * d->W0p * d->C0 < (1ll << 32) && (d->C1 == 0 || d->map1 || (long long)d->N * d->H1p * d->W1p * d->C1 < (1ll << 32)),
