@@ -464,10 +464,20 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
 
     # ------------------------------------------------------------------------------------------------ reference API
     def forward(self, x, nt, dt, remove_intermediate=True, tape=None):
-        """srvp.py:415-470.  Returns (x_, y, z, w, q_y_0_params, q_z_params, p_z_params, res)."""
-        assert remove_intermediate, 'remove_intermediate=False is not supported by the fused rollout'
+        """srvp.py:415-470.  Returns (x_, y, z, w, q_y_0_params, q_z_params, p_z_params, res).
+        remove_intermediate=False (srvp.py:402: every Euler sub-step is kept and decoded -- generation at 1/dt times the frame rate)
+        is an inference path: the composition of the granular entry points, as srvp.py:459-469 writes it."""
         n_euler = int(round(1 / dt))
         assert abs(n_euler * dt - 1) < 1e-6, 'dt must be the inverse of an integer (srvp.py:371)'
+        if not remove_intermediate:
+            assert not self.training, 'remove_intermediate=False: inference only (the ELBO of train.py compares x_ with nt data frames)'
+            tape = tape or {}
+            with torch.no_grad():
+                hx, skipco = self.encode(x)
+                w = self.infer_w(hx)
+                y_0, q_y_0 = self.infer_y(hx[:self.nt_inf], eps=tape.get('eps_y0'))
+                y, z, q_z, p_z, res = self.generate(y_0, hx, nt, dt, remove_intermediate=False, eps_z=tape.get('eps_z'))
+                return self.decode(w, y, skipco), y, z, w, q_y_0, q_z, p_z, res
         if self.training and torch.is_grad_enabled():
             return _SrvpForward.apply(self, x, nt, n_euler, tape, *self.parameters())
         with torch.no_grad():
@@ -599,8 +609,8 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
 
     @torch.no_grad()
     def generate(self, y_0, hx, nt, dt, remove_intermediate=True, eps_z=None):
-        """srvp.py:325-413 -> (y, z, q_z_params, p_z_params, res); hx may be [] (pure prior rollout, test.py:244)."""
-        assert remove_intermediate
+        """srvp.py:325-413 -> (y, z, q_z_params, p_z_params, res); hx may be [] (pure prior rollout, test.py:244).
+        remove_intermediate=False: y holds the state after EVERY Euler sub-step, (nt - 1) / dt + 1 rows (srvp.py:402)."""
         self._require_gpu()
         n_euler = int(round(1 / dt))
         B = y_0.shape[0]
@@ -618,5 +628,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         if T > 0:
             lat.posterior(hx.contiguous().float(), params, st)
         y, z, qz, pz, res = lat.generate(y_0.contiguous().float(), T, params, eps_z.contiguous().float(), st)
+        if not remove_intermediate:
+            y = lat.y_all[:lat.S + 1]                     # the rollout stores every sub-step anyway (BPTT / weight gradients)
         cl = lambda t: None if t is None else t.clone()
         return cl(y), (cl(z) if nt > 1 else None), cl(qz), (cl(pz) if nt > 1 else None), cl(res)

@@ -14,12 +14,17 @@ CFG_KEYS = ['nx', 'nc', 'nf', 'nhx', 'ny', 'nz', 'skipco', 'nt_inf', 'nh_inf', '
 
 def fixture_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, '*.npz'))
-                  if not os.path.basename(p).startswith(('known', 'metrics', 'mmnist', 'full_')))
+                  if not os.path.basename(p).startswith(('known', 'metrics', 'mmnist', 'full_', 'dense_')))
 
 
 def full_fixture_names():
     """Full-width reference runs of the BASELINE.json shapes (tests/make_golden.py gen_full)."""
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'full_*.npz')))
+
+
+def dense_fixture_names():
+    """remove_intermediate=False eval forwards of the reference (tests/make_golden.py gen_dense)."""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'dense_*.npz')))
 
 
 class Fixture:

@@ -8,6 +8,7 @@ fixtures under tests/golden/.  The fixtures are data only; the oracle (oracle/sr
 are both checked against them.  /root/reference does not exist on the GPU box, so this script is never run there.
 
     python tests/make_golden.py            # regenerate every fixture
+    python tests/make_golden.py --full     # only the full-width fixtures; --dense: only the remove_intermediate=False ones
 """
 import argparse
 import os
@@ -449,9 +450,53 @@ def gen_mmnist():
     print('mmnist fixture:', {k: v.shape for k, v in out.items() if k.endswith('videos')})
 
 
+def gen_dense(name, spec, srvp):
+    """remove_intermediate=False (srvp.py:402,415-470): eval forward that keeps and decodes every Euler sub-step, conditioning on
+    nt_cond frames and predicting beyond them.  Same seeded model / video as the fixture `name`; written to dense_<name>.npz."""
+    torch.set_num_threads(1)
+    ctor, T, B, n_euler = spec['ctor'], spec['T'], spec['B'], spec['n_euler']
+    cfg_keys = ['nx', 'nc', 'nf', 'nhx', 'ny', 'nz', 'skipco', 'nt_inf', 'nh_inf', 'nlayers_inf', 'nh_res', 'nlayers_res', 'archi']
+    cfg = dict(zip(cfg_keys, ctor))
+    torch.manual_seed(1)
+    model = srvp.StochasticLatentResidualVideoPredictor(*ctor)
+    model.init(res_gain=spec['res_gain'])
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if k.endswith('running_mean'):
+                v.copy_(0.1 * torch.randn(v.shape, generator=g))
+            elif k.endswith('running_var'):
+                v.copy_(1 + 0.3 * torch.rand(v.shape, generator=g))
+            elif k.endswith('.1.bias') or k.endswith('upconv.1.bias') or k.endswith('last_conv.1.bias'):
+                v.copy_(0.05 * torch.randn(v.shape, generator=g))
+    x = torch.from_numpy(synth_video(T, B, cfg['nc'], seed=123))
+    out = {'x': x.numpy()}
+    for k, v in model.state_dict().items():
+        out['sd0.' + k] = v.detach().numpy().copy()
+    model.eval()
+    nt_cond, nt_pred = max(cfg['nt_inf'], T - 1), T + 2
+    with torch.no_grad(), Tape() as tape:
+        o = model(x[:nt_cond], nt_pred, dt=1 / n_euler, remove_intermediate=False)
+    out.update(tape_arrays(tape, cfg, False))
+    out['nt_cond'], out['nt'], out['n_euler'] = np.array(nt_cond), np.array(nt_pred), np.array(n_euler)
+    for n_, v in zip(OUT_NAMES, o):
+        if v is not None:
+            out['out.' + n_] = v.numpy()
+    out['meta'] = np.array(repr(dict(ctor=list(ctor), T=T, B=B, n_euler=n_euler)))
+    np.savez_compressed(os.path.join(GOLDEN, 'dense_' + name + '.npz'), **out)
+    return tuple(o[0].shape)
+
+
+DENSE = ['tiny_vgg_nc3_skip1_e2', 'tiny_dcgan_nc1_skip0_e2']
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     srvp, ref_train, helper = import_reference()
+    if '--dense' in sys.argv:                              # only the remove_intermediate=False fixtures
+        for name in DENSE:
+            print(f'dense_{name}: frames', gen_dense(name, TINY[name], srvp), flush=True)
+        return
     if '--full' in sys.argv:                               # only the full-width fixtures (minutes of CPU time)
         for name, spec in FULL.items():
             loss = gen_full(name, spec, srvp, ref_train, helper)

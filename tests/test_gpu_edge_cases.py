@@ -202,3 +202,55 @@ def test_config_sweep_vs_oracle_fp32(cfg):
         if e > 1e-2 * max(grads_ref[k].double().norm().item(), floor):
             bad[k] = e / (grads_ref[k].double().norm().item() + 1e-30)
     assert not bad, bad
+
+
+@pytest.mark.parametrize('archi,nc,skipco,ne', [('vgg', 3, True, 2), ('dcgan', 1, False, 4)])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_remove_intermediate_false_decodes_every_euler_substep(archi, nc, skipco, ne, precision):
+    """forward(..., remove_intermediate=False) (srvp.py:402,415-470: generation at 1/dt times the frame rate): (nt - 1) / dt + 1 states
+    and frames, conditioning on T frames and predicting beyond them, against the oracle on the same draws; the integer-time rows
+    equal the default call."""
+    from oracle import srvp_oracle as O
+    T, B, nt = 4, 3, 6
+    ctor = (64, nc, 8, 16, 6, 5, skipco, 2, 16, 3, 32, 3, archi)
+    m = _model(ctor, seed=5)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(T, B, nc, 64, 64, generator=g)
+    tape = dict(eps_y0=torch.randn(B, 6, generator=g), eps_z=torch.randn(nt - 1, B, 5, generator=g))
+    ref = O.forward(sd, O.make_cfg(*ctor), x, nt, ne, tape, False, remove_intermediate=False)
+    m = m.cuda().eval().set_precision(precision)
+    tg = {k: v.cuda() for k, v in tape.items()}
+    outs = m(x.cuda(), nt, 1.0 / ne, remove_intermediate=False, tape=tg)
+    S = (nt - 1) * ne
+    assert outs[0].shape == (S + 1, B, nc, 64, 64) and outs[1].shape == (S + 1, B, 6) and outs[7].shape == (S, B, 6)
+    tol = 2e-5 if precision == 'fp32' else 3e-2
+    for i, (o, r) in enumerate(zip(outs, ref)):
+        assert (o is None) == (r is None)
+        if o is not None:
+            assert o.shape == r.shape, i
+            assert rel_l2(o, r) <= tol, (i, rel_l2(o, r))
+    dflt = m(x.cuda(), nt, 1.0 / ne, tape=tg)
+    assert torch.equal(dflt[1], outs[1][::ne])
+    assert rel_l2(dflt[0], outs[0][::ne]) <= (1e-6 if precision == 'fp32' else 2e-2)     # (other batch statistics? no: eval mode; other tile shapes)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_remove_intermediate_false_matches_reference_fixture(precision):
+    """The same call against outputs of the REAL reference (tests/golden/dense_*.npz, tests/make_golden.py --dense)."""
+    import srvp_amd
+    from golden_util import Fixture, OUT_NAMES, dense_fixture_names
+    for name in dense_fixture_names():
+        fx = Fixture(name)
+        nt_cond, nt, ne = int(fx.z['nt_cond']), int(fx.z['nt']), int(fx.z['n_euler'])
+        m = srvp_amd.StochasticLatentResidualVideoPredictor(*fx.meta['ctor'])
+        m.load_state_dict(fx.state('sd0'))
+        m = m.cuda().eval().set_precision(precision)
+        tape = {k: v.cuda() for k, v in fx.tape().items()}
+        outs = m(fx.t('x')[:nt_cond].cuda(), nt, 1.0 / ne, remove_intermediate=False, tape=tape)
+        for n, o in zip(OUT_NAMES, outs):
+            if o is None:
+                assert not fx.has('out.' + n)
+                continue
+            e = rel_l2(o, fx.t('out.' + n))
+            assert e <= (2e-5 if precision == 'fp32' else 3e-2), (name, n, e)

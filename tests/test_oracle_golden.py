@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import Fixture, OUT_NAMES, fixture_names, GOLDEN
+from golden_util import Fixture, OUT_NAMES, fixture_names, dense_fixture_names, GOLDEN
 from oracle import srvp_oracle as O
 
 torch.set_num_threads(1)
@@ -68,6 +68,21 @@ def test_eval_prediction_matches_reference(name):
             assert not fx.has('eval.' + n)
             continue
         close(o, fx.t('eval.' + n), 1e-4, 2e-5, n)
+
+
+@pytest.mark.parametrize('name', dense_fixture_names())
+def test_dense_forward_matches_reference(name):
+    """remove_intermediate=False (srvp.py:402): every Euler sub-step kept and decoded, prediction beyond the conditioning frames."""
+    fx = Fixture(name)
+    nt_cond, nt, ne = int(fx.z['nt_cond']), int(fx.z['nt']), int(fx.z['n_euler'])
+    with torch.no_grad():
+        outs = O.forward(fx.state('sd0'), fx.cfg, fx.t('x')[:nt_cond], nt, ne, fx.tape(), training=False, remove_intermediate=False)
+    assert outs[0].shape[0] == (nt - 1) * ne + 1
+    for n, o in zip(OUT_NAMES, outs):
+        if o is None:
+            assert not fx.has('out.' + n)
+            continue
+        close(o, fx.t('out.' + n), 1e-4, 2e-5, n)
 
 
 @pytest.mark.parametrize('name', fixture_names())
