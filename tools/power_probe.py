@@ -1,0 +1,49 @@
+"""Clock / power under the big conv layers vs a BN pass (evidence for the power-ceiling statement)."""
+import ctypes as C, os, sys, subprocess, threading, time, re
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import srvp_amd, bench
+from srvp_amd import _lib as L
+from srvp_amd.train import train
+cfg = bench.CONFIGS['bair']; B = 192; T = cfg['T']
+dev = torch.device('cuda', 0); torch.manual_seed(1)
+model = srvp_amd.StochasticLatentResidualVideoPredictor(*cfg['ctor']); model.init(res_gain=cfg['res_gain']); model.to(dev).train()
+optim = srvp_amd.FusedAdam(model, lr=3e-4)
+opt = srvp_amd.DotDict(dict(n_euler_steps=cfg['n_euler'], obs_scale=cfg['obs_scale'], beta_y=1.0, beta_z=cfg['beta_z'], l2_res=1.0))
+x = torch.rand(T, B, 3, 64, 64).to(dev)
+for _ in range(2): train(model, optim, None, x, dev, opt)
+torch.cuda.synchronize()
+pl = list(model._plans.values())[0]; st = L.stream()
+samples = []
+stop = False
+def poll():
+    while not stop:
+        try:
+            o = subprocess.run(['rocm-smi', '--showclocks', '--showpower'], capture_output=True, text=True, timeout=5).stdout
+            sclk = re.findall(r'sclk clock level.*?\((\d+)Mhz\)', o)
+            pw = re.findall(r'Power \(W\):\s*([\d.]+)', o)
+            samples.append((time.time(), sclk[0] if sclk else '?', pw[0] if pw else '?'))
+        except Exception as e:
+            samples.append((time.time(), 'err', str(e)[:40]))
+th = threading.Thread(target=poll); th.start()
+def phase(name, fn, secs=4.0):
+    t0 = time.time(); n = 0
+    while time.time() - t0 < secs:
+        for _ in range(50): fn()
+        torch.cuda.synchronize(); n += 50
+    t1 = time.time()
+    s = [(c, p) for (t, c, p) in samples if t0 + 1.0 <= t <= t1]
+    print(f'{name}: {1e3*(t1-t0)/n:.3f} ms/launch  samples(sclk MHz, W): {s[:6]}', flush=True)
+blk = pl['enc'].blocks[8]
+d = blk._fwd[0]
+phase('idle', lambda: None, 3.0)
+phase('enc08 fwd conv (512->512, 8x8)', lambda: L.call('srvp_conv_mfma', C.byref(d), st))
+blk1 = pl['enc'].blocks[1]
+phase('enc01 fwd conv (64->64, 64x64)', lambda: L.call('srvp_conv_mfma', C.byref(blk1._fwd[0]), st))
+a = torch.empty(600_000_000, dtype=torch.bfloat16, device=dev); b = torch.empty_like(a)
+phase('copy 1.2 GB (HBM bound)', lambda: b.copy_(a))
+w1 = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16); w2 = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+phase('hipBLASLt bf16 8192^3', lambda: torch.matmul(w1, w2))
+z1 = torch.zeros(8192, 8192, device=dev, dtype=torch.bfloat16)
+phase('hipBLASLt bf16 8192^3 on zeros', lambda: torch.matmul(z1, z1))
+stop = True; th.join()
