@@ -254,3 +254,53 @@ def test_remove_intermediate_false_matches_reference_fixture(precision):
                 continue
             e = rel_l2(o, fx.t('out.' + n))
             assert e <= (2e-5 if precision == 'fp32' else 3e-2), (name, n, e)
+
+
+@pytest.mark.parametrize('archi,nc,skipco', [('vgg', 3, True), ('dcgan', 1, False)])
+def test_four_training_steps_track_the_oracle(archi, nc, skipco):
+    """train.train four times in a row (fp32 mode; the weight packing, the weight-gradient unpacking and the skip convolutions run on
+    a second stream): the draws of every step are replayed through the oracle's train_step + Adam -- the loss of every step, the
+    BatchNorm running statistics and the parameters after the last step must agree (a stale packed weight, a late unpack or a
+    lost running-statistics update would show from step 2 on)."""
+    import srvp_amd
+    from oracle import srvp_oracle as O
+    from srvp_amd.train import train
+    T, B, ne, lr = 4, 5, 2, 1e-3
+    ctor = (64, nc, 8, 16, 6, 5, skipco, 2, 16, 3, 32, 3, archi)
+    m = _model(ctor, seed=9)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    cfg = O.make_cfg(*ctor)
+    hp = dict(obs_scale=0.7, beta_y=1.0, beta_z=1.5, l2_res=1.0)
+    m = m.cuda().train().set_precision('fp32')
+    optim = srvp_amd.FusedAdam(m, lr=lr)
+    opt = srvp_amd.DotDict(dict(n_euler_steps=ne, **hp))
+    g = torch.Generator().manual_seed(4)
+    adam = {}
+    torch.set_num_threads(8)
+    for step in range(4):
+        x = torch.rand(T, B, nc, 64, 64, generator=g)
+        loss, nll, kl_y0, kl_z = train(m, optim, None, x, torch.device('cuda'), opt)
+        tape = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in m.last_tape.items()}
+        scal, _, _ = O.train_step(sd, cfg, x, ne, tape, hp, adam, lr)
+        # (from the second step on the two parameter trajectories differ where a gradient is ~0: Adam's first updates are lr * sign(g),
+        # whatever |g| -- the small KL term feels that at the percent level, the loss does not)
+        assert abs(loss - scal['loss']) <= (2e-5 if step == 0 else 1e-4) * abs(scal['loss']), (step, loss, scal['loss'])
+        assert abs(nll - scal['nll']) <= (2e-5 if step == 0 else 1e-4) * abs(scal['nll']), (step, nll, scal['nll'])
+        assert abs(kl_z - scal['kl_z']) <= (1e-4 if step == 0 else 5e-2) * abs(scal['kl_z']) + 1e-6, (step, kl_z, scal['kl_z'])
+    torch.cuda.synchronize()
+    mine = m.state_dict()
+    moved = 0
+    for k, v in sd.items():
+        a = mine[k].detach().cpu()
+        if k.endswith('num_batches_tracked'):
+            assert int(a) == int(v) == 4, k
+        elif k.endswith('running_var'):
+            assert rel_l2(a, v) <= 3e-2, (k, rel_l2(a, v))      # (they follow the O(lr) differences of the weights, see above)
+        elif k.endswith('running_mean'):                        # (means of ~0: measured against the layer's standard deviation)
+            assert (a - v).abs().max().item() <= 3e-2 * sd[k[:-4] + 'var'].sqrt().max().item(), k
+        else:
+            # four Adam steps of size <= lr each: the parameters must have moved the same way (sign-sensitive where a gradient is ~0)
+            d = (a - v).abs()
+            assert d.max().item() <= 8 * lr and (d > lr).float().mean().item() < 0.25, (k, d.max().item(), (d > lr).float().mean().item())
+            moved += 1
+    assert moved > 10
