@@ -219,24 +219,32 @@ __device__ __forceinline__ void bn_bwd_g(const BnBwdK& a, int n, int y, int x, i
 // Pooled consumer (da_mode 2), whole 2x2 window (py, px) of image n at once: g[q][8] / raw[q][8] for the window pixels
 // q = 2*i + j.  Arg-max routing with torch's first-max tie rule (scan order (0,0),(0,1),(1,0),(1,1)).
 template <class E, int ACT>
-__device__ __forceinline__ void bn_bwd_g_window(const BnBwdK& a, int n, int py, int px, int cg, const float* sc, const float* sh,
-                                                float (*g)[8], float (*rawf)[8]) {
-    const int C = a.C, H = a.H, W = a.W, db = a.da_border, ab = a.act_border;
+__device__ __forceinline__ void bn_bwd_window_load(const BnBwdK& a, int n, int py, int px, int cg, float* t, float (*rawf)[8]) {
+    // the five loads of a window (pooled gradient + the four raw pixels), kept apart from the arithmetic so that a caller can put
+    // the loads of several windows in flight before the first use
+    const int C = a.C, H = a.H, W = a.W, db = a.da_border;
     const int Hh = H / 2, Wh = W / 2;
-    float t[8], w4[4][8];
-    El<E>::ld8((const E*)a.da + (((size_t)n * (Hh + 2 * db) + py + db) * (Wh + 2 * db) + px + db) * a.da_cstride + a.da_coff + cg * 8, t);
-    // The activations the forward max-pooled over are RECOMPUTED from raw (same fma, same activation, same bf16 rounding as
-    // bn_act_kernel stored them) instead of being read back: one full-size tensor read less in both BN-backward passes of the
-    // four pooled layers.
-    (void)ab;
+    El<E>::ld8_nt((const E*)a.da + (((size_t)n * (Hh + 2 * db) + py + db) * (Wh + 2 * db) + px + db) * a.da_cstride + a.da_coff + cg * 8, t);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int y = 2 * py + (q >> 1), x = 2 * px + (q & 1);
-        El<E>::ld8((const E*)a.raw + (((size_t)n * H + y) * W + x) * C + cg * 8, rawf[q]);
+        El<E>::ld8_nt((const E*)a.raw + (((size_t)n * H + y) * W + x) * C + cg * 8, rawf[q]);
+    }
+}
+
+template <class E, int ACT>
+__device__ __forceinline__ void bn_bwd_window_compute(const BnBwdK& a, int n, int py, int px, int cg, const float* sc, const float* sh,
+                                                      const float* t, const float (*rawf)[8], float (*g)[8]) {
+    const int C = a.C, H = a.H, W = a.W;
+    float w4[4][8];
+    // The activations the forward max-pooled over are RECOMPUTED from raw (same fma, same activation, same bf16 rounding as
+    // bn_act_kernel stored them) instead of being read back: one full-size tensor read less in both BN-backward passes of the
+    // four pooled layers.
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             w4[q][e] = El<E>::rnd(act_fwd(__builtin_fmaf(rawf[q][e], sc[e], sh[e]), ACT >= 0 ? ACT : a.act_kind));
-    }
     float d[4][8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -265,6 +273,15 @@ __device__ __forceinline__ void bn_bwd_g_window(const BnBwdK& a, int n, int py, 
         for (int e = 0; e < 8; ++e) g[q][e] = d[q][e] * act_bwd(rawf[q][e] * sc[e] + sh[e], ACT >= 0 ? ACT : a.act_kind);
 }
 
+// one window, loads and arithmetic together
+template <class E, int ACT>
+__device__ __forceinline__ void bn_bwd_g_window(const BnBwdK& a, int n, int py, int px, int cg, const float* sc, const float* sh,
+                                                float (*g)[8], float (*rawf)[8]) {
+    float t[8];
+    bn_bwd_window_load<E, ACT>(a, n, py, px, cg, t, rawf);
+    bn_bwd_window_compute<E, ACT>(a, n, py, px, cg, sc, sh, t, rawf, g);
+}
+
 template <class E, int MODE, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdK a, double* red) {
     const int CG = a.C / 8;
@@ -283,16 +300,38 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdK a, doub
         }
         if constexpr (MODE == 2) {
             // pooled: one thread per 2x2 window (window activations and the pooled gradient are read once)
+            // (one window per iteration: this loop is VALU-bound -- the four activations of a window are recomputed, rounded and
+            // arg-max-routed, ~800 instructions per 80 bytes -- and two windows in flight only cost occupancy: 477 -> 613 us)
             const unsigned P = (unsigned)a.N * (a.H / 2) * (a.W / 2), stride = gridDim.x * PPB;
             PixWalk w;
             w.init(blockIdx.x * PPB + pl, stride, a.H / 2, a.W / 2);
             for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
                 float g[4][8], rawf[4][8];
-                bn_bwd_g_window<E, ACT>(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
+                const int idx = a.da2 ? (a.da2_idx ? a.da2_idx[w.n] : w.n) : -1;
+                if (idx >= 0) {
+                    // frames that also receive a skip-connection gradient (one per sample): every window pixel contributes
+                    bn_bwd_g_window<E, ACT>(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                    for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { s1[e] += g[q][e]; s2[e] += g[q][e] * (rawf[q][e] - mu[e]) * is[e]; }
+                        for (int e = 0; e < 8; ++e) { s1[e] += g[q][e]; s2[e] += g[q][e] * (rawf[q][e] - mu[e]) * is[e]; }
+                    continue;
+                }
+                // otherwise only the arg-max pixel of a window carries gradient: the other three terms of both sums are exactly
+                // zero, so they are not formed (a third less arithmetic in this VALU-bound loop; same sums)
+                float t[8];
+                bn_bwd_window_load<E, ACT>(a, w.n, w.y, w.x, cg, t, rawf);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float bv = El<E>::rnd(act_fwd(__builtin_fmaf(rawf[0][e], sc[e], sh[e]), ACT >= 0 ? ACT : a.act_kind)), rb = rawf[0][e];
+#pragma unroll
+                    for (int q = 1; q < 4; ++q) {
+                        const float v = El<E>::rnd(act_fwd(__builtin_fmaf(rawf[q][e], sc[e], sh[e]), ACT >= 0 ? ACT : a.act_kind));
+                        if (v > bv) { bv = v; rb = rawf[q][e]; }             // torch's first-max tie rule: strictly greater replaces
+                    }
+                    const float gb = t[e] * act_bwd(rb * sc[e] + sh[e], ACT >= 0 ? ACT : a.act_kind);
+                    s1[e] += gb; s2[e] += gb * (rb - mu[e]) * is[e];
+                }
             }
         } else {
             const unsigned P = (unsigned)a.N * a.H * a.W, stride = gridDim.x * PPB;
@@ -300,15 +339,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdK a, doub
                 // plain consumer, unbordered gradient: both tensors are linear in the pixel index -- four pixels per
                 // iteration with all eight 16-byte loads issued up front (memory-level parallelism; the generic loop
                 // below has one pixel in flight per thread because its loads sit behind the loop-exit test)
+                // (the U groups of a workgroup are CONSECUTIVE pixels -- U * PPB * C contiguous elements per stream and iteration:
+                // a two-stream read microbenchmark sustains 7.1 TB/s with this pattern against 5.6-6.8 with the groups one grid
+                // apart)
                 constexpr int U = 4;
                 const E* da = (const E*)a.da;
-                const unsigned p0 = blockIdx.x * PPB + pl;
+                const unsigned p0 = blockIdx.x * (PPB * U) + pl;
                 for (unsigned p = p0; p < P; p += U * stride) {
                     float rv[U][8], dv[U][8];
                     bool ok[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        const unsigned pu = p + u * stride;
+                        const unsigned pu = p + u * PPB;
                         ok[u] = pu < P;
                         const size_t pc = ok[u] ? pu : p0;
                         El<E>::ld8_nt((const E*)a.raw + pc * a.C + cg * 8, rv[u]);
@@ -384,18 +426,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK a, const
     }
     if constexpr (MODE == 2) {
         const unsigned P = (unsigned)a.N * (a.H / 2) * (a.W / 2), stride = gridDim.x * PPB;
-        PixWalk w;
-        w.init(blockIdx.x * PPB + pl, stride, a.H / 2, a.W / 2);
-        for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
-            float g[4][8], rawf[4][8];
-            bn_bwd_g_window<E, ACT>(a, w.n, w.y, w.x, cg, sc, sh, g, rawf);
+        constexpr int U = 2;                         // two consecutive window groups per iteration, loads up front (see the reduction)
+        const unsigned p0 = blockIdx.x * (PPB * U) + pl;
+        PixWalk wk[U];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float o[8];
+        for (int u = 0; u < U; ++u) wk[u].init(p0 + u * PPB, U * stride, a.H / 2, a.W / 2);
+        for (unsigned p = p0; p < P; p += U * stride) {
+            float g[4][8], rawf[U][4][8], t[U][8];
+            bool ok[U];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = k1[e] * g[q][e] + k2[e] + k3[e] * rawf[q][e];
-                size_t off = (((size_t)w.n * (a.H + 2 * db) + 2 * w.y + (q >> 1) + db) * (a.W + 2 * db) + 2 * w.x + (q & 1) + db) * a.C + cg * 8;
-                El<E>::st8(draw + off, o);
+            for (int u = 0; u < U; ++u) {
+                ok[u] = p + u * PPB < P;
+                if (!ok[u]) { wk[u].n = 0; wk[u].y = 0; wk[u].x = 0; }
+                bn_bwd_window_load<E, ACT>(a, wk[u].n, wk[u].y, wk[u].x, cg, t[u], rawf[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                bn_bwd_window_compute<E, ACT>(a, wk[u].n, wk[u].y, wk[u].x, cg, sc, sh, t[u], rawf[u], g);
+                if (ok[u]) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float o[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = k1[e] * g[q][e] + k2[e] + k3[e] * rawf[u][q][e];
+                        size_t off = (((size_t)wk[u].n * (a.H + 2 * db) + 2 * wk[u].y + (q >> 1) + db) * (a.W + 2 * db) + 2 * wk[u].x + (q & 1) + db) * a.C + cg * 8;
+                        El<E>::st8(draw + off, o);
+                    }
+                }
+                wk[u].next();
             }
         }
         return;
@@ -405,6 +463,58 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK a, const
         // the B samples and loop over time inside, so the sum costs one extra store instead of re-reading draw
         const int Bs = a.N / a.tsum_T;
         const unsigned P = (unsigned)Bs * a.H * a.W, stride = gridDim.x * PPB;
+        if (MODE == 0 && !a.da_is_f32 && !a.da2 && a.da_border == 0) {
+            // U consecutive pixel groups per thread and time step, their 2 U loads issued up front; running sums over t in registers
+            // (same values and the same summation order over t as the one-pixel loop below)
+            constexpr int U = 4;
+            const E* da = (const E*)a.da;
+            const size_t hw = (size_t)a.H * a.W;
+            const unsigned p0 = blockIdx.x * (PPB * U) + pl;
+            PixWalk wk[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) wk[u].init(p0 + u * PPB, U * stride, a.H, a.W);
+            for (unsigned p = p0; p < P; p += U * stride) {
+                float acc[U][8];
+                bool ok[U];
+                size_t pix[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    ok[u] = p + u * PPB < P;
+                    if (!ok[u]) { wk[u].n = 0; wk[u].y = 0; wk[u].x = 0; }      // (past the end: reads pixel 0, stores nothing; last iteration)
+                    pix[u] = (size_t)wk[u].n * hw + (size_t)wk[u].y * a.W + wk[u].x;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[u][e] = 0.f;
+                }
+                for (int t = 0; t < a.tsum_T; ++t) {
+                    float rv[U][8], dv[U][8];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const size_t pc = (size_t)t * Bs * hw + pix[u];
+                        El<E>::ld8_nt((const E*)a.raw + pc * a.C + cg * 8, rv[u]);
+                        El<E>::ld8_nt(da + pc * a.da_cstride + a.da_coff + cg * 8, dv[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        float o[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float g = dv[u][e] * act_bwd(rv[u][e] * sc[e] + sh[e], ACT >= 0 ? ACT : a.act_kind);
+                            o[e] = k1[e] * g + k2[e] + k3[e] * rv[u][e]; acc[u][e] += o[e];
+                        }
+                        if (ok[u]) El<E>::st8(draw + draw_off(a, t * Bs + wk[u].n, wk[u].y, wk[u].x, cg, db), o);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (ok[u]) {
+                        const size_t soff = (((size_t)wk[u].n * (a.H + 2 * db) + wk[u].y + db) * (a.W + 2 * db) + wk[u].x + db) * a.C + cg * 8;
+                        El<E>::st8((E*)a.tsum + soff, acc[u]);
+                    }
+                    wk[u].next();
+                }
+            }
+            return;
+        }
         PixWalk w;
         w.init(blockIdx.x * PPB + pl, stride, a.H, a.W);
         for (unsigned p = blockIdx.x * PPB + pl; p < P; p += stride, w.next()) {
@@ -425,6 +535,41 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK a, const
         return;
     }
     const unsigned P = (unsigned)a.N * a.H * a.W, stride = gridDim.x * PPB;
+    if (MODE == 0 && !a.da_is_f32 && !a.da2 && a.da_border == 0) {
+        // plain consumer, unbordered gradient (both inputs linear in the pixel index): U consecutive pixel groups per iteration, all
+        // 2 U 16-byte loads issued before the first use (see bn_bwd_reduce_kernel; a read-read-write microbenchmark sustains
+        // 6.5 TB/s with this pattern, the one-pixel loop below ran at 5.1-6.0)
+        constexpr int U = 4;
+        const E* da = (const E*)a.da;
+        const unsigned p0 = blockIdx.x * (PPB * U) + pl;
+        PixWalk wk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) wk[u].init(p0 + u * PPB, U * stride, a.H, a.W);
+        for (unsigned p = p0; p < P; p += U * stride) {
+            float rv[U][8], dv[U][8];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned pu = p + u * PPB;
+                ok[u] = pu < P;
+                const size_t pc = ok[u] ? pu : p0;
+                El<E>::ld8_nt((const E*)a.raw + pc * a.C + cg * 8, rv[u]);
+                El<E>::ld8_nt(da + pc * a.da_cstride + a.da_coff + cg * 8, dv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float g = dv[u][e] * act_bwd(rv[u][e] * sc[e] + sh[e], ACT >= 0 ? ACT : a.act_kind);
+                    o[e] = k1[e] * g + k2[e] + k3[e] * rv[u][e];
+                }
+                if (ok[u]) El<E>::st8(draw + draw_off(a, wk[u].n, wk[u].y, wk[u].x, cg, db), o);
+                wk[u].next();
+            }
+        }
+        return;
+    }
     PixWalk w;
     w.init(blockIdx.x * PPB + pl, stride, a.H, a.W);
 #pragma unroll 2
@@ -534,7 +679,11 @@ extern "C" int srvp_bn_bwd_reduce(const srvp_bnbwd_desc* d, double* red, void* s
     long long P = (long long)k.N * k.H * k.W;
     SRVP_REQUIRE(P < (1ll << 31), "srvp_bn_bwd_reduce: too many pixels");
     if (k.da_mode == 2) P /= 4;
-    const dim3 g(grid_for(P, PPB * (k.da_mode == 2 ? 16 : 64)));   // >= 64 pixel rows per thread slot: the 2C fp64 atomics per workgroup must stay small beside its streaming work
+    // >= 64 pixel rows per thread slot: the 2C fp64 atomics per workgroup must stay small beside its streaming work -- unless that
+    // leaves fewer than 64 workgroups (the 1x1 encoder output: 3 workgroups walked 2304 rows in 100 us of dependent loads)
+    int rows = k.da_mode == 2 ? 16 : 64;
+    while (rows > 4 && P / ((long long)PPB * rows) < 64) rows /= 2;
+    const dim3 g(grid_for(P, PPB * rows));
     const bool lr = k.act_kind == ACT_LRELU;
     if (d->elem_f32) {
         auto kern = k.da_mode == 0 ? (lr ? bn_bwd_reduce_kernel<float, 0, ACT_LRELU> : bn_bwd_reduce_kernel<float, 0, -1>)
