@@ -482,13 +482,17 @@ struct HaloK {
 
 // Up to four launches that differ only in their descriptors (the four output phases of a sub-pixel upsample conv) run as
 // ONE grid: blockIdx.y selects the descriptor.
-struct HaloKN { HaloK k[4]; };
+struct HaloKN { HaloK k[4]; int n; };
 
 // BN = 256 (wave tile 128 x 128, 256 accumulator registers -> AGPRs, one workgroup per CU): every A fragment read from LDS
 // and every B fragment read from L2 feeds four MFMAs instead of two / four -- half the LDS and L1 bytes per flop.
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 256 ? 1 : 2))) void conv_halo_kernel(const HaloKN pk) {
-    const HaloK& p = pk.k[blockIdx.y];
+    // descriptor (output phase) = fastest-varying part of the logical workgroup index: the phases of one spatial tile read the SAME
+    // input patch and run back to back on one XCD, so phases 2-4 find it in L2 (as grid.y they ran a whole grid apart and the
+    // 0.3 GB input of the 64x64 stage entry was read from HBM four times)
+    const unsigned lb_all = xcd_remap(blockIdx.x, gridDim.x);
+    const HaloK& p = pk.k[pk.n > 1 ? lb_all % (unsigned)pk.n : 0u];
     constexpr int BK = 64, NT = 256, CPR = 8;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     // patch pieces per thread: 256-pixel tiles 11 * 256 16-byte pieces = 352 pixels >= 334 (13 = 416 pixels for the
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 256 ?
     const ConvK& a = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned lb = pk.n > 1 ? lb_all / (unsigned)pk.n : lb_all;
     const int n_tiles = a.Cout / BN;
     const int n0 = (lb % n_tiles) * BN;
     unsigned sp = lb / n_tiles;
@@ -721,7 +725,9 @@ int launch_halo_n(const srvp_conv_desc* d, int n, int bm, hipStream_t st) {
     }
     for (int i = n; i < 4; ++i) hn.k[i] = hn.k[0];
     SRVP_REQUIRE(blocks > 0 && blocks < (1ll << 31), "srvp_conv_mfma(halo): bad grid %lld", blocks);
-    hipLaunchKernelGGL((conv_halo_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, st, hn);
+    hn.n = n;
+    SRVP_REQUIRE(blocks * n < (1ll << 31), "srvp_conv_mfma(halo): bad grid %lld x %d", blocks, n);
+    hipLaunchKernelGGL((conv_halo_kernel<BM, BN, WM, WN>), dim3((unsigned)(blocks * n)), dim3(256), 0, st, hn);
     SRVP_CHECK_LAUNCH("srvp_conv_mfma(halo)");
     return SRVP_OK;
 }
