@@ -29,8 +29,8 @@ th = threading.Thread(target=poll); th.start()
 def phase(name, fn, secs=4.0):
     t0 = time.time(); n = 0
     while time.time() - t0 < secs:
-        for _ in range(50): fn()
-        torch.cuda.synchronize(); n += 50
+        for _ in range(50 if 'training step' not in name else 5): fn()
+        torch.cuda.synchronize(); n += 50 if 'training step' not in name else 5
     t1 = time.time()
     s = [(c, p) for (t, c, p) in samples if t0 + 1.0 <= t <= t1]
     print(f'{name}: {1e3*(t1-t0)/n:.3f} ms/launch  samples(sclk MHz, W): {s[:6]}', flush=True)
@@ -46,4 +46,5 @@ w1 = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16); w2 = torch.randn
 phase('hipBLASLt bf16 8192^3', lambda: torch.matmul(w1, w2))
 z1 = torch.zeros(8192, 8192, device=dev, dtype=torch.bfloat16)
 phase('hipBLASLt bf16 8192^3 on zeros', lambda: torch.matmul(z1, z1))
+phase('whole training step (B=192)', lambda: train(model, optim, None, x, dev, opt), 6.0)
 stop = True; th.join()
