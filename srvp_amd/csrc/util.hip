@@ -126,9 +126,15 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
         if (c4 < cg)
             for (long long r = r0 + ty; r < r1; r += 4) {
                 const float* p = parts + r * C + c4 * 4;
+                // all slab loads of a group of 8 in flight before the first add (the sum order stays z ascending)
                 f32x4_t v = *reinterpret_cast<const f32x4_t*>(p);
-#pragma unroll 8
-                for (int z = 1; z < splitk; ++z) { const f32x4_t u = *reinterpret_cast<const f32x4_t*>(p + z * slab); v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
+                for (int z0 = 1; z0 < splitk; z0 += 8) {
+                    f32x4_t u[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) u[i] = z0 + i < splitk ? *reinterpret_cast<const f32x4_t*>(p + (size_t)(z0 + i) * slab) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) if (z0 + i < splitk) { v[0] += u[i][0]; v[1] += u[i][1]; v[2] += u[i][2]; v[3] += u[i][3]; }
+                }
                 bf16_t o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { o[e] = f2bf(v[e]); s1[e] += v[e]; s2[e] += v[e] * v[e]; }
@@ -157,7 +163,10 @@ extern "C" int srvp_splitk_finish(const float* parts, int splitk, int64_t slab_e
                                   int stat_mod, void* stream) {
     SRVP_REQUIRE(parts && dst && splitk >= 1 && M > 0 && C > 0 && C % 4 == 0 && slab_elems >= M * C, "srvp_splitk_finish: bad args");
     SRVP_REQUIRE(!stats || stat_mod > 0, "srvp_splitk_finish: stat_mod");
-    const int rpb = 8;          // 2 rows per thread: the kernel is a chain of dependent slab loads, so many short workgroups
+    // latency-bound: one row per thread -- unless statistics are wanted: 2 C fp64 atomics per workgroup on 2 C / 16 cache lines made
+    // 576 workgroups take 55 us; ~64 workgroups then
+    int rpb = 4;
+    if (stats && (M + 63) / 64 > rpb) rpb = (int)((M + 63) / 64);
     hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, parts, splitk,
                        (long long)slab_elems, (long long)M, C, (bf16_t*)dst, stats, stat_mod, rpb);
     SRVP_CHECK_LAUNCH("srvp_splitk_finish");
