@@ -51,6 +51,7 @@ def _to_dev(v, dev):
 
 OVERLAP_WGRAD = os.environ.get('SRVP_OVERLAP_WGRAD', '1') != '0'
 OVERLAP_SKIP = os.environ.get('SRVP_OVERLAP_SKIP', '1') == '1'
+SKIP_LATE = os.environ.get('SRVP_SKIP_LATE', '1') == '1'        # hoisted skip convs under the rollout kernel (1) / under the inference chain (0)
 OVERLAP_PACK = os.environ.get('SRVP_OVERLAP_PACK', '1') == '1'    # decoder weight packing on the second stream, under the encoder
 
 
@@ -339,10 +340,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             pl['skip_map'].copy_(sel.repeat(nt))
             pl['skip_sel_t'].copy_(sel)
             pl['skip_sel'] = sel
-        s_done = None
-        if self.skipco and OVERLAP_SKIP and any(b.split for b in dec.blocks):
-            # the hoisted skip halves of the decoder need the encoder only: second stream, under the latent forward (a chain of
-            # small dependent kernels that leaves the GPU mostly idle)
+        def skips_on_side():
             if getattr(self, '_side_stream', None) is None:
                 self._side_stream = torch.cuda.Stream()
             ev = torch.cuda.Event()
@@ -350,11 +348,21 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             with torch.cuda.stream(self._side_stream):
                 self._side_stream.wait_event(ev)
                 dec.precompute_skips(L.stream())
-                s_done = torch.cuda.Event()
-                s_done.record()
+                done = torch.cuda.Event()
+                done.record()
+            return done
+        s_done = None
+        overlap_skips = self.skipco and OVERLAP_SKIP and any(b.split for b in dec.blocks)
+        if overlap_skips and not SKIP_LATE:
+            s_done = skips_on_side()
         w = lat.infer_w(hx, params, tape.get('t_w') if training else None, st)
         y0, q_y0 = lat.infer_y(hx[:self.nt_inf], params, tape['eps_y0'], st)
         lat.posterior(hx, params, st)
+        if overlap_skips and SKIP_LATE:
+            # the hoisted skip halves of the decoder need the encoder only: second stream, under the ROLLOUT kernel (one persistent
+            # launch on nh/32 x batch-tiles CUs that leaves the rest of the chip idle for 0.5 ms).  Issued earlier -- under the
+            # inference MLPs and the LSTM chain -- their big workgroups starved those small dependent kernels (15 -> 60-80 us each)
+            s_done = skips_on_side()
         y, z, qz, pz, res = lat.generate(y0, T, params, tape['eps_z'], st)
         z_in = torch.cat([w.repeat(nt, 1), y.reshape(nt * B, self.ny)], 1)
         if s_done is not None:
