@@ -245,12 +245,16 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             assert S == 1 or not training
             dev = self._device()
             enc = EncoderNet(self._enc_blocks, T * B, dev, training, f32=f32) if T > 0 else None
-            skip_map = torch.zeros(nt * B * S, dtype=torch.int32, device=dev) if self.skipco else None
-            skip_sel = torch.zeros(B, dtype=torch.int32, device=dev) if self.skipco else None
+            # the step's small index tensors live in ONE int32 buffer, filled by a single host-to-device copy per forward:
+            # [keep (T*B) | skip_idx (T*B) | skip_sel (B) | skip_map (nt*B*S)]  (a dozen tiny device kernels otherwise)
+            nk = max(T * B, 1)
+            ibuf = torch.zeros(2 * nk + B + nt * B * S, dtype=torch.int32, device=dev)
+            skip_sel = ibuf[2 * nk:2 * nk + B] if self.skipco else None
+            skip_map = ibuf[2 * nk + B:] if self.skipco else None
             dec = DecoderNet(self._dec_blocks, nt * B * S, dev, training, enc.skips if (self.skipco and enc) else None, skip_map,
                              skip_sel, f32=f32)
             lat = LatentNet(self._cfg(), T, B * S, nt, n_euler, dev, training)
-            pl = dict(enc=enc, dec=dec, lat=lat, skip_map=skip_map, skip_sel_t=skip_sel)
+            pl = dict(enc=enc, dec=dec, lat=lat, skip_map=skip_map, skip_sel_t=skip_sel, ibuf=ibuf, keep=ibuf[:nk], skip_idx=ibuf[nk:2 * nk])
             # keep at most two training plans alive (they own all activation memory)
             if training:
                 for k in [k for k in self._plans if isinstance(k[0], int) and k[4]]:
@@ -317,15 +321,20 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         t_skip = None
         if self.skipco and training:
             t_skip = tape['t_skip'] if tape is not None else torch.randint(T, size=(B,))
-        keep = pl.get('keep')
-        if keep is None:
-            keep = pl['keep'] = torch.zeros(T * B, dtype=torch.int32, device=dev)
+        keep = pl['keep']
         sel = None
         if self.skipco:
-            ar = torch.arange(B, device=dev, dtype=torch.int32)
-            sel = (_to_dev(t_skip, dev).to(torch.int32) * B + ar) if training else ((T - 1) * B + ar)
-            keep.zero_()
-            keep[sel.long()] = 1
+            # frame t_skip[b] * B + b of every sample: the index tensors are formed on the host (B integers) and travel in one copy
+            ts = t_skip.cpu().to(torch.int32) if training else torch.full((B,), T - 1, dtype=torch.int32)
+            sel_h = ts * B + torch.arange(B, dtype=torch.int32)
+            host = torch.zeros(pl['ibuf'].numel(), dtype=torch.int32)
+            host[sel_h.long()] = 1                                              # keep
+            host[T * B:2 * T * B] = -1
+            host[T * B + sel_h.long()] = torch.arange(B, dtype=torch.int32)    # skip_idx: frame -> sample (or -1)
+            host[2 * T * B:2 * T * B + B] = sel_h                               # skip_sel
+            host[2 * T * B + B:] = sel_h.repeat(nt)                             # skip_map
+            pl['ibuf'].copy_(host.pin_memory(), non_blocking=True)
+            sel = pl['skip_sel_t']
         hx = enc.forward(x.view(T * B, *x.shape[2:]), params, st, self.sync if training else None, keep=keep, packed=enc_packed)
         hx = hx.contiguous().view(T, B, self.nhx)
         # the draws come AFTER the encoder launches (same order within the CPU and the device generator as the reference, which
@@ -337,8 +346,6 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         tape = {k: (_to_dev(v, dev) if torch.is_tensor(v) else v) for k, v in tape.items()}
         self.last_tape = tape
         if self.skipco:
-            pl['skip_map'].copy_(sel.repeat(nt))
-            pl['skip_sel_t'].copy_(sel)
             pl['skip_sel'] = sel
         def skips_on_side():
             if getattr(self, '_side_stream', None) is None:
@@ -450,8 +457,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         skip_grads = None
         if self.skipco:
             skip_grads = {}
-            idx = torch.full((T * B,), -1, dtype=torch.int32, device=d_hx.device)
-            idx[pl['skip_sel'].long()] = torch.arange(B, dtype=torch.int32, device=d_hx.device)
+            idx = pl['skip_idx']                                   # frame -> sample whose skip connection it feeds, or -1 (forward)
             for stage, dsel in dec.skip_grads(nt, B, st).items():
                 skip_grads[stage] = (dsel, idx)
         nhp = cpad(self.nhx)
