@@ -503,3 +503,26 @@ def test_image_side_layers(nc, k, s, p):
     assert rel_err(dact[..., :c0r].permute(0, 3, 1, 2).float(), xin.grad[:, :c0r]) < 2 ** -6
     if c1r:
         assert rel_err(dact[..., f0.C:f0.C + c1r].permute(0, 3, 1, 2).float(), xin.grad[:, c0r:]) < 2 ** -6
+
+
+@pytest.mark.parametrize('M,C,sk,with_stats', [(2304, 128, 16, True), (37, 320, 5, False), (1, 8, 2, True), (288, 64, 64, True)])
+def test_splitk_finish(M, C, sk, with_stats):
+    """srvp_splitk_finish: fixed-order sum of the split-K slabs -> bf16 rows, + the per-column sum / sum of squares of the fp32 sums."""
+    from srvp_amd import _lib as L
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(M + C)
+    parts = torch.randn(sk, M, C, generator=g).to(dev)
+    dst = torch.full((M, C), 7.0, dtype=torch.bfloat16, device=dev)
+    stat_mod = C // 2 if C % 16 == 0 else C                      # columns fold onto stat_mod statistics channels
+    stats = torch.zeros(2, stat_mod, dtype=torch.float64, device=dev)
+    L.call('srvp_splitk_finish', L.ptr(parts), sk, M * C, M, C, L.ptr(dst), L.ptr(stats) if with_stats else None, stat_mod, L.stream())
+    torch.cuda.synchronize()
+    ref = parts[0].clone()
+    for z in range(1, sk):
+        ref += parts[z]                                            # the kernel's summation order (z ascending, fp32)
+    assert torch.equal(dst.view(torch.int16), ref.to(torch.bfloat16).view(torch.int16))
+    if with_stats:
+        r64 = ref.double().view(M, C // stat_mod, stat_mod)
+        assert rel_err(stats[0], r64.sum(dim=(0, 1))) < 1e-6 and rel_err(stats[1], (r64 ** 2).sum(dim=(0, 1))) < 1e-6
+    else:
+        assert stats.abs().max().item() == 0
