@@ -270,6 +270,13 @@ int srvp_act_bwd_f32(const float* pre_or_out, const float* dy, float* dx, int64_
  * recurrent part here.  Saves gate activations for backward.  Layout: [T][B][4*nh], gate order i,f,g,o. */
 int srvp_lstm_fwd(const float* gates_x, const float* w_hh, float* h_out, float* c_out, float* gates_act,
                   int T, int B, int nh, void* stream);
+/* the same forward as ONE persistent launch over the T steps (csrc/rollout_fused.hip: clusters of nh / 32 workgroups per 32-row batch
+ * tile, W_hh slices resident in registers, h exchanged with agent-scope accesses, one counter barrier per step).
+ * srvp_lstm_fused_ws_bytes: 0 = shape not eligible (nh in {64, 128, 256}), else the size of the zero-initialised-by-the-call workspace;
+ * gates_x is not modified (srvp_lstm_fwd copies it into gates_act first) */
+int64_t srvp_lstm_fused_ws_bytes(int T, int B, int nh);
+int srvp_lstm_fwd_fused(const float* gates_x, const float* w_hh, float* h_out, float* c_out, float* gates_act,
+                        int T, int B, int nh, void* ws, int64_t ws_bytes, void* stream);
 /* scratch: 2*B*nh floats */
 int srvp_lstm_bwd(const float* dh_out, const float* w_hh, const float* c_out, const float* gates_act,
                   float* dgates, float* scratch, int T, int B, int nh, void* stream);

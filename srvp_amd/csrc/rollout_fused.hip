@@ -475,6 +475,94 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------ LSTM
+// The posterior LSTM (nn.LSTM(nhx, nh, 1), reference module/srvp.py:132,366) as ONE persistent launch over its T steps, same
+// decomposition: 32-row batch tiles, a cluster of nh / 32 workgroups per tile, workgroup g owns hidden units [32 g, 32 g + 32)
+// -- the four gate rows of those units, one gate per wave, its nh x 32 slice of W_hh held in 128 VGPRs per lane (B operand of
+// v_mfma_f32_32x32x2_f32) for the whole kernel.  Per step: the h_{t-1} tile of the batch tile (written by the cluster with
+// agent-scope stores) is staged in LDS, each wave forms its gate, the cell update runs on the workgroup's 32 x 32 units with
+// the cell state in registers, one counter barrier.  (As launches: a GEMM + a cell kernel per step, 20 us of dependent
+// latency each.)
+struct LstmF {
+    int B, nh, T, G, ntiles, tile0, cl_per_xcd;
+    const float* gx; const float* whh; float* h; float* c; float* ga; unsigned* cnt;
+};
+
+__device__ __forceinline__ float sigmoid_l(float x) { return 1.f / (1.f + __expf(-x)); }
+
+template <int KST>      // nh / 2 MFMA k steps
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fused_fwd_kernel(const LstmF a) {
+    extern __shared__ float lds[];
+    constexpr int NH = 2 * KST, HLD = NH + 1;
+    float* Hs = lds;                          // [32][NH + 1]  h_{t-1} of this batch tile
+    float* Gs = lds + RT * HLD;               // [4][32][33]   activated gates of this workgroup's units
+    const int x = blockIdx.x & 7, kk = blockIdx.x >> 3;
+    const int cl = x * a.cl_per_xcd + kk / a.G, g = kk % a.G;
+    if (cl >= a.ntiles) return;
+    const int tid = threadIdx.x, lane = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lcol = lane & 31, lhalf = lane >> 5;
+    const int row0 = (a.tile0 + cl) * RT;
+    const int col = q * NH + g * CW + lcol;               // this lane's gate column (row of W_hh)
+    float wreg[KST];
+#pragma unroll
+    for (int j = 0; j < KST; ++j) wreg[j] = a.whh[(size_t)col * NH + 2 * j + lhalf];
+    float cst[4] = {0.f, 0.f, 0.f, 0.f};
+    unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;
+    const size_t gs = (size_t)a.B * 4 * NH, hs = (size_t)a.B * NH;
+    for (int t = 0; t < a.T; ++t) {
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+            acc[r] = row < a.B ? a.gx[gs * t + (size_t)row * 4 * NH + col] : 0.f;
+        }
+        if (t > 0) {
+            cluster_barrier(cnt, (unsigned)(t * a.G));     // every member has stored its slice of h_{t-1}
+            const float* hp = a.h + hs * (t - 1);
+            constexpr int NLD = RT * NH / 4 / 256;          // 16-byte pieces per thread (8 at nh = 256): all in flight, one wait
+            f32x4v hv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = tid + 256 * (i < NLD ? i : 0), row = idx / (NH / 4), c4 = idx % (NH / 4);
+                const int gr = row0 + row < a.B ? row0 + row : a.B - 1;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(hv[i]) : "v"(hp + (size_t)gr * NH + c4 * 4) : "memory");
+            }
+            WAIT8(hv, 0);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int idx = tid + 256 * i, row = idx / (NH / 4), c4 = idx % (NH / 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Hs[row * HLD + c4 * 4 + e] = hv[i][e];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < KST; ++j)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hs[lcol * HLD + 2 * j + lhalf], wreg[j], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+            const float v = q == 2 ? tanhf(acc[r]) : sigmoid_l(acc[r]);
+            if (row0 + rl < a.B) a.ga[gs * t + (size_t)(row0 + rl) * 4 * NH + col] = v;
+            Gs[(q * RT + rl) * 33 + lcol] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + 256 * e, rl = idx >> 5, u = idx & 31;
+            const float ig = Gs[(0 * RT + rl) * 33 + u], fg = Gs[(1 * RT + rl) * 33 + u], gg = Gs[(2 * RT + rl) * 33 + u], og = Gs[(3 * RT + rl) * 33 + u];
+            cst[e] = fg * cst[e] + ig * gg;
+            if (row0 + rl < a.B) {
+                const size_t o = hs * t + (size_t)(row0 + rl) * NH + g * CW + u;
+                a.c[o] = cst[e];
+                st_agent(a.h + o, og * tanhf(cst[e]));
+            }
+        }
+        __syncthreads();                                   // Gs is rewritten by the next step's gates
+    }
+}
+
 int g_fused = -1, g_ncu = 0;
 
 }  // namespace
@@ -558,5 +646,42 @@ int srvp_rollout_fused_bwd(const srvp_rollout_bwd_desc* d, hipStream_t st) {
         hipLaunchKernelGGL(kern, dim3(8 * cpx * k.G), dim3(256), lds, st, k);
     }
     SRVP_CHECK_LAUNCH("srvp_rollout_bwd(fused)");
+    return SRVP_OK;
+}
+
+// ---- persistent LSTM forward: 0 = not eligible (the caller keeps srvp_lstm_fwd), else the workspace size in bytes
+extern "C" int64_t srvp_lstm_fused_ws_bytes(int T, int B, int nh) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SRVP_LSTM_FUSED"); on = e ? atoi(e) : 1; }
+    if (!on || T < 1 || B < 1 || !(nh == 64 || nh == 128 || nh == 256)) return 0;
+    return (int64_t)((B + RT - 1) / RT) * 256;
+}
+extern "C" int srvp_lstm_fwd_fused(const float* gates_x, const float* w_hh, float* h_out, float* c_out, float* gates_act, int T, int B,
+                                   int nh, void* ws, int64_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SRVP_REQUIRE(gates_x && w_hh && h_out && c_out && gates_act && ws, "srvp_lstm_fwd_fused: null pointer");
+    const int64_t need = srvp_lstm_fused_ws_bytes(T, B, nh);
+    SRVP_REQUIRE(need > 0 && ws_bytes >= need, "srvp_lstm_fwd_fused: shape not eligible or workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)need);
+    if (!g_ncu) {
+        hipDeviceProp_t p; int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) p.multiProcessorCount = 256;
+        g_ncu = p.multiProcessorCount;
+    }
+    LstmF k{};
+    k.B = B; k.nh = nh; k.T = T; k.G = nh / CW; k.gx = gates_x; k.whh = w_hh; k.h = h_out; k.c = c_out; k.ga = gates_act; k.cnt = (unsigned*)ws;
+    const int tiles = (B + RT - 1) / RT;
+    const size_t lds = ((size_t)RT * (nh + 1) + 4 * RT * 33) * 4;
+    auto kern = nh == 256 ? lstm_fused_fwd_kernel<128> : (nh == 128 ? lstm_fused_fwd_kernel<64> : lstm_fused_fwd_kernel<32>);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_lstm_fwd_fused: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_lstm_fwd_fused: memset failed");
+    int cpx;
+    const int per = clusters_per_launch(k.G, tiles, cpx);
+    for (int t0 = 0; t0 < tiles; t0 += per) {
+        k.tile0 = t0; k.ntiles = tiles - t0 < per ? tiles - t0 : per; k.cl_per_xcd = cpx;
+        hipLaunchKernelGGL(kern, dim3(8 * cpx * k.G), dim3(256), lds, st, k);
+    }
+    SRVP_CHECK_LAUNCH("srvp_lstm_fwd_fused");
     return SRVP_OK;
 }

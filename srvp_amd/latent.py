@@ -168,8 +168,16 @@ class LatentNet:
         nh, nz = self.cfg['nh_inf'], self.cfg['nz']
         axpby(st, self.lstm_bias, 1.0, params['inf_z.bias_ih_l0'], 1.0, params['inf_z.bias_hh_l0'])
         linear_fwd(st, hx.view(T * B, -1), params['inf_z.weight_ih_l0'], self.lstm_bias, self.gates_x[:T * B])
-        L.call('srvp_lstm_fwd', L.ptr(self.gates_x), L.ptr(params['inf_z.weight_hh_l0']), L.ptr(self.hz), L.ptr(self.cz),
-               L.ptr(self.gates_act), T, B, nh, st)
+        need = int(L.load().srvp_lstm_fused_ws_bytes(T, B, nh))          # 0: shape not eligible for the persistent kernel
+        if need > 0:
+            ws = self.__dict__.get('_lstm_ws')
+            if ws is None or ws.numel() < need:
+                ws = self._lstm_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
+            L.call('srvp_lstm_fwd_fused', L.ptr(self.gates_x), L.ptr(params['inf_z.weight_hh_l0']), L.ptr(self.hz), L.ptr(self.cz),
+                   L.ptr(self.gates_act), T, B, nh, L.ptr(ws), need, st)
+        else:
+            L.call('srvp_lstm_fwd', L.ptr(self.gates_x), L.ptr(params['inf_z.weight_hh_l0']), L.ptr(self.hz), L.ptr(self.cz),
+                   L.ptr(self.gates_act), T, B, nh, st)
         if T > 1:
             nq = min(T - 1, self.F)
             linear_fwd(st, self.hz[B:(nq + 1) * B], params['q_z.weight'], params['q_z.bias'], self.q_z.view(-1, 2 * nz)[:nq * B])

@@ -215,3 +215,46 @@ def test_elbo_and_adam_kernels():
         grd = gr.to(dev)
         L.call('srvp_adam', L.ptr(pd_), L.ptr(grd), L.ptr(m), L.ptr(v), n, 3e-4, 0.9, 0.999, 1e-8, step, 1.0, st)
     assert (pd_.cpu() - sd['p']).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize('T,B,nh', [(12, 192, 256), (5, 37, 256), (1, 3, 128), (20, 100, 64), (7, 300, 128)])
+def test_persistent_lstm_forward(T, B, nh):
+    rel_l2 = lambda a, b: ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+    """srvp_lstm_fwd_fused (one persistent launch over the T steps) against the per-step launch sequence and against torch's
+    nn.LSTM recurrence on the CPU (srvp.py:132,366): hidden / cell states and the saved gate activations."""
+    import ctypes as C
+    from srvp_amd import _lib as L
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(T * 1000 + B + nh)
+    gx = torch.randn(T, B, 4 * nh, generator=g)                       # x W_ih^T + b_ih + b_hh, precomputed
+    whh = torch.randn(4 * nh, nh, generator=g) * (1.0 / nh ** 0.5)
+    gxd, wd = gx.to(dev), whh.to(dev)
+    st = L.stream()
+    outs = {}
+    for fused in (0, 1):
+        h = torch.full((T, B, nh), 7.0, device=dev); c = torch.full((T, B, nh), 7.0, device=dev); ga = torch.full((T, B, 4 * nh), 7.0, device=dev)
+        if fused:
+            need = int(L.load().srvp_lstm_fused_ws_bytes(T, B, nh))
+            assert need > 0
+            ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+            L.call('srvp_lstm_fwd_fused', L.ptr(gxd), L.ptr(wd), L.ptr(h), L.ptr(c), L.ptr(ga), T, B, nh, L.ptr(ws), need, st)
+        else:
+            L.call('srvp_lstm_fwd', L.ptr(gxd), L.ptr(wd), L.ptr(h), L.ptr(c), L.ptr(ga), T, B, nh, st)
+        torch.cuda.synchronize()
+        outs[fused] = (h.cpu(), c.cpu(), ga.cpu())
+    # CPU recurrence (gate order i, f, g, o)
+    hp, cp = torch.zeros(B, nh, dtype=torch.float64), torch.zeros(B, nh, dtype=torch.float64)
+    hs, cs = [], []
+    w64 = whh.double()
+    for t in range(T):
+        a = gx[t].double() + hp @ w64.t()
+        i, f, gg, o = torch.sigmoid(a[:, :nh]), torch.sigmoid(a[:, nh:2 * nh]), torch.tanh(a[:, 2 * nh:3 * nh]), torch.sigmoid(a[:, 3 * nh:])
+        cp = f * cp + i * gg
+        hp = o * torch.tanh(cp)
+        hs.append(hp); cs.append(cp)
+    href, cref = torch.stack(hs), torch.stack(cs)
+    for fused in (0, 1):
+        h, c, ga = outs[fused]
+        assert rel_l2(h, href) < 2e-6 and rel_l2(c, cref) < 2e-6, (fused, rel_l2(h, href), rel_l2(c, cref))
+    assert rel_l2(outs[1][2], outs[0][2]) < 2e-6
+    assert (gxd.cpu() == gx).all()                                     # the fused entry point leaves gates_x untouched
