@@ -192,11 +192,13 @@ def main():
         L.PROFILE, L.PROFILE_ONLY = {}, {'srvp_conv_mfma', 'srvp_conv_mfma_multi', 'srvp_wgrad_mfma'}
         train(fwd, optim, None, x, dev, opt)
         L.PROFILE, L.PROFILE_ONLY = None, None
-    # no cyclic-GC pause inside the timed region: the ~100 event objects of an instrumented step can trigger a full collection
-    # over the process's (large) object graph -- a 90 ms host stall, i.e. +7 ms per step of a 10-step run of the short-step configs
+    # Same garbage-collector treatment as a real run (srvp_amd.train.main: gc.collect(); gc.freeze() after set-up, collector left
+    # ON): the long-lived object graph (model, plans, descriptors) moves to the permanent generation, so the collections the
+    # ~100 event objects of an instrumented step trigger stay young-generation and cheap -- without it one of them walks the whole
+    # graph, a 90 ms host stall = +7 ms per step of a 10-step run of the short-step configs.
     import gc
     gc.collect()
-    gc.disable()
+    gc.freeze()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -209,7 +211,6 @@ def main():
             print(f'step {i} host t={1e3 * (time.perf_counter() - t0):.2f} ms', file=sys.stderr)
     barrier()
     dt = time.perf_counter() - t0
-    gc.enable()
     table = None
     if prof is not None and rank == 0:
         L.PROFILE = {}                      # untimed extra pass: every launch

@@ -272,6 +272,9 @@ int srvp_lstm_fwd(const float* gates_x, const float* w_hh, float* h_out, float* 
                   int T, int B, int nh, void* stream);
 /* the same forward as ONE persistent launch over the T steps (csrc/rollout_fused.hip: clusters of nh / 32 workgroups per 32-row batch
  * tile, W_hh slices resident in registers, h exchanged with agent-scope accesses, one counter barrier per step).
+ * (both persistent kernels: 0 is also returned when 8 * nh / 32 workgroups cannot be co-resident on the device; a cluster barrier
+ *  that waits longer than ~seconds -- workgroups not co-resident after all -- gives up and counts the event in word 1 of the tile's
+ *  256-byte counter block at the start of the workspace: results are then invalid, the device is not hung)
  * srvp_lstm_fused_ws_bytes: 0 = shape not eligible (nh in {64, 128, 256}), else the size of the zero-initialised-by-the-call workspace;
  * gates_x is not modified (srvp_lstm_fwd copies it into gates_act first) */
 int64_t srvp_lstm_fused_ws_bytes(int T, int B, int nh);

@@ -55,7 +55,14 @@ __device__ __forceinline__ void cluster_barrier(unsigned* cnt, unsigned target) 
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        // bounded spin (~seconds): if the cluster's workgroups are NOT co-resident (CU mask / partition / a device shared with
+        // another process: the launcher's eligibility test cannot see those) the kernel ends with garbage and a non-zero word
+        // word 1 of the tile's 256-byte counter block at the start of the workspace instead of hanging the device
+        unsigned spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 25)) { __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
     }
     __syncthreads();
 }
@@ -565,6 +572,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 int g_fused = -1, g_ncu = 0;
 
+int device_cus() {
+    if (!g_ncu) {
+        hipDeviceProp_t p; int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) p.multiProcessorCount = 256;
+        g_ncu = p.multiProcessorCount;
+    }
+    return g_ncu;
+}
+// The persistent kernels spin on inter-workgroup counters: every workgroup of a launch must be co-resident.  The smallest launch
+// is one cluster per XCD = 8 * G workgroups at one workgroup per CU (LDS), so a device (partition, CU mask) with fewer CUs than
+// that -- or a process that shares the device with others running the same kernels -- must keep the per-layer launch sequence:
+// SRVP_ROLLOUT_FUSED=0 / SRVP_LSTM_FUSED=0, or automatically when 8 * G exceeds the CU count.
+bool clusters_fit(int G) { return 8 * G <= device_cus(); }
+
 }  // namespace
 
 // 0 if this chain cannot run fused (the caller keeps the per-layer launch sequence), else the workspace size in bytes
@@ -575,6 +596,7 @@ extern "C" int64_t srvp_rollout_fused_ws_bytes(const srvp_rollout_desc* d) {
     if (d->nl < 2 || d->nl > MAX_NL || d->nh % CW != 0 || d->nh / CW > 32 || nin > KP0_MAX || d->ny > NYP_MAX || d->ny > d->nh ||
         d->nsteps < 1) return 0;
     if (!d->pz_external || !d->hid_dyn) return 0;
+    if (!clusters_fit(d->nh / CW)) return 0;
     const int kp0 = (nin + 15) / 16 * 16, nyp = (d->ny + 15) / 16 * 16;
     const size_t lds_f = ((size_t)(d->nl - 2) * d->nh * CW + RT * (kp0 + 1) + RT * d->ny + RT * 33 + NYP_MAX) * 4;
     const size_t lds_b = ((size_t)(d->nl - 2) * d->nh * CW + RT * (nyp + 1) + RT * d->ny + RT * 33) * 4;
@@ -584,11 +606,7 @@ extern "C" int64_t srvp_rollout_fused_ws_bytes(const srvp_rollout_desc* d) {
 }
 
 static int fused_common(const srvp_rollout_desc& f, RollF& k, void* ws) {
-    if (!g_ncu) {
-        hipDeviceProp_t p; int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) p.multiProcessorCount = 256;
-        g_ncu = p.multiProcessorCount;
-    }
+    device_cus();
     k.B = f.B; k.ny = f.ny; k.nz = f.nz; k.nh = f.nh; k.nl = f.nl; k.S = f.nsteps; k.ne = f.n_euler; k.G = f.nh / CW;
     k.nin = f.ny + f.nz; k.kp0 = (k.nin + 15) / 16 * 16; k.nyp = (f.ny + 15) / 16 * 16; k.dt = f.dt;
     for (int l = 0; l < MAX_NL; ++l) { k.W[l] = l < f.nl ? f.dyn_w[l] : nullptr; k.b[l] = l < f.nl ? f.dyn_b[l] : nullptr; }
@@ -654,6 +672,7 @@ extern "C" int64_t srvp_lstm_fused_ws_bytes(int T, int B, int nh) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("SRVP_LSTM_FUSED"); on = e ? atoi(e) : 1; }
     if (!on || T < 1 || B < 1 || !(nh == 64 || nh == 128 || nh == 256)) return 0;
+    if (!clusters_fit(nh / CW)) return 0;
     return (int64_t)((B + RT - 1) / RT) * 256;
 }
 extern "C" int srvp_lstm_fwd_fused(const float* gates_x, const float* w_hh, float* h_out, float* c_out, float* gates_act, int T, int B,
@@ -662,11 +681,7 @@ extern "C" int srvp_lstm_fwd_fused(const float* gates_x, const float* w_hh, floa
     SRVP_REQUIRE(gates_x && w_hh && h_out && c_out && gates_act && ws, "srvp_lstm_fwd_fused: null pointer");
     const int64_t need = srvp_lstm_fused_ws_bytes(T, B, nh);
     SRVP_REQUIRE(need > 0 && ws_bytes >= need, "srvp_lstm_fwd_fused: shape not eligible or workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)need);
-    if (!g_ncu) {
-        hipDeviceProp_t p; int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) p.multiProcessorCount = 256;
-        g_ncu = p.multiProcessorCount;
-    }
+    device_cus();
     LstmF k{};
     k.B = B; k.nh = nh; k.T = T; k.G = nh / CW; k.gx = gates_x; k.whh = w_hh; k.h = h_out; k.c = c_out; k.ga = gates_act; k.cnt = (unsigned*)ws;
     const int tiles = (B + RT - 1) / RT;

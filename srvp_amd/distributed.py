@@ -31,15 +31,27 @@ class NativeComm:
     def __init__(self, group=None):
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         lib = L.load()
+        # Every rank reaches the broadcast whatever happens on rank 0 (librccl missing, ncclGetUniqueId failing): rank 0 sends the
+        # error text instead of the id and ALL ranks raise, so the caller's fallback decision is the same everywhere -- a rank
+        # that raised before the broadcast would leave the others blocked inside it (mismatched collectives).
         ident = [None]
         if rank == 0:
             buf = C.create_string_buffer(128)
-            L.check(lib.srvp_comm_unique_id(buf), 'srvp_comm_unique_id')
-            ident = [bytes(buf.raw)]
+            if lib.srvp_comm_unique_id(buf) == 0:
+                ident = [bytes(buf.raw)]
+            else:
+                ident = ['error: ' + lib.srvp_last_error().decode()]
         dist.broadcast_object_list(ident, src=0, group=group)
+        if not isinstance(ident[0], bytes):
+            raise L.SrvpHipError(f'srvp_comm_unique_id failed on rank 0 ({ident[0]})')
         self.handle = C.c_void_p()
-        L.check(lib.srvp_comm_init(ident[0], rank, world, C.byref(self.handle)), 'srvp_comm_init')
         self.rank, self.world = rank, world
+        # communicator creation is itself collective inside RCCL; a rank whose srvp_comm_init fails reports it through the
+        # MIN all-reduce of Sync.__init__ (init_ok), it does not raise past its peers
+        self.init_error = None
+        if lib.srvp_comm_init(ident[0], rank, world, C.byref(self.handle)) != 0:
+            self.init_error = lib.srvp_last_error().decode()
+            self.handle = C.c_void_p()
 
     def allreduce(self, t):
         assert t.is_cuda and t.is_contiguous()
@@ -84,16 +96,27 @@ class Sync:
             native = (dist.get_backend(group) == 'nccl' and os.environ.get('SRVP_COMM', 'rccl') != 'torch'
                       and torch.cuda.is_available() and (self.world > 1 or self.force))
         if native:
+            made, why = [], None
+
+            def agree(ok):
+                flag = torch.tensor([1 if ok else 0], device='cuda')
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)      # every rank takes the same path
+                return int(flag.item()) == 1
             try:
-                g, s = NativeComm(group), NativeComm(group)
-                ok = torch.tensor([1 if (g.self_test() and s.self_test()) else 0], device='cuda')
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)        # every rank takes the same path
-                if int(ok.item()) == 1:
-                    self.native_grads, self.native_stats = g, s
-                else:
-                    g.close(), s.close()
-            except L.SrvpHipError as e:                  # librccl not loadable etc.: same on every rank
-                print(f'srvp_amd.distributed: native RCCL path unavailable ({e}); using torch.distributed')
+                for _ in range(2):                       # gradients, statistics
+                    made.append(NativeComm(group))
+                ok = all(c.init_error is None for c in made)
+                why = next((c.init_error for c in made if c.init_error), None)
+            except L.SrvpHipError as e:                  # raised on EVERY rank (NativeComm.__init__), so all ranks are here together
+                ok, why = False, str(e)
+            # two rounds of agreement: no rank enters the self-test's collectives unless every rank holds both communicators
+            ok = agree(ok) and agree(all(c.self_test() for c in made))
+            if ok:
+                self.native_grads, self.native_stats = made
+            else:
+                for c in made:                           # nothing created so far is leaked
+                    c.close()
+                print(f'srvp_amd.distributed: native RCCL path unavailable ({why or "failed on another rank / self-test"}); using torch.distributed')
         self.transport = 'rccl (C ABI, in-stream)' if self.native_stats is not None else f'torch.distributed ({dist.get_backend(group)})'
 
     def allreduce_stats(self, t, count):

@@ -172,9 +172,12 @@ def rank_rng_path(path, rank):
     return f'{path}.rng{rank}'
 
 
-def save_rank_rng(path, rank):
+def save_rank_rng(path, rank, itr=None):
+    """itr: the iteration the streams belong to -- load_train_state ignores a file whose iteration differs from the model's
+    (ranks write independently of rank 0's train_state.pt: a crash between the two writes, or a directory left by an earlier run,
+    would otherwise pair RNG state of iteration N with a model of iteration M unnoticed)."""
     tmp = rank_rng_path(path, rank) + '.tmp'
-    torch.save(_rng_state(), tmp)
+    torch.save(dict(_rng_state(), itr=itr), tmp)
     os.replace(tmp, rank_rng_path(path, rank))
 
 
@@ -199,9 +202,13 @@ def load_train_state(path, model, optimizer, lr_scheduler, device, rank=0, seed=
     rng = state.get('rng') or {}
     if rank > 0:
         rp = rank_rng_path(path, rank)
-        if os.path.exists(rp):
-            rng = torch.load(rp, map_location='cpu', weights_only=False)
+        own = torch.load(rp, map_location='cpu', weights_only=False) if os.path.exists(rp) else None
+        if own is not None and own.get('itr') == int(state['itr']):
+            rng = own
         else:
+            if own is not None:
+                print(f'srvp_amd.train: {rp} belongs to iteration {own.get("itr")}, the model to {state["itr"]}: RNG file ignored '
+                      '(seed-derived stream instead)')
             rng = dict(rng, numpy=None)
             np.random.seed(((seed or 0) + rank + 7919 * int(state['itr'])) % (2 ** 32))
     if rng.get('python') is not None:
@@ -294,7 +301,7 @@ def main(opt):
                 if itr >= opt.lr_scheduling_burnin:
                     lr_scheduler.step()
                 if local_rank > 0 and opt.chkpt_interval is not None and itr % opt.chkpt_interval == 0:
-                    save_rank_rng(os.path.join(opt.save_path, 'train_state.pt'), local_rank)
+                    save_rank_rng(os.path.join(opt.save_path, 'train_state.pt'), local_rank, itr)
                 if local_rank == 0:
                     if itr % opt.val_interval == 0 and val_loader is not None:
                         model.eval()
@@ -313,7 +320,7 @@ def main(opt):
         status_code = 130
     print('Saving...')
     if local_rank > 0:
-        save_rank_rng(os.path.join(opt.save_path, 'train_state.pt'), local_rank)
+        save_rank_rng(os.path.join(opt.save_path, 'train_state.pt'), local_rank, itr)
     if local_rank == 0:
         torch.save(model.state_dict(), os.path.join(opt.save_path, 'model.pt'))
         save_train_state(os.path.join(opt.save_path, 'train_state.pt'), model, optimizer, lr_scheduler, itr, best_val_metric)

@@ -48,12 +48,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--mode', choices=['hip', 'oracle'], required=True)
     ap.add_argument('--out', required=True)
+    ap.add_argument('--backend', choices=['gloo', 'nccl'], default='gloo',
+                    help='nccl: one rank per GPU over RCCL (needs >= world GPUs); srvp_amd.distributed then takes its native in-stream '
+                         'transport (csrc/comm.hip) unless SRVP_COMM=torch')
     a = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('gloo')
+        if a.backend == 'nccl':
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', rank)))
+        dist.init_process_group(a.backend)
     model, x, tape = problem()
     xs, ts = shard(x, tape, rank, world)
     n_local = xs.shape[1]
@@ -61,17 +66,19 @@ def main():
         import srvp_amd
         from srvp_amd import distributed as sdist
         from srvp_amd.train import fused_step
-        dev = torch.device('cuda', 0)
+        dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', rank)) if (a.backend == 'nccl' and world > 1) else 0)
         model = model.to(dev).train()
         if world > 1:
-            sdist.DataParallel(model, sdist.Sync(stat_group=dist.new_group()))
+            sync = sdist.Sync(stat_group=dist.new_group())
+            sdist.DataParallel(model, sync)
+            transport = sync.transport
         optim = srvp_amd.FusedAdam(model, lr=1e-3)
         optim.zero_grad()
         opt = srvp_amd.DotDict(dict(n_euler_steps=NE, **HP))
         acc = fused_step(model, xs.to(dev), opt, tape=ts)
         torch.cuda.synchronize()
         nll, kl_y0, kl_z, l2 = acc.cpu().tolist()
-        loss = torch.tensor([(nll + kl_y0 + kl_z + l2) / n_local], dtype=torch.float64)
+        loss = torch.tensor([(nll + kl_y0 + kl_z + l2) / n_local], dtype=torch.float64, device=dev if a.backend == 'nccl' else 'cpu')
         flat_g = model._flat[1][:sum(p.numel() for p in model.parameters())].detach().cpu().double()
         bufs = {k: v.detach().cpu().clone() for k, v in model.named_buffers()}
     else:
@@ -97,7 +104,7 @@ def main():
         dist.all_reduce(loss)
         loss /= world                                         # mean of the per-rank batch averages = global batch average
     if rank == 0:
-        torch.save(dict(loss=loss.item(), grad=flat_g, bufs=bufs), a.out)
+        torch.save(dict(loss=loss.item(), grad=flat_g, bufs=bufs, transport=locals().get('transport')), a.out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

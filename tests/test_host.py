@@ -189,3 +189,52 @@ def test_mnist_idx_reader_and_folds(tmp_path):
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mmnist.npz'))
     assert D.fold_ids(1000, 'val') == list(z['fold.val_1000'])
     assert D.fold_ids(1000, 'train')[:50] == list(z['fold.train_1000_head'])
+
+
+def test_integration_snippet_is_current():
+    """INTEGRATION.md prints the ctypes ConvDesc a maintainer would copy: it is generated from srvp_amd._lib.ConvDesc (whose
+    layout test_struct_layouts holds against include/srvp_hip.h), and must not fall behind it."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('gen_snip', os.path.join(root, 'tools', 'gen_integration_snippet.py'))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    cur = gen.current(open(os.path.join(root, 'INTEGRATION.md')).read())
+    assert cur is not None, 'markers missing'
+    assert cur == gen.snippet(), 'INTEGRATION.md ConvDesc snippet is stale: run python tools/gen_integration_snippet.py'
+    # and it really is the whole struct: executing the snippet's class gives the header's sizeof
+    import ctypes as C
+    from srvp_amd import _lib as L
+    body = cur.split('```python\n')[1].split('lib.srvp_conv_mfma.argtypes')[0].replace("lib = C.CDLL('srvp_amd/libsrvp_hip.so')", '')
+    ns = {}
+    exec(body, ns)
+    assert C.sizeof(ns['ConvDesc']) == C.sizeof(L.ConvDesc)
+
+
+def test_rank_rng_file_carries_its_iteration(tmp_path):
+    """a per-rank RNG file written at another iteration than the model state is ignored on resume (seed-derived
+    stream instead) -- ranks > 0 write theirs independently of rank 0's train_state.pt."""
+    import numpy as np
+    import torch
+    from srvp_amd import train as T
+
+    class _Obj:
+        def state_dict(self):
+            return {}
+
+        def load_state_dict(self, sd):
+            pass
+    path = str(tmp_path / 'train_state.pt')
+    T.save_train_state(path, _Obj(), _Obj(), _Obj(), 40, None)
+    np.random.seed(123)
+    T.save_rank_rng(path, 1, 40)
+    want = np.random.rand()
+    np.random.seed(5)
+    T.load_train_state(path, _Obj(), _Obj(), _Obj(), 'cpu', rank=1, seed=9)
+    assert np.random.rand() == want                          # matching iteration: the rank's own stream continues
+    np.random.seed(123)
+    T.save_rank_rng(path, 1, 30)                             # stale file (e.g. left by an earlier run)
+    T.load_train_state(path, _Obj(), _Obj(), _Obj(), 'cpu', rank=1, seed=9)
+    got = np.random.rand()
+    np.random.seed((9 + 1 + 7919 * 40) % (2 ** 32))
+    assert got == np.random.rand() and got != want           # ignored: seed-derived stream of (seed, rank, iteration)

@@ -29,15 +29,16 @@ def _free_port():
     return p
 
 
-def _run(mode, world, out):
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', SRVP_DIST_BACKEND='gloo')
+def _run(mode, world, out, backend='gloo', extra_env=None):
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', SRVP_DIST_BACKEND=backend)
+    env.update(extra_env or {})
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
         env.pop(k, None)
     if world == 1:
-        cmd = [sys.executable, WORKER, '--mode', mode, '--out', out]
+        cmd = [sys.executable, WORKER, '--mode', mode, '--out', out, '--backend', backend]
     else:
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
-               '--master-port', str(_free_port()), WORKER, '--mode', mode, '--out', out]
+               '--master-port', str(_free_port()), WORKER, '--mode', mode, '--out', out, '--backend', backend]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return torch.load(out, weights_only=False)
@@ -81,3 +82,27 @@ def test_hip_two_ranks_equal_one(tmp_path, world):
     finally:
         del os.environ['SRVP_PRECISION']
     _compare(one, many, 1e-6, 2e-3, 1e-5)       # (fp32 summation order on an ill-conditioned BN network: ~5e-4 on the gradient)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('comm', ['rccl', 'torch'])
+def test_hip_ranks_equal_one_over_rccl(tmp_path, comm):
+    """The same statement over the transport a multi-GPU node uses: one rank per GPU, backend nccl (= RCCL over xGMI), and
+    -- comm 'rccl' -- the native in-stream path of csrc/comm.hip (two communicators, collectives enqueued from the compute and
+    the weight-gradient streams), which single-GPU boxes can only exercise with one rank.  Needs >= 2 GPUs: skipped on the
+    1-GPU test boxes, runs on the driver's multi-GPU node."""
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip(f'{n} GPU visible: RCCL refuses two ranks on one device')
+    world = 2 if n < 4 else 3                  # B_GLOBAL = 6 splits over 2 and 3 ranks
+    os.environ['SRVP_PRECISION'] = 'fp32'
+    try:
+        one = _run('hip', 1, str(tmp_path / 'one.pt'))
+        many = _run('hip', world, str(tmp_path / 'many.pt'), backend='nccl', extra_env={'SRVP_COMM': comm})
+    finally:
+        del os.environ['SRVP_PRECISION']
+    if comm == 'rccl':
+        assert 'C ABI' in (many.get('transport') or ''), many.get('transport')     # the native path was selected (self-test passed)
+    else:
+        assert 'torch.distributed (nccl)' in (many.get('transport') or ''), many.get('transport')
+    _compare(one, many, 1e-6, 2e-3, 1e-5)
