@@ -33,6 +33,10 @@ CONFIGS = {
                  res_gain=1.41, batch=192, label='BAIR 64x64x3 vgg+skipco seq_len=12 n_euler=2'),
     'kth': dict(ctor=(64, 1, 64, 128, 50, 50, True, 3, 256, 3, 512, 4, 'vgg'), T=20, n_euler=2, obs_scale=0.2, beta_z=1.0,
                 res_gain=1.2, batch=100, label='KTH 64x64x1 vgg+skipco seq_len=20 n_euler=2'),
+    # Human3.6M (BASELINE.json config 5): training T=16, B=100; test.py protocol: 8 conditioning frames -> 53 frames, 100 samples
+    'human': dict(ctor=(64, 3, 64, 128, 50, 50, True, 3, 256, 3, 512, 4, 'vgg'), T=16, n_euler=2, obs_scale=0.2, beta_z=1.0,
+                  res_gain=1.2, batch=100, label='Human3.6M 64x64x3 vgg+skipco seq_len=16 n_euler=2',
+                  nt_cond=8, nt_test=53, batch_test=8, n_samples=100),
     'smmnist': dict(ctor=(64, 1, 64, 128, 20, 20, False, 5, 256, 3, 512, 4, 'dcgan'), T=15, n_euler=1, obs_scale=1.0, beta_z=2.0,
                     res_gain=1.41, batch=128, label='SM-MNIST 64x64x1 dcgan seq_len=15'),
 }
@@ -107,6 +111,122 @@ def cpu_baseline(cfg, seconds=20.0):
                        f'architecture at B={B}, T={T} ({B * T} frames/step, {dt:.2f} s/step)')
 
 
+def rollout_cpu_baseline(cfg, nt_cond, nt, seconds=15.0):
+    """The reference's protocol on the host cores through the oracle: one inference forward (encode + posterior on the conditioning
+    frames + prior rollout + decode of all nt frames) per sampled future, B = 1 video."""
+    from oracle import srvp_oracle as O
+    import srvp_amd
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = min(cores, 16)
+    torch.set_num_threads(cores)
+    torch.manual_seed(1)
+    m = srvp_amd.StochasticLatentResidualVideoPredictor(*cfg['ctor'])
+    m.init(cfg['res_gain'])
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    ocfg = O.make_cfg(*cfg['ctor'])
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(nt_cond, 1, cfg['ctor'][1], 64, 64, generator=g)
+    ny, nz = cfg['ctor'][4], cfg['ctor'][5]
+    t0, n = time.time(), 0
+    with torch.no_grad():
+        while time.time() - t0 < seconds or n < 2:
+            tape = dict(eps_y0=torch.randn(1, ny, generator=g), eps_z=torch.randn(nt - 1, 1, nz, generator=g))
+            O.forward(sd, ocfg, x, nt, cfg['n_euler'], tape, training=False)
+            n += 1
+    dt = (time.time() - t0) / n
+    return dict(value=nt / dt, unit='frames/s', cores=cores, kind='port',
+                sample=f'{n} oracle inference forwards (fp32, torch {torch.__version__} CPU): 1 video, {nt_cond} conditioning frames -> '
+                       f'{nt} decoded frames per sampled future ({dt:.2f} s each)')
+
+
+def rollout_bench(args, cfg, dev, world, rank, real_stdout):
+    """--mode rollout: reference test.py:219-246 / train.py:170-174 (best-of-S prediction) as model.sample launches."""
+    import srvp_amd
+    from srvp_amd import _lib as L
+    nt_cond, nt = cfg.get('nt_cond', 2), cfg.get('nt_test', 30)
+    B = args.batch if args.batch is not None else cfg.get('batch_test', 16)
+    S = args.samples if args.samples is not None else cfg.get('n_samples', 100)
+    torch.manual_seed(1)
+    model = srvp_amd.StochasticLatentResidualVideoPredictor(*cfg['ctor'])
+    model.init(res_gain=cfg['res_gain'])
+    model.to(dev).eval()
+    g = torch.Generator().manual_seed(123 + rank)
+    x = torch.rand(nt_cond, B, cfg['ctor'][1], 64, 64, generator=g).to(dev)
+    lim = int(os.environ.get('SRVP_EVAL_FRAMES', 9216))
+    chunk = max(1, min(S, lim // (nt * B)))
+    nchunks = -(-S // chunk)
+    dt_e = 1.0 / cfg['n_euler']
+
+    def step():
+        for _ in range(nchunks):                     # (the last chunk is drawn at the common size, like train.evaluate)
+            model.sample(x, nt, chunk, dt=dt_e)
+    for _ in range(max(1, args.warmup)):
+        step()
+    prof = None
+    if not args.no_kernel_timing:
+        L.PROFILE, L.PROFILE_ONLY = {}, {'srvp_conv_mfma', 'srvp_conv_mfma_multi'}
+        step()                                       # first timing event of the process: outside the timed region
+        L.PROFILE, L.PROFILE_ONLY = None, None
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = tmax.item()
+    if not args.no_kernel_timing:
+        prof = L.PROFILE = {}
+        L.PROFILE_ONLY = None
+        step()
+        torch.cuda.synchronize()
+        L.PROFILE = None
+    if rank != 0:
+        torch.distributed.destroy_process_group()
+        return
+    frames_step = nchunks * chunk * B * nt
+    fl = conv_flops(model, nt_cond * B, nt * B * chunk)          # encoder on the conditioning frames once per chunk, decoder on every frame
+    line = {
+        'metric': f'rollout decoded frames/sec ({cfg["label"].split(" seq_len")[0]}, {nt_cond} conditioning frames -> {nt}-frame horizon, {S} futures per video)',
+        'value': frames_step * world * args.steps / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': model.precision,
+        'data': 'synthetic (uniform random conditioning frames, random-init weights)',
+        'config': {'workload': f'{cfg["label"].split(" seq_len")[0]} rollout: nt_cond={nt_cond}, seq_len_test={nt}, n_samples={S}, test batch {B}',
+                   'per_gpu_batch': B, 'samples_per_call': chunk, 'calls_per_step': nchunks, 'parallelism': f'dp{world} (replicas)',
+                   'step': 'model.sample: one encoding of the conditioning frames, posterior on them, prior rollout and decoding of every '
+                           'frame of every future (reference test.py:237-246 runs one inference forward + generate + decode per future)'},
+        'model_flops_frac_of_bf16_peak': ((fl['fwd_all']) * nchunks * world * args.steps / dt) / (PEAK_BF16_TFLOPS * 1e12 * world),
+    }
+    if prof:
+        full = {name: sum(a.elapsed_time(b) for a, b in evs) for name, evs in prof.items()}
+        conv_ms = full.get('srvp_conv_mfma', 0.0) + full.get('srvp_conv_mfma_multi', 0.0)
+        nl = len(prof.get('srvp_conv_mfma', [])) + len(prof.get('srvp_conv_mfma_multi', []))
+        ach = fl['fwd_mfma'] * nchunks / (conv_ms * 1e-3) / 1e12
+        line['roofline'] = {'bound': 'mfma', 'kernel': 'conv_halo_kernel / conv_mfma_kernel (srvp_conv_mfma: decoder + encoder forward implicit GEMMs)',
+                            'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': None,
+                            'algorithmic_flops_per_launch': fl['fwd_mfma'] * nchunks / max(1, nl), 'launches_per_step': nl,
+                            'ms_per_step': conv_ms, 'avg_launch_us': conv_ms / max(1, nl) * 1e3,
+                            'note': 'algorithmic = 2*MACs of the reference layer definitions for every decoded frame; the hoisted skip '
+                                    'half and the sub-pixel convolutions execute fewer'}
+        line['kernel_ms_per_step'] = {k: round(v, 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1])}
+        line['kernel_ms_total'] = round(sum(full.values()), 3)
+    if world == 1 and not args.no_cpu_baseline:
+        line['cpu_baseline'] = rollout_cpu_baseline(cfg, nt_cond, nt)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(line) + '\n').encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -120,6 +240,11 @@ def main():
     ap.add_argument('--h2d', choices=['none', 'u8'], default='none',
                     help="u8: every step starts from a pinned uint8 host batch (H2D copy + device-side /255 collate inside the timed "
                          "region, as reference train.py:84 pays it); default: batch resident in HBM (the contract's `value`)")
+    ap.add_argument('--mode', choices=['train', 'rollout'], default='train',
+                    help="rollout: the long-horizon prediction protocol of reference test.py:219-246 (config 5: --config human -> 8 conditioning "
+                         "frames, 53-frame horizon, 100 sampled futures per video, test batch 8) through model.sample; one step = the "
+                         "S futures of one test batch, value = decoded frames/s")
+    ap.add_argument('--samples', type=int, default=None, help='rollout mode: futures per video (default: the recipe, 100)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
@@ -152,6 +277,8 @@ def main():
         sync = sdist.init_process_group(backend)
 
     cfg = CONFIGS[args.config]
+    if args.mode == 'rollout':
+        return rollout_bench(args, cfg, dev, world, rank, real_stdout)
     T = cfg['T']
     if args.batch is None:
         args.batch = cfg['batch']

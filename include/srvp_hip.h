@@ -155,6 +155,15 @@ int srvp_bn_act_keep_f32(const void* raw, const float* scale, const float* shift
                          void* dst, int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep_frames,
                          void* stream);
 
+/* srvp_bn_finalize + srvp_bn_act_keep(_f32) as ONE launch (replaces the two-kernel sequence placed by conv.py:103-106 in training
+ * mode): every workgroup derives the coefficients from `stats` / `count` once into LDS (same fp64 expressions as
+ * srvp_bn_finalize: bit-identical values), workgroup 0 stores scale / shift / mean / invstd and updates the running statistics. */
+int srvp_bn_finalize_act(const void* raw, const double* stats, double count, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
+                         float* mean, float* invstd, int C_real, float eps, float momentum, int act, int N, int H, int W, int C,
+                         void* dst, int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep_frames,
+                         int elem_f32, void* stream);
+
 /* backward of activation+BN.  dA comes from one or two places:
  *   main: tensor `da` with channel stride da_cstride / offset da_coff, mode 0 = same resolution,
  *         mode 1 = gradient of the nearest-x2-upsampled tensor (sum the 2x2 block),
@@ -185,6 +194,10 @@ int srvp_bn_bwd_finalize(const double* red, double count, const float* scale, co
                          void* stream);
 /* pass 2: draw = scale*(g - mean_g - xhat*mean_gx) -> bf16 tensor with border `dst_border` */
 int srvp_bn_bwd_apply(const srvp_bnbwd_desc* d, const float* coef, void* draw, int dst_border, void* stream);
+/* srvp_bn_bwd_finalize (has_bn = 1) + srvp_bn_bwd_apply as ONE launch: coefficients derived per workgroup into LDS, workgroup 0
+ * adds dgamma / dbeta (times param_grad_scale) and stores `coef` (may be NULL); d->mean / d->invstd required */
+int srvp_bn_bwd_finalize_apply(const srvp_bnbwd_desc* d, const double* red, double count, float* dgamma, float* dbeta, float* coef,
+                               int C_real, float param_grad_scale, void* draw, int dst_border, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Small-channel layers (first encoder conv, last decoder conv; conv.py:174,200,304,353), direct fp32 VALU
@@ -375,6 +388,13 @@ int srvp_frames_u8_to_f32(const void* in_u8, float* out, int B, int T, int H, in
  * out_u8 uint8 [B][T][nx][nx] (the reference's per-video arrays); either may be NULL. */
 int srvp_mmnist_render(const void* digits_u8, int n_digits, int dh, int dw, const int* idx, const int* pos, int B, int T,
                        int num_digits, int nx, float* out, void* out_u8, void* stream);
+/* The trajectories themselves on the device (data/mmnist.py:113-237: digit index, start, speed, bounces with a fresh speed at every
+ * wall contact): one thread per object, counter-based Philox4x32-10 keyed by `seed`, counter (draw block, object, batch_counter) --
+ * batch k of a run is a function of (seed, k) alone.  idx int32 [B][num_digits], pos int32 [B][num_digits][T][2] (row, column offset:
+ * the inputs of srvp_mmnist_render), contacts (optional) int32 [B][num_digits] = wall contacts of each object.  Equal to the
+ * reference generator in distribution, not in its np.random stream. */
+int srvp_mmnist_trajectories(uint64_t seed, uint64_t batch_counter, int B, int num_digits, int T, int nx, int dh, int dw,
+                             int max_speed, int deterministic, int n_digits, int* idx, int* pos, int* contacts, void* stream);
 int srvp_cast_f32_bf16(const float* src, void* dst, int64_t rows, int cols, int dst_cols, void* stream);
 /* dst bf16 [M][C] = sum_z parts[z * slab_elems + m * C + c] (z ascending), the slabs of an srvp_conv_mfma launch with splitk > 1;
  * stats (may be NULL): += per-column sum and sum of squares of the fp32 sums (column c -> stats[c % stat_mod], stats[stat_mod + c %

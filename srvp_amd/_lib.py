@@ -96,6 +96,9 @@ _SIGS = {
     'srvp_bn_act': ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp], c_i32),
     'srvp_bn_act_keep': ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp], c_i32),
     'srvp_bn_act_keep_f32': ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp], c_i32),
+    'srvp_bn_finalize_act': ([c_vp, c_vp, c_f64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_f32, c_i32, c_i32, c_i32, c_i32,
+                             c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp], c_i32),
+    'srvp_bn_bwd_finalize_apply': ([C.POINTER(BnBwdDesc), c_vp, c_f64, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_i32, c_vp], c_i32),
     'srvp_bn_bwd_reduce': ([C.POINTER(BnBwdDesc), c_vp, c_vp], c_i32),
     'srvp_bn_bwd_finalize': ([c_vp, c_f64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp], c_i32),
     'srvp_bn_bwd_apply': ([C.POINTER(BnBwdDesc), c_vp, c_vp, c_i32, c_vp], c_i32),
@@ -138,6 +141,7 @@ _SIGS = {
     'srvp_fill_f64': ([c_vp, c_i64, c_f64, c_vp], c_i32),
     'srvp_frames_u8_to_f32': ([c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_mmnist_render': ([c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp], c_i32),
+    'srvp_mmnist_trajectories': ([C.c_uint64, C.c_uint64] + [c_i32] * 9 + [c_vp, c_vp, c_vp, c_vp], c_i32),
     'srvp_cast_f32_bf16': ([c_vp, c_vp, c_i64, c_i32, c_i32, c_vp], c_i32),
     'srvp_splitk_finish': ([c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp], c_i32),
     'srvp_pad_f32': ([c_vp, c_vp, c_i64, c_i32, c_i32, c_vp], c_i32),

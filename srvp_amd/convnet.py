@@ -19,6 +19,10 @@ from . import _lib as L
 CP = 32                      # channel padding granule
 SUBPIX = os.environ.get('SRVP_SUBPIX', '1') != '0'
 S2D = os.environ.get('SRVP_SUBPIX_S2D', '1') != '0'
+BN_FUSED_FINALIZE = os.environ.get('SRVP_BN_FUSED_FINALIZE', '1') != '0'    # bn_finalize / bn_bwd_finalize folded into bn_act / bn_bwd_apply
+# encoder weight gradients on the second stream when the batch is small (<= this many frames): grids of 100-600 workgroups do not
+# fill the chip, so the weight gradient of block i runs beside the BatchNorm backward / data gradient of block i - 1
+ENC_WGRAD_SIDE_MAXN = int(os.environ.get('SRVP_ENC_WGRAD_SIDE_MAXN', '0'))
 S_QUAD = os.environ.get('SRVP_S_QUAD', '1') != '0'        # hoisted skip half stored pixel-quad-major (16-byte loads in the consumers)
 SPLITK = int(os.environ.get('SRVP_CONV_SPLITK', '16'))    # tiny-M long-K launches: K steps shared over this many workgroups
 # Sub-pixel form of "nearest x2 upsample, then 3x3 conv" (conv.py:331-349): output phase a in {0,1} of a row pair reads
@@ -772,6 +776,11 @@ class ConvNetBase:
     def _bn_forward(self, blk, params, st, sync, keep=None):
         N, C_ = blk.N, blk.cout
         scale, shift, mean, invstd = (blk.coef[i] for i in range(4))
+        out, pool = blk.out, blk.pool
+        act_args = (blk.act, N, blk.OH, blk.OW, C_,
+                    L.ptr(out.t) if out is not None else None, out.b if out is not None else 0,
+                    L.ptr(pool.t) if pool is not None else None, pool.b if pool is not None else 0,
+                    L.ptr(blk.out_f32), L.ptr(keep) if pool is not None else None)
         if blk.has_bn:
             bk = blk.spec['bnkey']
             g, b = params[bk + '.weight'], params[bk + '.bias']
@@ -780,17 +789,18 @@ class ConvNetBase:
                 count = float(N * blk.OH * blk.OW)
                 if sync is not None:
                     count = sync.allreduce_stats(blk.stats, count)
+                blk.count = count
+                if BN_FUSED_FINALIZE:
+                    L.call('srvp_bn_finalize_act', L.ptr(blk.raw), L.ptr(blk.stats), count, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(nbt),
+                           L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), blk.cout_r, BN_EPS, BN_MOMENTUM, *act_args,
+                           1 if blk.f32 else 0, st)
+                    return
                 L.call('srvp_bn_finalize', L.ptr(blk.stats), count, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(nbt),
                        L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), C_, blk.cout_r, BN_EPS, BN_MOMENTUM, st)
-                blk.count = count
             else:
                 L.call('srvp_bn_eval_coeffs', L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(scale), L.ptr(shift), C_,
                        blk.cout_r, BN_EPS, st)
-        out, pool = blk.out, blk.pool
-        L.call('srvp_bn_act_keep_f32' if blk.f32 else 'srvp_bn_act_keep', L.ptr(blk.raw), L.ptr(scale), L.ptr(shift), blk.act, N, blk.OH, blk.OW, C_,
-               L.ptr(out.t) if out is not None else None, out.b if out is not None else 0,
-               L.ptr(pool.t) if pool is not None else None, pool.b if pool is not None else 0,
-               L.ptr(blk.out_f32), L.ptr(keep) if pool is not None else None, st)
+        L.call('srvp_bn_act_keep_f32' if blk.f32 else 'srvp_bn_act_keep', L.ptr(blk.raw), L.ptr(scale), L.ptr(shift), *act_args, st)
 
     def _block_forward(self, blk, params, st, sync, x=None, keep=None):
         if blk.role == 'in':
@@ -826,6 +836,8 @@ class ConvNetBase:
         d.da_is_f32 = 1 if da.get('f32') else 0
         d.da2, d.da2_idx = L.ptr(da.get('da2')), L.ptr(da.get('da2_idx'))
         d.N, d.H, d.W, d.C = blk.N, blk.OH, blk.OW, blk.cout
+        if blk.split and blk.draw_b == 1:
+            d.tsum, d.tsum_T = L.ptr(blk.draw_sum), blk.N // blk.B      # time-summed gradient for the hoisted skip half
         if blk.has_bn:
             L.call('srvp_bn_bwd_reduce', C.byref(d), L.ptr(blk.red), st)
             local = float(blk.N * blk.OH * blk.OW)
@@ -835,12 +847,16 @@ class ConvNetBase:
             bk = blk.spec['bnkey']
             # (count / local = number of ranks whose sums are in `red`: the parameter gradients are formed from the global sums
             # and must come out world times smaller, see srvp_hip.h)
+            if BN_FUSED_FINALIZE:
+                L.call('srvp_bn_bwd_finalize_apply', C.byref(d), L.ptr(blk.red), count, L.ptr(grads[bk + '.weight']), L.ptr(grads[bk + '.bias']),
+                       L.ptr(blk.bcoef), blk.cout_r, local / count, L.ptr(blk.draw), blk.draw_b, st)
+                return
             L.call('srvp_bn_bwd_finalize', L.ptr(blk.red), count, L.ptr(blk.coef[0]), L.ptr(blk.coef[2]), L.ptr(blk.coef[3]),
                    L.ptr(grads[bk + '.weight']), L.ptr(grads[bk + '.bias']), L.ptr(blk.bcoef), blk.cout, blk.cout_r, 1, local / count, st)
-        else:
+        elif not getattr(blk, '_bcoef_const', False):
+            # block without BatchNorm: constant coefficients (1, 0, 0), written once
             L.call('srvp_bn_bwd_finalize', None, 1.0, None, None, None, None, None, L.ptr(blk.bcoef), blk.cout, blk.cout_r, 0, 1.0, st)
-        if blk.split and blk.draw_b == 1:
-            d.tsum, d.tsum_T = L.ptr(blk.draw_sum), blk.N // blk.B      # time-summed gradient for the hoisted skip half
+            blk._bcoef_const = True
         L.call('srvp_bn_bwd_apply', C.byref(d), L.ptr(blk.bcoef), L.ptr(blk.draw), blk.draw_b, st)
 
     @staticmethod
@@ -999,7 +1015,15 @@ class EncoderNet(ConvNetBase):
                 L.call('srvp_conv_in_wgrad_f32' if blk.f32 else 'srvp_conv_in_wgrad', L.ptr(x), L.ptr(blk.draw), L.ptr(grads[w]), blk.N, blk.cin_r[0], 64, 64,
                        blk.cout, blk.cout_r, blk.k, blk.s, blk.p, st)
             else:
-                self._mfma_backward(blk, grads, st)
+                if side is not None and self.N <= ENC_WGRAD_SIDE_MAXN:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    with torch.cuda.stream(side):
+                        side.wait_event(ev)
+                        self._wgrad(blk, L.stream())
+                    self._mfma_backward(blk, grads, st, wgrad=False)
+                else:
+                    self._mfma_backward(blk, grads, st)
                 pooled = blk.spec['pre'] == 'pool'
                 da = dict(t=blk.dcat, mode=2 if pooled else 0, cstride=blk.dcat_c, coff=0, border=0)
         if not unpacked:

@@ -61,6 +61,20 @@ struct PixWalk {
     }
 };
 
+// Finalize folded into the consumer (srvp_bn_finalize_act / srvp_bn_bwd_finalize_apply): every workgroup derives the per-channel
+// coefficients ONCE into LDS (thread t: channels t, t + 256, ... -- the same fp64 expressions as the stand-alone finalize kernels,
+// so the values are bit-identical), workgroup 0 also stores them / updates the running statistics / adds the parameter
+// gradients.  42 dependent ~6 us launches per step less.  (Every THREAD deriving the coefficients of its own eight channels --
+// 8 fp64 divisions + square roots x 256 threads x 4096 workgroups -- was measured slower than the separate launches, round 1.)
+struct BnFin {
+    const double* stats; double count; const float* gamma; const float* beta; float* rmean; float* rvar; long long* nbt;
+    float* scale; float* shift; float* mean; float* invstd; int C_real; float eps, momentum;
+};
+struct BnBwdFin {
+    const double* red; double count; float* dgamma; float* dbeta; float* coef; int C_real; float pscale;
+};
+constexpr int BN_MAX_C = 2048;       // C / 8 <= 256 channel groups
+
 // ACT >= 0: the activation is a compile-time constant (LeakyReLU, all but two layers of each network); ACT < 0: run-time
 // `act` -- a per-element switch over five activations with exp / division bodies that the compiler cannot hoist out of the
 // pixel loops, which made these HBM-streaming kernels instruction-bound.
@@ -68,17 +82,45 @@ template <class E, bool POOL, int ACT>
 __global__ __launch_bounds__(256) void bn_act_kernel(const E* __restrict__ raw, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, int act, int N, int H, int W, int C,
                                                      E* __restrict__ dst, int db, E* __restrict__ dpool, int pb,
-                                                     float* __restrict__ dst_f32, const int* __restrict__ keep) {
+                                                     float* __restrict__ dst_f32, const int* __restrict__ keep, const BnFin fin) {
     if (ACT >= 0) act = ACT;
     const int CG = C / 8;
     const int PPB = blockDim.x / CG;             // (pooled) pixels handled in parallel by one workgroup
     const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
-    if (pl >= PPB) return;
+    float sc[8], sh[8];
+    if (fin.stats) {
+        __shared__ float s_coef[2 * BN_MAX_C];
+        const bool lead = blockIdx.x == 0;
+        if (lead && threadIdx.x == 0 && fin.nbt) *fin.nbt += 1;
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            float scv = 0.f, shv = 0.f, mv = 0.f, isv = 0.f;
+            if (c < fin.C_real) {
+                const double m = fin.stats[c] / fin.count;
+                double var = fin.stats[C + c] / fin.count - m * m;
+                if (var < 0.) var = 0.;
+                const double is = 1.0 / sqrt(var + (double)fin.eps);
+                const float g = fin.gamma ? fin.gamma[c] : 1.f, b = fin.beta ? fin.beta[c] : 0.f;
+                mv = (float)m; isv = (float)is; scv = (float)(g * is); shv = (float)(b - m * g * is);
+                if (lead && fin.rmean) {
+                    const double unb = fin.count > 1. ? var * fin.count / (fin.count - 1.) : var;
+                    fin.rmean[c] = (1.f - fin.momentum) * fin.rmean[c] + fin.momentum * (float)m;
+                    fin.rvar[c] = (1.f - fin.momentum) * fin.rvar[c] + fin.momentum * (float)unb;
+                }
+            }
+            s_coef[c] = scv; s_coef[C + c] = shv;
+            if (lead) { fin.scale[c] = scv; fin.shift[c] = shv; fin.mean[c] = mv; fin.invstd[c] = isv; }
+        }
+        __syncthreads();
+        if (pl >= PPB) return;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = s_coef[cg * 8 + e]; sh[e] = s_coef[C + cg * 8 + e]; }
+    } else {
+        if (pl >= PPB) return;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = scale[cg * 8 + e]; sh[e] = shift[cg * 8 + e]; }
+    }
     const int OH = POOL ? H / 2 : H, OW = POOL ? W / 2 : W;
     const unsigned P = (unsigned)N * OH * OW, stride = gridDim.x * PPB;
-    float sc[8], sh[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { sc[e] = scale[cg * 8 + e]; sh[e] = shift[cg * 8 + e]; }
     PixWalk w;
     w.init(blockIdx.x * PPB + pl, stride, OH, OW);
     constexpr int R = POOL ? 2 : 1;
@@ -413,16 +455,46 @@ __global__ void bn_bwd_finalize_kernel(const double* red, double count, const fl
 
 template <class E, int MODE, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK a, const float* __restrict__ coef,
-                                                           E* __restrict__ draw, int db) {
+                                                           E* __restrict__ draw, int db, const BnBwdFin fin) {
     const int CG = a.C / 8;
     const int PPB = blockDim.x / CG;
     const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
-    if (pl >= PPB) return;
     float sc[8], sh[8], k1[8], k2[8], k3[8];
+    if (fin.red) {
+        __shared__ float s_k[3 * BN_MAX_C];
+        const bool lead = blockIdx.x == 0;
+        const int C = a.C;
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            float c1 = 0.f, c2 = 0.f, c3 = 0.f;
+            if (c < fin.C_real) {
+                const double sg = fin.red[c], sgx = fin.red[C + c];
+                if (lead) {
+                    if (fin.dgamma) fin.dgamma[c] += (float)(sgx * fin.pscale);
+                    if (fin.dbeta) fin.dbeta[c] += (float)(sg * fin.pscale);
+                }
+                const double mg = sg / fin.count, mgx = sgx / fin.count;
+                const double k1d = a.scale[c];
+                const double k3d = -k1d * mgx * a.invstd[c];
+                const double k2d = -k1d * mg - k3d * a.mean[c];
+                c1 = (float)k1d; c2 = (float)k2d; c3 = (float)k3d;
+            }
+            s_k[c] = c1; s_k[C + c] = c2; s_k[2 * C + c] = c3;
+            if (lead && fin.coef) { fin.coef[c] = c1; fin.coef[C + c] = c2; fin.coef[2 * C + c] = c3; }
+        }
+        __syncthreads();
+        if (pl >= PPB) return;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        sc[e] = a.scale[cg * 8 + e]; sh[e] = a.shift[cg * 8 + e];
-        k1[e] = coef[cg * 8 + e]; k2[e] = coef[a.C + cg * 8 + e]; k3[e] = coef[2 * a.C + cg * 8 + e];
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = a.scale[cg * 8 + e]; sh[e] = a.shift[cg * 8 + e];
+            k1[e] = s_k[cg * 8 + e]; k2[e] = s_k[C + cg * 8 + e]; k3[e] = s_k[2 * C + cg * 8 + e];
+        }
+    } else {
+        if (pl >= PPB) return;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = a.scale[cg * 8 + e]; sh[e] = a.shift[cg * 8 + e];
+            k1[e] = coef[cg * 8 + e]; k2[e] = coef[a.C + cg * 8 + e]; k3[e] = coef[2 * a.C + cg * 8 + e];
+        }
     }
     if constexpr (MODE == 2) {
         const unsigned P = (unsigned)a.N * (a.H / 2) * (a.W / 2), stride = gridDim.x * PPB;
@@ -632,7 +704,8 @@ extern "C" int srvp_bn_eval_coeffs(const float* gamma, const float* beta, const 
 namespace {
 template <class E>
 int bn_act_launch(const void* raw, const float* scale, const float* shift, int act, int N, int H, int W, int C, void* dst,
-                  int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep, void* stream) {
+                  int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep, void* stream,
+                  const BnFin fin = BnFin{}) {
     SRVP_REQUIRE(raw && scale && shift && C % 8 == 0, "srvp_bn_act: bad args");
     hipStream_t st = (hipStream_t)stream;
     if (dst_pool) {
@@ -641,13 +714,13 @@ int bn_act_launch(const void* raw, const float* scale, const float* shift, int a
         SRVP_REQUIRE(C / 8 <= 256 && (long long)N * H * W < (1ll << 31), "srvp_bn_act: C=%d / size unsupported", C);
         auto kern = act == ACT_LRELU ? bn_act_kernel<E, true, ACT_LRELU> : bn_act_kernel<E, true, -1>;
         hipLaunchKernelGGL(kern, dim3(grid_for(total, (256 / (C / 8)) * 2)), dim3(256), 0, st, (const E*)raw, scale, shift,
-                           act, N, H, W, C, (E*)dst, dst_border, (E*)dst_pool, pool_border, dst_f32, (const int*)keep);
+                           act, N, H, W, C, (E*)dst, dst_border, (E*)dst_pool, pool_border, dst_f32, (const int*)keep, fin);
     } else {
         long long total = (long long)N * H * W;
         SRVP_REQUIRE(C / 8 <= 256 && total < (1ll << 31), "srvp_bn_act: C=%d / size unsupported", C);
         auto kern = act == ACT_LRELU ? bn_act_kernel<E, false, ACT_LRELU> : bn_act_kernel<E, false, -1>;
         hipLaunchKernelGGL(kern, dim3(grid_for(total, (256 / (C / 8)) * 4)), dim3(256), 0, st, (const E*)raw, scale, shift,
-                           act, N, H, W, C, (E*)dst, dst_border, (E*)nullptr, 0, dst_f32, (const int*)nullptr);
+                           act, N, H, W, C, (E*)dst, dst_border, (E*)nullptr, 0, dst_f32, (const int*)nullptr, fin);
     }
     SRVP_CHECK_LAUNCH("srvp_bn_act");
     return SRVP_OK;
@@ -663,6 +736,17 @@ extern "C" int srvp_bn_act_keep_f32(const void* raw, const float* scale, const f
                                     void* dst, int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep,
                                     void* stream) {
     return bn_act_launch<float>(raw, scale, shift, act, N, H, W, C, dst, dst_border, dst_pool, pool_border, dst_f32, keep, stream);
+}
+
+extern "C" int srvp_bn_finalize_act(const void* raw, const double* stats, double count, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift, float* mean,
+                                    float* invstd, int C_real, float eps, float momentum, int act, int N, int H, int W, int C, void* dst,
+                                    int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep, int elem_f32,
+                                    void* stream) {
+    SRVP_REQUIRE(stats && scale && shift && mean && invstd && C > 0 && C <= BN_MAX_C && count > 0, "srvp_bn_finalize_act: bad args");
+    BnFin fin{stats, count, gamma, beta, running_mean, running_var, (long long*)nbt, scale, shift, mean, invstd, C_real, eps, momentum};
+    if (elem_f32) return bn_act_launch<float>(raw, scale, shift, act, N, H, W, C, dst, dst_border, dst_pool, pool_border, dst_f32, keep, stream, fin);
+    return bn_act_launch<bf16_t>(raw, scale, shift, act, N, H, W, C, dst, dst_border, dst_pool, pool_border, dst_f32, keep, stream, fin);
 }
 
 extern "C" int srvp_bn_act(const void* raw, const float* scale, const float* shift, int act, int N, int H, int W, int C,
@@ -711,11 +795,24 @@ extern "C" int srvp_bn_bwd_finalize(const double* red, double count, const float
     return SRVP_OK;
 }
 
+namespace {
+int bn_bwd_apply_launch(const srvp_bnbwd_desc* d, const float* coef, void* draw, int dst_border, void* stream, const BnBwdFin fin);
+}
 extern "C" int srvp_bn_bwd_apply(const srvp_bnbwd_desc* d, const float* coef, void* draw, int dst_border, void* stream) {
+    SRVP_REQUIRE(coef, "srvp_bn_bwd_apply: null pointer");
+    return bn_bwd_apply_launch(d, coef, draw, dst_border, stream, BnBwdFin{});
+}
+extern "C" int srvp_bn_bwd_finalize_apply(const srvp_bnbwd_desc* d, const double* red, double count, float* dgamma, float* dbeta,
+                                          float* coef, int C_real, float param_grad_scale, void* draw, int dst_border, void* stream) {
+    SRVP_REQUIRE(d && red && count > 0 && d->mean && d->invstd && d->C <= BN_MAX_C, "srvp_bn_bwd_finalize_apply: bad args");
+    return bn_bwd_apply_launch(d, coef, draw, dst_border, stream, BnBwdFin{red, count, dgamma, dbeta, coef, C_real, param_grad_scale});
+}
+namespace {
+int bn_bwd_apply_launch(const srvp_bnbwd_desc* d, const float* coef, void* draw, int dst_border, void* stream, const BnBwdFin fin) {
     BnBwdK k;
     int rc = fill_k(d, k);
     if (rc) return rc;
-    SRVP_REQUIRE(coef && draw, "srvp_bn_bwd_apply: null pointer");
+    SRVP_REQUIRE(draw, "srvp_bn_bwd_apply: null pointer");
     const int CG = k.C / 8, PPB = 256 / CG;
     long long P = (long long)k.N * k.H * k.W;
     SRVP_REQUIRE(P < (1ll << 31), "srvp_bn_bwd_apply: too many pixels");
@@ -727,14 +824,15 @@ extern "C" int srvp_bn_bwd_apply(const srvp_bnbwd_desc* d, const float* coef, vo
         auto kern = k.da_mode == 0 ? (lr ? bn_bwd_apply_kernel<float, 0, ACT_LRELU> : bn_bwd_apply_kernel<float, 0, -1>)
                   : k.da_mode == 1 ? (lr ? bn_bwd_apply_kernel<float, 1, ACT_LRELU> : bn_bwd_apply_kernel<float, 1, -1>)
                                    : (lr ? bn_bwd_apply_kernel<float, 2, ACT_LRELU> : bn_bwd_apply_kernel<float, 2, -1>);
-        hipLaunchKernelGGL(kern, g, dim3(256), 0, (hipStream_t)stream, k, coef, (float*)draw, dst_border);
+        hipLaunchKernelGGL(kern, g, dim3(256), 0, (hipStream_t)stream, k, coef, (float*)draw, dst_border, fin);
         SRVP_CHECK_LAUNCH("srvp_bn_bwd_apply(f32)");
         return SRVP_OK;
     }
     auto kern = k.da_mode == 0 ? (lr ? bn_bwd_apply_kernel<bf16_t, 0, ACT_LRELU> : bn_bwd_apply_kernel<bf16_t, 0, -1>)
               : k.da_mode == 1 ? (lr ? bn_bwd_apply_kernel<bf16_t, 1, ACT_LRELU> : bn_bwd_apply_kernel<bf16_t, 1, -1>)
                                : (lr ? bn_bwd_apply_kernel<bf16_t, 2, ACT_LRELU> : bn_bwd_apply_kernel<bf16_t, 2, -1>);
-    hipLaunchKernelGGL(kern, g, dim3(256), 0, (hipStream_t)stream, k, coef, (bf16_t*)draw, dst_border);
+    hipLaunchKernelGGL(kern, g, dim3(256), 0, (hipStream_t)stream, k, coef, (bf16_t*)draw, dst_border, fin);
     SRVP_CHECK_LAUNCH("srvp_bn_bwd_apply");
     return SRVP_OK;
 }
+}  // namespace

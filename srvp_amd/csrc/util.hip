@@ -93,6 +93,108 @@ extern "C" int srvp_mmnist_render(const void* digits_u8, int n_digits, int dh, i
     return SRVP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Stochastic Moving-MNIST TRAJECTORIES on the device (the process of reference data/mmnist.py:113-237: per object a
+// random digit, a uniform start position and integer speed, straight motion inside the box [0, nx - dh] x [0, nx - dw], and at
+// every wall contact a fresh uniform speed pointed back inside (stochastic variant) or a plain reflection (deterministic
+// variant), the rest of the time step spent with the new speed).  One thread per object; the bounce loop lives in registers.
+//
+// Formulation (not the reference's "step outside, then find the wall that was crossed" but the equivalent ray / box walk): with
+// time budget tau = 1 per frame, the time to the first wall along the motion is th = min over the axes of (wall - s) / v; the
+// object moves min(th, tau), and at a contact (th < tau) the speed is redrawn / reflected and the walk continues with the
+// remaining budget.  An exact corner contact (both axes within 1e-12) turns both components, as the reference does.
+//
+// Randomness: counter-based Philox4x32-10, key = seed, counter = (block of four draws, object, batch counter): any batch of any
+// run is reproducible from (seed, batch index) alone, on any number of ranks -- and NOT the reference's global np.random stream
+// (a sequential Mersenne twister with a data-dependent number of draws per object cannot be reproduced in parallel); equality with
+// the reference is distributional (tests/test_gpu_metrics.py), equality with the CPU restatement oracle/mmnist_philox.py is exact.
+namespace {
+struct Philox {
+    unsigned k0, k1, c0, c1, c2, c3, out[4];
+    int have;
+    __device__ void init(unsigned long long seed, unsigned obj, unsigned long long batch) {
+        k0 = (unsigned)seed; k1 = (unsigned)(seed >> 32); c0 = 0; c1 = obj; c2 = (unsigned)batch; c3 = (unsigned)(batch >> 32); have = 0;
+    }
+    __device__ void block() {
+        unsigned a0 = c0, a1 = c1, a2 = c2, a3 = c3, x0 = k0, x1 = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const unsigned long long p0 = (unsigned long long)0xD2511F53u * a0, p1 = (unsigned long long)0xCD9E8D57u * a2;
+            const unsigned n0 = (unsigned)(p1 >> 32) ^ a1 ^ x0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ a3 ^ x1, n3 = (unsigned)p0;
+            a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+            x0 += 0x9E3779B9u; x1 += 0xBB67AE85u;
+        }
+        out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
+        ++c0; have = 4;
+    }
+    __device__ unsigned next() {
+        if (!have) block();
+        const unsigned v = have == 4 ? out[0] : have == 3 ? out[1] : have == 2 ? out[2] : out[3];
+        --have;
+        return v;
+    }
+    // uniform integer in [0, n): Lemire's multiply-shift with rejection (unbiased)
+    __device__ unsigned below(unsigned n) {
+        unsigned long long m = (unsigned long long)next() * n;
+        unsigned l = (unsigned)m;
+        if (l < n) {
+            const unsigned t = (0u - n) % n;
+            while (l < t) { m = (unsigned long long)next() * n; l = (unsigned)m; }
+        }
+        return (unsigned)(m >> 32);
+    }
+};
+
+__global__ void mmnist_traj_kernel(unsigned long long seed, unsigned long long batch, int B, int nd, int T, int x_max, int y_max,
+                                   int max_speed, int deterministic, int n_digits, int* __restrict__ idx, int* __restrict__ pos,
+                                   int* __restrict__ contacts) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= B * nd) return;
+    Philox g;
+    g.init(seed, (unsigned)o, batch);
+    idx[o] = (int)g.below((unsigned)n_digits);
+    double sx = (double)g.below((unsigned)x_max + 1u), sy = (double)g.below((unsigned)y_max + 1u);
+    const unsigned span = 2u * (unsigned)max_speed + 1u;
+    int vx = (int)g.below(span) - max_speed, vy = (int)g.below(span) - max_speed;
+    int nc = 0;
+    for (int t = 0; t < T; ++t) {
+        pos[((size_t)o * T + t) * 2 + 0] = (int)rint(sx);
+        pos[((size_t)o * T + t) * 2 + 1] = (int)rint(sy);
+        double tau = 1.0;
+        for (int it = 0; it < 64 && tau > 0.0; ++it) {
+            const double inf = 1e300;
+            const double tx = vx > 0 ? ((double)x_max - sx) / vx : (vx < 0 ? (0.0 - sx) / vx : inf);
+            const double ty = vy > 0 ? ((double)y_max - sy) / vy : (vy < 0 ? (0.0 - sy) / vy : inf);
+            const double th = tx < ty ? tx : ty;
+            if (th >= tau) { sx += vx * tau; sy += vy * tau; break; }
+            const bool hx = tx <= th + 1e-12, hy = ty <= th + 1e-12;
+            sx += vx * th; sy += vy * th; tau -= th;
+            const int wx = hx ? (vx > 0 ? 1 : -1) : 0, wy = hy ? (vy > 0 ? 1 : -1) : 0;     // which wall: +1 = far, -1 = near
+            if (hx) sx = vx > 0 ? (double)x_max : 0.0;
+            if (hy) sy = vy > 0 ? (double)y_max : 0.0;
+            if (!deterministic) { vx = (int)g.below(span) - max_speed; vy = (int)g.below(span) - max_speed; }
+            if (wx) vx = wx > 0 ? -abs(vx) : abs(vx);
+            if (wy) vy = wy > 0 ? -abs(vy) : abs(vy);
+            ++nc;
+        }
+        // (guard against accumulated rounding: the object never leaves the box)
+        sx = sx < 0.0 ? 0.0 : (sx > x_max ? (double)x_max : sx);
+        sy = sy < 0.0 ? 0.0 : (sy > y_max ? (double)y_max : sy);
+    }
+    if (contacts) contacts[o] = nc;
+}
+}  // namespace
+extern "C" int srvp_mmnist_trajectories(uint64_t seed, uint64_t batch_counter, int B, int num_digits, int T, int nx, int dh, int dw,
+                                        int max_speed, int deterministic, int n_digits, int* idx, int* pos, int* contacts, void* stream) {
+    SRVP_REQUIRE(idx && pos && B > 0 && num_digits > 0 && T > 0 && nx >= dh && nx >= dw && dh > 0 && dw > 0 && max_speed >= 0 && n_digits > 0,
+                 "srvp_mmnist_trajectories: bad args");
+    const int n = B * num_digits;
+    hipLaunchKernelGGL(mmnist_traj_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, (unsigned long long)seed,
+                       (unsigned long long)batch_counter, B, num_digits, T, nx - dh, nx - dw, max_speed, deterministic, n_digits, idx, pos, contacts);
+    SRVP_CHECK_LAUNCH("srvp_mmnist_trajectories");
+    return SRVP_OK;
+}
+
 extern "C" int srvp_cast_f32_bf16(const float* src, void* dst, int64_t rows, int cols, int dst_cols, void* stream) {
     long long n = (long long)rows * dst_cols;
     if (n <= 0) return SRVP_OK;

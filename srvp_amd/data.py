@@ -96,12 +96,14 @@ class MovingMNISTLoader:
 
 def make_loaders(opt, local_rank):
     if opt.dataset == 'smmnist':
-        # trajectories on the host in the reference's np.random order, frames assembled on the device
+        # trajectories (Philox, one thread per object) and frames both generated on the device
         from .mmnist import MovingMNISTBatches
         digits = mnist_digits(opt.data_dir)
         dev = torch.device('cuda', torch.cuda.current_device())
+        # distinct streams per rank (the reference seeds numpy with seed + local_rank, train.py:226-228) and for validation
         mk = lambda fold, T: MovingMNISTBatches(digits[fold_ids(len(digits), fold)], opt.nx, T, opt.max_speed, opt.deterministic,
-                                                opt.ndigits, device=dev)
+                                                opt.ndigits, device=dev,
+                                                seed=(int(opt.seed or 0) + local_rank) * 2 + (1 if fold == 'val' else 0))
         train_loader = MovingMNISTLoader(mk('train', opt.seq_len), opt.batch_size)
         val_loader = None
         if local_rank == 0:

@@ -60,20 +60,75 @@ def test_metrics_errors_and_identity():
 
 
 @pytest.mark.parametrize('case', ['s15', 's30', 'd20', 'fast3'])
-def test_mmnist_batches_vs_reference_fixture(case):
-    """srvp_mmnist_render (whole batch assembled on the device) under the reference's np.random stream == the
-    reference generator's uint8 videos, and the float batch == its collate_fn output, bit for bit."""
+def test_mmnist_render_vs_reference_fixture(case):
+    """srvp_mmnist_render (whole batch assembled on the device) on the reference's trajectories (oracle restatement
+    under the reference's np.random stream) == the reference generator's uint8 videos, and the float batch == its collate_fn
+    output, bit for bit."""
     from srvp_amd import mmnist as MM
+    from oracle import mmnist_ref as R
     z = np.load(GOLDEN + '/mmnist.npz')
     T, ms, det, nd, seed, B = [int(v) for v in z[f'{case}.cfg']]
     gen = MM.MovingMNISTBatches(list(z['digits']), 64, T, ms, bool(det), nd)
     np.random.seed(seed)
-    u8 = gen.videos_u8(B)
+    idx, pos = R.draw(len(z['digits']), 28, 28, 64, T, ms, bool(det), nd, B)
+    x, u8 = gen.render(idx, pos, True, True)
     assert u8.dtype == torch.uint8 and (u8.cpu().numpy() == z[f'{case}.videos']).all()
-    np.random.seed(seed)
-    x = gen.batch(B)
     assert x.shape == (T, B, 1, 64, 64)
     ref = torch.from_numpy(z[f'{case}.videos']).float().div(255).permute(1, 0, 2, 3).unsqueeze(2)
     assert torch.equal(x.cpu(), ref)
     if case == 's15':
         assert torch.equal(x.cpu(), torch.from_numpy(z['s15.batch']))
+
+
+@pytest.mark.parametrize('T,ms,det,nd,B', [(15, 4, False, 2, 16), (30, 9, False, 3, 5), (20, 4, True, 2, 8), (12, 1, False, 1, 3)])
+def test_mmnist_device_trajectories_equal_cpu_restatement(T, ms, det, nd, B):
+    """The trajectory kernel against the CPU restatement of the same algorithm (oracle/mmnist_ref.philox_trajectories: same
+    Philox4x32-10 stream, same float64 ray / box walk): digit indices, every rounded position and the contact counts, bit for bit,
+    for two batch counters; batches differ from each other and are reproducible."""
+    from srvp_amd import mmnist as MM
+    from oracle import mmnist_ref as R
+    z = np.load(GOLDEN + '/mmnist.npz')
+    gen = MM.MovingMNISTBatches(list(z['digits']), 64, T, ms, det, nd, seed=1234567890123)
+    outs = []
+    for k in range(2):
+        idx, pos, con = (t.cpu().numpy().copy() for t in gen.trajectories(B, want_contacts=True))
+        ri, rp, rc = R.philox_trajectories(1234567890123, k, B, nd, T, 64, 28, 28, ms, det, len(z['digits']))
+        assert (idx == ri).all() and (pos == rp).all() and (con == rc).all(), k
+        assert pos.min() >= 0 and pos.max() <= 64 - 28
+        outs.append(pos)
+    assert (outs[0] != outs[1]).any()
+    gen.counter = 0
+    assert (gen.trajectories(B)[1].cpu().numpy() == outs[0]).all()
+
+
+@pytest.mark.parametrize('ms,det', [(4, False), (9, False), (4, True)])
+def test_mmnist_device_generator_matches_reference_in_distribution(ms, det):
+    """The device generator draws from the reference's process (data/mmnist.py:113-237): 8192 device trajectories against 3000 of
+    the reference restatement (oracle/mmnist_ref.trajectory, itself bit-equal to the reference under np.random.seed): start
+    position marginals, per-frame position mean and spread, displacement-magnitude distribution late in the sequence (after
+    redraws at the walls) and the fraction of objects touching a wall per frame.  Thresholds = several standard errors."""
+    from srvp_amd import mmnist as MM
+    from oracle import mmnist_ref as R
+    z = np.load(GOLDEN + '/mmnist.npz')
+    T, nx, d = 15, 64, 28
+    gen = MM.MovingMNISTBatches(list(z['digits']), nx, T, ms, det, 2, seed=99)
+    dev = np.concatenate([gen.trajectories(1024)[1].cpu().numpy().reshape(-1, T, 2) for _ in range(4)]).astype(np.float64)   # 8192
+    np.random.seed(4242)
+    ref = np.array([[(r, c) for r, c, _, _ in R.trajectory(d, d, nx, T, ms, det)] for _ in range(3000)], dtype=np.float64)
+    n = min(len(dev), len(ref))
+    se = lambda v: v.std() / np.sqrt(n)
+    hi = nx - d
+    for ax in (0, 1):
+        hd = np.bincount(dev[:, 0, ax].astype(int), minlength=hi + 1) / len(dev)
+        hr = np.bincount(ref[:, 0, ax].astype(int), minlength=hi + 1) / len(ref)
+        assert np.abs(hd - hr).max() < 0.012, np.abs(hd - hr).max()                      # start positions: uniform on {0..36}
+        for t in range(T):
+            assert abs(dev[:, t, ax].mean() - ref[:, t, ax].mean()) < 5 * se(ref[:, t, ax]) + 0.05, (ax, t)
+            assert abs(dev[:, t, ax].std() - ref[:, t, ax].std()) < 0.06 * ref[:, t, ax].std() + 0.05, (ax, t)
+        wd = ((dev[:, :, ax] == 0) | (dev[:, :, ax] == hi)).mean(0)                       # on-wall fraction per frame
+        wr = ((ref[:, :, ax] == 0) | (ref[:, :, ax] == hi)).mean(0)
+        assert np.abs(wd - wr).max() < 0.03, (wd, wr)
+        dd, dr = np.abs(np.diff(dev[:, -6:, ax], axis=1)).ravel(), np.abs(np.diff(ref[:, -6:, ax], axis=1)).ravel()
+        hd = np.bincount(dd.astype(int), minlength=ms + 2)[:ms + 2] / len(dd)
+        hr = np.bincount(dr.astype(int), minlength=ms + 2)[:ms + 2] / len(dr)
+        assert np.abs(hd - hr).max() < 0.02, (hd, hr)                                      # speeds after redraws

@@ -152,17 +152,17 @@ MM_CASES = ['s15', 's30', 'd20', 'fast3']
 
 @pytest.mark.parametrize('case', MM_CASES)
 def test_mmnist_trajectories_and_videos_vs_reference_fixture(case):
-    """the host trajectory code of srvp_amd.mmnist consumes np.random exactly as the reference generator does
+    """SURVEY §8f-2, pinning the ORACLE: oracle/mmnist_ref.py consumes np.random exactly as the reference generator does
     (data/mmnist.py:116-237) -- same trajectories, and (with the oracle's numpy frame assembly) the same uint8 videos, bit for
-    bit, as tests/golden/mmnist.npz (made from the reference under np.random.seed)."""
+    bit, as tests/golden/mmnist.npz (made from the reference under np.random.seed).  The product's device generator is compared
+    with this restatement in distribution (tests/test_gpu_metrics.py)."""
     import numpy as np
     from oracle import srvp_oracle as O
-    from srvp_amd import mmnist as MM
+    from oracle import mmnist_ref as MM
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mmnist.npz'))
     T, ms, det, nd, seed, B = [int(v) for v in z[f'{case}.cfg']]
-    gen = MM.MovingMNISTBatches(list(z['digits']), 64, T, ms, bool(det), nd, device='cpu')
     np.random.seed(seed)
-    idx, pos = gen.draw(B)
+    idx, pos = MM.draw(len(z['digits']), 28, 28, 64, T, ms, bool(det), nd, B)
     assert (O.mmnist_render(z['digits'], idx, pos, 64) == z[f'{case}.videos']).all()
     np.random.seed(seed + 1000)
     tr = np.array([MM.trajectory(28, 28, 64, T, ms, bool(det)) for _ in range(20)], dtype=np.int64)
@@ -238,3 +238,18 @@ def test_rank_rng_file_carries_its_iteration(tmp_path):
     got = np.random.rand()
     np.random.seed((9 + 1 + 7919 * 40) % (2 ** 32))
     assert got == np.random.rand() and got != want           # ignored: seed-derived stream of (seed, rank, iteration)
+
+
+def test_philox_restatement_known_answers():
+    """oracle/mmnist_ref.Philox is Philox4x32-10: the published known-answer vectors of Random123 (kat_vectors: counter / key all
+    zero, all ones, and the digits of pi)."""
+    from oracle.mmnist_ref import Philox
+
+    def block(ctr, key):
+        g = Philox(key[0] | (key[1] << 32), 0, 0)
+        g.c = list(ctr)
+        g._block()
+        return g.buf
+    assert block((0, 0, 0, 0), (0, 0)) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert block((0xffffffff,) * 4, (0xffffffff, 0xffffffff)) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert block((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
