@@ -161,8 +161,8 @@ def rollout_bench(args, cfg, dev, world, rank, real_stdout):
     dt_e = 1.0 / cfg['n_euler']
 
     def step():
-        for _ in range(nchunks):                     # (the last chunk is drawn at the common size, like train.evaluate)
-            model.sample(x, nt, chunk, dt=dt_e)
+        # one encoding + one latent pass for all S futures, decoded `chunk` futures at a time (as train.evaluate does)
+        model.sample(x, nt, S, dt=dt_e, chunk=chunk)
     for _ in range(max(1, args.warmup)):
         step()
     prof = None
@@ -193,8 +193,8 @@ def rollout_bench(args, cfg, dev, world, rank, real_stdout):
     if rank != 0:
         torch.distributed.destroy_process_group()
         return
-    frames_step = nchunks * chunk * B * nt
-    fl = conv_flops(model, nt_cond * B, nt * B * chunk)          # encoder on the conditioning frames once per chunk, decoder on every frame
+    frames_step = S * B * nt
+    fl = conv_flops(model, nt_cond * B, nt * B * chunk)          # per decoder pass (the encoder runs once per step: counted nchunks times, <1 %)
     line = {
         'metric': f'rollout decoded frames/sec ({cfg["label"].split(" seq_len")[0]}, {nt_cond} conditioning frames -> {nt}-frame horizon, {S} futures per video)',
         'value': frames_step * world * args.steps / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

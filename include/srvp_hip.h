@@ -271,6 +271,17 @@ int srvp_linear_wgrad_f32(const float* delta, int64_t ld_delta, const float* act
                           float* gb, int M, int N, int K, void* stream);
 /* dst[blk * dst_stride + i] += src[blk * n + i], i < n, blk < nblk (p_z input gradients added onto the frame-start states) */
 int srvp_add_blocks_f32(float* dst, int64_t dst_stride, const float* src, int nblk, int64_t n, void* stream);
+/* Glue between the latent path and the conv stacks (srvp.py:216-221 and its backward; srvp.py:246-250, 268 backward):
+ *  srvp_latent_to_z: decoder input rows dst[t*B+b] = [w[b] | y[t][b] | 0-padding to Cz] (bf16, or fp32 with dst_f32), y rows of frame t
+ *                    at y + t * y_tstride;
+ *  srvp_dz_split:    d_w[b] = sum_t dz[t*B+b][:nh] (+ d_w_add), d_y[t][b] = dz[t*B+b][nh:nh+ny] (+ d_y_add), d_y rows at d_y + t * dy_tstride;
+ *  srvp_rows_scatter_add_f32: dst[idx[r]] += src[r] (idx int64 or int32). */
+int srvp_latent_to_z(const float* w, const float* y, int64_t y_tstride, void* dst, int nt, int B, int nh, int ny, int Cz,
+                     int dst_f32, void* stream);
+int srvp_dz_split(const void* dz, int Cz, int elem_f32, int nt, int B, int nh, int ny, const float* d_w_add, const float* d_y_add,
+                  float* d_w, float* d_y, int64_t dy_tstride, void* stream);
+int srvp_rows_scatter_add_f32(float* dst, const void* idx, int idx_is_i64, const float* src, int64_t rows, int C, void* stream);
+
 /* out = a*x + b*y (y may be NULL) */
 int srvp_axpby_f32(float* out, float a, const float* x, float b, const float* y, int64_t n, void* stream);
 /* column sums: out[n] (+)= sum_m A[m][n] */

@@ -116,6 +116,9 @@ _SIGS = {
     'srvp_gemm_f32': ([c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_linear_wgrad_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_add_blocks_f32': ([c_vp, c_i64, c_vp, c_i32, c_i64, c_vp], c_i32),
+    'srvp_latent_to_z': ([c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
+    'srvp_dz_split': ([c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp], c_i32),
+    'srvp_rows_scatter_add_f32': ([c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_vp], c_i32),
     'srvp_axpby_f32': ([c_vp, c_f32, c_vp, c_f32, c_vp, c_i64, c_vp], c_i32),
     'srvp_colsum_f32': ([c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_act_bwd_f32': ([c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp], c_i32),

@@ -22,7 +22,8 @@ S2D = os.environ.get('SRVP_SUBPIX_S2D', '1') != '0'
 BN_FUSED_FINALIZE = os.environ.get('SRVP_BN_FUSED_FINALIZE', '1') != '0'    # bn_finalize / bn_bwd_finalize folded into bn_act / bn_bwd_apply
 # encoder weight gradients on the second stream when the batch is small (<= this many frames): grids of 100-600 workgroups do not
 # fill the chip, so the weight gradient of block i runs beside the BatchNorm backward / data gradient of block i - 1
-ENC_WGRAD_SIDE_MAXN = int(os.environ.get('SRVP_ENC_WGRAD_SIDE_MAXN', '0'))
+# (same-box A/B, ms per step off / on: 9.40 / 9.02 at 24 sequences per GPU, 14.35 / 13.69 at 48, 22.75 / 22.89 at 96, 42.00 / 41.57 at 192)
+ENC_WGRAD_SIDE_MAXN = int(os.environ.get('SRVP_ENC_WGRAD_SIDE_MAXN', '1000000'))
 S_QUAD = os.environ.get('SRVP_S_QUAD', '1') != '0'        # hoisted skip half stored pixel-quad-major (16-byte loads in the consumers)
 SPLITK = int(os.environ.get('SRVP_CONV_SPLITK', '16'))    # tiny-M long-K launches: K steps shared over this many workgroups
 # Sub-pixel form of "nearest x2 upsample, then 3x3 conv" (conv.py:331-349): output phase a in {0,1} of a row pair reads
@@ -1073,9 +1074,15 @@ class DecoderNet(ConvNetBase):
                 L.call('srvp_conv_mfma', C.byref(blk._fwd[0]), st)
         self._skips_done = True
 
-    def forward(self, z_f32, params, st, sync=None):
-        """z_f32: fp32 [N][nz_real]"""
-        L.call('srvp_pad_f32' if self.f32 else 'srvp_cast_f32_bf16', L.ptr(z_f32), L.ptr(self.z.t), self.N, z_f32.shape[1], self.z.C, st)
+    def forward(self, z_f32, params, st, sync=None, latent=None):
+        """z_f32: fp32 [N][nz_real], or None with latent = (w fp32 [B][nh], y fp32 base pointer tensor, y_tstride, nt, B, nh, ny): the rows
+        [w[b] | y[t][b]] are then assembled by the library (srvp.py:216-221) straight into the padded decoder input."""
+        if latent is not None:
+            w, y, y_ts, nt, B, nh, ny = latent
+            assert nt * B == self.N
+            L.call('srvp_latent_to_z', L.ptr(w), L.ptr(y), y_ts, L.ptr(self.z.t), nt, B, nh, ny, self.z.C, 1 if self.f32 else 0, st)
+        else:
+            L.call('srvp_pad_f32' if self.f32 else 'srvp_cast_f32_bf16', L.ptr(z_f32), L.ptr(self.z.t), self.N, z_f32.shape[1], self.z.C, st)
         if self.training:
             self.zero_forward_accumulators()
         for blk in self.blocks[:-1]:

@@ -508,6 +508,77 @@ extern "C" int srvp_add_blocks_f32(float* dst, int64_t dst_stride, const float* 
     return SRVP_OK;
 }
 
+// ---- glue between the latent path and the conv stacks (was torch.cat / .sum(0) / index_add_: model arithmetic belongs here)
+namespace {
+// decoder input rows (srvp.py:216-221): dst[t*B + b][c] = c < nh ? w[b][c] : c < nh + ny ? y[t][b][c - nh] : 0 (channel padding)
+template <class E>
+__global__ void latent_to_z_kernel(const float* __restrict__ w, const float* __restrict__ y, long long y_tstride, E* __restrict__ dst,
+                                   int nt, int B, int nh, int ny, int Cz) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nt * B * Cz) return;
+    const int c = (int)(i % Cz); const long long r = i / Cz;
+    const int b = (int)(r % B), t = (int)(r / B);
+    float v = 0.f;
+    if (c < nh) v = w[(size_t)b * nh + c];
+    else if (c < nh + ny) v = y[(size_t)t * y_tstride + (size_t)b * ny + (c - nh)];
+    El<E>::st(dst + i, v);
+}
+// gradient of the decoder input -> d_w[b][c] = sum_t dz[t*B+b][c] (+ d_w_add), d_y[t][b][c] = dz[t*B+b][nh+c] (+ d_y_add) (the
+// backward of the time-expansion of w and of the concatenation, srvp.py:216-221)
+template <class E>
+__global__ void dz_split_kernel(const E* __restrict__ dz, int Cz, int nt, int B, int nh, int ny, const float* __restrict__ d_w_add,
+                                const float* __restrict__ d_y_add, float* __restrict__ d_w, float* __restrict__ d_y, long long dy_tstride) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nw = (long long)B * nh, nyy = (long long)nt * B * ny;
+    if (i < nw) {
+        const int c = (int)(i % nh), b = (int)(i / nh);
+        float s = 0.f;
+        for (int t = 0; t < nt; ++t) s += El<E>::ld(dz + ((size_t)t * B + b) * Cz + c);         // fixed order: deterministic
+        d_w[i] = s + (d_w_add ? d_w_add[i] : 0.f);
+    } else if (i < nw + nyy) {
+        const long long j = i - nw;
+        const int c = (int)(j % ny); const long long r = j / ny;
+        const int b = (int)(r % B), t = (int)(r / B);
+        d_y[(size_t)t * dy_tstride + (size_t)b * ny + c] = El<E>::ld(dz + (size_t)r * Cz + nh + c) + (d_y_add ? d_y_add[j] : 0.f);
+    }
+}
+// dst[idx[r]][c] += src[r][c]   (rows of idx are distinct in every use here; atomics keep it correct if they are not)
+__global__ void rows_scatter_add_kernel(float* __restrict__ dst, const long long* __restrict__ idx64, const int* __restrict__ idx32,
+                                        const float* __restrict__ src, long long rows, int C) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * C) return;
+    const long long r = i / C; const int c = (int)(i - r * C);
+    const long long d = idx64 ? idx64[r] : (long long)idx32[r];
+    atomicAdd(dst + d * C + c, src[i]);
+}
+}  // namespace
+extern "C" int srvp_latent_to_z(const float* w, const float* y, int64_t y_tstride, void* dst, int nt, int B, int nh, int ny, int Cz,
+                                int dst_f32, void* stream) {
+    SRVP_REQUIRE(w && y && dst && nt > 0 && B > 0 && nh + ny <= Cz, "srvp_latent_to_z: bad args");
+    const long long n = (long long)nt * B * Cz;
+    if (dst_f32) hipLaunchKernelGGL(latent_to_z_kernel<float>, g1(n), dim3(256), 0, (hipStream_t)stream, w, y, (long long)y_tstride, (float*)dst, nt, B, nh, ny, Cz);
+    else hipLaunchKernelGGL(latent_to_z_kernel<bf16_t>, g1(n), dim3(256), 0, (hipStream_t)stream, w, y, (long long)y_tstride, (bf16_t*)dst, nt, B, nh, ny, Cz);
+    SRVP_CHECK_LAUNCH("srvp_latent_to_z");
+    return SRVP_OK;
+}
+extern "C" int srvp_dz_split(const void* dz, int Cz, int elem_f32, int nt, int B, int nh, int ny, const float* d_w_add, const float* d_y_add,
+                             float* d_w, float* d_y, int64_t dy_tstride, void* stream) {
+    SRVP_REQUIRE(dz && d_w && d_y && nt > 0 && B > 0 && nh + ny <= Cz, "srvp_dz_split: bad args");
+    const long long n = (long long)B * nh + (long long)nt * B * ny;
+    if (elem_f32) hipLaunchKernelGGL(dz_split_kernel<float>, g1(n), dim3(256), 0, (hipStream_t)stream, (const float*)dz, Cz, nt, B, nh, ny, d_w_add, d_y_add, d_w, d_y, (long long)dy_tstride);
+    else hipLaunchKernelGGL(dz_split_kernel<bf16_t>, g1(n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz, Cz, nt, B, nh, ny, d_w_add, d_y_add, d_w, d_y, (long long)dy_tstride);
+    SRVP_CHECK_LAUNCH("srvp_dz_split");
+    return SRVP_OK;
+}
+extern "C" int srvp_rows_scatter_add_f32(float* dst, const void* idx, int idx_is_i64, const float* src, int64_t rows, int C, void* stream) {
+    SRVP_REQUIRE(dst && idx && src && C > 0, "srvp_rows_scatter_add_f32: bad args");
+    if (rows <= 0) return SRVP_OK;
+    hipLaunchKernelGGL(rows_scatter_add_kernel, g1((long long)rows * C), dim3(256), 0, (hipStream_t)stream, dst,
+                       idx_is_i64 ? (const long long*)idx : nullptr, idx_is_i64 ? nullptr : (const int*)idx, src, (long long)rows, C);
+    SRVP_CHECK_LAUNCH("srvp_rows_scatter_add_f32");
+    return SRVP_OK;
+}
+
 extern "C" int srvp_axpby_f32(float* out, float a, const float* x, float b, const float* y, int64_t n, void* stream) {
     SRVP_REQUIRE(out && x, "srvp_axpby_f32: null pointer");
     if (n <= 0) return SRVP_OK;

@@ -108,12 +108,137 @@ __device__ __forceinline__ const srvp_pack_job* locate_job(const srvp_pack_job* 
     return nullptr;
 }
 
-__global__ __launch_bounds__(256) void pack_multi_kernel(const srvp_pack_job* __restrict__ jobs, int njobs) {
+// ---- LDS-tiled path (conv / convT weights: the taps are the innermost axis of the fp32 tensor and one of the two channel axes
+// comes next with stride TS = min(sj, sk) <= 16): a workgroup moves a tile of 8 "outer" x 64 "inner" channel indices x TS taps.  On
+// the fp32 side the tile is 8 contiguous runs of 64 * TS floats (coalesced; the item-per-thread path above touches 64 different
+// lines per wave instruction there and sustains 0.3-0.8 TB/s); the packed side moves as 16- / 32-byte pieces; the transposition
+// between the two happens in LDS.  Same values and the same summation order as the paths above.
+constexpr int PT_OUT = 8, PT_INN = 64;
+__device__ __forceinline__ bool tile_ok(const srvp_pack_desc& d, int& TS, bool& inner_k) {
+    if (!vec_ok(d)) return false;
+    inner_k = d.sk < d.sj;
+    const long long ts = inner_k ? d.sk : d.sj;
+    if (ts < 1 || ts > 16) return false;
+    TS = (int)ts;
+    for (int t = 0; t < d.ntaps; ++t)
+        if (d.tap_set[t] == 0 ? d.tap_off[t] >= TS : (d.tap_set[t] >> TS) != 0) return false;
+    return (inner_k ? d.K : d.J) % 8 == 0;
+}
+// padded (outer, inner) -> element offset of tap 0 in the fp32 tensor, or -1 (channel padding)
+__device__ __forceinline__ long long tile_src_base(const srvp_pack_desc& d, bool inner_k, int po, int pi) {
+    const int pj = inner_k ? po : pi, pk = inner_k ? pi : po;
+    if (pj >= d.J || pk >= d.K) return -1;
+    const int jr = real_index(pj, d.J0, d.J0r, d.J1r), kr = real_index(pk, d.K0, d.K0r, d.K1r);
+    return (jr >= 0 && kr >= 0) ? (long long)jr * d.sj + (long long)kr * d.sk : -1;
+}
+__device__ __forceinline__ long long packed_off(const srvp_pack_desc& d, int t, int jj, int k) {
+    if (d.layout == 1) {
+        const int cc = k >> 6, kk = (k >> 4) & 3, kh = (k >> 3) & 1;
+        const int KC = d.kc_total ? d.kc_total : (d.K >> 6);
+        return ((((long long)(t * KC + cc + d.kc_off) * 4 + kk) * (d.J >> 5) + (jj >> 5)) * 64 + kh * 32 + (jj & 31)) * 8;
+    }
+    return ((long long)t * d.J + jj) * d.K + k;
+}
+
+__device__ void pack_job_tiled(const srvp_pack_job& j, unsigned wg, unsigned nwg, int TS, bool inner_k, float* lds) {
+    const srvp_pack_desc& d = j.d;
+    const float* __restrict__ src = (const float*)j.src;
+    bf16_t* __restrict__ dst = (bf16_t*)j.dst;
+    const int OUT = inner_k ? d.J : d.K, INN = inner_k ? d.K : d.J;
+    const int to = (OUT + PT_OUT - 1) / PT_OUT, ti = (INN + PT_INN - 1) / PT_INN;
+    const int pitch = PT_INN * TS + 1;
+    const int ntaps = d.ntaps;
+    for (int tile = (int)wg; tile < to * ti; tile += (int)nwg) {
+        const int o0 = (tile / ti) * PT_OUT, i0 = (tile % ti) * PT_INN;
+        __syncthreads();
+        for (int e = threadIdx.x; e < PT_OUT * PT_INN * TS; e += 256) {
+            const int o = e / (PT_INN * TS), rem = e - o * (PT_INN * TS), i = rem / TS, tp = rem - i * TS;
+            const long long b = tile_src_base(d, inner_k, o0 + o, i0 + i);
+            lds[o * pitch + rem] = b >= 0 ? src[b + tp] : 0.f;
+        }
+        __syncthreads();
+        // packed items of the tile: (tap, j, eight consecutive k)
+        const int nj = inner_k ? PT_OUT : PT_INN, nk8 = (inner_k ? PT_INN : PT_OUT) / 8;
+        for (int it = threadIdx.x; it < ntaps * nj * nk8; it += 256) {
+            // inner index fastest: consecutive threads write neighbouring pieces
+            int t, jl, k8;
+            if (inner_k) { k8 = it % nk8; jl = (it / nk8) % nj; t = it / (nk8 * nj); }
+            else { jl = it % nj; k8 = (it / nj) % nk8; t = it / (nj * nk8); }
+            const int jj = (inner_k ? o0 : i0) + jl, k = (inner_k ? i0 : o0) + k8 * 8;
+            if (jj >= d.J || k >= d.K) continue;
+            const int off = d.tap_off[t], set = d.tap_set[t];
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float* cell = inner_k ? lds + jl * pitch + (k8 * 8 + e) * TS : lds + (k8 * 8 + e) * pitch + jl * TS;
+                if (set == 0) v[e] = cell[off];
+                else {
+                    float a = 0.f;
+                    for (int sidx = 0; sidx < 16; ++sidx) if ((set >> sidx) & 1) a += cell[sidx];     // fp32 sum, one rounding, fixed order
+                    v[e] = a;
+                }
+            }
+            *reinterpret_cast<u32x4_t*>(dst + packed_off(d, t, jj, k)) = pack8(v);
+        }
+    }
+}
+
+__device__ void unpack_job_tiled(const srvp_pack_job& j, unsigned wg, unsigned nwg, int TS, bool inner_k, float* lds) {
+    const srvp_pack_desc& d = j.d;
+    const float* __restrict__ src = (const float*)j.src;       // packed fp32 gradient [t][J][K] (tap-major)
+    float* __restrict__ dst = (float*)j.dst;
+    const int OUT = inner_k ? d.J : d.K, INN = inner_k ? d.K : d.J;
+    const int to = (OUT + PT_OUT - 1) / PT_OUT, ti = (INN + PT_INN - 1) / PT_INN;
+    const int pitch = PT_INN * TS + 1;
+    const int ntaps = d.ntaps;
+    unsigned need = 0;
+    for (int t = 0; t < ntaps; ++t) need |= d.tap_set[t] ? (unsigned)d.tap_set[t] : 1u << d.tap_off[t];
+    for (int tile = (int)wg; tile < to * ti; tile += (int)nwg) {
+        const int o0 = (tile / ti) * PT_OUT, i0 = (tile % ti) * PT_INN;
+        __syncthreads();
+        for (int e = threadIdx.x; e < PT_OUT * pitch; e += 256) lds[e] = 0.f;
+        __syncthreads();
+        // one thread per (j, eight consecutive k) walks the packed taps in order (the sums over packed taps that share a source tap
+        // are formed in a fixed order) -- 64 items per tile
+        const int nj = inner_k ? PT_OUT : PT_INN, nk8 = (inner_k ? PT_INN : PT_OUT) / 8;
+        for (int it = threadIdx.x; it < nj * nk8; it += 256) {
+            int jl, k8;
+            if (inner_k) { k8 = it % nk8; jl = it / nk8; } else { jl = it % nj; k8 = it / nj; }
+            const int jj = (inner_k ? o0 : i0) + jl, k = (inner_k ? i0 : o0) + k8 * 8;
+            if (jj >= d.J || k >= d.K) continue;
+            for (int t = 0; t < ntaps; ++t) {
+                const unsigned m = d.tap_set[t] ? (unsigned)d.tap_set[t] : 1u << d.tap_off[t];
+                const float* sp = src + ((long long)t * d.J + jj) * d.K + k;
+                const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(sp), hi = *reinterpret_cast<const f32x4_t*>(sp + 4);
+                for (int sidx = 0; sidx < TS; ++sidx)
+                    if ((m >> sidx) & 1) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float* cell = inner_k ? lds + jl * pitch + (k8 * 8 + e) * TS : lds + (k8 * 8 + e) * pitch + jl * TS;
+                            cell[sidx] += e < 4 ? lo[e] : hi[e - 4];
+                        }
+                    }
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < PT_OUT * PT_INN * TS; e += 256) {
+            const int o = e / (PT_INN * TS), rem = e - o * (PT_INN * TS), i = rem / TS, tp = rem - i * TS;
+            if (!((need >> tp) & 1)) continue;
+            const long long b = tile_src_base(d, inner_k, o0 + o, i0 + i);
+            if (b >= 0) dst[b + tp] += lds[o * pitch + rem];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_multi_kernel(const srvp_pack_job* __restrict__ jobs, int njobs, int g_pack_tiled) {
     unsigned wg, nwg;
     const srvp_pack_job* jp = locate_job(jobs, njobs, wg, nwg);
     if (!jp) return;
     const srvp_pack_job& j = *jp;
     const srvp_pack_desc& d = j.d;
+    __shared__ float tile_lds[PT_OUT * (PT_INN * 16 + 1)];
+    int TS; bool inner_k;
+    if (g_pack_tiled && tile_ok(d, TS, inner_k)) { pack_job_tiled(j, wg, nwg, TS, inner_k, tile_lds); return; }
     if (!vec_ok(d)) {
         PackArgs a;
         job_args(j, a);
@@ -171,12 +296,15 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const srvp_pack_job* __
         }
     }
 }
-__global__ __launch_bounds__(256) void unpack_multi_kernel(const srvp_pack_job* __restrict__ jobs, int njobs) {
+__global__ __launch_bounds__(256) void unpack_multi_kernel(const srvp_pack_job* __restrict__ jobs, int njobs, int g_pack_tiled) {
     unsigned wg, nwg;
     const srvp_pack_job* jp = locate_job(jobs, njobs, wg, nwg);
     if (!jp) return;
     const srvp_pack_job& j = *jp;
     const srvp_pack_desc& d = j.d;
+    __shared__ float tile_lds[PT_OUT * (PT_INN * 16 + 1)];
+    int TS; bool inner_k;
+    if (g_pack_tiled && tile_ok(d, TS, inner_k)) { unpack_job_tiled(j, wg, nwg, TS, inner_k, tile_lds); return; }
     if (!vec_ok(d)) {
         PackArgs a;
         job_args(j, a);
@@ -415,16 +543,21 @@ extern "C" int srvp_unpack_wgrad(const float* src, float* dst, const srvp_pack_d
     return SRVP_OK;
 }
 
+static int pack_tiled() {       // A/B switch SRVP_PACK_TILED (default 1)
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SRVP_PACK_TILED"); on = e ? atoi(e) : 1; }
+    return on;
+}
 extern "C" int srvp_pack_weight_multi(const srvp_pack_job* jobs_dev, int njobs, int64_t total_wgs, void* stream) {
     SRVP_REQUIRE(jobs_dev && njobs > 0 && total_wgs > 0 && total_wgs < (1ll << 31), "srvp_pack_weight_multi: bad args");
-    hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)total_wgs), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
+    hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)total_wgs), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs, pack_tiled());
     SRVP_CHECK_LAUNCH("srvp_pack_weight_multi");
     return SRVP_OK;
 }
 
 extern "C" int srvp_unpack_wgrad_multi(const srvp_pack_job* jobs_dev, int njobs, int64_t total_wgs, void* stream) {
     SRVP_REQUIRE(jobs_dev && njobs > 0 && total_wgs > 0 && total_wgs < (1ll << 31), "srvp_unpack_wgrad_multi: bad args");
-    hipLaunchKernelGGL(unpack_multi_kernel, dim3((unsigned)total_wgs), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
+    hipLaunchKernelGGL(unpack_multi_kernel, dim3((unsigned)total_wgs), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs, pack_tiled());
     SRVP_CHECK_LAUNCH("srvp_unpack_wgrad_multi");
     return SRVP_OK;
 }

@@ -23,11 +23,17 @@ def linear_fwd(st, x, w, b, out, act=L.ACT_NONE):
     return out
 
 
-def linear_bwd(st, x, w, dy, gw, gb, dx=None, dx_acc=0):
-    """dy: [M][N] (contiguous).  gw += dy^T x ; gb += colsum(dy) ; dx (+)= dy w"""
+def linear_bwd(st, x, w, dy, gw, gb, dx=None, dx_acc=0, defer=None):
+    """dy: [M][N] (contiguous).  gw += dy^T x ; gb += colsum(dy) ; dx (+)= dy w
+    defer (list or None): the weight / bias gradient launch is appended as a closure fn(stream) instead of being issued (it feeds
+    nothing but the optimizer: the caller runs it on a second stream)."""
     M, K = x.shape
     N = w.shape[0]
-    L.call('srvp_linear_wgrad_f32', L.ptr(dy), N, L.ptr(x), K, L.ptr(gw), K, L.ptr(gb), N, K, M, st)      # weight + bias gradient
+    wg = lambda s_: L.call('srvp_linear_wgrad_f32', L.ptr(dy), N, L.ptr(x), K, L.ptr(gw), K, L.ptr(gb), N, K, M, s_)      # weight + bias gradient
+    if defer is not None:
+        defer.append(wg)
+    else:
+        wg(st)
     if dx is not None:
         _gemm(st, dy, N, 1, w, K, 1, None, dx, K, M, K, N, acc=dx_acc)
 
@@ -215,19 +221,22 @@ class LatentNet:
         return y, self.z[:self.F], (self.q_z[:nq] if nq > 0 else None), self.p_z[:self.F], self.res[:self.S]
 
     # ------------------------------------------------------------------------------------------------
-    def backward(self, hx, params, grads, eps_y0, eps_z, d_y, d_w, d_qy0, d_qz, d_pz, d_res, d_z, st):
+    def backward(self, hx, params, grads, eps_y0, eps_z, d_y, d_w, d_qy0, d_qz, d_pz, d_res, d_z, st, defer=None):
         """
         Gradients wrt the latent-path outputs -> parameter gradients (accumulated into `grads`) and d_hx (T*B, nhx).
         Any d_* may be None.  Training forward (n_data = T = nt) must have run.
+        d_y == 'in_place': the caller has already written the state gradients into self.d_y_all (zero elsewhere).
+        defer (list or None): weight-gradient launches (off the critical path) are collected as closures fn(stream).
         """
         cfg, B, T, ne, S, F = self.cfg, self.B, self.T, self.ne, self.S, self.F
         ny, nz, nh, nhr, nhx = cfg['ny'], cfg['nz'], cfg['nh_inf'], cfg['nh_res'], cfg['nhx']
         nlr = self.nl_res
         self.d_hx.zero_()
         # ---- rollout
-        self.d_y_all.zero_()
-        if d_y is not None:
-            self.d_y_all[::ne].copy_(d_y)
+        if not (isinstance(d_y, str) and d_y == 'in_place'):
+            self.d_y_all.zero_()
+            if d_y is not None:
+                self.d_y_all[::ne].copy_(d_y)
         bd = L.RolloutBwdDesc()
         bd.f = self._rd
         bd.d_y_all, bd.d_z, bd.d_pz, bd.d_res = L.ptr(self.d_y_all), L.ptr(d_z), L.ptr(d_pz), L.ptr(d_res)
@@ -270,8 +279,13 @@ class LatentNet:
                     # p_z input = state at the start of every frame: y_all[f*ne]
                     # (contiguous rows: with B == 1 the strided slice reshapes to a VIEW whose row stride is ne * ny, not ny)
                     a_prev = self.y_all[0:S:ne].reshape(nrow, ny).contiguous()
-                L.call('srvp_linear_wgrad_f32', L.ptr(delta), width, L.ptr(a_prev), cin, L.ptr(grads[k + '.weight']), cin,
-                       L.ptr(grads[k + '.bias']), cout, cin, nrow, st)
+                wg = (lambda s_, delta=delta, width=width, a_prev=a_prev, cin=cin, k=k, cout=cout, nrow=nrow:
+                      L.call('srvp_linear_wgrad_f32', L.ptr(delta), width, L.ptr(a_prev), cin, L.ptr(grads[k + '.weight']), cin,
+                             L.ptr(grads[k + '.bias']), cout, cin, nrow, s_))
+                if defer is not None:
+                    defer.append(wg)
+                else:
+                    wg(st)
         # ---- q_z + LSTM
         nq = T - 1
         if nq > 0:
@@ -279,16 +293,22 @@ class LatentNet:
             dq = self.d_qz_tot[:nq].view(nq * B, 2 * nz)
             self.d_hz[:B].zero_()
             linear_bwd(st, self.hz[B:T * B], params['q_z.weight'], dq, grads['q_z.weight'], grads['q_z.bias'],
-                       dx=self.d_hz[B:T * B])
+                       dx=self.d_hz[B:T * B], defer=defer)
             L.call('srvp_lstm_bwd', L.ptr(self.d_hz), L.ptr(params['inf_z.weight_hh_l0']), L.ptr(self.cz), L.ptr(self.gates_act),
                    L.ptr(self.dgates), L.ptr(self.lstm_scratch), T, B, nh, st)
             dg = self.dgates[:T * B]
             # W_hh: sum_t dgates[t]^T h_{t-1}
-            _gemm(st, dg[B:], 1, 4 * nh, self.hz[:(T - 1) * B], nh, 1, None, grads['inf_z.weight_hh_l0'], nh, 4 * nh, nh,
-                  (T - 1) * B, acc=1)
+            whh = lambda s_: _gemm(s_, dg[B:], 1, 4 * nh, self.hz[:(T - 1) * B], nh, 1, None, grads['inf_z.weight_hh_l0'], nh, 4 * nh, nh,
+                                   (T - 1) * B, acc=1)
+            bhh = lambda s_: L.call('srvp_colsum_f32', L.ptr(dg), 4 * nh, L.ptr(grads['inf_z.bias_hh_l0']), T * B, 4 * nh, 1, s_)
+            if defer is not None:
+                defer.extend([whh, bhh])
+            else:
+                whh(st)
             linear_bwd(st, hx.view(T * B, nhx), params['inf_z.weight_ih_l0'], dg, grads['inf_z.weight_ih_l0'],
-                       grads['inf_z.bias_ih_l0'], dx=self.d_hx, dx_acc=1)
-            L.call('srvp_colsum_f32', L.ptr(dg), 4 * nh, L.ptr(grads['inf_z.bias_hh_l0']), T * B, 4 * nh, 1, st)
+                       grads['inf_z.bias_ih_l0'], dx=self.d_hx, dx_acc=1, defer=defer)
+            if defer is None:
+                bhh(st)
         # ---- y_0
         L.call('srvp_rsample_bwd', L.ptr(self.q_y0), L.ptr(eps_y0), L.ptr(self.d_y0), L.ptr(self.d_qy0_tot), B, ny, 0, st)
         if d_qy0 is not None:
@@ -298,22 +318,26 @@ class LatentNet:
         for i in range(len(keys) - 1, -1, -1):
             x_in = self.qy_in if i == 0 else self.qy_hid[i - 1]
             dx = self.d_qy_in if i == 0 else self.d_qy_hid[i - 1]
-            linear_bwd(st, x_in, params[keys[i] + '.weight'], dcur, grads[keys[i] + '.weight'], grads[keys[i] + '.bias'], dx=dx)
+            linear_bwd(st, x_in, params[keys[i] + '.weight'], dcur, grads[keys[i] + '.weight'], grads[keys[i] + '.bias'], dx=dx, defer=defer)
             if i > 0:
                 L.call('srvp_act_bwd_f32', L.ptr(self.qy_hid[i - 1]), L.ptr(dx), L.ptr(dx), dx.numel(), L.ACT_RELU, 1, st)
             dcur = dx
         ti = self.nt_inf
-        self.d_hx.view(T, B, nhx)[:ti] += self.d_qy_in.view(B, ti, nhx).permute(1, 0, 2)
+        # d_hx[t][b] += d_qy_in[b][t] for the first nt_inf frames (backward of the (B, nt_inf * nhx) flattening, srvp.py:268)
+        rows = self.__dict__.get('_qy_rows')
+        if rows is None:
+            rows = self._qy_rows = (torch.arange(ti, dtype=torch.int32).view(1, ti) * B + torch.arange(B, dtype=torch.int32).view(B, 1)).reshape(-1).to(self.dev)
+        L.call('srvp_rows_scatter_add_f32', L.ptr(self.d_hx), L.ptr(rows), 0, L.ptr(self.d_qy_in), B * ti, nhx, st)
         # ---- w
         if d_w is not None:
             L.call('srvp_act_bwd_f32', L.ptr(self.w), L.ptr(d_w), L.ptr(self.d_wpre), d_w.numel(), L.ACT_TANH, 1, st)
             linear_bwd(st, self.hsum, params['w_inf.0.weight'], self.d_wpre, grads['w_inf.0.weight'], grads['w_inf.0.bias'],
-                       dx=self.d_hsum)
+                       dx=self.d_hsum, defer=defer)
             dp = self.d_proj.view(ti, B, nh)
             for i in range(ti):
                 L.call('srvp_act_bwd_f32', L.ptr(self.proj.view(ti, B, nh)[i]), L.ptr(self.d_hsum), L.ptr(dp[i]), B * nh,
                        L.ACT_RELU, 1, st)
             linear_bwd(st, self.h_sel, params['w_proj.0.weight'], self.d_proj, grads['w_proj.0.weight'], grads['w_proj.0.bias'],
-                       dx=self.d_hsel)
-            self.d_hx.index_add_(0, self.w_rows, self.d_hsel)
+                       dx=self.d_hsel, defer=defer)
+            L.call('srvp_rows_scatter_add_f32', L.ptr(self.d_hx), L.ptr(self.w_rows), 1, L.ptr(self.d_hsel), self.w_rows.numel(), nhx, st)
         return self.d_hx

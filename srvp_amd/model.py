@@ -235,11 +235,14 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
                 p.grad = g
         return {k: p.grad for k, p in self.named_parameters()}
 
-    def _plan(self, T, B, nt, n_euler, training, S=1):
+    def _plan(self, T, B, nt, n_euler, training, S=1, S_lat=None):
         """S > 1 (inference only): the conditioning frames are encoded once for B videos, the latent path and the decoder run
-        on B*S (video, sample) rows -- row s*B + b -- sharing the B skip tensors / hoisted skip halves through the image maps."""
+        on B*S (video, sample) rows -- row s*B + b -- sharing the B skip tensors / hoisted skip halves through the image maps.
+        S_lat > S: the latent path carries S_lat samples per video at once (its chains are latency-bound: 800 rows cost what 160
+        do) while the decoder, whose activations set the memory footprint, works through them S at a time."""
         f32 = self.precision == 'fp32'
-        key = (T, B, nt, n_euler, training, str(self._device()) + ('/fp32' if f32 else '')) + ((S,) if S > 1 else ())
+        S_lat = S if S_lat is None else S_lat
+        key = (T, B, nt, n_euler, training, str(self._device()) + ('/fp32' if f32 else '')) + ((S,) if S > 1 or S_lat > 1 else ()) + ((S_lat,) if S_lat != S else ())
         pl = self._plans.get(key)
         if pl is None:
             assert S == 1 or not training
@@ -253,7 +256,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             skip_map = ibuf[2 * nk + B:] if self.skipco else None
             dec = DecoderNet(self._dec_blocks, nt * B * S, dev, training, enc.skips if (self.skipco and enc) else None, skip_map,
                              skip_sel, f32=f32)
-            lat = LatentNet(self._cfg(), T, B * S, nt, n_euler, dev, training)
+            lat = LatentNet(self._cfg(), T, B * S_lat, nt, n_euler, dev, training)
             pl = dict(enc=enc, dec=dec, lat=lat, skip_map=skip_map, skip_sel_t=skip_sel, ibuf=ibuf, keep=ibuf[:nk], skip_idx=ibuf[nk:2 * nk])
             # keep at most two training plans alive (they own all activation memory)
             if training:
@@ -371,29 +374,34 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             # inference MLPs and the LSTM chain -- their big workgroups starved those small dependent kernels (15 -> 60-80 us each)
             s_done = skips_on_side()
         y, z, qz, pz, res = lat.generate(y0, T, params, tape['eps_z'], st)
-        z_in = torch.cat([w.repeat(nt, 1), y.reshape(nt * B, self.ny)], 1)
         if s_done is not None:
             torch.cuda.current_stream().wait_event(s_done)
         if pack_done is not None:
             torch.cuda.current_stream().wait_event(pack_done)
-        x_flat = dec.forward(z_in, params, st, self.sync if training else None)
+        # decoder input rows [w[b] | y[t][b]] (srvp.py:216-221) assembled by the library from w and the stored states y_all[t * n_euler]
+        x_flat = dec.forward(None, params, st, self.sync if training else None,
+                             latent=(w, lat.y_all, lat.ne * B * self.ny, nt, B, self.nh_inf, self.ny))
         x_ = x_flat.view(nt, B, *x_flat.shape[1:])
         pl['hx'], pl['x'] = hx, x
         self._last_plan = pl
         return x_, y, z, w, q_y0, qz, pz, res
 
     @torch.no_grad()
-    def sample(self, x, nt, n_samples, dt=1.0, tape=None):
+    def sample(self, x, nt, n_samples, dt=1.0, tape=None, chunk=None):
         """n_samples stochastic futures of every video from ONE encoding of the conditioning frames x (T, B, C,
         64, 64) -- what train.evaluate (train.py:170-174) / test.py:237-246 obtain from n_samples forward passes, each of
         which re-encodes the same frames.  Inference mode only.  Returns x_ (nt, n_samples, B, C, 64, 64).
-        tape (optional): eps_y0 (n_samples*B, ny), eps_z (nt-1, n_samples*B, nz), row s*B + b."""
+        tape (optional): eps_y0 (n_samples*B, ny), eps_z (nt-1, n_samples*B, nz), row s*B + b.
+        chunk (optional): decode `chunk` samples per video at a time (bounds the activation memory: nt * B * chunk frames resident);
+        the encoder and the whole latent path -- posterior on the conditioning frames, prior rollout: a latency-bound chain whose
+        cost does not depend on the number of rows -- still run ONCE for all n_samples."""
         assert not self.training, 'sample() is an inference entry point (model.eval())'
         dev = self._require_gpu()
         n_euler = int(round(1 / dt))
         T, B, S = x.shape[0], x.shape[1], int(n_samples)
+        Sd = S if (chunk is None or chunk >= S) else max(1, int(chunk))
         st = L.stream()
-        pl = self._plan(T, B, nt, n_euler, False, S=S)
+        pl = self._plan(T, B, nt, n_euler, False, S=Sd, S_lat=S)
         params = self._named_tensors()
         self._pack(pl, params, st)
         if tape is None:
@@ -404,16 +412,24 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         hx = enc.forward(x.view(T * B, *x.shape[2:]), params, st, None).contiguous().view(T, B, self.nhx)
         if self.skipco:
             sel = (T - 1) * B + torch.arange(B, device=dev, dtype=torch.int32)
-            pl['skip_map'].copy_(sel.repeat(nt * S))
+            pl['skip_map'].copy_(sel.repeat(nt * Sd))
             pl['skip_sel_t'].copy_(sel)
         hx_s = hx.repeat(1, S, 1).contiguous()                          # (T, S*B, nhx): row s*B + b
         w = lat.infer_w(hx_s, params, None, st)
         y0, _ = lat.infer_y(hx_s[:self.nt_inf], params, tape['eps_y0'], st)
         lat.posterior(hx_s, params, st)
-        y = lat.generate(y0, T, params, tape['eps_z'], st)[0]
-        z_in = torch.cat([w.repeat(nt, 1), y.reshape(nt * B * S, self.ny)], 1)
-        x_flat = dec.forward(z_in, params, st, None)
-        return x_flat.view(nt, S, B, *x_flat.shape[1:]).clone()
+        lat.generate(y0, T, params, tape['eps_z'], st)
+        if Sd == S:
+            x_flat = dec.forward(None, params, st, None, latent=(w, lat.y_all, lat.ne * B * S * self.ny, nt, B * S, self.nh_inf, self.ny))
+            return x_flat.view(nt, S, B, *x_flat.shape[1:]).clone()
+        out = torch.empty(nt, S, B, *dec.x_out.shape[1:], dtype=torch.float32, device=dev)
+        for s0 in range(0, S, Sd):
+            # the last chunk is decoded at the common size (one decoder plan per evaluation shape), re-using the final samples
+            s0 = min(s0, S - Sd)
+            x_flat = dec.forward(None, params, st, None, latent=(w[s0 * B:], lat.y_all[:, s0 * B:], lat.ne * B * S * self.ny, nt, B * Sd,
+                                                                  self.nh_inf, self.ny))
+            out[:, s0:s0 + Sd] = x_flat.view(nt, Sd, B, *x_flat.shape[1:])
+        return out
 
     def _backward_impl(self, d_x, d_y, d_w, d_qy0, d_qz, d_pz, d_res):
         pl = self._last_plan
@@ -443,17 +459,27 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
                     self.sync.grads_ready('decoder', self)
                 wg_done = torch.cuda.Event()
                 wg_done.record()
-        dzf = dz[:, :self.nh_inf + self.ny].float()
-        d_w_tot = dzf[:, :self.nh_inf].reshape(nt, B, self.nh_inf).sum(0)
-        if d_w is not None:
-            d_w_tot = d_w_tot + d_w
-        d_y_tot = dzf[:, self.nh_inf:].reshape(nt, B, self.ny)
-        if d_y is not None:
-            d_y_tot = d_y_tot + d_y
+        # backward of the time-expansion of w and of the concatenation [w | y_t] (srvp.py:216-221): d_w = sum over time, d_y_t straight
+        # into the rollout's state-gradient buffer (frame t = Euler step t * n_euler)
+        if not hasattr(lat, 'd_w_tot'):
+            lat.d_w_tot = torch.empty(B, self.nh_inf, dtype=torch.float32, device=dz.device)
+        lat.d_y_all.zero_()
+        L.call('srvp_dz_split', L.ptr(dz), dz.shape[1], 1 if dz.dtype == torch.float32 else 0, nt, B, self.nh_inf, self.ny,
+               L.ptr(cz(d_w)), L.ptr(cz(d_y)), L.ptr(lat.d_w_tot), L.ptr(lat.d_y_all), lat.ne * B * self.ny, st)
         if self.sync is not None and not overlap:
             self.sync.grads_ready('decoder', self)
-        d_hx = lat.backward(pl['hx'], params, grads, tape['eps_y0'], tape['eps_z'], d_y_tot.contiguous(), d_w_tot.contiguous(),
-                            cz(d_qy0), cz(d_qz), cz(d_pz), cz(d_res), None, st)
+        deferred = [] if overlap else None
+        d_hx = lat.backward(pl['hx'], params, grads, tape['eps_y0'], tape['eps_z'], 'in_place', lat.d_w_tot,
+                            cz(d_qy0), cz(d_qz), cz(d_pz), cz(d_res), None, st, defer=deferred)
+        if deferred:
+            # the latent networks' weight gradients feed nothing but the optimizer: second stream, under the encoder backward
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self._side_stream):
+                self._side_stream.wait_event(ev)
+                s2 = L.stream()
+                for fn in deferred:
+                    fn(s2)
         skip_grads = None
         if self.skipco:
             skip_grads = {}
@@ -501,7 +527,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
 
     def drop_sample_plans(self):
         """Frees the S > 1 inference plans of sample() (activation buffers for S futures per video)."""
-        for k in [k for k in self._plans if isinstance(k[0], int) and len(k) > 6]:
+        for k in [k for k in self._plans if isinstance(k[0], int) and len(k) > 6]:      # (keys with a sample count)
             del self._plans[k]
 
     def _infer_plan(self, T, B, nt, n_euler=1):

@@ -129,12 +129,10 @@ def evaluate(forward_fn, val_loader, device, opt):
                 # in chunks of <= SRVP_EVAL_FRAMES decoded frames (9216 frames of VGG-64 keep ~31 GB of the 288 GB resident)
                 lim = int(os.environ.get('SRVP_EVAL_FRAMES', 9216))
                 chunk = max(1, min(opt.n_samples_test, lim // max(1, nt * n_b)))
-                samples = []
-                for s0 in range(0, opt.n_samples_test, chunk):
-                    # the last chunk is drawn at the common chunk size and the surplus samples are discarded: one inference
-                    # plan (activation buffers) per evaluation shape instead of one per distinct chunk size
-                    xs = model.sample(x_inf, nt, chunk, dt=1 / opt.n_euler_steps)
-                    samples.extend(xs[:, i] for i in range(min(chunk, opt.n_samples_test - s0)))
+                # ONE call: the encoder and the latent path (posterior + prior rollout: latency-bound, batch-size independent) run once
+                # for all samples, the decoder works through them `chunk` at a time
+                xs = model.sample(x_inf, nt, opt.n_samples_test, dt=1 / opt.n_euler_steps, chunk=chunk)
+                samples = (xs[:, i] for i in range(opt.n_samples_test))
             else:
                 samples = (forward_fn(x_inf, nt, dt=1 / opt.n_euler_steps)[0] for _ in range(opt.n_samples_test))
             for x_s in samples:
@@ -287,6 +285,8 @@ def main(opt):
     import gc
     gc.collect()
     gc.freeze()
+    import time as _time
+    t_loop, t_val, itr0 = _time.perf_counter(), 0.0, itr
     try:
         while not finished:
             if sampler is not None:
@@ -305,7 +305,9 @@ def main(opt):
                 if local_rank == 0:
                     if itr % opt.val_interval == 0 and val_loader is not None:
                         model.eval()
+                        _tv = _time.perf_counter()
                         val_metric = evaluate(model, val_loader, device, opt)
+                        t_val += _time.perf_counter() - _tv
                         if best_val_metric is None or best_val_metric > val_metric:
                             best_val_metric = val_metric
                             torch.save(model.state_dict(), os.path.join(opt.save_path, 'model_best.pt'))
@@ -318,6 +320,12 @@ def main(opt):
                               f'val {val_metric} best {best_val_metric}', flush=True)
     except KeyboardInterrupt:
         status_code = 130
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if itr > itr0 + 1:
+        dt_loop = _time.perf_counter() - t_loop
+        print(f'{itr - itr0} iterations in {dt_loop:.1f} s: {1e3 * (dt_loop - t_val) / (itr - itr0):.2f} ms / iteration (data + step + logging), '
+              f'validation {t_val:.1f} s', flush=True)
     print('Saving...')
     if local_rank > 0:
         save_rank_rng(os.path.join(opt.save_path, 'train_state.pt'), local_rank, itr)

@@ -469,6 +469,11 @@ def test_batched_samples_match_per_sample_forward(archi, nc, skipco):
         ref = m(x, nt, 0.5, tape=tape)[0]
         assert torch.allclose(xs[:, s], ref, atol=2e-3, rtol=0), (s, (xs[:, s] - ref).abs().max().item())
     assert (xs[:, 0] - xs[:, 1]).abs().max() > 2e-2             # the samples do differ
+    # decoder chunking (chunk = 2 of the 3 samples per pass; the encoder and the latent path still run once): same frames, bit for bit
+    # in the samples the two passes do not share and in the ones they do
+    xc = m.sample(x, nt, S, dt=0.5, tape=dict(eps_y0=eps_y0, eps_z=eps_z), chunk=2)
+    assert torch.equal(xc, xs)
+    assert torch.equal(m.sample(x, nt, S, dt=0.5, tape=dict(eps_y0=eps_y0, eps_z=eps_z), chunk=1), xs)
 
 
 def test_evaluate_best_of_n_psnr():
