@@ -84,6 +84,13 @@ typedef struct {
                                    * element (n, Y, X, c) at ((((n DHp + Y) q + X % q) (DWp / q / 4) + (X / q) / 4) C + c) 4 + (X / q) % 4,
                                    * so that four consecutive output columns of a consumer lane are one 16-byte load.  Consumers need
                                    * so == q and OW % 4 == 0; same values, another layout */
+    /* BatchNorm-backward reduction of the PRODUCER layer fused into a data-gradient launch (halo kernel only; conv.py:103-104 backward):
+     * this launch writes dA = gradient wrt the activated output of a conv -> BN -> LeakyReLU block whose raw (pre-BN) output is
+     * bnr_raw [N][OH][OW][Cout] (same shape as dst).  With bnr_red != NULL the epilogue also accumulates, per channel,
+     *   bnr_red[0][c] += sum g,  bnr_red[1][c] += sum g * (raw - mean) * invstd,   g = bf16(dA) * f'(scale * raw + shift)
+     * i.e. exactly what srvp_bn_bwd_reduce (da_mode 0) computes from the stored dA and raw -- one read of dA and one launch less
+     * per layer.  bnr_coef: fp32 [4][Cout] = scale, shift, mean, invstd of that layer. */
+    const void* bnr_raw; const float* bnr_coef; double* bnr_red;
 } srvp_conv_desc;
 int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
 /* 1 (default): 3x3 stride-1 single-source convolutions run on the halo-tiled kernel (input patch staged in LDS once
@@ -91,6 +98,8 @@ int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
 int srvp_conv_set_halo(int on);
 /* 1 if this descriptor will run on the halo-tiled kernel, which wants its weights fragment-major (pack layout 1) */
 int srvp_conv_wants_fragmajor(const srvp_conv_desc* d);
+/* 1 if this descriptor will run on the halo-tiled kernel (the only one that takes bnr_red) */
+int srvp_conv_runs_on_halo(const srvp_conv_desc* d);
 /* d[0..n-1]: as n calls of srvp_conv_mfma; launches that run on the same halo-kernel variant with the same grid (the four
  * output phases of a sub-pixel upsample convolution) are issued as ONE grid */
 int srvp_conv_mfma_multi(const srvp_conv_desc* d, int n, void* stream);

@@ -33,7 +33,8 @@ class ConvDesc(C.Structure):
                 ('stats', c_vp), ('stat_mod', c_i32),
                 ('out_f32', c_vp), ('out_nc', c_i32), ('out_sigmoid', c_i32),
                 ('map0', c_vp), ('dst_is_f32', c_i32), ('add_f32', c_vp), ('add_mod', c_i32), ('wt_fragmajor', c_i32),
-                ('tap_phase_chunks', c_i32), ('elem_f32', c_i32), ('splitk', c_i32), ('f32_quad', c_i32)]
+                ('tap_phase_chunks', c_i32), ('elem_f32', c_i32), ('splitk', c_i32), ('f32_quad', c_i32),
+                ('bnr_raw', c_vp), ('bnr_coef', c_vp), ('bnr_red', c_vp)]
 
 
 class WgradDesc(C.Structure):
@@ -87,6 +88,7 @@ _SIGS = {
     'srvp_conv_mfma': ([C.POINTER(ConvDesc), c_vp], c_i32),
     'srvp_conv_set_halo': ([c_i32], c_i32),
     'srvp_conv_wants_fragmajor': ([C.POINTER(ConvDesc)], c_i32),
+    'srvp_conv_runs_on_halo': ([C.POINTER(ConvDesc)], c_i32),
     'srvp_conv_mfma_multi': ([C.POINTER(ConvDesc), c_i32, c_vp], c_i32),
     'srvp_wgrad_mfma': ([C.POINTER(WgradDesc), c_vp], c_i32),
     'srvp_wgrad_set_tr': ([c_i32], c_i32),

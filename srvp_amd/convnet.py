@@ -24,6 +24,12 @@ BN_FUSED_FINALIZE = os.environ.get('SRVP_BN_FUSED_FINALIZE', '1') != '0'    # bn
 # fill the chip, so the weight gradient of block i runs beside the BatchNorm backward / data gradient of block i - 1
 # (same-box A/B, ms per step off / on: 9.40 / 9.02 at 24 sequences per GPU, 14.35 / 13.69 at 48, 22.75 / 22.89 at 96, 42.00 / 41.57 at 192)
 ENC_WGRAD_SIDE_MAXN = int(os.environ.get('SRVP_ENC_WGRAD_SIDE_MAXN', '1000000'))
+# BatchNorm-backward reduction of a producer layer inside the data-gradient launch of its (plain 3x3) consumer (srvp_conv_desc.bnr_*)
+BN_FUSED_REDUCE = os.environ.get('SRVP_BN_FUSED_REDUCE', '1') != '0'
+# decoder weight gradients issued on the second stream block by block (each right behind its BatchNorm backward) instead of all after
+# the decoder's data-gradient chain: the MFMA-bound weight gradients then run beside the HBM-bound BatchNorm passes of the blocks below
+# (measured, same box: 41.70 vs 41.21 ms per step at 192 sequences with / without, 8.88 vs 8.86 at 24: off)
+DEC_WGRAD_EARLY = os.environ.get('SRVP_DEC_WGRAD_EARLY', '0') != '0'
 S_QUAD = os.environ.get('SRVP_S_QUAD', '1') != '0'        # hoisted skip half stored pixel-quad-major (16-byte loads in the consumers)
 SPLITK = int(os.environ.get('SRVP_CONV_SPLITK', '16'))    # tiny-M long-K launches: K steps shared over this many workgroups
 # Sub-pixel form of "nearest x2 upsample, then 3x3 conv" (conv.py:331-349): output phase a in {0,1} of a row pair reads
@@ -824,8 +830,8 @@ class ConvNetBase:
             blk.finish_fwd(st)
         self._bn_forward(blk, params, st, sync, keep)
 
-    def _bn_backward(self, blk, params, grads, da, st, sync):
-        """da: dict(t, mode, cstride, coff, border, f32, da2, da2_idx).  Produces blk.draw (and BN param grads)."""
+    @staticmethod
+    def _bnbwd_desc(blk, da):
         d = L.BnBwdDesc()
         d.elem_f32 = 1 if blk.f32 else 0
         d.draw_s2d = 1 if getattr(blk, 's2d', False) else 0
@@ -837,10 +843,16 @@ class ConvNetBase:
         d.da_is_f32 = 1 if da.get('f32') else 0
         d.da2, d.da2_idx = L.ptr(da.get('da2')), L.ptr(da.get('da2_idx'))
         d.N, d.H, d.W, d.C = blk.N, blk.OH, blk.OW, blk.cout
+        return d
+
+    def _bn_backward(self, blk, params, grads, da, st, sync):
+        """da: dict(t, mode, cstride, coff, border, f32, da2, da2_idx).  Produces blk.draw (and BN param grads)."""
+        d = self._bnbwd_desc(blk, da)
         if blk.split and blk.draw_b == 1:
             d.tsum, d.tsum_T = L.ptr(blk.draw_sum), blk.N // blk.B      # time-summed gradient for the hoisted skip half
         if blk.has_bn:
-            L.call('srvp_bn_bwd_reduce', C.byref(d), L.ptr(blk.red), st)
+            if not getattr(blk, '_reduce_fused', False):       # (else: accumulated by the consumer's data-gradient launch, _fuse_bn_reduce)
+                L.call('srvp_bn_bwd_reduce', C.byref(d), L.ptr(blk.red), st)
             local = float(blk.N * blk.OH * blk.OW)
             count = local
             if sync is not None:
@@ -907,6 +919,30 @@ class ConvNetBase:
         c = self._job_table(jobs, self.dev, self.__dict__.setdefault('_unpack_cache', {}), True)
         L.call('srvp_unpack_wgrad_multi', L.ptr(c['table']), c['n'], c['mx'], st)
 
+    def _fuse_bn_reduce(self):
+        """Pairs (producer P, consumer Q) where Q is a plain 3x3 stride-1 block reading P's activated output at the same resolution
+        and nothing else adds to that gradient (no pooling, upsampling or skip connection in between): Q's data-gradient launch then
+        carries P's raw output / coefficients and accumulates P's two BatchNorm-backward sums in its epilogue
+        (srvp_conv_desc.bnr_*), and P's srvp_bn_bwd_reduce launch -- a second read of (dA, raw) -- is dropped."""
+        if not (BN_FUSED_REDUCE and self.training and not self.f32):
+            return
+        lib = L.load()
+        for q in self.blocks:
+            if q.role != 'mfma' or getattr(q, 'geom', None) != 'same' or not getattr(q, '_dg', None):
+                continue
+            # an upsampling consumer qualifies in its space-to-depth form only: its data gradient is then ONE launch that writes the
+            # gradient wrt the LOW-resolution source, already summed over each 2x2 cell -- the producer's dA
+            if (q.ups or q.subpix) and not (q.subpix and q.s2d):
+                continue
+            p = next((b for b in self.blocks if b.out is not None and b.out is q.srcs[0]), None)
+            if p is None or not p.has_bn or p.act != L.ACT_LRELU or p.spec.get('skip_out') is not None or p.pool is not None:
+                continue
+            d = q._dg[0]
+            if tuple(p.raw.shape) != tuple(q.dcat.shape) or d.Cout != p.cout or not int(lib.srvp_conv_runs_on_halo(C.byref(d))):
+                continue
+            d.bnr_raw, d.bnr_coef, d.bnr_red = L.ptr(p.raw), L.ptr(p.coef), L.ptr(p.red)
+            p._reduce_fused = True
+
     def _pool_accumulators(self):
         """Re-homes the per-step accumulators of all blocks (BN statistics, BN-backward sums, weight-gradient tiles) in three flat
         buffers, so that clearing them is three fills per network instead of one per tensor (torch._foreach_zero_ on a list of
@@ -969,6 +1005,7 @@ class EncoderNet(ConvNetBase):
                 if training:
                     blk._dg = blk.dgrad_descs()
                     blk._wg = blk.wgrad_desc()
+        self._fuse_bn_reduce()
         # keyed by the decoder's skip index (deepest first, conv.py:153): encoder stage s feeds decoder block 3 - s
         self.skips = {3 - sp['skip_out']: b.out for sp, b in zip(specs, self.blocks) if sp['skip_out'] is not None}
         self.nh_r = specs[-1]['cout']
@@ -1061,6 +1098,7 @@ class DecoderNet(ConvNetBase):
             if training:
                 blk._dg = blk.dgrad_descs()
                 blk._wg = blk.wgrad_desc()
+        self._fuse_bn_reduce()
         ob = self.blocks[-1]
         self.nc = ob.cout_r
         self.x_out = ob.x_out
@@ -1095,12 +1133,15 @@ class DecoderNet(ConvNetBase):
 
     def deferred_wgrads(self, grads, st):
         """The weight gradients of a backward(..., defer_wgrad=True): nothing downstream but the optimizer needs them, so the
-        caller runs them on a second stream, concurrently with the latency-bound latent backward that follows."""
-        for blk in self.blocks:
-            if blk is self.blocks[-1] and self._f32_out():
-                self._out_wgrad_f32(grads, st)
-            else:
-                self._wgrad(blk, st)
+        caller runs them on a second stream, concurrently with the latency-bound latent backward that follows.  (With `side` given
+        to backward() they were already issued there block by block; only the unpacking is left.)"""
+        if not getattr(self, '_wgrads_issued', False):
+            for blk in self.blocks:
+                if blk is self.blocks[-1] and self._f32_out():
+                    self._out_wgrad_f32(grads, st)
+                else:
+                    self._wgrad(blk, st)
+        self._wgrads_issued = False
         self.unpack_wgrads(grads, st)
 
     def _f32_out(self):
@@ -1118,10 +1159,19 @@ class DecoderNet(ConvNetBase):
         L.call('srvp_conv_in_wgrad_f32' if self.f32 else 'srvp_conv_in_wgrad', L.ptr(self.dpre_f32), L.ptr(f0.t), L.ptr(grads[ob.spec['key'] + '.weight']),
                self.N, ob.cout_r, 64, 64, f0.C, ob.cin_r[0], ob.k, ob.s, ob.p, st)
 
-    def backward(self, d_x, params, grads, st, sync=None, defer_wgrad=False):
-        """d_x: fp32 (N, C, 64, 64).  Returns dz bf16 [N][nz_padded]; skip gradients are left in the blocks' dcat."""
+    def backward(self, d_x, params, grads, st, sync=None, defer_wgrad=False, side=None):
+        """d_x: fp32 (N, C, 64, 64).  Returns dz bf16 [N][nz_padded]; skip gradients are left in the blocks' dcat.
+        side (torch stream, with defer_wgrad): every block's weight gradient is issued there as soon as its output gradient exists."""
         ob = self.blocks[-1]
         self.zero_backward_accumulators()
+        early = defer_wgrad and side is not None and DEC_WGRAD_EARLY
+
+        def on_side(fn):
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                fn(L.stream())
         # The data-gradient of the image-side layer contracts over nc*k*k <= 48 values per pixel: as an MFMA conv on the
         # padded bf16 gradient it wastes 10x the work.  It IS the first-layer forward kernel with the gradient frames as
         # the "image" and the ConvTranspose weight (Cin, nc, k, k) read as (O, I, k, k): exact fp32 on the matrix cores.
@@ -1135,9 +1185,13 @@ class DecoderNet(ConvNetBase):
         if f32_out:
             if not defer_wgrad:
                 self._out_wgrad_f32(grads, st)
+            elif early:
+                on_side(lambda s_: self._out_wgrad_f32(grads, s_))
             L.call('srvp_conv_in_fwd_f32' if self.f32 else 'srvp_conv_in_fwd', L.ptr(self.dpre_f32), L.ptr(params[ob.spec['key'] + '.weight']), L.ptr(ob.dcat), None,
                    self.N, ob.cout_r, 64, 64, ob.ctot, ob.cin_r[0], ob.k, ob.s, ob.p, st)
         else:
+            if early:
+                on_side(lambda s_: self._wgrad(ob, s_))
             self._mfma_backward(ob, grads, st, wgrad=not defer_wgrad)
         nxt = ob
         for i in range(len(self.blocks) - 2, -1, -1):
@@ -1145,8 +1199,11 @@ class DecoderNet(ConvNetBase):
             # (a sub-pixel consumer hands back the gradient already summed over each 2x2 upsample cell)
             da = dict(t=nxt.dcat, mode=1 if (blk.spec['post_up'] and not nxt.subpix) else 0, cstride=nxt.dcat_c, coff=0, border=0)
             self._bn_backward(blk, params, grads, da, st, sync)
+            if early:
+                on_side(lambda s_, blk=blk: self._wgrad(blk, s_))
             self._mfma_backward(blk, grads, st, wgrad=not defer_wgrad)
             nxt = blk
+        self._wgrads_issued = bool(early)
         if not defer_wgrad:
             self.unpack_wgrads(grads, st)
         return self.blocks[0].dcat.view(self.N, -1)

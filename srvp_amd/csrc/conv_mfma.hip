@@ -35,6 +35,7 @@ struct ConvK {
     int f32_quad;              // > 0: the fp32 tensor (dst of a dst_is_f32 launch / add_f32) is pixel-quad-major for consumer stride f32_quad
     int splitk;                // > 1 (generic kernel, fp32 destination): blockIdx.y walks its share of the K steps into slab blockIdx.y
     long long slab;            // elements per split-K slab
+    const bf16_t* bnr_raw; const float* bnr_coef; double* bnr_red;     // fused BatchNorm-backward reduction of the producer (srvp_hip.h)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -133,7 +134,61 @@ __device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[TM][TN], const Con
             }
         return;
     }
-    if (a.stats && all_valid) {
+    if (a.bnr_red) {
+        // ---- fused BatchNorm-backward reduction of the producer layer (srvp_conv_desc.bnr_*): the accumulators ARE dA of that
+        // layer; its raw tile [BM px][BN ch] comes global -> LDS by LDS-DMA (16-byte pieces, lane-linear = row-major), then every
+        // lane walks its 16 * TM pixels of its TN channels: g = bf16(dA) * lrelu'(scale raw + shift), sums of g and g * xhat.
+        constexpr int PCS = BN / 8;                            // 16-byte pieces per pixel row
+        constexpr int NPC = BM * PCS / NT;                     // pieces per thread
+        static_assert((BM * PCS) % NT == 0, "raw tile pieces");
+        bf16_t* Rs = reinterpret_cast<bf16_t*>(smem);          // [BM][BN] (fits the staging area: BN <= LDC)
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            const int q = tid + i * NT;
+            const int row = q / PCS, pc = q - row * PCS;
+            int n = 0, oy = 0, ox = 0;
+            if (!rowmap(row, n, oy, ox)) { n = a.N - 1; oy = 0; ox = 0; }
+            const unsigned off = (((unsigned)n * a.DHp + oy) * a.DWp + ox) * a.Cdst + n0 + pc * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.bnr_raw + off), (lptr_t)(Rs + ((size_t)i * NT + wid * 64) * 8), 16, 0, 0);
+        }
+        float csc[TN], csh[TN], cmu[TN], cis[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = n0 + wn * (TN * 32) + j * 32 + lcol;
+            csc[j] = a.bnr_coef[c]; csh[j] = a.bnr_coef[a.Cdst + c]; cmu[j] = a.bnr_coef[2 * a.Cdst + c]; cis[j] = a.bnr_coef[3 * a.Cdst + c];
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): the tile has landed
+        __syncthreads();
+        bool okr[TM][16];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int n, oy, ox;
+                okr[i][r] = all_valid || rowmap(wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf, n, oy, ox);
+            }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+            const int col = wn * (TN * 32) + j * 32 + lcol;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                    const float rawv = bf2f(Rs[row * BN + col]);
+                    const float da = bf2f(f2bf(acc[i][j][r]));                       // dA as the tensor stores it (what apply reads back)
+                    const float pre = rawv * csc[j] + csh[j];
+                    float g = da * (pre > 0.f ? 1.f : LRELU_SLOPE);
+                    g = okr[i][r] ? g : 0.f;
+                    s1 += g; s2 += g * (rawv - cmu[j]) * cis[j];
+                }
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (lhalf == 0) { red[(wm * BN + col) * 2 + 0] = s1; red[(wm * BN + col) * 2 + 1] = s2; }
+        }
+        __syncthreads();                                       // every wave is done with the raw tile: the staging below reuses it
+    } else if (a.stats && all_valid) {
         // every row of the tile is a real output pixel (workgroup-uniform): no per-row masks
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -219,13 +274,18 @@ __device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[TM][TN], const Con
                 Cs[row * LDC + col] = f2bf(acc[i][j][r]);
             }
     __syncthreads();
-    if (a.stats && tid < BN) {
+    if ((a.stats || a.bnr_red) && tid < BN) {
         double s1 = 0., s2 = 0.;
 #pragma unroll
         for (int w = 0; w < WM; ++w) { s1 += red[(w * BN + tid) * 2]; s2 += red[(w * BN + tid) * 2 + 1]; }
-        int ch = (n0 + tid) % a.stat_mod;
-        atomicAdd(a.stats + ch, s1);
-        atomicAdd(a.stats + a.stat_mod + ch, s2);
+        if (a.bnr_red) {
+            atomicAdd(a.bnr_red + n0 + tid, s1);
+            atomicAdd(a.bnr_red + a.Cdst + n0 + tid, s2);
+        } else {
+            int ch = (n0 + tid) % a.stat_mod;
+            atomicAdd(a.stats + ch, s1);
+            atomicAdd(a.stats + a.stat_mod + ch, s2);
+        }
     }
     // copy-out: thread -> (16-byte channel chunk ch, rows row0 + k * RSTEP).  Unrolled in groups of four with the LDS reads
     // of a group issued before its stores and the descriptor fields hoisted (as a rolled loop hipcc re-loaded them from the
@@ -456,6 +516,7 @@ static int fill_convk(const srvp_conv_desc* d, ConvK& k) {
     k.Cdst = d->Cdst; k.cdst_off = d->cdst_off; k.stats = d->stats; k.stat_mod = d->stat_mod;
     k.out_f32 = d->out_f32; k.out_nc = d->out_nc; k.out_sigmoid = d->out_sigmoid;
     k.map0 = d->map0; k.dst_is_f32 = d->dst_is_f32; k.add_f32 = d->add_f32; k.add_mod = d->add_mod;
+    k.bnr_raw = (const bf16_t*)d->bnr_raw; k.bnr_coef = d->bnr_coef; k.bnr_red = d->bnr_red;
     return SRVP_OK;
 }
 
@@ -802,6 +863,8 @@ int launch(const srvp_conv_desc* d, hipStream_t st) {
 
 extern "C" int srvp_conv_set_halo(int on) { g_halo = on; return SRVP_OK; }
 
+extern "C" int srvp_conv_runs_on_halo(const srvp_conv_desc* d) { return d && halo_variant(d) ? 1 : 0; }
+
 extern "C" int srvp_conv_wants_fragmajor(const srvp_conv_desc* d) { return d && (halo_variant(d) || generic_wants_fragmajor(d)) ? 1 : 0; }
 
 extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
@@ -835,6 +898,10 @@ extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
                                       (d->add_f32 == nullptr || (d->so == d->f32_quad && d->OW % 4 == 0)) && d->cdst_off == 0),
                  "srvp_conv_mfma: f32_quad = %d needs an fp32 S tensor whose width is a multiple of 4 x the consumer stride (and so == f32_quad, OW %% 4 == 0 on the consumer)", d->f32_quad);
     SRVP_REQUIRE(!(d->elem_f32 && d->splitk > 1), "srvp_conv_mfma: splitk is not available in fp32 parity mode");
+    SRVP_REQUIRE(!d->bnr_red || (d->bnr_raw && d->bnr_coef && !d->elem_f32 && !d->stats && !d->dst_is_f32 && !d->out_f32 && d->so == 1 && d->ooy == 0 &&
+                                 d->oox == 0 && d->cdst_off == 0 && d->Cdst == d->Cout && d->DHp == d->OH && d->DWp == d->OW && halo_variant(d) &&
+                                 (long long)d->N * d->OH * d->OW * d->Cout < (1ll << 32)),
+                 "srvp_conv_mfma: bnr_red (fused BatchNorm-backward reduction) needs a plain bf16 data-gradient launch on the halo kernel");
     if (d->elem_f32) return srvp_conv_f32_launch(d, st);
     SRVP_REQUIRE((long long)d->N * d->H0p * d->W0p * d->C0 < (1ll << 32) && (d->C1 == 0 || d->map1 || (long long)d->N * d->H1p * d->W1p * d->C1 < (1ll << 32)),
                  "srvp_conv_mfma: source tensors must have fewer than 2^32 elements");

@@ -98,7 +98,30 @@ __host__ __device__ inline int pack_job_wgs(long long total) {
     return (int)(w < 1 ? 1 : (w > 256 ? 256 : w));
 }
 // blockIdx.x -> (job, workgroup within the job, workgroups of the job)
+// (the job sizes are read by all threads in ONE parallel round and scanned from LDS: a serial walk of the table in global memory
+// was ~40 dependent ~1 us loads at the head of every workgroup -- most of the 0.2-0.3 ms these launches took, whatever the copy loop)
 __device__ __forceinline__ const srvp_pack_job* locate_job(const srvp_pack_job* jobs, int njobs, unsigned& wg, unsigned& nwg) {
+    __shared__ unsigned s_n[256];
+    __shared__ int s_job;
+    __shared__ unsigned s_wg;
+    if (njobs <= 256) {
+        for (int i = threadIdx.x; i < njobs; i += blockDim.x)
+            s_n[i] = (unsigned)pack_job_wgs((long long)jobs[i].d.ntaps * jobs[i].d.J * jobs[i].d.K);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned w = blockIdx.x;
+            int found = -1;
+            for (int i = 0; i < njobs; ++i) {
+                if (w < s_n[i]) { found = i; break; }
+                w -= s_n[i];
+            }
+            s_job = found; s_wg = w;
+        }
+        __syncthreads();
+        if (s_job < 0) return nullptr;
+        wg = s_wg; nwg = s_n[s_job];
+        return jobs + s_job;
+    }
     wg = blockIdx.x;
     for (int i = 0; i < njobs; ++i) {
         nwg = (unsigned)pack_job_wgs((long long)jobs[i].d.ntaps * jobs[i].d.J * jobs[i].d.K);
@@ -151,10 +174,25 @@ __device__ void pack_job_tiled(const srvp_pack_job& j, unsigned wg, unsigned nwg
     for (int tile = (int)wg; tile < to * ti; tile += (int)nwg) {
         const int o0 = (tile / ti) * PT_OUT, i0 = (tile % ti) * PT_INN;
         __syncthreads();
-        for (int e = threadIdx.x; e < PT_OUT * PT_INN * TS; e += 256) {
-            const int o = e / (PT_INN * TS), rem = e - o * (PT_INN * TS), i = rem / TS, tp = rem - i * TS;
-            const long long b = tile_src_base(d, inner_k, o0 + o, i0 + i);
-            lds[o * pitch + rem] = b >= 0 ? src[b + tp] : 0.f;
+        // (loads in batches of eight per thread, all issued before the first LDS store: one at a time, each iteration waited for its
+        // own HBM round trip -- 18-32 of them in a row per tile)
+        constexpr int LU = 8;
+        for (int e0 = threadIdx.x; e0 < PT_OUT * PT_INN * TS; e0 += 256 * LU) {
+            float v[LU];
+            int la[LU];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int e = e0 + u * 256;
+                la[u] = -1; v[u] = 0.f;
+                if (e < PT_OUT * PT_INN * TS) {
+                    const int o = e / (PT_INN * TS), rem = e - o * (PT_INN * TS), i = rem / TS, tp = rem - i * TS;
+                    const long long b = tile_src_base(d, inner_k, o0 + o, i0 + i);
+                    la[u] = o * pitch + rem;
+                    if (b >= 0) v[u] = src[b + tp];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < LU; ++u) if (la[u] >= 0) lds[la[u]] = v[u];
         }
         __syncthreads();
         // packed items of the tile: (tap, j, eight consecutive k)
@@ -206,10 +244,18 @@ __device__ void unpack_job_tiled(const srvp_pack_job& j, unsigned wg, unsigned n
             if (inner_k) { k8 = it % nk8; jl = it / nk8; } else { jl = it % nj; k8 = it / nj; }
             const int jj = (inner_k ? o0 : i0) + jl, k = (inner_k ? i0 : o0) + k8 * 8;
             if (jj >= d.J || k >= d.K) continue;
-            for (int t = 0; t < ntaps; ++t) {
+            f32x4_t plo[SRVP_MAX_TAPS], phi[SRVP_MAX_TAPS];
+#pragma unroll
+            for (int t = 0; t < SRVP_MAX_TAPS; ++t)
+                if (t < ntaps) {
+                    const float* sp = src + ((long long)t * d.J + jj) * d.K + k;
+                    plo[t] = *reinterpret_cast<const f32x4_t*>(sp); phi[t] = *reinterpret_cast<const f32x4_t*>(sp + 4);
+                }
+#pragma unroll
+            for (int t = 0; t < SRVP_MAX_TAPS; ++t) {
+                if (t >= ntaps) break;
                 const unsigned m = d.tap_set[t] ? (unsigned)d.tap_set[t] : 1u << d.tap_off[t];
-                const float* sp = src + ((long long)t * d.J + jj) * d.K + k;
-                const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(sp), hi = *reinterpret_cast<const f32x4_t*>(sp + 4);
+                const f32x4_t lo = plo[t], hi = phi[t];
                 for (int sidx = 0; sidx < TS; ++sidx)
                     if ((m >> sidx) & 1) {
 #pragma unroll
@@ -221,11 +267,24 @@ __device__ void unpack_job_tiled(const srvp_pack_job& j, unsigned wg, unsigned n
             }
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < PT_OUT * PT_INN * TS; e += 256) {
-            const int o = e / (PT_INN * TS), rem = e - o * (PT_INN * TS), i = rem / TS, tp = rem - i * TS;
-            if (!((need >> tp) & 1)) continue;
-            const long long b = tile_src_base(d, inner_k, o0 + o, i0 + i);
-            if (b >= 0) dst[b + tp] += lds[o * pitch + rem];
+        constexpr int LU = 8;
+        for (int e0 = threadIdx.x; e0 < PT_OUT * PT_INN * TS; e0 += 256 * LU) {
+            float v[LU];
+            long long ga[LU];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int e = e0 + u * 256;
+                ga[u] = -1; v[u] = 0.f;
+                if (e < PT_OUT * PT_INN * TS) {
+                    const int o = e / (PT_INN * TS), rem = e - o * (PT_INN * TS), i = rem / TS, tp = rem - i * TS;
+                    if ((need >> tp) & 1) {
+                        const long long b = tile_src_base(d, inner_k, o0 + o, i0 + i);
+                        if (b >= 0) { ga[u] = b + tp; v[u] = dst[b + tp] + lds[o * pitch + rem]; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < LU; ++u) if (ga[u] >= 0) dst[ga[u]] = v[u];
         }
     }
 }

@@ -446,10 +446,11 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         # The decoder's weight gradients feed nothing but the optimizer: they run on a second stream, concurrently with the
         # latent backward (a ~3 ms chain of tiny dependent kernels that leaves the GPU almost idle) and the encoder backward
         overlap = OVERLAP_WGRAD
-        dz = dec.backward(cz(d_x).view(nt * B, *dec.x_out.shape[1:]), params, grads, st, self.sync, defer_wgrad=overlap)
+        if overlap and getattr(self, '_side_stream', None) is None:
+            self._side_stream = torch.cuda.Stream()
+        dz = dec.backward(cz(d_x).view(nt * B, *dec.x_out.shape[1:]), params, grads, st, self.sync, defer_wgrad=overlap,
+                          side=self._side_stream if overlap else None)
         if overlap:
-            if getattr(self, '_side_stream', None) is None:
-                self._side_stream = torch.cuda.Stream()
             ev = torch.cuda.Event()
             ev.record()
             with torch.cuda.stream(self._side_stream):

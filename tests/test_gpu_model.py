@@ -632,3 +632,62 @@ def test_bench_contract():
     for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert k in rf, k
     assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B', [3, 8])
+def test_fused_bn_backward_reduction_equals_separate_pass(B):
+    """srvp_conv_desc.bnr_* (BatchNorm-backward sums of the producer accumulated in the epilogue of the consumer's data-gradient
+    launch) against the separate srvp_bn_bwd_reduce pass, at full VGG widths:
+      * sharp: after a training step, for every producer whose reduction was fused, the separate kernel is run on the very tensors
+        the step left behind (dA = the consumer's data gradient, raw, coefficients) -- the two pairs of per-channel sums agree to
+        1e-5 (same terms g = bf16(dA) f'(.), g xhat; fp32 partial sums in another order);
+      * end to end: the same step with the fusion switched off gives the same loss and parameter gradients within the band a 1-ulp
+        change of a BatchNorm coefficient opens on 12-32 frames of an untrained bf16 network."""
+    import ctypes as C
+    import srvp_amd
+    from srvp_amd import convnet, _lib as L
+    from srvp_amd.train import fused_step
+    dev = torch.device('cuda')
+    ctor = (64, 3, 64, 128, 50, 50, True, 2, 256, 3, 512, 4, 'vgg')
+    T, ne = 4, 2
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(T, B, 3, 64, 64, generator=g).to(dev)
+    tape = dict(t_skip=torch.randint(T, (B,), generator=g), t_w=torch.stack([torch.randperm(T, generator=g)[:2] for _ in range(B)], 1),
+                eps_y0=torch.randn(B, 50, generator=g), eps_z=torch.randn(T - 1, B, 50, generator=g))
+    opt = srvp_amd.DotDict(dict(n_euler_steps=ne, obs_scale=0.5, beta_y=1.0, beta_z=1.0, l2_res=1.0))
+    grads, fused_layers = {}, {}
+    old = convnet.BN_FUSED_REDUCE
+    try:
+        for mode in (True, False):
+            convnet.BN_FUSED_REDUCE = mode
+            torch.manual_seed(1)
+            m = srvp_amd.StochasticLatentResidualVideoPredictor(*ctor)
+            m.init(1.41)
+            m.to(dev).train()
+            o = srvp_amd.FusedAdam(m, lr=1e-3)
+            o.zero_grad()
+            acc = fused_step(m, x, opt, tape=tape)
+            torch.cuda.synchronize()
+            grads[mode] = ({k: p.grad.detach().clone() for k, p in m.named_parameters()}, acc.cpu())
+            pl = m._last_plan
+            nets = (pl['enc'], pl['dec'])
+            fused_layers[mode] = sum(1 for net in nets for b in net.blocks if getattr(b, '_reduce_fused', False))
+            if mode:
+                for net in nets:
+                    for q in net.blocks:
+                        p = next((b for b in net.blocks if b.out is not None and q.srcs and b.out is q.srcs[0]), None)
+                        if p is None or not getattr(p, '_reduce_fused', False):
+                            continue
+                        d = net._bnbwd_desc(p, dict(t=q.dcat, mode=0, cstride=q.dcat_c, coff=0, border=0))
+                        ref = torch.zeros_like(p.red)
+                        L.call('srvp_bn_bwd_reduce', C.byref(d), L.ptr(ref), L.stream())
+                        torch.cuda.synchronize()
+                        err = ((p.red - ref).abs().max() / (ref.abs().max() + 1e-30)).item()
+                        assert err < 1e-5, (p.spec['key'], err)
+    finally:
+        convnet.BN_FUSED_REDUCE = old
+    assert fused_layers[True] >= 12 and fused_layers[False] == 0, fused_layers     # 6 encoder + 5 + 4 (sub-pixel consumers) decoder layers
+    assert torch.allclose(grads[True][1], grads[False][1], rtol=1e-12)              # the forward is the same code
+    worst = max(((grads[True][0][k] - grads[False][0][k]).norm() / (grads[False][0][k].norm() + 1e-30)).item() for k in grads[True][0])
+    assert worst < 5e-2, worst
