@@ -348,6 +348,25 @@ def main():
     elif prof is not None:
         for _ in range(2):
             train(fwd, optim, None, x, dev, opt)
+    # context for `roofline.achieved`: the same launches with NOTHING running beside them.  Since round 3 every weight gradient runs
+    # on the second stream, concurrently with the data-gradient / BatchNorm kernels of the main stream (a faster step, and launch
+    # durations that include the sharing); two more untimed steps with the second stream switched off give the kernels' own rate.
+    unshared = None
+    if prof is not None:
+        import srvp_amd.model as _m
+        import srvp_amd.convnet as _cn
+        saved = (_m.OVERLAP_WGRAD, _m.OVERLAP_SKIP, _m.OVERLAP_PACK, _cn.ENC_WGRAD_SIDE_MAXN)
+        _m.OVERLAP_WGRAD, _m.OVERLAP_SKIP, _m.OVERLAP_PACK, _cn.ENC_WGRAD_SIDE_MAXN = False, False, False, 0
+        try:
+            train(fwd, optim, None, x, dev, opt)
+            L.PROFILE, L.PROFILE_ONLY = {}, {'srvp_conv_mfma', 'srvp_conv_mfma_multi', 'srvp_wgrad_mfma'}
+            for _ in range(2):
+                train(fwd, optim, None, x, dev, opt)
+            torch.cuda.synchronize()
+            unshared, L.PROFILE, L.PROFILE_ONLY = L.PROFILE, None, None
+        finally:
+            _m.OVERLAP_WGRAD, _m.OVERLAP_SKIP, _m.OVERLAP_PACK, _cn.ENC_WGRAD_SIDE_MAXN = saved
+            L.PROFILE, L.PROFILE_ONLY = None, None
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -430,6 +449,16 @@ def main():
                             'algorithmic_bytes_per_launch': fl['bytes_mfma'] / max(1, nlaunch),
                             'launches_per_step': nlaunch, 'ms_per_step': per[dom], 'avg_launch_us': per[dom] / max(1, nlaunch) * 1e3,
                             'timed_with_events': f'{n_prof_steps} of the {args.steps} timed steps (every {EVENT_EVERY}th)'}
+        if unshared and rank == 0:
+            um = sum(a.elapsed_time(b) for k in ('srvp_conv_mfma', 'srvp_conv_mfma_multi') for a, b in unshared.get(k, [])) / 2
+            uw = sum(a.elapsed_time(b) for a, b in unshared.get('srvp_wgrad_mfma', [])) / 2
+            line['roofline']['unshared'] = {
+                'what': 'the same launches in 2 extra untimed steps with the second stream switched off (nothing runs beside them): the '
+                        "kernels' own rate; `achieved` above is measured inside the timed steps, where the weight gradients of the second "
+                        'stream share the chip with these launches',
+                'ms_per_step': um, 'achieved': (fl['fwd_mfma'] + fl['dgrad_mfma']) / (um * 1e-3) / 1e12,
+                'frac': (fl['fwd_mfma'] + fl['dgrad_mfma']) / (um * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                'wgrad_ms_per_step': uw, 'wgrad_achieved': fl['wgrad_mfma'] / (uw * 1e-3) / 1e12 if uw else None}
         wg = fl['wgrad_mfma'] / (per['srvp_wgrad_mfma'] * 1e-3) / 1e12
         line['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'wgrad_halo_kernel / wgrad_mfma_kernel', 'achieved': wg, 'peak': PEAK_BF16_TFLOPS,
                                   'unit': 'TFLOP/s', 'frac': wg / PEAK_BF16_TFLOPS, 'ms_per_step': per['srvp_wgrad_mfma']}

@@ -23,6 +23,10 @@ sys.path.insert(0, ROOT)
 
 
 def main():
+    # RCCL prints a version banner through C stdio at communicator creation: keep stdout for the JSON line
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     from srvp_amd import distributed as sdist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -56,7 +60,7 @@ def main():
             loop(kind, 20)
             out[f'C{C}_{kind}_us'] = round(loop(kind), 2)
     if rank == 0:
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + '\n').encode())
     dist.destroy_process_group()
 
 
