@@ -98,7 +98,7 @@ int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
 int srvp_conv_set_halo(int on);
 /* 1 if this descriptor will run on the halo-tiled kernel, which wants its weights fragment-major (pack layout 1) */
 int srvp_conv_wants_fragmajor(const srvp_conv_desc* d);
-/* 1 if this descriptor will run on the halo-tiled kernel (the only one that takes bnr_red) */
+/* 0, or the pixel-tile size (>= 256: eligible for bnr_red) of the halo-tiled kernel variant this descriptor will run on */
 int srvp_conv_runs_on_halo(const srvp_conv_desc* d);
 /* d[0..n-1]: as n calls of srvp_conv_mfma; launches that run on the same halo-kernel variant with the same grid (the four
  * output phases of a sub-pixel upsample convolution) are issued as ONE grid */
@@ -216,6 +216,11 @@ int srvp_bn_bwd_finalize_apply(const srvp_bnbwd_desc* d, const double* red, doub
 int srvp_conv_in_fwd(const float* x, const float* w, void* raw, double* stats,
                      int N, int Cin, int H, int W, int Cout, int Cout_real, int k, int s, int p, void* stream);
 /* dW[Cout_real][Cin][k][k] += sum draw * x   (draw: bf16 padded(border 1) [N][OH+2][OW+2][Cout]) */
+/* srvp_conv_in_fwd used as the DATA GRADIENT of the image-side output layer (conv.py:353 backward: x = gradient frames (N, nc, 64, 64),
+ * w = the ConvTranspose weight (Cin_layer, nc, 3, 3) read as (O, I, k, k), raw = dA of the producer block [N][64][64][Cout]) with the
+ * producer's BatchNorm-backward sums accumulated in the same launch: bnr_raw / bnr_coef / bnr_red as in srvp_conv_desc.bnr_*. */
+int srvp_conv_in_fwd_bnr(const float* x, const float* w, void* raw, int N, int Cin, int H, int W, int Cout, int Cout_real, int k, int s,
+                         int p, const void* bnr_raw, const float* bnr_coef, double* bnr_red, void* stream);
 int srvp_conv_in_wgrad(const float* x, const void* draw, float* dw,
                        int N, int Cin, int H, int W, int Cout, int Cout_real, int k, int s, int p, void* stream);
 /* fp32 parity mode: raw / draw are fp32 NHWC tensors (direct fp32 kernels: an fmaf chain in (ci, kh, kw) order) */

@@ -105,6 +105,7 @@ _SIGS = {
     'srvp_bn_bwd_finalize': ([c_vp, c_f64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp], c_i32),
     'srvp_bn_bwd_apply': ([C.POINTER(BnBwdDesc), c_vp, c_vp, c_i32, c_vp], c_i32),
     'srvp_conv_in_fwd': ([c_vp, c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp], c_i32),
+    'srvp_conv_in_fwd_bnr': ([c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp, c_vp, c_vp, c_vp], c_i32),
     'srvp_conv_in_wgrad': ([c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp], c_i32),
     'srvp_conv_in_fwd_f32': ([c_vp, c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp], c_i32),
     'srvp_conv_in_wgrad_f32': ([c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp], c_i32),

@@ -938,7 +938,7 @@ class ConvNetBase:
             if p is None or not p.has_bn or p.act != L.ACT_LRELU or p.spec.get('skip_out') is not None or p.pool is not None:
                 continue
             d = q._dg[0]
-            if tuple(p.raw.shape) != tuple(q.dcat.shape) or d.Cout != p.cout or not int(lib.srvp_conv_runs_on_halo(C.byref(d))):
+            if tuple(p.raw.shape) != tuple(q.dcat.shape) or d.Cout != p.cout or int(lib.srvp_conv_runs_on_halo(C.byref(d))) < 256:
                 continue
             d.bnr_raw, d.bnr_coef, d.bnr_red = L.ptr(p.raw), L.ptr(p.coef), L.ptr(p.red)
             p._reduce_fused = True
@@ -1187,8 +1187,18 @@ class DecoderNet(ConvNetBase):
                 self._out_wgrad_f32(grads, st)
             elif early:
                 on_side(lambda s_: self._out_wgrad_f32(grads, s_))
-            L.call('srvp_conv_in_fwd_f32' if self.f32 else 'srvp_conv_in_fwd', L.ptr(self.dpre_f32), L.ptr(params[ob.spec['key'] + '.weight']), L.ptr(ob.dcat), None,
-                   self.N, ob.cout_r, 64, 64, ob.ctot, ob.cin_r[0], ob.k, ob.s, ob.p, st)
+            prod = self.blocks[-2] if len(self.blocks) > 1 else None
+            fuse = (BN_FUSED_REDUCE and not self.f32 and prod is not None and prod.out is ob.srcs[0] and prod.has_bn and prod.act == L.ACT_LRELU
+                    and (ob.k, ob.s, ob.p) == (3, 1, 1) and tuple(prod.raw.shape) == tuple(ob.dcat.shape))
+            if fuse:
+                # ... with the BatchNorm-backward sums of the producer block accumulated in the same launch (_fuse_bn_reduce)
+                L.call('srvp_conv_in_fwd_bnr', L.ptr(self.dpre_f32), L.ptr(params[ob.spec['key'] + '.weight']), L.ptr(ob.dcat), self.N, ob.cout_r, 64, 64,
+                       ob.ctot, ob.cin_r[0], ob.k, ob.s, ob.p, L.ptr(prod.raw), L.ptr(prod.coef), L.ptr(prod.red), st)
+            else:
+                L.call('srvp_conv_in_fwd_f32' if self.f32 else 'srvp_conv_in_fwd', L.ptr(self.dpre_f32), L.ptr(params[ob.spec['key'] + '.weight']), L.ptr(ob.dcat), None,
+                       self.N, ob.cout_r, 64, 64, ob.ctot, ob.cin_r[0], ob.k, ob.s, ob.p, st)
+            if prod is not None:
+                prod._reduce_fused = bool(fuse)
         else:
             if early:
                 on_side(lambda s_: self._wgrad(ob, s_))

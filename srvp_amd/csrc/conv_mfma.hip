@@ -134,61 +134,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[TM][TN], const Con
             }
         return;
     }
-    if (a.bnr_red) {
-        // ---- fused BatchNorm-backward reduction of the producer layer (srvp_conv_desc.bnr_*): the accumulators ARE dA of that
-        // layer; its raw tile [BM px][BN ch] comes global -> LDS by LDS-DMA (16-byte pieces, lane-linear = row-major), then every
-        // lane walks its 16 * TM pixels of its TN channels: g = bf16(dA) * lrelu'(scale raw + shift), sums of g and g * xhat.
-        constexpr int PCS = BN / 8;                            // 16-byte pieces per pixel row
-        constexpr int NPC = BM * PCS / NT;                     // pieces per thread
-        static_assert((BM * PCS) % NT == 0, "raw tile pieces");
-        bf16_t* Rs = reinterpret_cast<bf16_t*>(smem);          // [BM][BN] (fits the staging area: BN <= LDC)
-#pragma unroll
-        for (int i = 0; i < NPC; ++i) {
-            const int q = tid + i * NT;
-            const int row = q / PCS, pc = q - row * PCS;
-            int n = 0, oy = 0, ox = 0;
-            if (!rowmap(row, n, oy, ox)) { n = a.N - 1; oy = 0; ox = 0; }
-            const unsigned off = (((unsigned)n * a.DHp + oy) * a.DWp + ox) * a.Cdst + n0 + pc * 8;
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.bnr_raw + off), (lptr_t)(Rs + ((size_t)i * NT + wid * 64) * 8), 16, 0, 0);
-        }
-        float csc[TN], csh[TN], cmu[TN], cis[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int c = n0 + wn * (TN * 32) + j * 32 + lcol;
-            csc[j] = a.bnr_coef[c]; csh[j] = a.bnr_coef[a.Cdst + c]; cmu[j] = a.bnr_coef[2 * a.Cdst + c]; cis[j] = a.bnr_coef[3 * a.Cdst + c];
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): the tile has landed
-        __syncthreads();
-        bool okr[TM][16];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int n, oy, ox;
-                okr[i][r] = all_valid || rowmap(wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf, n, oy, ox);
-            }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float s1 = 0.f, s2 = 0.f;
-            const int col = wn * (TN * 32) + j * 32 + lcol;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                    const float rawv = bf2f(Rs[row * BN + col]);
-                    const float da = bf2f(f2bf(acc[i][j][r]));                       // dA as the tensor stores it (what apply reads back)
-                    const float pre = rawv * csc[j] + csh[j];
-                    float g = da * (pre > 0.f ? 1.f : LRELU_SLOPE);
-                    g = okr[i][r] ? g : 0.f;
-                    s1 += g; s2 += g * (rawv - cmu[j]) * cis[j];
-                }
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
-            if (lhalf == 0) { red[(wm * BN + col) * 2 + 0] = s1; red[(wm * BN + col) * 2 + 1] = s2; }
-        }
-        __syncthreads();                                       // every wave is done with the raw tile: the staging below reuses it
-    } else if (a.stats && all_valid) {
+    if (a.stats && all_valid) {
         // every row of the tile is a real output pixel (workgroup-uniform): no per-row masks
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -274,18 +220,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[TM][TN], const Con
                 Cs[row * LDC + col] = f2bf(acc[i][j][r]);
             }
     __syncthreads();
-    if ((a.stats || a.bnr_red) && tid < BN) {
+    if (a.stats && tid < BN) {
         double s1 = 0., s2 = 0.;
 #pragma unroll
         for (int w = 0; w < WM; ++w) { s1 += red[(w * BN + tid) * 2]; s2 += red[(w * BN + tid) * 2 + 1]; }
-        if (a.bnr_red) {
-            atomicAdd(a.bnr_red + n0 + tid, s1);
-            atomicAdd(a.bnr_red + a.Cdst + n0 + tid, s2);
-        } else {
-            int ch = (n0 + tid) % a.stat_mod;
-            atomicAdd(a.stats + ch, s1);
-            atomicAdd(a.stats + a.stat_mod + ch, s2);
-        }
+        int ch = (n0 + tid) % a.stat_mod;
+        atomicAdd(a.stats + ch, s1);
+        atomicAdd(a.stats + a.stat_mod + ch, s2);
     }
     // copy-out: thread -> (16-byte channel chunk ch, rows row0 + k * RSTEP).  Unrolled in groups of four with the LDS reads
     // of a group issued before its stores and the descriptor fields hoisted (as a rolled loop hipcc re-loaded them from the
@@ -299,6 +240,68 @@ __device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[TM][TN], const Con
     const size_t img = (size_t)a.DHp * DWp * Cdst;
     bf16_t* dbase = a.dst + a.cdst_off + n0 + ch * 8;
     const bf16_t* cbase = Cs + row0 * LDC + ch * 8;
+    constexpr bool BNR_FITS = RSTEP * BN * 2 * 4 <= BM * LDC * 2;     // (all 256-pixel variants; the launcher sends nothing else here)
+    if constexpr (BNR_FITS) if (a.bnr_red) {
+        // ---- fused BatchNorm-backward reduction of the PRODUCER layer (srvp_conv_desc.bnr_*): this launch's output IS dA of that
+        // layer.  The copy-out loop already walks the tile as (pixel row, 16-byte channel chunk): beside the bf16 dA piece it reads
+        // from the staging area, a thread loads the matching piece of the producer's raw output straight from global memory (same
+        // offset as the store: both tensors are [N][H][W][C], one coalesced 256-byte run per pixel), forms g = dA * lrelu'(scale raw
+        // + shift) on the values AS STORED (what srvp_bn_bwd_apply reads back) and keeps sum g, sum g * xhat of its eight channels in
+        // registers; the RSTEP row groups are then summed through LDS and added with one fp64 atomic pair per channel and workgroup.
+        const bf16_t* rbase = a.bnr_raw + n0 + ch * 8;
+        float csc[8], csh[8], cmu[8], cis[8], s1[8], s2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = n0 + ch * 8 + e;
+            csc[e] = a.bnr_coef[c]; csh[e] = a.bnr_coef[Cdst + c]; cmu[e] = a.bnr_coef[2 * Cdst + c]; cis[e] = a.bnr_coef[3 * Cdst + c];
+            s1[e] = 0.f; s2[e] = 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < ITER; g += G) {
+            u32x4_t v[G], rw[G];
+            size_t off[G];
+            bool ok[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int row = row0 + (g + u) * RSTEP;
+                int n, oy, ox;
+                ok[u] = rowmap(row, n, oy, ox);
+                if (!ok[u]) { n = 0; oy = 0; ox = 0; }
+                off[u] = (size_t)n * img + (size_t)(unsigned)(((oy * so + ooy) * DWp + ox * so + oox) * Cdst);
+                rw[u] = *reinterpret_cast<const u32x4_t*>(rbase + off[u]);
+                v[u] = *reinterpret_cast<const u32x4_t*>(cbase + (g + u) * RSTEP * LDC);
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                if (ok[u]) *reinterpret_cast<u32x4_t*>(dbase + off[u]) = v[u];
+                float da[8], rv[8];
+                unpack8(v[u], da);
+                unpack8(rw[u], rv);
+                const float m = ok[u] ? 1.f : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float gg = m * da[e] * ((rv[e] * csc[e] + csh[e]) > 0.f ? 1.f : LRELU_SLOPE);
+                    s1[e] += gg; s2[e] += gg * (rv[e] - cmu[e]) * cis[e];
+                }
+            }
+        }
+        __syncthreads();                                   // every thread is done with the staging tile: it now holds the partial sums
+        float* Ps = reinterpret_cast<float*>(smem);        // [RSTEP][BN][2]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            Ps[(row0 * BN + ch * 8 + e) * 2 + 0] = s1[e];
+            Ps[(row0 * BN + ch * 8 + e) * 2 + 1] = s2[e];
+        }
+        __syncthreads();
+        if (tid < BN) {
+            double t1 = 0., t2 = 0.;
+#pragma unroll
+            for (int r = 0; r < RSTEP; ++r) { t1 += Ps[(r * BN + tid) * 2]; t2 += Ps[(r * BN + tid) * 2 + 1]; }
+            atomicAdd(a.bnr_red + n0 + tid, t1);
+            atomicAdd(a.bnr_red + Cdst + n0 + tid, t2);
+        }
+        return;
+    }
 #pragma unroll
     for (int g = 0; g < ITER; g += G) {
         u32x4_t v[G];
@@ -863,7 +866,7 @@ int launch(const srvp_conv_desc* d, hipStream_t st) {
 
 extern "C" int srvp_conv_set_halo(int on) { g_halo = on; return SRVP_OK; }
 
-extern "C" int srvp_conv_runs_on_halo(const srvp_conv_desc* d) { return d && halo_variant(d) ? 1 : 0; }
+extern "C" int srvp_conv_runs_on_halo(const srvp_conv_desc* d) { return d ? halo_variant(d) : 0; }
 
 extern "C" int srvp_conv_wants_fragmajor(const srvp_conv_desc* d) { return d && (halo_variant(d) || generic_wants_fragmajor(d)) ? 1 : 0; }
 
@@ -899,7 +902,7 @@ extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
                  "srvp_conv_mfma: f32_quad = %d needs an fp32 S tensor whose width is a multiple of 4 x the consumer stride (and so == f32_quad, OW %% 4 == 0 on the consumer)", d->f32_quad);
     SRVP_REQUIRE(!(d->elem_f32 && d->splitk > 1), "srvp_conv_mfma: splitk is not available in fp32 parity mode");
     SRVP_REQUIRE(!d->bnr_red || (d->bnr_raw && d->bnr_coef && !d->elem_f32 && !d->stats && !d->dst_is_f32 && !d->out_f32 && d->so == 1 && d->ooy == 0 &&
-                                 d->oox == 0 && d->cdst_off == 0 && d->Cdst == d->Cout && d->DHp == d->OH && d->DWp == d->OW && halo_variant(d) &&
+                                 d->oox == 0 && d->cdst_off == 0 && d->Cdst == d->Cout && d->DHp == d->OH && d->DWp == d->OW && halo_variant(d) >= 256 &&
                                  (long long)d->N * d->OH * d->OW * d->Cout < (1ll << 32)),
                  "srvp_conv_mfma: bnr_red (fused BatchNorm-backward reduction) needs a plain bf16 data-gradient launch on the halo kernel");
     if (d->elem_f32) return srvp_conv_f32_launch(d, st);

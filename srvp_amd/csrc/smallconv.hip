@@ -214,10 +214,11 @@ __device__ __forceinline__ void in_load_patch(const float* __restrict__ x, float
     }
 }
 
-template <int KS, int S, int CIN, int NTL>
+template <int KS, int S, int CIN, int NTL, bool BNR = false>
 __global__ __launch_bounds__(256) void conv_in_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                bf16_t* __restrict__ raw, double* stats, int N, int Cout,
-                                                               int Cout_real, int tiles_per_wg) {
+                                                               int Cout_real, int tiles_per_wg, const bf16_t* __restrict__ bnr_raw,
+                                                               const float* __restrict__ bnr_coef, double* bnr_red) {
     typedef InGeom<KS, S, CIN> Gm;
     constexpr int LDC = 64 + 8;
     __shared__ float wsh[Gm::STEPS * 2][64];             // B operand [k][cout], zero for padded k / cout
@@ -239,6 +240,17 @@ __global__ __launch_bounds__(256) void conv_in_fwd_mfma_kernel(const float* __re
     const long long t0 = (long long)blockIdx.x * tiles_per_wg;
     constexpr int NP = (CIN * Gm::PH * Gm::PWp + 255) / 256;
     float pv[NP];
+    // (BNR is a template parameter: as a run-time branch its 48 registers cost the forward instantiation a wave of occupancy)
+    float bsc[8], bsh[8], bmu[8], bis[8], b1[8], b2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bsc[e] = bsh[e] = bmu[e] = bis[e] = b1[e] = b2[e] = 0.f; }
+    if constexpr (BNR) {
+        const int c0 = (tid % (Cout / 8)) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bsc[e] = bnr_coef[c0 + e]; bsh[e] = bnr_coef[Cout + c0 + e]; bmu[e] = bnr_coef[2 * Cout + c0 + e]; bis[e] = bnr_coef[3 * Cout + c0 + e];
+        }
+    }
     if (t0 < ntiles) in_fetch_patch<KS, S, CIN, NP>(x, pv, (int)(t0 / Gm::TPI), (int)(t0 % Gm::TPI));
     for (int it = 0; it < tiles_per_wg; ++it) {
         const long long tile = t0 + it;
@@ -280,10 +292,46 @@ __global__ __launch_bounds__(256) void conv_in_fwd_mfma_kernel(const float* __re
         // the 128 pixels of a tile are contiguous in the NHWC output: 128 * Cout bf16
         bf16_t* dst = raw + (size_t)tile * 128 * Cout;
         const int cch = Cout / 8;
+        if constexpr (BNR) {
+            // this launch is the DATA GRADIENT of the image-side output layer (the gradient frames are its "image"): its output is dA of
+            // the producer block, whose BatchNorm-backward sums are accumulated here (as srvp_conv_desc.bnr_* does in the MFMA
+            // convolutions) -- 256 % cch == 0, so a thread keeps its channel chunk over the tiles and its sums stay in registers
+            const bf16_t* rsrc = bnr_raw + (size_t)tile * 128 * Cout;
+            for (int q = tid; q < 128 * cch; q += 256) {
+                const int row = q / cch, ch = q % cch;
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(Cs + row * LDC + ch * 8);
+                const u32x4_t rw = *reinterpret_cast<const u32x4_t*>(rsrc + (size_t)row * Cout + ch * 8);
+                *reinterpret_cast<u32x4_t*>(dst + (size_t)row * Cout + ch * 8) = v;
+                float da[8], rv[8];
+                unpack8(v, da);
+                unpack8(rw, rv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float gg = da[e] * ((rv[e] * bsc[e] + bsh[e]) > 0.f ? 1.f : LRELU_SLOPE);
+                    b1[e] += gg; b2[e] += gg * (rv[e] - bmu[e]) * bis[e];
+                }
+            }
+            continue;
+        }
         for (int q = tid; q < 128 * cch; q += 256) {
             const int row = q / cch, ch = q % cch;
             *reinterpret_cast<u32x4_t*>(dst + (size_t)row * Cout + ch * 8) = *reinterpret_cast<const u32x4_t*>(Cs + row * LDC + ch * 8);
         }
+    }
+    if constexpr (BNR) {
+        __syncthreads();
+        float* Ps = reinterpret_cast<float*>(Cs);                 // [256 / cch][Cout][2] partial sums (<= 128 * LDC * 2 bytes)
+        const int cch = Cout / 8, ch = tid % cch, grp = tid / cch;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { Ps[(grp * Cout + ch * 8 + e) * 2] = b1[e]; Ps[(grp * Cout + ch * 8 + e) * 2 + 1] = b2[e]; }
+        __syncthreads();
+        if (tid < Cout) {
+            double t1 = 0., t2 = 0.;
+            for (int r = 0; r < 256 / cch; ++r) { t1 += Ps[(r * Cout + tid) * 2]; t2 += Ps[(r * Cout + tid) * 2 + 1]; }
+            atomicAdd(bnr_red + tid, t1);
+            atomicAdd(bnr_red + Cout + tid, t2);
+        }
+        return;
     }
     if (!stats) return;
 #pragma unroll
@@ -501,15 +549,18 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_mfma3_kernel(const float* _
 }
 
 template <int KS, int S, int CIN>
-static void launch_in_fwd(const float* x, const float* w, bf16_t* raw, double* stats, int N, int Cout, int Cout_real, hipStream_t st) {
+static void launch_in_fwd(const float* x, const float* w, bf16_t* raw, double* stats, int N, int Cout, int Cout_real, hipStream_t st,
+                          const bf16_t* bnr_raw = nullptr, const float* bnr_coef = nullptr, double* bnr_red = nullptr) {
     const long long ntiles = (long long)N * InGeom<KS, S, CIN>::TPI;
     const int tpw = ntiles >= 32768 ? 8 : (ntiles >= 16 ? 2 : 1);
-    if (Cout == 64)
-        hipLaunchKernelGGL((conv_in_fwd_mfma_kernel<KS, S, CIN, 2>), dim3((unsigned)((ntiles + tpw - 1) / tpw)), dim3(256), 0, st, x, w, raw, stats,
-                           N, Cout, Cout_real, tpw);
+    const dim3 grid((unsigned)((ntiles + tpw - 1) / tpw));
+    if (bnr_red) {
+        if (Cout == 64) hipLaunchKernelGGL((conv_in_fwd_mfma_kernel<KS, S, CIN, 2, true>), grid, dim3(256), 0, st, x, w, raw, stats, N, Cout, Cout_real, tpw, bnr_raw, bnr_coef, bnr_red);
+        else hipLaunchKernelGGL((conv_in_fwd_mfma_kernel<KS, S, CIN, 1, true>), grid, dim3(256), 0, st, x, w, raw, stats, N, Cout, Cout_real, tpw, bnr_raw, bnr_coef, bnr_red);
+    } else if (Cout == 64)
+        hipLaunchKernelGGL((conv_in_fwd_mfma_kernel<KS, S, CIN, 2>), grid, dim3(256), 0, st, x, w, raw, stats, N, Cout, Cout_real, tpw, bnr_raw, bnr_coef, bnr_red);
     else
-        hipLaunchKernelGGL((conv_in_fwd_mfma_kernel<KS, S, CIN, 1>), dim3((unsigned)((ntiles + tpw - 1) / tpw)), dim3(256), 0, st, x, w, raw, stats,
-                           N, Cout, Cout_real, tpw);
+        hipLaunchKernelGGL((conv_in_fwd_mfma_kernel<KS, S, CIN, 1>), grid, dim3(256), 0, st, x, w, raw, stats, N, Cout, Cout_real, tpw, bnr_raw, bnr_coef, bnr_red);
 }
 template <int KS, int S, int CIN>
 static void launch_in_wgrad(const float* x, const bf16_t* draw, float* dw, int N, int Cout, int Cout_real, hipStream_t st) {
@@ -602,6 +653,19 @@ extern "C" int srvp_conv_in_fwd(const float* x, const float* w, void* raw, doubl
         return SRVP_OK;
     }
     return conv_in_fwd_valu<bf16_t>(x, w, raw, stats, N, Cin, H, W, Cout, Cout_real, k, s, p, stream);
+}
+
+// srvp_conv_in_fwd as the data gradient of the image-side OUTPUT layer (x = gradient frames, w = the ConvTranspose weight read as
+// (O, I, k, k), raw = dA of the producer block) with that block's BatchNorm-backward sums fused in (see srvp_conv_desc.bnr_*)
+extern "C" int srvp_conv_in_fwd_bnr(const float* x, const float* w, void* raw, int N, int Cin, int H, int W, int Cout, int Cout_real, int k, int s,
+                                    int p, const void* bnr_raw, const float* bnr_coef, double* bnr_red, void* stream) {
+    SRVP_REQUIRE(x && w && raw && bnr_raw && bnr_coef && bnr_red, "srvp_conv_in_fwd_bnr: null pointer");
+    SRVP_REQUIRE(in_mfma_ok(Cin, H, W, Cout, k, s, p) && s == 1 && k == 3, "srvp_conv_in_fwd_bnr: shape not served by the MFMA image-side kernel (3x3 stride 1, 64x64, Cout 32 / 64)");
+    hipStream_t st = (hipStream_t)stream;
+    if (Cin == 3) launch_in_fwd<3, 1, 3>(x, w, (bf16_t*)raw, nullptr, N, Cout, Cout_real, st, (const bf16_t*)bnr_raw, bnr_coef, bnr_red);
+    else launch_in_fwd<3, 1, 1>(x, w, (bf16_t*)raw, nullptr, N, Cout, Cout_real, st, (const bf16_t*)bnr_raw, bnr_coef, bnr_red);
+    SRVP_CHECK_LAUNCH("srvp_conv_in_fwd_bnr");
+    return SRVP_OK;
 }
 
 extern "C" int srvp_conv_in_wgrad(const float* x, const void* draw, float* dw, int N, int Cin, int H, int W, int Cout,
