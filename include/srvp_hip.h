@@ -29,6 +29,9 @@ extern "C" {
 #define SRVP_ACT_SIGMOID 4
 
 int srvp_version(void);
+/* a non-blocking HIP stream of the lowest priority of the device (the product's second stream: weight gradients / packing, work off the
+ * critical path); *priority_out (optional) receives that priority.  The caller owns the stream (hipStreamDestroy). */
+int srvp_stream_create_low_priority(void** stream_out, int* priority_out);
 const char* srvp_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------

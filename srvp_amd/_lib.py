@@ -85,6 +85,7 @@ class RolloutBwdDesc(C.Structure):
 
 _SIGS = {
     'srvp_version': ([], c_i32),
+    'srvp_stream_create_low_priority': ([C.POINTER(c_vp), C.POINTER(c_i32)], c_i32),
     'srvp_conv_mfma': ([C.POINTER(ConvDesc), c_vp], c_i32),
     'srvp_conv_set_halo': ([c_i32], c_i32),
     'srvp_conv_wants_fragmajor': ([C.POINTER(ConvDesc)], c_i32),

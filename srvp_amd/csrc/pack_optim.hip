@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const srvp_pack_job* __
     const srvp_pack_desc& d = j.d;
     __shared__ float tile_lds[PT_OUT * (PT_INN * 16 + 1)];
     int TS; bool inner_k;
-    if (g_pack_tiled && tile_ok(d, TS, inner_k)) { pack_job_tiled(j, wg, nwg, TS, inner_k, tile_lds); return; }
+    if ((g_pack_tiled & 1) && tile_ok(d, TS, inner_k)) { pack_job_tiled(j, wg, nwg, TS, inner_k, tile_lds); return; }
     if (!vec_ok(d)) {
         PackArgs a;
         job_args(j, a);
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void unpack_multi_kernel(const srvp_pack_job* 
     const srvp_pack_desc& d = j.d;
     __shared__ float tile_lds[PT_OUT * (PT_INN * 16 + 1)];
     int TS; bool inner_k;
-    if (g_pack_tiled && tile_ok(d, TS, inner_k)) { unpack_job_tiled(j, wg, nwg, TS, inner_k, tile_lds); return; }
+    if ((g_pack_tiled & 2) && tile_ok(d, TS, inner_k)) { unpack_job_tiled(j, wg, nwg, TS, inner_k, tile_lds); return; }
     if (!vec_ok(d)) {
         PackArgs a;
         job_args(j, a);
@@ -602,9 +602,13 @@ extern "C" int srvp_unpack_wgrad(const float* src, float* dst, const srvp_pack_d
     return SRVP_OK;
 }
 
-static int pack_tiled() {       // A/B switch SRVP_PACK_TILED (default 1)
+// A/B switch SRVP_PACK_TILED: bit 0 = pack, bit 1 = unpack on the LDS-tiled path.  Default 2: the tiled UNPACK (a read-modify-write of the
+// fp32 gradient whose item-per-thread form touched 64 lines per wave instruction) went 0.63 -> 0.29 ms in isolation, 0.89 -> 0.36 ms
+// inside the 192-sequence step; the tiled PACK measured no faster than the item-per-thread form (0.44 vs 0.40 ms: its writes, 16-byte
+// pieces of a fragment-major tensor, are the scattered side either way) and stays off.
+static int pack_tiled() {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("SRVP_PACK_TILED"); on = e ? atoi(e) : 1; }
+    if (on < 0) { const char* e = getenv("SRVP_PACK_TILED"); on = e ? atoi(e) : 2; }
     return on;
 }
 extern "C" int srvp_pack_weight_multi(const srvp_pack_job* jobs_dev, int njobs, int64_t total_wgs, void* stream) {

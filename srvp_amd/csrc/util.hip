@@ -13,6 +13,21 @@ void srvp_set_error(const char* fmt, ...) {
 extern "C" const char* srvp_last_error(void) { return g_err; }
 extern "C" int srvp_version(void) { return 1; }
 
+// A non-blocking stream of the LOWEST priority the device offers: the product's second stream (weight gradients, packing) -- work that
+// feeds nothing but the optimizer -- so that whenever both streams have workgroups ready the dispatcher serves the critical path first.
+extern "C" int srvp_stream_create_low_priority(void** stream_out, int* priority_out) {
+    SRVP_REQUIRE(stream_out, "srvp_stream_create_low_priority: null pointer");
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    SRVP_REQUIRE(e == hipSuccess, "hipDeviceGetStreamPriorityRange: %s", hipGetErrorString(e));
+    hipStream_t st = nullptr;
+    e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least);
+    SRVP_REQUIRE(e == hipSuccess, "hipStreamCreateWithPriority(%d): %s", least, hipGetErrorString(e));
+    *stream_out = (void*)st;
+    if (priority_out) *priority_out = least;
+    return SRVP_OK;
+}
+
 namespace {
 __global__ void fill_f64_kernel(double* p, long long n, double v) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -55,6 +55,24 @@ SKIP_LATE = os.environ.get('SRVP_SKIP_LATE', '1') == '1'        # hoisted skip c
 OVERLAP_PACK = os.environ.get('SRVP_OVERLAP_PACK', '1') == '1'    # decoder weight packing on the second stream, under the encoder
 
 
+SIDE_PRIORITY = os.environ.get('SRVP_SIDE_PRIORITY', 'default')      # 'low' / 'default' / 'high' (A/B switch)
+
+
+def _make_side_stream():
+    """The second stream (weight gradients, weight packing, hoisted skip convolutions: everything off the critical path).
+    Measured at three stream priorities (same box, ms per step at 192 sequences / 24 sequences): lowest priority of the device
+    (srvp_stream_create_low_priority) 40.76 / 8.78 -- the deprioritised weight gradients pile up behind the main stream's last kernel --
+    default 40.60 / 8.76: default kept."""
+    if SIDE_PRIORITY == 'low':
+        import ctypes as C
+        h, pr = C.c_void_p(), C.c_int32()
+        L.check(L.load().srvp_stream_create_low_priority(C.byref(h), C.byref(pr)), 'srvp_stream_create_low_priority')
+        return torch.cuda.ExternalStream(h.value)
+    if SIDE_PRIORITY == 'high':
+        return torch.cuda.Stream(priority=-1)
+    return torch.cuda.Stream()
+
+
 class _Holder(nn.Module):
     """Generic container (stands for nn.Sequential / nn.ModuleList levels of the reference)."""
 
@@ -280,7 +298,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             pl['dec'].pack_weights(params, st)
             return None, None
         if getattr(self, '_side_stream', None) is None:
-            self._side_stream = torch.cuda.Stream()
+            self._side_stream = _make_side_stream()
         ev = torch.cuda.Event()
         ev.record()
         with torch.cuda.stream(self._side_stream):
@@ -352,7 +370,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             pl['skip_sel'] = sel
         def skips_on_side():
             if getattr(self, '_side_stream', None) is None:
-                self._side_stream = torch.cuda.Stream()
+                self._side_stream = _make_side_stream()
             ev = torch.cuda.Event()
             ev.record()
             with torch.cuda.stream(self._side_stream):
@@ -447,7 +465,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         # latent backward (a ~3 ms chain of tiny dependent kernels that leaves the GPU almost idle) and the encoder backward
         overlap = OVERLAP_WGRAD
         if overlap and getattr(self, '_side_stream', None) is None:
-            self._side_stream = torch.cuda.Stream()
+            self._side_stream = _make_side_stream()
         dz = dec.backward(cz(d_x).view(nt * B, *dec.x_out.shape[1:]), params, grads, st, self.sync, defer_wgrad=overlap,
                           side=self._side_stream if overlap else None)
         if overlap:
