@@ -39,6 +39,10 @@ SPLITK = int(os.environ.get('SRVP_CONV_SPLITK', '16'))    # tiny-M long-K launch
 # of the folded weights (summed in fp32 from the fp32 masters, rounded to bf16 once).
 SUB_R = {0: [(0,), (1, 2)], 1: [(0, 1), (2,)]}
 SUB_D = [(2,), (1, 2), (0, 1), (0,)]
+# Transposed 4x4 stride-2 convolution (DCGAN decoder, conv.py:299-304), BACKWARD over the space-to-depth output gradient: input row ih
+# collects output rows 2 ih - 1 + kh; output row parity a -> [(kernel index kh, padded row offset dy into the s2d tensor)]
+S2D_UP = {0: [(1, 1), (3, 2)], 1: [(0, 0), (2, 1)]}
+S2D_UP_ON = os.environ.get('SRVP_UP_S2D', '1') != '0'
 
 
 def _tapset(rows, cols, k=3):
@@ -173,6 +177,14 @@ class Block:
                         and srcs[0].W >= (8 if self.cout == 64 else 4) and srcs[0].H >= 4
                         and (srcs[0].W & (srcs[0].W - 1)) == 0 and (srcs[0].H & (srcs[0].H - 1)) == 0
                         and 4 * N * (srcs[0].H + 2) * (srcs[0].W + 2) * self.cout < 2 ** 32)
+        # The same machinery for the transposed 4x4 stride-2 blocks of the DCGAN decoder (conv.py:299-304): with the output gradient
+        # stored space-to-depth, the data gradient (a 16-tap stride-2 gather on the generic kernel) is ONE halo convolution with the four
+        # taps of each chunk's phase, and the 16 weight-gradient taps read their phase slice at unit stride.
+        self.s2d_up = bool(S2D and S2D_UP_ON and role == 'mfma' and getattr(self, 'geom', None) == 'up' and training and not f32
+                           and self.cout % 64 == 0 and self.Hin >= 4 and (self.Hin & (self.Hin - 1)) == 0 and self.Win == self.Hin
+                           and (self.Hin * self.Win <= 256 or self.Hin % 16 == 0) and all(f.C % 32 == 0 for f in srcs)
+                           and 4 * N * (self.Hin + 2) * (self.Win + 2) * self.cout < 2 ** 32)
+        self.s2d = self.s2d or self.s2d_up
         if role != 'out':
             self.raw = torch.empty(N, self.OH, self.OW, self.cout, dtype=self.adt, device=device)
             C_ = self.cout
@@ -222,7 +234,22 @@ class Block:
             pd = getattr(self, name, None)
             if pd is not None:
                 pd.dst_f32 = 1 if self.f32 else 0
-        if self.s2d and self.wt_d is not None:
+        if self.s2d_up and self.wt_d is not None:
+            # data-gradient weights over the space-to-depth output gradient: [4 taps (u, v)][ctot][K = 4 phases x cout], fragment-major,
+            # phase (a, b) = K chunks [ph cout/64, (ph + 1) cout/64) holding kernel taps (kh, kw) = (S2D_UP[a][u], S2D_UP[b][v])
+            co_p = self.cout
+            self.pd_ph = []
+            for ph, (a, b) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+                offs = [kh * self.k + kw for kh, _ in S2D_UP[a] for kw, _ in S2D_UP[b]]
+                d = _pack_desc(offs, self.pd.J, self.pd.K, (self.pd.J0, self.pd.J0r, self.pd.J1r), (self.pd.K0, self.pd.K0r, self.pd.K1r),
+                               self.pd.sj, self.pd.sk)
+                d.layout, d.kc_total, d.kc_off, d.dst_f32 = 1, 4 * co_p // 64, ph * co_p // 64, 0
+                self.pd_ph.append(d)
+            # weight-gradient taps grouped by phase (tap t' = ph * 4 + u * 2 + v reads the phase-ph slice of the gradient)
+            order = [kh * self.k + kw for a, b in [(0, 0), (0, 1), (1, 0), (1, 1)] for kh, _ in S2D_UP[a] for kw, _ in S2D_UP[b]]
+            pu = self.pu
+            self.pu = _pack_desc(order, pu.J, pu.K, (pu.J0, pu.J0r, pu.J1r), (pu.K0, pu.K0r, pu.K1r), pu.sj, pu.sk)
+        elif self.s2d and self.wt_d is not None:
             # data-gradient weights of the space-to-depth form: packed [4 taps (u, v)][cin][K = 4 phases x cout], fragment-major;
             # phase (a, b) occupies the K chunks [ph cout/64, (ph + 1) cout/64) and holds the folded taps R[a][u] x R[b][v]
             # transposed -- one pack job per phase (srvp_pack_desc.kc_off)
@@ -607,6 +634,17 @@ class Block:
                 d.N, d.OH, d.OW = N, self.OH, self.OW
                 d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox = L.ptr(self.dcat), self.Hin, self.Win, 2, py, px
                 out.append(d)
+        elif self.geom == 'up' and self.s2d_up:
+            d = base()
+            d.src0, d.C0, d.H0p, d.W0p = L.ptr(self.draw), 4 * self.cout, self.Hin + 2, self.Win + 2
+            d.ntaps = 4
+            ent = [(dy, dx) for a, b in [(0, 0), (0, 1), (1, 0), (1, 1)] for _, dy in S2D_UP[a] for _, dx in S2D_UP[b]]
+            d.dy, d.dx = L.taps([e[0] for e in ent]), L.taps([e[1] for e in ent])
+            d.tap_phase_chunks = self.cout // 64
+            d.si, d.wt = 1, L.ptr(self.wt_d)
+            d.N, d.OH, d.OW = N, self.Hin, self.Win
+            d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox = L.ptr(self.dcat), self.Hin, self.Win, 1, 0, 0
+            out.append(d)
         elif self.geom == 'up':
             d = base()
             # dIn[ih] = sum_kh dOut[2 ih - 1 + kh] -> padded 2 ih + kh (bd = 1)
@@ -634,7 +672,36 @@ class Block:
             out.append(d)
         return out
 
+    def _wgrad_s2d_up(self):
+        """Weight gradient of a transposed 4x4 stride-2 block from its space-to-depth output gradient: ONE 16-tap launch of the per-tap
+        kernel, tap t' = ph * 4 + u * 2 + v reading the phase-ph channel slice at offset (dy, dx) of S2D_UP, unit stride (the plain
+        form samples the bordered gradient at stride 2)."""
+        d = L.WgradDesc()
+        self._src_fields(d, None)
+        b_in = self.srcs[0].b
+        d.ntaps = 16
+        d.dy, d.dx = L.taps([b_in] * 16), L.taps([b_in] * 16)
+        ent = [(dy, dx) for a, b in [(0, 0), (0, 1), (1, 0), (1, 1)] for _, dy in S2D_UP[a] for _, dx in S2D_UP[b]]
+        d.si, d.so = 1, 1
+        d.ooy, d.oox = L.taps([e[0] for e in ent]), L.taps([e[1] for e in ent])
+        d.dout, d.Cout, d.dout_cstride, d.dout_coff, d.dout_phase_taps = L.ptr(self.draw), self.cout, 4 * self.cout, 0, 4
+        d.DHp, d.DWp = self.Hin + 2, self.Win + 2
+        d.N, d.OH, d.OW = self.N, self.Hin, self.Win
+        d.dw = L.ptr(self.dw)
+        bj = 128 if self.cout % 128 == 0 else 64
+        bc = 32
+        for cand in (128, 64):
+            if d.C0 % cand == 0 and (d.C1 == 0 or d.C1 % cand == 0):
+                bc = cand
+                break
+        tiles = (self.cout // bj) * (self.ctot // bc) * 16
+        chunks = (self.N * self.Hin * self.Win + 31) // 32
+        d.splitk = int(max(1, min((1024 + tiles - 1) // tiles, chunks // 4 if chunks >= 4 else 1)))
+        return d
+
     def wgrad_desc(self):
+        if self.s2d_up:
+            return self._wgrad_s2d_up()
         if self.s2d:
             main = self._wgrad_s2d()
             return main + [self._wgrad_one('s')] if self.split else main
