@@ -119,7 +119,7 @@ def test_bf16_elbo_gate_bair_384_frames():
     assert min(gcos[k] for k in short) >= 0.98, sorted(((k, gcos[k]) for k in short), key=lambda kv: kv[1])[:4]
 
 
-@pytest.mark.parametrize('name,nc,T,B', [('kth', 1, 20, 20), ('human', 3, 16, 26)])
+@pytest.mark.parametrize('name,nc,T,B', [('kth', 1, 20, 20), ('human', 3, 16, 26), ('smmnist', 1, 15, 26)])
 def test_elbo_gate_undiluted_recipes_400_frames(name, nc, T, B):
     """The north_star gate on the recipes whose ELBO is NOT dominated by the model-independent NLL constant: KTH (config 3: nc=1,
     T=20) and Human3.6M (config 5: nc=3, T=16), both nt_inf=3, obs_scale 0.2, res_gain 1.2 (README.md:111-122), full layer widths,
@@ -133,23 +133,26 @@ def test_elbo_gate_undiluted_recipes_400_frames(name, nc, T, B):
         loss undamped.  The oracle itself with nothing but the product's forward rounding points inserted (O.PRECISION = 'bf16',
         exact fp32 arithmetic otherwise) is 2.4e-3 (KTH) off the fp32 oracle: no implementation that stores bf16 activations
         meets 1e-4 HERE, whereas it does on the BAIR recipe (test above: 3e-6).  Asserted: the HIP path is no further from fp32
-        than 2x that numerics model, and within 1.5e-3 of the model itself (the kernels implement the algorithm)."""
+        than 2x that numerics model, and within 1.5e-3 of the model itself (the kernels implement the algorithm).
+    'smmnist' runs the same comparison on config 2's recipe (DCGAN, no skip connections, ny = nz = 20, nt_inf = 5, n_euler = 1, beta_z = 2,
+    obs_scale 1, 390 frames): there the production bf16 path itself is held to the north_star 1e-4."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from make_golden import synth_video
     import srvp_amd
     from oracle import srvp_oracle as O
     from srvp_amd.train import elbo_terms_and_grads
-    ne = 2
-    ctor = (64, nc, 64, 128, 50, 50, True, 3, 256, 3, 512, 4, 'vgg')
+    dcgan = name == 'smmnist'
+    ne = 1 if dcgan else 2
+    ctor = (64, nc, 64, 128, 20, 20, False, 5, 256, 3, 512, 4, 'dcgan') if dcgan else (64, nc, 64, 128, 50, 50, True, 3, 256, 3, 512, 4, 'vgg')
     torch.manual_seed(1)
     model = srvp_amd.StochasticLatentResidualVideoPredictor(*ctor)
-    model.init(1.2)
+    model.init(1.41 if dcgan else 1.2)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     g = torch.Generator().manual_seed(321)
     x = torch.from_numpy(synth_video(T, B, nc, seed=77))
-    tape = _train_tape(T, B, 3, 50, 50, True, g)
-    hp = dict(obs_scale=0.2, beta_y=1.0, beta_z=1.0, l2_res=1.0)
+    tape = _train_tape(T, B, ctor[7], ctor[4], ctor[5], ctor[6], g)
+    hp = dict(obs_scale=1.0, beta_y=1.0, beta_z=2.0, l2_res=1.0) if dcgan else dict(obs_scale=0.2, beta_y=1.0, beta_z=1.0, l2_res=1.0)
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -178,17 +181,20 @@ def test_elbo_gate_undiluted_recipes_400_frames(name, nc, T, B):
             x_ = outs[0].clone()
             acc, _ = elbo_terms_and_grads(model, xg, outs, opt, want_grads=False)
         nll, kl_y0, kl_z, l2 = acc.cpu().tolist()
-        return (nll + kl_y0 + kl_z + l2) / B, nll / B, x_
+        return (nll + hp['beta_y'] * kl_y0 + hp['beta_z'] * kl_z + hp['l2_res'] * l2) / B, nll / B, x_
     l32, n32, x32 = hip('fp32')
     l16, n16, x16 = hip('bf16')
     rel = lambda a, b: abs(a - b) / abs(b)
-    const = T * nc * 64 * 64 * (torch.log(torch.tensor(0.2)).item() + 0.9189385332)        # the model-independent part of the NLL per video
+    const = T * nc * 64 * 64 * (torch.log(torch.tensor(hp['obs_scale'])).item() + 0.9189385332)   # the model-independent part of the NLL per video
     res = dict(fp32_mode_vs_fp32=rel(l32, ref_loss), fp32_mode_nll=rel(n32, ref_nll), bf16_vs_fp32=rel(l16, ref_loss), bf16_nll_vs_fp32=rel(n16, ref_nll),
                model_vs_fp32=rel(mod_loss, ref_loss), model_nll_vs_fp32=rel(mod_nll, ref_nll), bf16_vs_model=rel(l16, mod_loss),
                bf16_nll_vs_model=rel(n16, mod_nll), x_maxabs_fp32_mode=(x32.double().cpu() - outs_ref[0].double()).abs().max().item(),
                x_maxabs_bf16=(x16.double().cpu() - outs_ref[0].double()).abs().max().item())
     report(test=f'elbo_gate_{name}', frames=T * B, loss_ref=ref_loss, nll_constant_per_video=const, data_term_per_video=ref_nll - const, **res)
-    assert abs(ref_nll - const) > 0.5 * abs(ref_nll), 'the data term should carry this NLL'
+    if dcgan:
+        assert res['bf16_vs_fp32'] <= 1e-4 and res['bf16_nll_vs_fp32'] <= 1e-4, res          # north_star, production precision
+    else:
+        assert abs(ref_nll - const) > 0.5 * abs(ref_nll), 'the data term should carry this NLL'
     assert res['fp32_mode_vs_fp32'] <= 1e-5 and res['fp32_mode_nll'] <= 1e-5, res      # north_star (1e-4) with margin, parity mode
     assert res['x_maxabs_fp32_mode'] <= 1e-4, res
     assert res['bf16_vs_fp32'] <= 2 * res['model_vs_fp32'] + 1e-4, res                  # bf16 storage: bounded by the numerics model
