@@ -552,7 +552,9 @@ template <int KS, int S, int CIN>
 static void launch_in_fwd(const float* x, const float* w, bf16_t* raw, double* stats, int N, int Cout, int Cout_real, hipStream_t st,
                           const bf16_t* bnr_raw = nullptr, const float* bnr_coef = nullptr, double* bnr_red = nullptr) {
     const long long ntiles = (long long)N * InGeom<KS, S, CIN>::TPI;
-    const int tpw = ntiles >= 32768 ? 8 : (ntiles >= 16 ? 2 : 1);
+    static int tpw_env = -1;
+    if (tpw_env < 0) { const char* e = getenv("SRVP_IN_TPW_F"); tpw_env = e ? atoi(e) : 0; }
+    const int tpw = tpw_env > 0 ? tpw_env : (ntiles >= 32768 ? 8 : (ntiles >= 16 ? 2 : 1));
     const dim3 grid((unsigned)((ntiles + tpw - 1) / tpw));
     if (bnr_red) {
         if (Cout == 64) hipLaunchKernelGGL((conv_in_fwd_mfma_kernel<KS, S, CIN, 2, true>), grid, dim3(256), 0, st, x, w, raw, stats, N, Cout, Cout_real, tpw, bnr_raw, bnr_coef, bnr_red);
@@ -565,7 +567,9 @@ static void launch_in_fwd(const float* x, const float* w, bf16_t* raw, double* s
 template <int KS, int S, int CIN>
 static void launch_in_wgrad(const float* x, const bf16_t* draw, float* dw, int N, int Cout, int Cout_real, hipStream_t st) {
     const long long ntiles = (long long)N * InGeom<KS, S, CIN>::TPI;
-    const int tpw = ntiles >= 32768 ? 16 : (ntiles >= 16 ? 2 : 1);
+    static int tpw_env = -1;
+    if (tpw_env < 0) { const char* e = getenv("SRVP_IN_TPW_W"); tpw_env = e ? atoi(e) : 0; }
+    const int tpw = tpw_env > 0 ? tpw_env : (ntiles >= 32768 ? 16 : (ntiles >= 16 ? 2 : 1));
     static int split3 = -1;     // A/B switch: 1 = three-term bf16 split on the bf16 matrix cores, 0 = fp32 MFMA
     if (split3 < 0) { const char* e = getenv("SRVP_IN_WGRAD_SPLIT3"); split3 = e ? atoi(e) : 1; }
     const dim3 grid((unsigned)((ntiles + tpw - 1) / tpw));
