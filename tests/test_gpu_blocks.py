@@ -426,7 +426,110 @@ def test_bn_act_fwd_bwd(mode, C_):
     else:
         (F.max_pool2d(bf(a2).detach() + (a2 - a2.detach()), 2, 2) * da[..., :C_].permute(0, 3, 1, 2).float().cpu()).sum().backward()
     assert rel_err(dgamma, gm.grad) < 5e-3 and rel_err(dbeta, bt.grad) < 5e-3
+    # ---- the one-launch forms (srvp_bn_finalize_act, srvp_bn_bwd_finalize_apply: coefficients derived per workgroup in LDS) must
+    # reproduce the separate finalize + act / finalize + apply launches BIT FOR BIT: outputs, coefficients, running statistics,
+    # parameter gradients
+    rm2, rv2 = torch.zeros(C_, device=dev), torch.ones(C_, device=dev)
+    nbt2 = torch.zeros((), dtype=torch.int64, device=dev)
+    coef2 = torch.zeros(4, Cp, device=dev)
+    out2 = Feat(N, H, H, C_, dev)
+    pool2 = Feat(N, H // 2, H // 2, C_, dev) if mode == 'pool' else None
+    L.call('srvp_bn_finalize_act', L.ptr(raw), L.ptr(stats), cnt, L.ptr(gamma), L.ptr(beta), L.ptr(rm2), L.ptr(rv2), L.ptr(nbt2),
+           L.ptr(coef2[0]), L.ptr(coef2[1]), L.ptr(coef2[2]), L.ptr(coef2[3]), C_, BN_EPS, BN_MOMENTUM, L.ACT_LRELU, N, H, H, Cp,
+           L.ptr(out2.t), 1, L.ptr(pool2.t) if pool2 else None, 1, None, None, 0, st)
+    draw2 = torch.zeros_like(draw)
+    bcoef2 = torch.zeros(3, Cp, device=dev)
+    dgamma2, dbeta2 = torch.zeros(C_, device=dev), torch.zeros(C_, device=dev)
+    L.call('srvp_bn_bwd_finalize_apply', C.byref(d), L.ptr(red), cnt, L.ptr(dgamma2), L.ptr(dbeta2), L.ptr(bcoef2), C_, 1.0, L.ptr(draw2), 1, st)
+    torch.cuda.synchronize()
+    assert torch.equal(out2.t, out.t) and torch.equal(coef2, coef) and torch.equal(rm2, rm) and torch.equal(rv2, rv) and int(nbt2) == 1
+    assert pool is None or torch.equal(pool2.t, pool.t)
+    assert torch.equal(draw2, draw) and torch.equal(bcoef2, bcoef) and torch.equal(dgamma2, dgamma) and torch.equal(dbeta2, dbeta)
     del keep
+
+
+def test_latent_glue_kernels():
+    """srvp_latent_to_z / srvp_dz_split / srvp_rows_scatter_add_f32 (the decoder-input assembly [w | y_t] of srvp.py:216-221, its
+    backward, and the backward of the row gathers) against the torch expressions they replaced, exactly."""
+    from srvp_amd import _lib as L
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(12)
+    nt, B, nh, ny, ne = 5, 7, 24, 10, 2
+    Cz = 64
+    w = torch.randn(B, nh, generator=g).to(dev)
+    y_all = torch.randn((nt - 1) * ne + 1, B, ny, generator=g).to(dev)
+    st = L.stream()
+    for dt_, f32 in ((torch.bfloat16, 0), (torch.float32, 1)):
+        z = torch.full((nt * B, Cz), 7.0, dtype=dt_, device=dev)
+        L.call('srvp_latent_to_z', L.ptr(w), L.ptr(y_all), ne * B * ny, L.ptr(z), nt, B, nh, ny, Cz, f32, st)
+        ref = torch.zeros(nt * B, Cz, device=dev)
+        ref[:, :nh + ny] = torch.cat([w.repeat(nt, 1), y_all[::ne].reshape(nt * B, ny)], 1)
+        assert torch.equal(z.float(), ref.to(dt_).float())
+        dz = torch.randn(nt * B, Cz, generator=g).to(dev).to(dt_)
+        d_w_add, d_y_add = torch.randn(B, nh, generator=g).to(dev), torch.randn(nt, B, ny, generator=g).to(dev)
+        d_w = torch.empty(B, nh, device=dev)
+        d_y_all = torch.zeros_like(y_all)
+        L.call('srvp_dz_split', L.ptr(dz), Cz, f32, nt, B, nh, ny, L.ptr(d_w_add), L.ptr(d_y_add), L.ptr(d_w), L.ptr(d_y_all), ne * B * ny, st)
+        dzf = dz.float()
+        sw = torch.zeros(B, nh, device=dev)
+        for t in range(nt):                                   # the kernel's summation order (t ascending, then the addend)
+            sw = sw + dzf[t * B:(t + 1) * B, :nh]
+        assert torch.equal(d_w, sw + d_w_add)
+        assert torch.equal(d_y_all[::ne], dzf[:, nh:nh + ny].reshape(nt, B, ny) + d_y_add)
+        assert d_y_all[1::ne].abs().max().item() == 0
+    dst = torch.randn(40, 16, generator=g).to(dev)
+    ref = dst.clone()
+    idx = torch.randperm(40, generator=g)[:9].to(dev)
+    src = torch.randn(9, 16, generator=g).to(dev)
+    L.call('srvp_rows_scatter_add_f32', L.ptr(dst), L.ptr(idx), 1, L.ptr(src), 9, 16, st)
+    ref.index_add_(0, idx, src)
+    assert torch.equal(dst, ref)
+    dst2 = ref.clone()
+    L.call('srvp_rows_scatter_add_f32', L.ptr(dst2), L.ptr(idx.to(torch.int32)), 0, L.ptr(src), 9, 16, st)
+    assert torch.equal(dst2, ref.index_add(0, idx, src))
+
+
+@pytest.mark.parametrize('kind,cin,cout,k,split', [('conv', 128, 64, 3, False), ('conv', 96, 40, 3, False), ('convT', 64, 128, 4, False),
+                                                   ('conv', 64, 128, 4, False), ('conv', 128, 64, 3, True)])
+def test_unpack_tiled_equals_item_path(kind, cin, cout, k, split, monkeypatch):
+    """The LDS-tiled srvp_unpack_wgrad_multi path (SRVP_PACK_TILED bit 1, the default) adds exactly what the item-per-thread path adds
+    to the fp32 gradient: every layout the networks use -- OIHW / IOHW, padded channel counts, two channel segments (skip concat)."""
+    import subprocess, sys, os, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys, json, torch, ctypes as C
+sys.path.insert(0, {root!r})
+from srvp_amd import _lib as L
+from srvp_amd.convnet import Block, Feat, ConvNetBase
+dev = torch.device('cuda')
+g = torch.Generator().manual_seed(5)
+N, Hs = 2, 8
+f0 = Feat(N, Hs, Hs, {cin}, dev)
+srcs = [f0]
+skip_map = None
+if {split}:
+    f1 = Feat(2, Hs, Hs, {cin} // 2, dev); srcs.append(f1)
+    skip_map = torch.zeros(N, dtype=torch.int32, device=dev)
+c_tot = {cin} + ({cin} // 2 if {split} else 0)
+spec = dict(kind={kind!r}, key='w', bnkey='bn', cin=c_tot, cout={cout}, k={k}, s=(2 if {k} == 4 else 1), p=1, act='leaky_relu')
+blk = Block(spec, 'mfma', srcs, False, N, dev, True, skip_map=skip_map)
+blk.dw.copy_(torch.randn(blk.dw.shape, generator=g))
+wshape = ({cout}, c_tot, {k}, {k}) if {kind!r} == 'conv' else (c_tot, {cout}, {k}, {k})
+gw = torch.randn(*wshape, generator=g).to(dev)
+net = ConvNetBase(); net.dev = dev
+jobs = blk.unpack_jobs(gw)
+c = net._job_table(jobs, dev, dict(), True)
+L.call('srvp_unpack_wgrad_multi', L.ptr(c['table']), c['n'], c['mx'], L.stream())
+torch.cuda.synchronize()
+torch.save(gw.cpu(), sys.argv[1])
+"""
+    outs = []
+    for mode in ('2', '0'):
+        path = os.path.join(os.environ.get('TMPDIR', '/tmp'), f'unpack_{mode}_{kind}_{cin}_{cout}_{k}_{int(split)}.pt')
+        r = subprocess.run([sys.executable, '-c', code, path], env=dict(os.environ, SRVP_PACK_TILED=mode), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(path))
+    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize('nc,k,s,p', [(3, 3, 1, 1), (1, 4, 2, 1), (3, 4, 2, 1)])
