@@ -404,6 +404,16 @@ int srvp_comm_destroy(void* comm);
 int srvp_allreduce_f64(void* comm, double* buf, int64_t n, void* stream);
 int srvp_allreduce_f32(void* comm, float* buf, int64_t n, void* stream);
 int srvp_bcast_bytes(void* comm, void* buf, int64_t nbytes, int root, void* stream);
+/* PROTOTYPE, SRVP_COMM=peer: the SyncBatchNorm statistics exchange as a one-sided peer read (csrc/comm.hip).  Every rank creates a slab
+ * (device memory, exported through hipIpc: ipc_handle64 receives the 64-byte handle), opens the other ranks' slabs, and a collective is one
+ * single-workgroup launch per rank: publish buf[0..n) at data_off of the own slab, raise the flag at flag_off to `seq`, wait (bounded: 5 s,
+ * then *err_flag = 1) until every peer's flag reaches `seq`, replace buf by the sum over ranks taken in rank order.  The caller alternates
+ * two (data_off, flag_off) parities per call site and increases seq with every use.  world <= 8; slabs: HOST array of `world` device pointers. */
+int srvp_peer_slab_create(int64_t bytes, void** dev_ptr, void* ipc_handle64);
+int srvp_peer_slab_open(const void* ipc_handle64, void** dev_ptr);
+int srvp_peer_slab_close(void* dev_ptr, int owned);
+int srvp_peer_allreduce_f64(double* buf, int n, int rank, int world, void* const* slabs, int64_t data_off, int64_t flag_off,
+                            uint64_t seq, int* err_flag, void* stream);
 
 /* misc */
 int srvp_fill_f64(double* p, int64_t n, double v, void* stream);

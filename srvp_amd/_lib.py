@@ -145,6 +145,10 @@ _SIGS = {
     'srvp_allreduce_f64': ([c_vp, c_vp, c_i64, c_vp], c_i32),
     'srvp_allreduce_f32': ([c_vp, c_vp, c_i64, c_vp], c_i32),
     'srvp_bcast_bytes': ([c_vp, c_vp, c_i64, c_i32, c_vp], c_i32),
+    'srvp_peer_slab_create': ([c_i64, C.POINTER(c_vp), c_vp], c_i32),
+    'srvp_peer_slab_open': ([c_vp, C.POINTER(c_vp)], c_i32),
+    'srvp_peer_slab_close': ([c_vp, c_i32], c_i32),
+    'srvp_peer_allreduce_f64': ([c_vp, c_i32, c_i32, c_i32, C.POINTER(c_vp), c_i64, c_i64, C.c_uint64, c_vp, c_vp], c_i32),
     'srvp_fill_f64': ([c_vp, c_i64, c_f64, c_vp], c_i32),
     'srvp_frames_u8_to_f32': ([c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_mmnist_render': ([c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp], c_i32),

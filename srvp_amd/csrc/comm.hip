@@ -90,3 +90,92 @@ extern "C" int srvp_bcast_bytes(void* comm, void* buf, int64_t nbytes, int root,
     RCCL_CHECK(g_api.Broadcast(buf, buf, (size_t)nbytes, ncclUint8, root, (ncclComm_t)comm, (hipStream_t)stream), "ncclBroadcast");
     return SRVP_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PROTOTYPE (SRVP_COMM=peer): the SyncBatchNorm statistics exchange (reference train.py:278-283) as a one-sided peer read instead of
+// an all-reduce.  84 of these per VGG step feed the very next kernel, each a few KB: through RCCL every one is a collective kernel
+// with its own rendezvous (~10-20 us on xGMI), which at 24 sequences per GPU is 1-1.7 ms of a ~9 ms step.  Here every rank owns a
+// slab (device memory shared with the other ranks of the node through hipIpc); a collective is ONE single-workgroup launch per rank:
+// publish the local sums into the own slab (system-scope stores), raise the own flag to the sequence number, wait for the peers'
+// flags (bounded spin), read their sums over xGMI and add them in rank order -- the same order on every rank, so all ranks hold
+// bit-identical totals.  Two parities per slot: a rank can only reach use n + 2 of a slot after every peer has finished use n.
+// Validated on ranks that share one device (tests/test_two_rank_equality.py); the cross-device memory model (uncached slab,
+// system-scope accesses) has not been exercised on hardware yet.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct PeerK { double* slab[8]; int rank, world; long long data_off, flag_off; unsigned long long seq; int* err; };
+
+__global__ __launch_bounds__(256) void peer_allreduce_kernel(double* buf, int n, const PeerK k) {
+    double* own = (double*)((char*)k.slab[k.rank] + k.data_off);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) __hip_atomic_store(own + i, buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store((unsigned long long*)((char*)k.slab[k.rank] + k.flag_off), k.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < k.world && (int)threadIdx.x != k.rank) {
+        const unsigned long long* f = (const unsigned long long*)((char*)k.slab[threadIdx.x] + k.flag_off);
+        const long long t0 = wall_clock64();                   // 100 MHz
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < k.seq) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > 500000000ll) { bad = 1; break; }       // 5 s: a peer never arrived -- give up, flag the error
+        }
+    }
+    __syncthreads();
+    if (bad) { if (threadIdx.x == 0 && k.err) *k.err = 1; return; }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double tot = 0.;
+        for (int p = 0; p < k.world; ++p)
+            tot += p == k.rank ? buf[i] : __hip_atomic_load((const double*)((char*)k.slab[p] + k.data_off) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        buf[i] = tot;
+    }
+}
+}  // namespace
+
+extern "C" int srvp_peer_slab_create(int64_t bytes, void** dev_ptr, void* ipc_handle64) {
+    SRVP_REQUIRE(bytes > 0 && dev_ptr && ipc_handle64, "srvp_peer_slab_create: bad args");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    void* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&p, (size_t)bytes); }
+    SRVP_REQUIRE(e == hipSuccess, "srvp_peer_slab_create: allocation of %lld bytes failed: %s", (long long)bytes, hipGetErrorString(e));
+    e = hipMemset(p, 0, (size_t)bytes);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_peer_slab_create: memset failed: %s", hipGetErrorString(e));
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) { (void)hipFree(p); }
+    SRVP_REQUIRE(e == hipSuccess, "srvp_peer_slab_create: hipIpcGetMemHandle failed: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 exported?)", hipGetErrorString(e));
+    memcpy(ipc_handle64, &h, sizeof(h));
+    *dev_ptr = p;
+    return SRVP_OK;
+}
+extern "C" int srvp_peer_slab_open(const void* ipc_handle64, void** dev_ptr) {
+    SRVP_REQUIRE(ipc_handle64 && dev_ptr, "srvp_peer_slab_open: bad args");
+    hipIpcMemHandle_t h;
+    memcpy(&h, ipc_handle64, sizeof(h));
+    void* p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_peer_slab_open: hipIpcOpenMemHandle failed: %s", hipGetErrorString(e));
+    *dev_ptr = p;
+    return SRVP_OK;
+}
+extern "C" int srvp_peer_slab_close(void* dev_ptr, int owned) {
+    if (!dev_ptr) return SRVP_OK;
+    hipError_t e = owned ? hipFree(dev_ptr) : hipIpcCloseMemHandle(dev_ptr);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_peer_slab_close: %s", hipGetErrorString(e));
+    return SRVP_OK;
+}
+extern "C" int srvp_peer_allreduce_f64(double* buf, int n, int rank, int world, void* const* slabs, int64_t data_off, int64_t flag_off,
+                                       uint64_t seq, int* err_flag, void* stream) {
+    SRVP_REQUIRE(buf && slabs && n > 0 && world >= 1 && world <= 8 && rank >= 0 && rank < world && data_off % 8 == 0 && flag_off % 8 == 0,
+                 "srvp_peer_allreduce_f64: bad args (world <= 8)");
+    PeerK k{};
+    for (int p = 0; p < world; ++p) { SRVP_REQUIRE(slabs[p], "srvp_peer_allreduce_f64: slab %d not mapped", p); k.slab[p] = (double*)slabs[p]; }
+    k.rank = rank; k.world = world; k.data_off = data_off; k.flag_off = flag_off; k.seq = seq; k.err = err_flag;
+    hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, buf, n, k);
+    SRVP_CHECK_LAUNCH("srvp_peer_allreduce_f64");
+    return SRVP_OK;
+}

@@ -78,6 +78,81 @@ class NativeComm:
             self.handle = C.c_void_p()
 
 
+class PeerStats:
+    """PROTOTYPE (SRVP_COMM=peer): SyncBatchNorm statistics through one-sided peer reads of hipIpc-shared slabs instead of all-reduce
+    collectives (csrc/comm.hip: srvp_peer_*).  One slot (two parities) per call site, assigned in order of first use -- the launch
+    sequence is the same on every rank; seq counts the uses of the slot.  Ranks of ONE node only (hipIpc), world <= 8."""
+
+    SLOTS, NMAX = 128, 2 * 2048          # call sites (42 BatchNorm layers x 2 directions = 84 for VGG), doubles per collective
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if self.world > 8:
+            raise L.SrvpHipError('peer statistics exchange: at most 8 ranks (one node)')
+        lib = L.load()
+        self.stride = self.NMAX * 8 + 128                    # data + a 128-byte line for the flag
+        nbytes = self.SLOTS * 2 * self.stride
+        self.own, handle = C.c_void_p(), C.create_string_buffer(64)
+        err = None
+        if lib.srvp_peer_slab_create(nbytes, C.byref(self.own), handle) != 0:
+            err = lib.srvp_last_error().decode()
+        # every rank reaches the gather whatever happened locally; a failure anywhere fails the construction everywhere
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, (err, bytes(handle.raw)), group=group)
+        self.ptrs = (C.c_void_p * self.world)()
+        bad = [f'rank {r}: {e}' for r, (e, _) in enumerate(gathered) if e]
+        if bad:
+            if err is None:
+                lib.srvp_peer_slab_close(self.own, 1)
+            raise L.SrvpHipError('; '.join(bad))
+        handles = [h for _, h in gathered]
+        for r, h in enumerate(handles):
+            if r == self.rank:
+                self.ptrs[r] = self.own
+            else:
+                p = C.c_void_p()
+                L.check(lib.srvp_peer_slab_open(h, C.byref(p)), 'srvp_peer_slab_open')
+                self.ptrs[r] = p
+        self.err = torch.zeros(1, dtype=torch.int32, device='cuda')
+        self.slot_of, self.uses = {}, {}
+
+    def allreduce(self, t):
+        assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float64 and t.numel() <= self.NMAX
+        key = t.data_ptr()
+        slot = self.slot_of.setdefault(key, len(self.slot_of))
+        if slot >= self.SLOTS:
+            raise L.SrvpHipError('peer statistics exchange: more call sites than slots')
+        n = self.uses.get(slot, 0) + 1
+        self.uses[slot] = n
+        off = (slot * 2 + (n & 1)) * self.stride
+        L.call('srvp_peer_allreduce_f64', L.ptr(t), t.numel(), self.rank, self.world, self.ptrs, off, off + self.NMAX * 8, n, L.ptr(self.err), L.stream())
+
+    def check(self):
+        """(synchronises) raises if a collective gave up waiting for a peer."""
+        if int(self.err.item()) != 0:
+            raise L.SrvpHipError('peer statistics exchange: a rank waited 5 s for a peer that never published its sums')
+
+    def self_test(self):
+        want = self.world * (self.world + 1) / 2
+        t = torch.full((2, 64), float(self.rank + 1), dtype=torch.float64, device='cuda')
+        for _ in range(3):                                   # three uses: both parities and the reuse of the first
+            u = t.clone()
+            self.slot_of[u.data_ptr()] = self.SLOTS - 1      # (the last slot is the test's)
+            self.allreduce(u)
+            del self.slot_of[u.data_ptr()]
+            if not bool((u == want).all().item()):
+                return False
+        return int(self.err.item()) == 0
+
+    def close(self):
+        lib = L.load()
+        for r in range(self.world):
+            if self.ptrs[r]:
+                lib.srvp_peer_slab_close(self.ptrs[r], 1 if r == self.rank else 0)
+                self.ptrs[r] = None
+
+
 class Sync:
     def __init__(self, group=None, stat_group=None, native=None):
         self.group = group
@@ -118,11 +193,38 @@ class Sync:
                     c.close()
                 print(f'srvp_amd.distributed: native RCCL path unavailable ({why or "failed on another rank / self-test"}); using torch.distributed')
         self.transport = 'rccl (C ABI, in-stream)' if self.native_stats is not None else f'torch.distributed ({dist.get_backend(group)})'
+        # SRVP_COMM=peer (prototype): statistics through peer reads of hipIpc-shared slabs; gradients keep the transport chosen above
+        self.peer = None
+        if os.environ.get('SRVP_COMM') == 'peer' and torch.cuda.is_available() and (self.world > 1 or self.force):
+            made = None
+            try:
+                made = PeerStats(group)
+                ok = True
+            except L.SrvpHipError as e:
+                print(f'srvp_amd.distributed: peer statistics exchange unavailable ({e})')
+                ok = False
+            agree = lambda v: self._agree(v, group)
+            ok = agree(ok) and agree(made.self_test())
+            if ok:
+                self.peer = made
+                self.transport += ' + peer-read statistics (hipIpc slabs)'
+            elif made is not None:
+                made.close()
+
+    @staticmethod
+    def _agree(ok, group):
+        """True iff `ok` on every rank (the decision must be the same everywhere).  On the backend's own device type."""
+        dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+        flag = torch.tensor([1 if ok else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return int(flag.item()) == 1
 
     def allreduce_stats(self, t, count):
         """In-place sum of a small fp64 statistics tensor over ranks; returns the global element count."""
         if self.sync_bn and (self.world > 1 or self.force):
-            if self.native_stats is not None:
+            if self.peer is not None:
+                self.peer.allreduce(t)
+            elif self.native_stats is not None:
                 self.native_stats.allreduce(t)
             else:
                 dist.all_reduce(t, group=self.stat_group)

@@ -106,3 +106,21 @@ def test_hip_ranks_equal_one_over_rccl(tmp_path, comm):
     else:
         assert 'torch.distributed (nccl)' in (many.get('transport') or ''), many.get('transport')
     _compare(one, many, 1e-6, 2e-3, 1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world', [2, 3])
+def test_hip_ranks_equal_one_peer_statistics(tmp_path, world):
+    """PROTOTYPE transport SRVP_COMM=peer (csrc/comm.hip srvp_peer_*): the SyncBatchNorm statistics of every layer and direction
+    exchanged by one-sided reads of hipIpc-shared slabs (publish, flag, wait, sum in rank order) instead of all-reduce collectives --
+    N ranks sharing the test box's one GPU (gradients over gloo) against one process on the global batch, in fp32 mode at the tight
+    tolerances.  What this does NOT cover: the slabs live on one device here, so the cross-device memory model (uncached allocation,
+    system-scope accesses over xGMI) is exercised only on a multi-GPU node."""
+    os.environ['SRVP_PRECISION'] = 'fp32'
+    try:
+        one = _run('hip', 1, str(tmp_path / 'one.pt'))
+        many = _run('hip', world, str(tmp_path / 'many.pt'), backend='gloo', extra_env={'SRVP_COMM': 'peer'})
+    finally:
+        del os.environ['SRVP_PRECISION']
+    assert 'peer-read' in (many.get('transport') or ''), many.get('transport')
+    _compare(one, many, 1e-6, 2e-3, 1e-5)

@@ -6,6 +6,9 @@ collective through torch.distributed -- so DESIGN §5's cost estimate becomes a 
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/allreduce_latency.py
     SRVP_FORCE_COLLECTIVES=1 python tools/allreduce_latency.py          # one rank: call-path overhead only (no peer)
+    SRVP_COMM=peer ... (either form)                                     # adds the peer-read prototype (srvp_peer_allreduce_f64)
+    SRVP_COMM=peer SRVP_DIST_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 ...   # two ranks sharing ONE GPU: the
+                                                                         # protocol's own cost (publish, flag, wait, read), no xGMI
 
 Rank 0 prints one JSON line: microseconds per (kernel, all-reduce) pair for C in {64, 512}, both transports, and the pure
 kernel-pair baseline.
@@ -34,8 +37,9 @@ def main():
         os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('SRVP_FORCE_COLLECTIVES', '1')
-    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-    sync = sdist.init_process_group('nccl')
+    backend = os.environ.get('SRVP_DIST_BACKEND', 'nccl')       # gloo: ranks sharing one GPU (peer path only; RCCL refuses that)
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) if backend == 'nccl' else 0)
+    sync = sdist.init_process_group(backend)
     out = dict(world=world, transport=sync.transport, iters=200)
     for C in (64, 512):
         t = torch.zeros(2, C, dtype=torch.float64, device='cuda')
@@ -51,11 +55,14 @@ def main():
                     sync.native_stats.allreduce(t)
                 elif kind == 'torch':
                     dist.all_reduce(t, group=sync.stat_group)
+                elif kind == 'peer':
+                    sync.peer.allreduce(t)
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / n * 1e6
-        for kind in ('none', 'native', 'torch'):
-            if kind == 'native' and sync.native_stats is None:
-                out[f'C{C}_native_us'] = None
+        for kind in ('none', 'native', 'peer', 'torch'):
+            if (kind == 'native' and sync.native_stats is None) or (kind == 'peer' and getattr(sync, 'peer', None) is None) or \
+                    (kind == 'torch' and backend != 'nccl'):
+                out[f'C{C}_{kind}_us'] = None
                 continue
             loop(kind, 20)
             out[f'C{C}_{kind}_us'] = round(loop(kind), 2)
