@@ -280,6 +280,9 @@ def main(opt):
         itr, best_val_metric = load_train_state(os.path.join(resume_dir, 'train_state.pt'), model, optimizer, lr_scheduler, device,
                                                 rank=local_rank, seed=opt.seed)
         print(f'Resumed from {resume_dir} at iteration {itr}')
+        gen = getattr(train_loader, 'gen', None)
+        if gen is not None and hasattr(gen, 'counter'):
+            gen.counter = itr          # device Moving-MNIST generator: batch k is a function of (seed, k) -- continue the same data stream
     # the plans / descriptor tables built by the first steps are long-lived: keep them out of the cyclic collector's generations
     # (a full collection over them is a ~90 ms host stall, several steps' worth at the small configurations)
     import gc
