@@ -242,9 +242,26 @@ class Sync:
             off += p.numel()
         return enc_end, dec_end, off
 
+    def _poll_peer_error(self):
+        """Once per step, without a device sync: the error word of the peer exchange as it stood one step ago."""
+        if self.peer is None:
+            return
+        host = self.__dict__.get('_peer_err_host')
+        if host is None:
+            host = self._peer_err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._peer_err_event = None
+        if self._peer_err_event is not None and self._peer_err_event.query() and int(host[0]) != 0:
+            raise L.SrvpHipError('peer statistics exchange: a rank waited 5 s for a peer that never published its sums '
+                                 '(results since then are invalid); set SRVP_COMM=rccl')
+        host.copy_(self.peer.err, non_blocking=True)
+        self._peer_err_event = torch.cuda.Event()
+        self._peer_err_event.record()
+
     def grads_ready(self, what, model):
         if self.world == 1 and not self.force:
             return
+        if what == 'all':
+            self._poll_peer_error()
         flat_g = model._flat[1]
         enc_end, dec_end, total = self._slices(model)
         if self.native_grads is not None:
