@@ -154,7 +154,11 @@ def test_hip_vs_full_width_reference_fixture(name, precision):
                    e_loss=abs(loss - ref[0]) / abs(ref[0]))
         except Exception:
             pass
-        assert abs(loss - ref[0]) <= 3e-4 * abs(ref[0]), (loss, ref[0])
+        # measured (rounds 2-3, several boxes): C2 8e-6, C3 2-4e-6, C4 1.1-1.2e-5, C5 2.4e-4 (32 frames at obs_scale 0.2 / res_gain 1.2: the
+        # ill-conditioned point of tests/test_gpu_parity_gate.py::test_elbo_gate_undiluted_recipes_400_frames) -- bounds = measured + 25 %
+        # where the value is stable, x4 where it sits at the rounding-noise floor and moves with the order of the statistics atomics
+        bound = {'full_c2_smmnist_dcgan': 4e-5, 'full_c3_kth_vgg': 2e-5, 'full_c4_bair_vgg': 5e-5, 'full_c5_human_vgg': 3e-4}.get(name, 3e-4)
+        assert abs(loss - ref[0]) <= bound * abs(ref[0]), (loss, ref[0], bound)
         assert (frame_samples(outs_c[0].cpu()) - fx.t('train.x_')).abs().max().item() <= 3e-2
         for n, o in zip(OUT_NAMES[1:], outs_c[1:]):
             assert rel_l2(o, fx.t('train.' + n)) <= 6e-2, n

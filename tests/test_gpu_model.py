@@ -220,7 +220,7 @@ def test_full_width_vs_oracle(archi, nc, skipco, ne, B, T):
            median_grad_model=sorted(gerr_m.values())[len(gerr_m) // 2])
     # vs the reference arithmetic (fp32 oracle): the north_star ELBO tolerance, measured on 16-40 frames (the BN batch of
     # the benchmark configuration is 2304 frames, where the rounding noise averages further down)
-    assert e_loss < 2e-4, (loss, scal['loss'])
+    assert e_loss < (1.4e-4 if archi == 'vgg' else 5e-6), (loss, scal['loss'])       # measured 1.07e-4 (vgg, 16 frames) / 1e-6 (dcgan): + 25 % / x5
     assert max_abs(x_, outs_ref[0]) < 3e-2
     # vs the same algorithm under the product's numerics model: the kernels implement the algorithm
     vgg = archi == 'vgg'

@@ -1,4 +1,6 @@
-"""How much does an HBM-bound BatchNorm pass gain from running beside an MFMA-bound convolution?  (sizing the half-batch pipelining idea)"""
+"""How much does an HBM-bound BatchNorm pass gain from running beside an MFMA-bound convolution of the next layer?  (sizing the idea of
+pipelining half batches through the forward; DESIGN.md section 3: nothing -- concurrent = serial under the power cap.)
+usage: python tools/overlap_probe.py"""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import srvp_amd, bench
