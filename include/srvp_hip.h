@@ -174,7 +174,12 @@ int srvp_bn_finalize_act(const void* raw, const double* stats, double count, con
                          float* running_mean, float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
                          float* mean, float* invstd, int C_real, float eps, float momentum, int act, int N, int H, int W, int C,
                          void* dst, int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep_frames,
-                         int elem_f32, void* stream);
+                         int elem_f32, int dst_s2d, void* stream);
+/* dst_s2d = 1: `dst` is written SPACE-TO-DEPTH, [N][H/2+2][W/2+2][4C] with a 1-pixel zero border -- pixel (y, x) at position (y/2, x/2),
+ * channel group (y&1)*2 + (x&1) -- the layout a 4x4 stride-2 consumer (DCGAN encoder, conv.py:174-179) convolves as a 2x2-tap-per-phase
+ * stride-1 halo convolution (srvp_conv_desc.tap_phase_chunks); no pooling then.  srvp_bn_act_s2d: the same store for the two-launch /
+ * eval-mode path (bf16). */
+int srvp_bn_act_s2d(const void* raw, const float* scale, const float* shift, int act, int N, int H, int W, int C, void* dst, void* stream);
 
 /* backward of activation+BN.  dA comes from one or two places:
  *   main: tensor `da` with channel stride da_cstride / offset da_coff, mode 0 = same resolution,

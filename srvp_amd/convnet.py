@@ -43,6 +43,7 @@ SUB_D = [(2,), (1, 2), (0, 1), (0,)]
 # collects output rows 2 ih - 1 + kh; output row parity a -> [(kernel index kh, padded row offset dy into the s2d tensor)]
 S2D_UP = {0: [(1, 1), (3, 2)], 1: [(0, 0), (2, 1)]}
 S2D_UP_ON = os.environ.get('SRVP_UP_S2D', '1') != '0'
+DOWN_S2D = os.environ.get('SRVP_DOWN_S2D', '1') != '0'        # 4x4 stride-2 encoder layers on a space-to-depth source (no skip connections)
 
 
 def _tapset(rows, cols, k=3):
@@ -64,11 +65,18 @@ def cpad(c):
 class Feat:
     """NHWC bf16 tensor [N][H+2b][W+2b][C] with zero border b; Cr = number of real channels."""
 
-    def __init__(self, N, H, W, Cr, device, b=1, C=None, dtype=torch.bfloat16):
-        """dtype: torch.bfloat16 (production) or torch.float32 (precision = 'fp32' parity mode)."""
+    def __init__(self, N, H, W, Cr, device, b=1, C=None, dtype=torch.bfloat16, s2d=False):
+        """dtype: torch.bfloat16 (production) or torch.float32 (precision = 'fp32' parity mode).
+        s2d: stored SPACE-TO-DEPTH for a 4x4 stride-2 consumer, [N][H/2+2][W/2+2][4 C] with a 1-pixel zero border: pixel (y, x) at position
+        (y/2, x/2), channel group (y&1)*2 + (x&1) (written that way by srvp_bn_finalize_act / srvp_bn_act_s2d)."""
         self.N, self.H, self.W, self.Cr, self.b = N, H, W, Cr, b
         self.C = cpad(Cr) if C is None else C
-        self.t = torch.zeros(N, H + 2 * b, W + 2 * b, self.C, dtype=dtype, device=device)
+        self.s2d = bool(s2d)
+        if self.s2d:
+            assert b == 1 and H % 2 == 0 and W % 2 == 0
+            self.t = torch.zeros(N, H // 2 + 2, W // 2 + 2, 4 * self.C, dtype=dtype, device=device)
+        else:
+            self.t = torch.zeros(N, H + 2 * b, W + 2 * b, self.C, dtype=dtype, device=device)
 
     @property
     def Hp(self):
@@ -79,14 +87,35 @@ class Feat:
         return self.W + 2 * self.b
 
     def interior(self):
+        assert not self.s2d, 'space-to-depth tensor: use get_nhwc() / put_nhwc()'
         b = self.b
         return self.t[:, b:b + self.H, b:b + self.W, :self.Cr]
 
+    def _s2d_view(self):
+        # [N][H/2][2 (y&1)][W/2][2 (x&1)][C] view of the interior of the space-to-depth tensor
+        return self.t[:, 1:-1, 1:-1].reshape(self.N, self.H // 2, self.W // 2, 2, 2, self.C).permute(0, 1, 3, 2, 4, 5)
+
+    def get_nhwc(self):
+        """[N][H][W][Cr] copy of the interior, whatever the layout."""
+        if self.s2d:
+            return self._s2d_view().reshape(self.N, self.H, self.W, self.C)[..., :self.Cr].clone()
+        return self.interior().clone()
+
+    def put_nhwc(self, x):
+        """x: [N][H][W][Cr] -> interior (border and channel padding stay zero)."""
+        if self.s2d:
+            v = torch.zeros(self.N, self.H, self.W, self.C, dtype=self.t.dtype, device=self.t.device)
+            v[..., :self.Cr] = x
+            inner = v.reshape(self.N, self.H // 2, 2, self.W // 2, 2, self.C).permute(0, 1, 3, 2, 4, 5).reshape(self.N, self.H // 2, self.W // 2, 4 * self.C)
+            self.t[:, 1:-1, 1:-1].copy_(inner)
+        else:
+            self.interior().copy_(x)
+
     def to_nchw(self):
-        return self.interior().permute(0, 3, 1, 2).float().contiguous()
+        return self.get_nhwc().permute(0, 3, 1, 2).float().contiguous()
 
     def load_nchw(self, x):
-        self.interior().copy_(x.permute(0, 2, 3, 1))
+        self.put_nhwc(x.permute(0, 2, 3, 1))
 
 
 def _pack_desc(taps_off, J, K, Jsegs, Ksegs, sj, sk, tap_sets=None):
@@ -162,6 +191,11 @@ class Block:
         # that half; 21 % of all VGG conv FLOPs at T = 12).  Same arithmetic, different summation order.
         self.split = (role == 'mfma' and len(srcs) == 2 and skip_sel is not None and getattr(self, 'geom', None) == 'same')
         self.B = int(skip_sel.numel()) if self.split else 0
+        # 4x4 stride-2 convolution over a SPACE-TO-DEPTH source (DCGAN encoder, conv.py:174-179): forward = one halo launch with the four
+        # taps of each 64-channel chunk's phase (K = 16 C exactly), weight gradient = the per-tap kernel with the roles of its two operands
+        # swapped (the s2d tensor goes in as the channel-sliced "gradient" operand, srvp_wgrad_desc.dout_phase_taps)
+        self.s2d_in = bool(role == 'mfma' and getattr(self, 'geom', None) == 'down' and len(srcs) == 1 and getattr(srcs[0], 's2d', False))
+        assert not any(getattr(f, 's2d', False) for f in srcs) or self.s2d_in, 'a space-to-depth source needs a 4x4 stride-2 consumer'
         # sub-pixel evaluation of the upsampled 3x3 conv (main input only; a hoisted skip half stays a plain conv)
         self.subpix = bool(SUBPIX and role == 'mfma' and ups and getattr(self, 'geom', None) == 'same' and
                            (len(srcs) == 1 or self.split) and self.k == 3)
@@ -234,6 +268,22 @@ class Block:
             pd = getattr(self, name, None)
             if pd is not None:
                 pd.dst_f32 = 1 if self.f32 else 0
+        if self.s2d_in:
+            # forward weights over the space-to-depth source: [4 taps (u, v)][cout][K = 4 phases x C], fragment-major; phase (a, b) holds the
+            # kernel taps (kh, kw) = (S2D_UP[a][u], S2D_UP[b][v]) (input row 2 oy - 1 + kh: the same parity table as the transposed blocks)
+            c0p = self.srcs[0].C
+            self.pf_ph = []
+            for ph, (a, b) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+                offs = [kh * self.k + kw for kh, _ in S2D_UP[a] for kw, _ in S2D_UP[b]]
+                d = _pack_desc(offs, self.pf.J, self.pf.K, (self.pf.J0, self.pf.J0r, self.pf.J1r), (self.pf.K0, self.pf.K0r, self.pf.K1r),
+                               self.pf.sj, self.pf.sk)
+                d.layout, d.kc_total, d.kc_off, d.dst_f32 = 1, 4 * c0p // 64, ph * c0p // 64, 0
+                self.pf_ph.append(d)
+            if self.training:
+                # weight gradient comes out TRANSPOSED, [16 taps grouped by phase][Cin][Cout] (operand roles swapped in _wgrad_s2d_in)
+                order = [kh * self.k + kw for a, b in [(0, 0), (0, 1), (1, 0), (1, 1)] for kh, _ in S2D_UP[a] for kw, _ in S2D_UP[b]]
+                pu = self.pu
+                self.pu = _pack_desc(order, pu.K, pu.J, (pu.K0, pu.K0r, pu.K1r), (pu.J0, pu.J0r, pu.J1r), pu.sk, pu.sj)
         if self.s2d_up and self.wt_d is not None:
             # data-gradient weights over the space-to-depth output gradient: [4 taps (u, v)][ctot][K = 4 phases x cout], fragment-major,
             # phase (a, b) = K chunks [ph cout/64, (ph + 1) cout/64) holding kernel taps (kh, kw) = (S2D_UP[a][u], S2D_UP[b][v])
@@ -324,7 +374,7 @@ class Block:
 
     def pack_jobs(self, w):
         """[(fp32 source pointer, packed destination tensor, pack descriptor)] of this block's weight buffers."""
-        jobs = [(L.ptr(w), self.wt_f, self.pf)]
+        jobs = [(L.ptr(w), self.wt_f, d) for d in self.pf_ph] if self.s2d_in else [(L.ptr(w), self.wt_f, self.pf)]
         if self.wt_d is not None and self.s2d:
             jobs += [(L.ptr(w), self.wt_d, d) for d in self.pd_ph]
         elif self.wt_d is not None:
@@ -343,7 +393,8 @@ class Block:
         return [(self.dw, L.ptr(gw), self.pu)]
 
     def pack(self, w, st):
-        L.call('srvp_pack_weight', L.ptr(w), L.ptr(self.wt_f), C.byref(self.pf), st)
+        for d in (self.pf_ph if self.s2d_in else [self.pf]):
+            L.call('srvp_pack_weight', L.ptr(w), L.ptr(self.wt_f), C.byref(d), st)
         if self.wt_d is not None and self.s2d:
             for d in self.pd_ph:
                 L.call('srvp_pack_weight', L.ptr(w), L.ptr(self.wt_d), C.byref(d), st)
@@ -424,9 +475,31 @@ class Block:
         d.dy = L.taps([t[0] for t in taps])
         d.dx = L.taps([t[1] for t in taps])
 
+    def _fwd_s2d_in(self):
+        f0 = self.srcs[0]
+        d = L.ConvDesc()
+        d.src0, d.C0, d.H0p, d.W0p, d.ups0 = L.ptr(f0.t), 4 * f0.C, f0.H // 2 + 2, f0.W // 2 + 2, 0
+        d.src1, d.C1, d.H1p, d.W1p, d.ups1, d.map1 = None, 0, 1, 1, 0, None
+        d.ntaps = 4
+        ent = [(dy, dx) for a, b in [(0, 0), (0, 1), (1, 0), (1, 1)] for _, dy in S2D_UP[a] for _, dx in S2D_UP[b]]
+        d.dy, d.dx = L.taps([e[0] for e in ent]), L.taps([e[1] for e in ent])
+        d.tap_phase_chunks = f0.C // 64
+        d.si, d.wt, d.Cout = 1, L.ptr(self.wt_f), self.cout
+        d.N, d.OH, d.OW = self.N, self.OH, self.OW
+        d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox, d.Cdst, d.cdst_off = L.ptr(self.raw), self.OH, self.OW, 1, 0, 0, self.cout, 0
+        use_stats = self.has_bn and self.training
+        d.stats, d.stat_mod = (L.ptr(self.stats) if use_stats else None), self.cout
+        d.out_f32, d.out_nc, d.out_sigmoid = None, 0, 0
+        d.wt_fragmajor, d.elem_f32 = 1, 0
+        assert int(L.load().srvp_conv_runs_on_halo(C.byref(d))) >= 128, 'space-to-depth forward is not eligible for the halo kernel'
+        return [d]
+
     def fwd_descs(self):
         """List of ConvDesc for the forward convolution (4 for the transposed stride-2 phases, else 1)."""
         self.__dict__.pop('_fwd_arr', None)
+        if self.s2d_in:
+            self._fwd_fin = None
+            return self._fwd_s2d_in()
         out = self._fwd_descs_raw()
         if self.split:
             self._set_layout(out[:1], self.pf_s)       # conv_s(skip)
@@ -699,7 +772,35 @@ class Block:
         d.splitk = int(max(1, min((1024 + tiles - 1) // tiles, chunks // 4 if chunks >= 4 else 1)))
         return d
 
+    def _wgrad_s2d_in(self):
+        """Weight gradient of a 4x4 stride-2 block whose source is stored space-to-depth, on the per-tap kernel with the operand ROLES
+        SWAPPED: the s2d source is the channel-sliced operand (tap t' = ph * 4 + u * 2 + v reads the phase-ph slice at offset (dy, dx) of
+        S2D_UP, unit stride), the block's own output gradient the plain one -- so the result is dW transposed, [16][Cin][Cout]
+        (self.pu is the matching descriptor)."""
+        f0 = self.srcs[0]
+        bd = self.draw_b
+        d = L.WgradDesc()
+        d.src0, d.C0, d.H0p, d.W0p, d.ups0 = L.ptr(self.draw), self.cout, self.OH + 2 * bd, self.OW + 2 * bd, 0
+        d.src1, d.C1, d.H1p, d.W1p, d.ups1, d.map1 = None, 0, 1, 1, 0, None
+        d.ntaps = 16
+        d.dy, d.dx = L.taps([bd] * 16), L.taps([bd] * 16)
+        ent = [(dy, dx) for a, b in [(0, 0), (0, 1), (1, 0), (1, 1)] for _, dy in S2D_UP[a] for _, dx in S2D_UP[b]]
+        d.si, d.so = 1, 1
+        d.ooy, d.oox = L.taps([e[0] for e in ent]), L.taps([e[1] for e in ent])
+        d.dout, d.Cout, d.dout_cstride, d.dout_coff, d.dout_phase_taps = L.ptr(f0.t), f0.C, 4 * f0.C, 0, 4
+        d.DHp, d.DWp = f0.H // 2 + 2, f0.W // 2 + 2
+        d.N, d.OH, d.OW = self.N, self.OH, self.OW
+        d.dw = L.ptr(self.dw)
+        bj = 128 if f0.C % 128 == 0 else 64
+        bc = 128 if self.cout % 128 == 0 else (64 if self.cout % 64 == 0 else 32)
+        tiles = (f0.C // bj) * (self.cout // bc) * 16
+        chunks = (self.N * self.OH * self.OW + 31) // 32
+        d.splitk = int(max(1, min((1024 + tiles - 1) // tiles, chunks // 4 if chunks >= 4 else 1)))
+        return d
+
     def wgrad_desc(self):
+        if self.s2d_in:
+            return self._wgrad_s2d_in()
         if self.s2d_up:
             return self._wgrad_s2d_up()
         if self.s2d:
@@ -867,13 +968,16 @@ class ConvNetBase:
                 if BN_FUSED_FINALIZE:
                     L.call('srvp_bn_finalize_act', L.ptr(blk.raw), L.ptr(blk.stats), count, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(nbt),
                            L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), blk.cout_r, BN_EPS, BN_MOMENTUM, *act_args,
-                           1 if blk.f32 else 0, st)
+                           1 if blk.f32 else 0, 1 if (out is not None and out.s2d) else 0, st)
                     return
                 L.call('srvp_bn_finalize', L.ptr(blk.stats), count, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(nbt),
                        L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), C_, blk.cout_r, BN_EPS, BN_MOMENTUM, st)
             else:
                 L.call('srvp_bn_eval_coeffs', L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(scale), L.ptr(shift), C_,
                        blk.cout_r, BN_EPS, st)
+        if out is not None and out.s2d:
+            L.call('srvp_bn_act_s2d', L.ptr(blk.raw), L.ptr(scale), L.ptr(shift), blk.act, N, blk.OH, blk.OW, C_, L.ptr(out.t), st)
+            return
         L.call('srvp_bn_act_keep_f32' if blk.f32 else 'srvp_bn_act_keep', L.ptr(blk.raw), L.ptr(scale), L.ptr(shift), *act_args, st)
 
     def _block_forward(self, blk, params, st, sync, x=None, keep=None):
@@ -1043,7 +1147,9 @@ class ConvNetBase:
 class EncoderNet(ConvNetBase):
     """conv.py:129-154 on N = T*B frames: x fp32 (N, C, 64, 64) -> hx fp32 (N, nh) and the stage outputs (skips)."""
 
-    def __init__(self, specs, N, device, training, f32=False):
+    def __init__(self, specs, N, device, training, f32=False, use_skips=True):
+        """use_skips: the stage outputs feed decoder skip connections (they are then read by decoder convolutions in the plain layout).
+        Without them (DCGAN without --skipco: config 2) the activations consumed by the 4x4 stride-2 layers are stored space-to-depth."""
         self.N, self.dev, self.training, self.f32 = N, device, training, bool(f32)
         adt = torch.float32 if f32 else torch.bfloat16
         self.blocks = []
@@ -1053,12 +1159,19 @@ class EncoderNet(ConvNetBase):
             blk = Block(sp, role, [] if role == 'in' else [cur], False, N, device, training, f32=f32)
             last = i == len(specs) - 1
             nxt_pool = (not last) and specs[i + 1]['pre'] == 'pool'
+            nxt = None if last else specs[i + 1]
+            # the activation is stored space-to-depth when its consumer is a 4x4 stride-2 convolution that the halo kernel can take
+            # (64-multiple channels, power-of-two output grid of whole images per tile or 16-multiples) and nothing else reads it
+            oh2 = blk.OH // 2
+            s2d_out = bool(DOWN_S2D and not f32 and not use_skips and nxt is not None and nxt['kind'] == 'conv'
+                           and (nxt['k'], nxt['s'], nxt['p']) == (4, 2, 1) and not nxt_pool and cpad(blk.cout_r) % 64 == 0
+                           and blk.OH % 2 == 0 and blk.OH == blk.OW and oh2 >= 4 and (oh2 & (oh2 - 1)) == 0 and (oh2 * oh2 <= 256 or oh2 % 16 == 0))
             if last:
                 blk.out_f32 = torch.empty(N, blk.cout, dtype=torch.float32, device=device)
                 cur = None
             else:
                 need_full = (sp['skip_out'] is not None) or not nxt_pool or training
-                blk.out = Feat(N, blk.OH, blk.OW, blk.cout_r, device, dtype=adt) if need_full else None
+                blk.out = Feat(N, blk.OH, blk.OW, blk.cout_r, device, dtype=adt, s2d=s2d_out) if need_full else None
                 if nxt_pool:
                     blk.pool = Feat(N, blk.OH // 2, blk.OW // 2, blk.cout_r, device, dtype=adt)
                     cur = blk.pool

@@ -82,7 +82,8 @@ template <class E, bool POOL, int ACT>
 __global__ __launch_bounds__(256) void bn_act_kernel(const E* __restrict__ raw, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, int act, int N, int H, int W, int C,
                                                      E* __restrict__ dst, int db, E* __restrict__ dpool, int pb,
-                                                     float* __restrict__ dst_f32, const int* __restrict__ keep, const BnFin fin) {
+                                                     float* __restrict__ dst_f32, const int* __restrict__ keep, const BnFin fin,
+                                                     const int dst_s2d) {
     if (ACT >= 0) act = ACT;
     const int CG = C / 8;
     const int PPB = blockDim.x / CG;             // (pooled) pixels handled in parallel by one workgroup
@@ -144,7 +145,10 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const E* __restrict__ raw, 
                 // keep (pooled layers): the full-resolution activation is only ever read for the frames that feed a skip
                 // connection (one per sample); the pooled tensor carries everything else forward
                 if (dst && (!keep || keep[n])) {
-                    size_t doff = (((size_t)n * (H + 2 * db) + yy + db) * (W + 2 * db) + xx + db) * C + cg * 8;
+                    // dst_s2d: the activated tensor is stored SPACE-TO-DEPTH for a 4x4 stride-2 consumer, [N][H/2+2][W/2+2][4C] with a 1-pixel
+                    // border: pixel (y, x) -> position (y/2, x/2), channel group (y&1)*2 + (x&1) (srvp_conv_desc.tap_phase_chunks)
+                    size_t doff = dst_s2d ? ((((size_t)n * (H / 2 + 2) + (yy >> 1) + 1) * (W / 2 + 2) + (xx >> 1) + 1) * 4 + ((yy & 1) * 2 + (xx & 1))) * C + cg * 8
+                                          : (((size_t)n * (H + 2 * db) + yy + db) * (W + 2 * db) + xx + db) * C + cg * 8;
                     El<E>::st8_nt(dst + doff, f);
                 }
                 if (dst_f32) {
@@ -705,7 +709,8 @@ namespace {
 template <class E>
 int bn_act_launch(const void* raw, const float* scale, const float* shift, int act, int N, int H, int W, int C, void* dst,
                   int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep, void* stream,
-                  const BnFin fin = BnFin{}) {
+                  const BnFin fin = BnFin{}, int dst_s2d = 0) {
+    SRVP_REQUIRE(!dst_s2d || (dst && !dst_pool && H % 2 == 0 && W % 2 == 0), "srvp_bn_act: a space-to-depth destination needs even H, W and no pooling");
     SRVP_REQUIRE(raw && scale && shift && C % 8 == 0, "srvp_bn_act: bad args");
     hipStream_t st = (hipStream_t)stream;
     if (dst_pool) {
@@ -714,13 +719,13 @@ int bn_act_launch(const void* raw, const float* scale, const float* shift, int a
         SRVP_REQUIRE(C / 8 <= 256 && (long long)N * H * W < (1ll << 31), "srvp_bn_act: C=%d / size unsupported", C);
         auto kern = act == ACT_LRELU ? bn_act_kernel<E, true, ACT_LRELU> : bn_act_kernel<E, true, -1>;
         hipLaunchKernelGGL(kern, dim3(grid_for(total, (256 / (C / 8)) * 2)), dim3(256), 0, st, (const E*)raw, scale, shift,
-                           act, N, H, W, C, (E*)dst, dst_border, (E*)dst_pool, pool_border, dst_f32, (const int*)keep, fin);
+                           act, N, H, W, C, (E*)dst, dst_border, (E*)dst_pool, pool_border, dst_f32, (const int*)keep, fin, dst_s2d);
     } else {
         long long total = (long long)N * H * W;
         SRVP_REQUIRE(C / 8 <= 256 && total < (1ll << 31), "srvp_bn_act: C=%d / size unsupported", C);
         auto kern = act == ACT_LRELU ? bn_act_kernel<E, false, ACT_LRELU> : bn_act_kernel<E, false, -1>;
         hipLaunchKernelGGL(kern, dim3(grid_for(total, (256 / (C / 8)) * 4)), dim3(256), 0, st, (const E*)raw, scale, shift,
-                           act, N, H, W, C, (E*)dst, dst_border, (E*)nullptr, 0, dst_f32, (const int*)nullptr, fin);
+                           act, N, H, W, C, (E*)dst, dst_border, (E*)nullptr, 0, dst_f32, (const int*)nullptr, fin, dst_s2d);
     }
     SRVP_CHECK_LAUNCH("srvp_bn_act");
     return SRVP_OK;
@@ -742,11 +747,16 @@ extern "C" int srvp_bn_finalize_act(const void* raw, const double* stats, double
                                     float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift, float* mean,
                                     float* invstd, int C_real, float eps, float momentum, int act, int N, int H, int W, int C, void* dst,
                                     int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep, int elem_f32,
-                                    void* stream) {
+                                    int dst_s2d, void* stream) {
     SRVP_REQUIRE(stats && scale && shift && mean && invstd && C > 0 && C <= BN_MAX_C && count > 0, "srvp_bn_finalize_act: bad args");
     BnFin fin{stats, count, gamma, beta, running_mean, running_var, (long long*)nbt, scale, shift, mean, invstd, C_real, eps, momentum};
-    if (elem_f32) return bn_act_launch<float>(raw, scale, shift, act, N, H, W, C, dst, dst_border, dst_pool, pool_border, dst_f32, keep, stream, fin);
-    return bn_act_launch<bf16_t>(raw, scale, shift, act, N, H, W, C, dst, dst_border, dst_pool, pool_border, dst_f32, keep, stream, fin);
+    if (elem_f32) return bn_act_launch<float>(raw, scale, shift, act, N, H, W, C, dst, dst_border, dst_pool, pool_border, dst_f32, keep, stream, fin, dst_s2d);
+    return bn_act_launch<bf16_t>(raw, scale, shift, act, N, H, W, C, dst, dst_border, dst_pool, pool_border, dst_f32, keep, stream, fin, dst_s2d);
+}
+// srvp_bn_act_keep with a space-to-depth destination (eval mode / separate-finalize path of a block whose consumer is a 4x4 stride-2 conv)
+extern "C" int srvp_bn_act_s2d(const void* raw, const float* scale, const float* shift, int act, int N, int H, int W, int C, void* dst,
+                               void* stream) {
+    return bn_act_launch<bf16_t>(raw, scale, shift, act, N, H, W, C, dst, 1, nullptr, 0, nullptr, nullptr, stream, BnFin{}, 1);
 }
 
 extern "C" int srvp_bn_act(const void* raw, const float* scale, const float* shift, int act, int N, int H, int W, int C,

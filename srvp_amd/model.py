@@ -265,7 +265,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         if pl is None:
             assert S == 1 or not training
             dev = self._device()
-            enc = EncoderNet(self._enc_blocks, T * B, dev, training, f32=f32) if T > 0 else None
+            enc = EncoderNet(self._enc_blocks, T * B, dev, training, f32=f32, use_skips=bool(self.skipco)) if T > 0 else None
             # the step's small index tensors live in ONE int32 buffer, filled by a single host-to-device copy per forward:
             # [keep (T*B) | skip_idx (T*B) | skip_sel (B) | skip_map (nt*B*S)]  (a dozen tiny device kernels otherwise)
             nk = max(T * B, 1)

@@ -24,15 +24,15 @@ def rel_err(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
 
 
-def make_feat(N, H, W, Cr, dev, gen):
+def make_feat(N, H, W, Cr, dev, gen, s2d=False):
     from srvp_amd.convnet import Feat
-    f = Feat(N, H, W, Cr, dev)
-    f.interior().copy_(torch.randn(N, H, W, Cr, generator=gen) * 0.5)
+    f = Feat(N, H, W, Cr, dev, s2d=s2d)
+    f.put_nhwc((torch.randn(N, H, W, Cr, generator=gen) * 0.5).to(dev))
     return f
 
 
 def feat_nchw(f):
-    return f.interior().permute(0, 3, 1, 2).float().cpu()
+    return f.get_nhwc().permute(0, 3, 1, 2).float().cpu()
 
 
 CASES = [
@@ -64,15 +64,21 @@ CASES = [
     ('convT', 4, 2, 1, 512, 0, False, 4, 256, 4),      # DCGAN decoder.conv.0
     ('conv', 4, 1, 0, 512, 0, False, 4, 128, 7),       # encoder.last_conv at full width (K = 8192)
     ('convT', 4, 1, 0, 306, 0, False, 1, 512, 5),      # decoder.first_upconv at full width (nh_inf + ny = 306)
+    # ---- 4x4 stride-2 convolutions over a SPACE-TO-DEPTH source (11th field): forward on the halo kernel with per-phase taps, weight
+    # gradient with swapped operand roles (DCGAN encoder without skip connections: config 2)
+    ('conv', 4, 2, 1, 64, 0, False, 32, 128, 3, True),   # encoder.conv.1: 64 -> 128 @ 32 -> 16 (one whole 16x16 image per tile)
+    ('conv', 4, 2, 1, 128, 0, False, 16, 256, 5, True),  # encoder.conv.2: 128 -> 256 @ 16 -> 8, ragged image count
+    ('conv', 4, 2, 1, 256, 0, False, 8, 512, 6, True),   # encoder.conv.3: 256 -> 512 @ 8 -> 4 (K = 4096)
 ]
 
 
-@pytest.mark.parametrize('case', CASES, ids=[f'{c[0]}{c[1]}s{c[2]}_{c[4]}+{c[5]}_{"up" if c[6] else "id"}_{c[8]}' for c in CASES])
+@pytest.mark.parametrize('case', CASES, ids=[f'{c[0]}{c[1]}s{c[2]}_{c[4]}+{c[5]}_{"up" if c[6] else "id"}_{c[8]}{"_s2d" if len(c) > 10 else ""}' for c in CASES])
 @pytest.mark.parametrize('use_tr', [1, 0])
 def test_block_conv_fwd_bwd(case, use_tr):
     from srvp_amd import _lib as L
     from srvp_amd.convnet import Block, Feat
-    kind, k, s, p, c0r, c1r, ups, Hs, cout, N = case
+    kind, k, s, p, c0r, c1r, ups, Hs, cout, N = case[:10]
+    s2d_src = len(case) > 10 and case[10]
     dev = torch.device('cuda')
     # (hash() of a tuple holding strings changes from process to process: a fixed seed per case keeps the run reproducible)
     g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()) % 1000)
@@ -80,7 +86,7 @@ def test_block_conv_fwd_bwd(case, use_tr):
         f0 = Feat(N, 1, 1, c0r, dev, b=0)
         f0.interior().copy_(torch.randn(N, 1, 1, c0r, generator=g))
     else:
-        f0 = make_feat(N, Hs, Hs, c0r, dev, g)
+        f0 = make_feat(N, Hs, Hs, c0r, dev, g, s2d=s2d_src)
     srcs = [f0]
     skip_map = None
     Hin = Hs * 2 if ups else Hs
@@ -91,6 +97,7 @@ def test_block_conv_fwd_bwd(case, use_tr):
         skip_map = torch.tensor([(n % NB) * 2 + 1 for n in range(N)], dtype=torch.int32, device=dev)
     spec = dict(kind=kind, key='w', bnkey='bn', cin=c0r + c1r, cout=cout, k=k, s=s, p=p, act='leaky_relu')
     blk = Block(spec, 'mfma', srcs, ups, N, dev, True, skip_map=skip_map)
+    assert blk.s2d_in == bool(s2d_src)
     blk._fwd, blk._dg, blk._wg = blk.fwd_descs(), blk.dgrad_descs(), blk.wgrad_desc()
     wshape = (cout, c0r + c1r, k, k) if kind == 'conv' else (c0r + c1r, cout, k, k)
     w = (torch.randn(*wshape, generator=g) * 0.1).to(dev)
