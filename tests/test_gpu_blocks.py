@@ -443,7 +443,7 @@ def test_bn_act_fwd_bwd(mode, C_):
     pool2 = Feat(N, H // 2, H // 2, C_, dev) if mode == 'pool' else None
     L.call('srvp_bn_finalize_act', L.ptr(raw), L.ptr(stats), cnt, L.ptr(gamma), L.ptr(beta), L.ptr(rm2), L.ptr(rv2), L.ptr(nbt2),
            L.ptr(coef2[0]), L.ptr(coef2[1]), L.ptr(coef2[2]), L.ptr(coef2[3]), C_, BN_EPS, BN_MOMENTUM, L.ACT_LRELU, N, H, H, Cp,
-           L.ptr(out2.t), 1, L.ptr(pool2.t) if pool2 else None, 1, None, None, 0, st)
+           L.ptr(out2.t), 1, L.ptr(pool2.t) if pool2 else None, 1, None, None, 0, 0, st)
     draw2 = torch.zeros_like(draw)
     bcoef2 = torch.zeros(3, Cp, device=dev)
     dgamma2, dbeta2 = torch.zeros(C_, device=dev), torch.zeros(C_, device=dev)

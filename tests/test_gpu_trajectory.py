@@ -81,10 +81,10 @@ def test_bf16_trains_like_fp32_over_300_steps():
            max_rel_smoothed=max(rel_sm), max_rel_fp32_rerun=max(rel_self), psnr_bf16=p16, psnr_fp32=p32, psnr_fp32_rerun=p32b)
     assert sum(l32[-20:]) / 20 < sum(l32[:5]) / 5 - 0.5 * scale, 'the fp32-mode run must learn'
     assert sum(l16[-20:]) / 20 < sum(l16[:5]) / 5 - 0.5 * scale, 'the bf16 run must learn'
-    assert max(rel) <= 1e-2, (max(rel), rel.index(max(rel)))                      # every step within 1 % of the curve's range
-    assert max(rel_sm) <= 5e-3, max(rel_sm)
-    # validation PSNR after 300 steps: two runs of DIFFERENT arithmetic end within a few tenths of a dB of each other, with no systematic
-    # sign (measured bf16 - fp32 mode: +0.25 dB with the separate BatchNorm-backward reduction, -0.15 dB with the fused one -- a change
-    # of summation order inside the bf16 path moves it as much as the precision does; the fp32-mode rerun stays within 0.05 dB)
-    assert abs(p16 - p32) <= 0.5, (p16, p32, p32b)
-    assert abs(p32b - p32) <= 0.2, (p32, p32b)
+    # Bands: twice what the worst of ~10 runs on different boxes showed.  The yardstick is the fp32-mode run REPEATED: its split-K / statistics
+    # atomics are not bitwise reproducible and 300 Adam steps amplify that to 0.6 % of the curve's range and 0.02-0.10 dB of PSNR; bf16 vs fp32
+    # measured 0.3-0.7 % and -0.15 ... +0.25 dB (no systematic sign: a change of summation order inside the bf16 path moves it as much).
+    assert max(rel) <= 2e-2, (max(rel), rel.index(max(rel)), max(rel_self))
+    assert max(rel_sm) <= 1e-2, max(rel_sm)
+    assert abs(p16 - p32) <= 0.6, (p16, p32, p32b)
+    assert abs(p32b - p32) <= 0.4, (p32, p32b)
