@@ -468,16 +468,10 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             self._side_stream = _make_side_stream()
         dz = dec.backward(cz(d_x).view(nt * B, *dec.x_out.shape[1:]), params, grads, st, self.sync, defer_wgrad=overlap,
                           side=self._side_stream if overlap else None)
+        ev_dec = None
         if overlap:
-            ev = torch.cuda.Event()
-            ev.record()
-            with torch.cuda.stream(self._side_stream):
-                self._side_stream.wait_event(ev)
-                dec.deferred_wgrads(grads, L.stream())
-                if self.sync is not None:
-                    self.sync.grads_ready('decoder', self)
-                wg_done = torch.cuda.Event()
-                wg_done.record()
+            ev_dec = torch.cuda.Event()
+            ev_dec.record()                       # the decoder's output gradients exist: its weight gradients may start (second stream, below)
         # backward of the time-expansion of w and of the concatenation [w | y_t] (srvp.py:216-221): d_w = sum over time, d_y_t straight
         # into the rollout's state-gradient buffer (frame t = Euler step t * n_euler)
         if not hasattr(lat, 'd_w_tot'):
@@ -490,15 +484,19 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         deferred = [] if overlap else None
         d_hx = lat.backward(pl['hx'], params, grads, tape['eps_y0'], tape['eps_z'], 'in_place', lat.d_w_tot,
                             cz(d_qy0), cz(d_qz), cz(d_pz), cz(d_res), None, st, defer=deferred)
-        if deferred:
-            # the latent networks' weight gradients feed nothing but the optimizer: second stream, under the encoder backward
-            ev = torch.cuda.Event()
-            ev.record()
+        if overlap:
+            # (host order: the main-stream launches of the latent backward -- the critical path -- go out BEFORE the ~25 second-stream
+            # launches of the decoder's weight gradients, which only wait for ev_dec on the device: a host that is just ahead of the device
+            # -- small batches, a profiler attached -- then does not leave the main queue empty for the 0.25 ms the enqueueing takes)
             with torch.cuda.stream(self._side_stream):
-                self._side_stream.wait_event(ev)
-                s2 = L.stream()
-                for fn in deferred:
-                    fn(s2)
+                self._side_stream.wait_event(ev_dec)
+                dec.deferred_wgrads(grads, L.stream())
+                if self.sync is not None:
+                    self.sync.grads_ready('decoder', self)
+        ev_lat = None
+        if deferred:
+            ev_lat = torch.cuda.Event()
+            ev_lat.record()                       # every delta the latent weight gradients read exists
         skip_grads = None
         if self.skipco:
             skip_grads = {}
@@ -513,6 +511,14 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             d_hx_p = d_hx
         enc.backward(pl['x'].view(T * B, *pl['x'].shape[2:]), d_hx_p, skip_grads, params, grads, st, self.sync,
                      side=self._side_stream if overlap else None)
+        if deferred:
+            # the latent networks' weight gradients feed nothing but the optimizer: second stream, behind the encoder's (enqueued last so
+            # that the encoder backward's main-stream launches are not held up on the host)
+            with torch.cuda.stream(self._side_stream):
+                self._side_stream.wait_event(ev_lat)
+                s2 = L.stream()
+                for fn in deferred:
+                    fn(s2)
         if overlap:
             # (the side stream holds the decoder's weight gradients + unpack and, behind them, the encoder's unpack)
             side_done = torch.cuda.Event()
