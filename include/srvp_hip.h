@@ -326,6 +326,11 @@ int srvp_lstm_fwd(const float* gates_x, const float* w_hh, float* h_out, float* 
 int64_t srvp_lstm_fused_ws_bytes(int T, int B, int nh);
 int srvp_lstm_fwd_fused(const float* gates_x, const float* w_hh, float* h_out, float* c_out, float* gates_act,
                         int T, int B, int nh, void* ws, int64_t ws_bytes, void* stream);
+/* the backward recurrence likewise as ONE persistent launch (same clusters, W_hh[gate rows][own 32 units] slices in registers, the gate
+ * gradients of a step exchanged through dgates itself, one counter barrier per step); same eligibility and workspace as the forward.
+ * dh_out: gradient wrt the LSTM outputs [T][B][nh]; writes dgates [T][B][4 nh] (what srvp_lstm_bwd writes). */
+int srvp_lstm_bwd_fused(const float* dh_out, const float* w_hh, const float* c_out, const float* gates_act, float* dgates,
+                        int T, int B, int nh, void* ws, int64_t ws_bytes, void* stream);
 /* scratch: 2*B*nh floats */
 int srvp_lstm_bwd(const float* dh_out, const float* w_hh, const float* c_out, const float* gates_act,
                   float* dgates, float* scratch, int T, int B, int nh, void* stream);

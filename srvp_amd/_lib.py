@@ -130,6 +130,7 @@ _SIGS = {
     'srvp_lstm_fwd': ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_lstm_fused_ws_bytes': ([c_i32, c_i32, c_i32], c_i64),
     'srvp_lstm_fwd_fused': ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp], c_i32),
+    'srvp_lstm_bwd_fused': ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp], c_i32),
     'srvp_lstm_bwd': ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_rollout_fwd': ([C.POINTER(RolloutDesc), c_vp], c_i32),
     'srvp_rollout_fused_ws_bytes': ([C.POINTER(RolloutDesc)], c_i64),

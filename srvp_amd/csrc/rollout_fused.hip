@@ -570,6 +570,98 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// The BACKWARD recurrence of the posterior LSTM as ONE persistent launch (srvp_lstm_bwd_fused), the mirror image of the forward kernel:
+// workgroup g of a cluster owns hidden units [32 g, 32 g + 32) of a 32-row batch tile.  Per step t (T-1 ... 0): the cell backward of its
+// 32 x 32 units (dh = dh_out[t] + the carry, dc carried in registers) writes the four gate gradients of those units into dgates[t]
+// (agent-scope stores: the other members read them); one counter barrier; the whole dgates[t] tile of the batch tile [32][4 nh] is
+// staged in LDS and every wave contracts ITS gate's nh columns with its W_hh[gate rows][own 32 units] slice held in 128 VGPRs per lane
+// (B operand of v_mfma_f32_32x32x2_f32: dh_carry[b][u] = sum_k dgates[b][k] W_hh[k][u]); the four partial tiles are summed through LDS
+// into the carry registers.  (As launches: a cell kernel + a GEMM per step, ~18 us of dependent latency each.)
+struct LstmB {
+    int B, nh, T, G, ntiles, tile0, cl_per_xcd;
+    const float* dh_out; const float* whh; const float* c; const float* ga; float* dgates; unsigned* cnt;
+};
+
+template <int KST>      // nh / 2 MFMA k steps per wave (one gate's nh columns)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fused_bwd_kernel(const LstmB a) {
+    extern __shared__ float lds[];
+    constexpr int NH = 2 * KST, DLD = 4 * NH + 1;
+    float* Ds = lds;                          // [32][4 NH + 1]  gate gradients of this batch tile at step t
+    float* Ps = lds + RT * DLD;               // [4][32][33]     the four waves' partial carries
+    const int x = blockIdx.x & 7, kk = blockIdx.x >> 3;
+    const int cl = x * a.cl_per_xcd + kk / a.G, g = kk % a.G;
+    if (cl >= a.ntiles) return;
+    const int tid = threadIdx.x, lane = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lcol = lane & 31, lhalf = lane >> 5;
+    const int row0 = (a.tile0 + cl) * RT;
+    float wreg[KST];
+#pragma unroll
+    for (int j = 0; j < KST; ++j) wreg[j] = a.whh[(size_t)(q * NH + 2 * j + lhalf) * NH + g * CW + lcol];
+    float dcs[4] = {0.f, 0.f, 0.f, 0.f}, dhc[4] = {0.f, 0.f, 0.f, 0.f};
+    unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;
+    const size_t gs = (size_t)a.B * 4 * NH, hs = (size_t)a.B * NH;
+    unsigned target = 0;
+    for (int t = a.T - 1; t >= 0; --t) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + 256 * e, rl = idx >> 5, u = idx & 31;
+            if (row0 + rl >= a.B) continue;
+            const size_t ho = hs * t + (size_t)(row0 + rl) * NH + g * CW + u;
+            const size_t go = gs * t + (size_t)(row0 + rl) * 4 * NH + g * CW + u;
+            const float ig = a.ga[go], fg = a.ga[go + NH], gg = a.ga[go + 2 * NH], og = a.ga[go + 3 * NH];
+            const float dh = a.dh_out[ho] + dhc[e];
+            const float tc = tanhf(a.c[ho]);
+            const float dc = dcs[e] + dh * og * (1.f - tc * tc);
+            const float cp = t > 0 ? a.c[ho - hs] : 0.f;
+            st_agent(a.dgates + go, dc * gg * ig * (1.f - ig));
+            st_agent(a.dgates + go + NH, dc * cp * fg * (1.f - fg));
+            st_agent(a.dgates + go + 2 * NH, dc * ig * (1.f - gg * gg));
+            st_agent(a.dgates + go + 3 * NH, dh * tc * og * (1.f - og));
+            dcs[e] = dc * fg;
+        }
+        if (t == 0) break;
+        cluster_barrier(cnt, target += (unsigned)a.G);          // every member has stored its gate gradients of step t
+        {
+            const float* dp = a.dgates + gs * t;
+            constexpr int NLD = RT * 4 * NH / 4 / 256;            // 16-byte pieces per thread (32 at nh = 256), eight in flight at a time
+#pragma unroll
+            for (int i0 = 0; i0 < NLD; i0 += 8) {
+                f32x4v hv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int idx = tid + 256 * (i0 + i < NLD ? i0 + i : 0), row = idx / NH, c4 = idx % NH;      // (4 NH / 4 = NH pieces per row)
+                    const int gr = row0 + row < a.B ? row0 + row : a.B - 1;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(hv[i]) : "v"(dp + (size_t)gr * 4 * NH + c4 * 4) : "memory");
+                }
+                WAIT8(hv, 0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (i0 + i >= NLD) break;
+                    const int idx = tid + 256 * (i0 + i), row = idx / NH, c4 = idx % NH;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Ds[row * DLD + c4 * 4 + e] = hv[i][e];
+                }
+            }
+        }
+        __syncthreads();
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KST; ++j)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ds[lcol * DLD + q * NH + 2 * j + lhalf], wreg[j], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Ps[(q * RT + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * 33 + lcol] = acc[r];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + 256 * e, rl = idx >> 5, u = idx & 31;
+            dhc[e] = (Ps[(0 * RT + rl) * 33 + u] + Ps[(1 * RT + rl) * 33 + u]) + (Ps[(2 * RT + rl) * 33 + u] + Ps[(3 * RT + rl) * 33 + u]);
+        }
+        __syncthreads();                                   // Ds / Ps are rewritten by the next step
+    }
+}
+
 int g_fused = -1, g_ncu = 0;
 
 int device_cus() {
@@ -698,5 +790,34 @@ extern "C" int srvp_lstm_fwd_fused(const float* gates_x, const float* w_hh, floa
         hipLaunchKernelGGL(kern, dim3(8 * cpx * k.G), dim3(256), lds, st, k);
     }
     SRVP_CHECK_LAUNCH("srvp_lstm_fwd_fused");
+    return SRVP_OK;
+}
+
+
+// ---- persistent LSTM backward recurrence: same eligibility / workspace as the forward (srvp_lstm_fused_ws_bytes)
+extern "C" int srvp_lstm_bwd_fused(const float* dh_out, const float* w_hh, const float* c_out, const float* gates_act, float* dgates, int T,
+                                   int B, int nh, void* ws, int64_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SRVP_REQUIRE(dh_out && w_hh && c_out && gates_act && dgates && ws, "srvp_lstm_bwd_fused: null pointer");
+    const int64_t need = srvp_lstm_fused_ws_bytes(T, B, nh);
+    SRVP_REQUIRE(need > 0 && ws_bytes >= need, "srvp_lstm_bwd_fused: shape not eligible or workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)need);
+    device_cus();
+    LstmB k{};
+    k.B = B; k.nh = nh; k.T = T; k.G = nh / CW; k.dh_out = dh_out; k.whh = w_hh; k.c = c_out; k.ga = gates_act; k.dgates = dgates; k.cnt = (unsigned*)ws;
+    const int tiles = (B + RT - 1) / RT;
+    const size_t lds = ((size_t)RT * (4 * nh + 1) + 4 * RT * 33) * 4;
+    SRVP_REQUIRE(lds <= 160 * 1024, "srvp_lstm_bwd_fused: %zu bytes of LDS", lds);
+    auto kern = nh == 256 ? lstm_fused_bwd_kernel<128> : (nh == 128 ? lstm_fused_bwd_kernel<64> : lstm_fused_bwd_kernel<32>);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_lstm_bwd_fused: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_lstm_bwd_fused: memset failed");
+    int cpx;
+    const int per = clusters_per_launch(k.G, tiles, cpx);
+    for (int t0 = 0; t0 < tiles; t0 += per) {
+        k.tile0 = t0; k.ntiles = tiles - t0 < per ? tiles - t0 : per; k.cl_per_xcd = cpx;
+        hipLaunchKernelGGL(kern, dim3(8 * cpx * k.G), dim3(256), lds, st, k);
+    }
+    SRVP_CHECK_LAUNCH("srvp_lstm_bwd_fused");
     return SRVP_OK;
 }

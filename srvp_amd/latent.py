@@ -44,6 +44,7 @@ def axpby(st, out, a, x, b=0.0, y=None):
 
 import os
 PZ_BATCHED = os.environ.get('SRVP_PZ_BATCHED', '1') != '0'
+LSTM_BWD_FUSED = os.environ.get('SRVP_LSTM_BWD_FUSED', '1') != '0'
 
 
 def mlp_keys(prefix, n):
@@ -294,8 +295,14 @@ class LatentNet:
             self.d_hz[:B].zero_()
             linear_bwd(st, self.hz[B:T * B], params['q_z.weight'], dq, grads['q_z.weight'], grads['q_z.bias'],
                        dx=self.d_hz[B:T * B], defer=defer)
-            L.call('srvp_lstm_bwd', L.ptr(self.d_hz), L.ptr(params['inf_z.weight_hh_l0']), L.ptr(self.cz), L.ptr(self.gates_act),
-                   L.ptr(self.dgates), L.ptr(self.lstm_scratch), T, B, nh, st)
+            ws = self.__dict__.get('_lstm_ws')
+            if LSTM_BWD_FUSED and ws is not None and int(L.load().srvp_lstm_fused_ws_bytes(T, B, nh)) > 0:
+                # the recurrence as one persistent launch (csrc/rollout_fused.hip), like the forward that allocated the workspace
+                L.call('srvp_lstm_bwd_fused', L.ptr(self.d_hz), L.ptr(params['inf_z.weight_hh_l0']), L.ptr(self.cz), L.ptr(self.gates_act),
+                       L.ptr(self.dgates), T, B, nh, L.ptr(ws), ws.numel(), st)
+            else:
+                L.call('srvp_lstm_bwd', L.ptr(self.d_hz), L.ptr(params['inf_z.weight_hh_l0']), L.ptr(self.cz), L.ptr(self.gates_act),
+                       L.ptr(self.dgates), L.ptr(self.lstm_scratch), T, B, nh, st)
             dg = self.dgates[:T * B]
             # W_hh: sum_t dgates[t]^T h_{t-1}
             whh = lambda s_: _gemm(s_, dg[B:], 1, 4 * nh, self.hz[:(T - 1) * B], nh, 1, None, grads['inf_z.weight_hh_l0'], nh, 4 * nh, nh,
