@@ -227,6 +227,26 @@ def rollout_bench(args, cfg, dev, world, rank, real_stdout):
     os.write(real_stdout, (json.dumps(line) + '\n').encode())
 
 
+def self_launch(n):
+    """Re-exec this command line under torch.distributed.run with n ranks; returns its exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    # the launcher's own chatter (warnings about OMP_NUM_THREADS etc.) goes to stderr already; the children inherit fd 1
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        print(f'bench.py: the {n}-rank launch exited with status {rc}', file=sys.stderr)
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -248,6 +268,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks ourselves (one process per GPU under torch.distributed.run,
+        # rendezvous on 127.0.0.1 at a free port -- the reference's launcher, README.md:99-103 / train.py:205-219); rank 0 of the
+        # children prints the ONE JSON line on the stdout they inherit from this process.
+        return self_launch(args.gpus)
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner through C stdio at
     # communicator creation): everything that goes to file descriptor 1 during the run is sent to stderr, and the JSON line is
     # written to the real stdout at the very end.

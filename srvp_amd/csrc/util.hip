@@ -122,7 +122,7 @@ extern "C" int srvp_mmnist_render(const void* digits_u8, int n_digits, int dh, i
 // Randomness: counter-based Philox4x32-10, key = seed, counter = (block of four draws, object, batch counter): any batch of any
 // run is reproducible from (seed, batch index) alone, on any number of ranks -- and NOT the reference's global np.random stream
 // (a sequential Mersenne twister with a data-dependent number of draws per object cannot be reproduced in parallel); equality with
-// the reference is distributional (tests/test_gpu_metrics.py), equality with the CPU restatement oracle/mmnist_philox.py is exact.
+// the reference is distributional (tests/test_gpu_metrics.py), equality with the CPU restatement oracle/mmnist_ref.py (philox_trajectories) is exact.
 namespace {
 struct Philox {
     unsigned k0, k1, c0, c1, c2, c3, out[4];

@@ -383,6 +383,31 @@ def test_single_rank_collectives(tmp_path):
     assert abs(l0 - l1) <= 1e-4 * abs(l0), (l0, l1)
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver calls it: no WORLD_SIZE in the environment) starts its two
+    ranks itself (torch.distributed.run on 127.0.0.1), runs the data-parallel step -- SyncBN statistics + gradient all-reduce -- and
+    rank 0 prints the ONE JSON line.  On a 1-GPU box the two ranks share the device, which RCCL refuses: SRVP_DIST_BACKEND=gloo is
+    the diagnostic transport for that (the measured configuration is RCCL, one rank per GPU)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    if torch.cuda.device_count() < 2:
+        env['SRVP_DIST_BACKEND'] = 'gloo'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--batch', '8', '--steps', '3', '--warmup', '1',
+                        '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['scaling'] == 'weak'
+    assert d['config']['collectives'] and d['config']['global_batch'] == 16 and d['config']['parallelism'] == 'dp2'
+    assert 'strong_scaling' in d and d['strong_scaling']['per_gpu_batch'] == 96
+    assert abs(d['value'] - 16 * 12 * 3 / (d['ms_per_step'] * 3 / 1e3)) < 1e-6 * d['value']
+    assert d['loss'] == d['loss']
+
+
 def test_resume_train_state(tmp_path):
     """save_train_state / load_train_state continue a run -- same losses as the uninterrupted run (up to the
     order of the fp64 statistics atomics), optimizer moments and LR schedule included; config.json is written as JSON."""
