@@ -279,6 +279,14 @@ int srvp_pack_weight_multi(const srvp_pack_job* jobs_dev, int njobs, int64_t tot
 int srvp_unpack_wgrad_multi(const srvp_pack_job* jobs_dev, int njobs, int64_t total_wgs, void* stream);
 /* workgroups the multi launches give a job of `total` = ntaps*J*K elements; total_wgs above = the sum over the jobs */
 int srvp_pack_job_wgs(int64_t total);
+/* Tile form of the two launches above (round 4): one workgroup per small tile (pack: 32 j x 16 k x all taps, unpack: 16 j x 32 k x all
+ * taps; halved j for 4x4 kernels) with the job descriptor staged in LDS -- 8 workgroups per CU instead of 2-3, one dependent round of
+ * global loads per workgroup.  srvp_pack_job_tiles(d, unpack) = tiles of a job, 0 if the job is not eligible (fp32 packed tensors,
+ * taps not innermost, channel counts not multiples of the tile): such jobs go through the multi launches.  `jobs_dev` of the _tiles
+ * launches holds eligible jobs only (at most 256), total_tiles = the sum of their tile counts.  Byte-identical results. */
+int srvp_pack_job_tiles(const srvp_pack_desc* d, int unpack);
+int srvp_pack_weight_tiles(const srvp_pack_job* jobs_dev, int njobs, int64_t total_tiles, void* stream);
+int srvp_unpack_wgrad_tiles(const srvp_pack_job* jobs_dev, int njobs, int64_t total_tiles, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Latent path: Linear / MLP / LSTM / residual Euler rollout (module/mlp.py, module/srvp.py:229-413), fp32.

@@ -117,6 +117,9 @@ _SIGS = {
     'srvp_pack_weight_multi': ([c_vp, c_i32, c_i64, c_vp], c_i32),
     'srvp_unpack_wgrad_multi': ([c_vp, c_i32, c_i64, c_vp], c_i32),
     'srvp_pack_job_wgs': ([c_i64], c_i32),
+    'srvp_pack_job_tiles': ([C.POINTER(PackDesc), c_i32], c_i32),
+    'srvp_pack_weight_tiles': ([c_vp, c_i32, c_i64, c_vp], c_i32),
+    'srvp_unpack_wgrad_tiles': ([c_vp, c_i32, c_i64, c_vp], c_i32),
     'srvp_unpack_wgrad': ([c_vp, c_vp, C.POINTER(PackDesc), c_vp], c_i32),
     'srvp_gemm_f32': ([c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_linear_wgrad_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),

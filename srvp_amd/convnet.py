@@ -19,6 +19,7 @@ from . import _lib as L
 CP = 32                      # channel padding granule
 SUBPIX = os.environ.get('SRVP_SUBPIX', '1') != '0'
 S2D = os.environ.get('SRVP_SUBPIX_S2D', '1') != '0'
+PACK_TILES = os.environ.get('SRVP_PACK_TILES', '1') != '0'      # 0: every pack / unpack job through the multi kernels (A/B)
 BN_FUSED_FINALIZE = os.environ.get('SRVP_BN_FUSED_FINALIZE', '1') != '0'    # bn_finalize / bn_bwd_finalize folded into bn_act / bn_bwd_apply
 # encoder weight gradients on the second stream when the batch is small (<= this many frames): grids of 100-600 workgroups do not
 # fill the chip, so the weight gradient of block i runs beside the BatchNorm backward / data gradient of block i - 1
@@ -963,7 +964,7 @@ class ConvNetBase:
             if blk.training:
                 count = float(N * blk.OH * blk.OW)
                 if sync is not None:
-                    count = sync.allreduce_stats(blk.stats, count)
+                    count = sync.allreduce_stats(blk.stats, count, site=(bk, 'f'))
                 blk.count = count
                 if BN_FUSED_FINALIZE:
                     L.call('srvp_bn_finalize_act', L.ptr(blk.raw), L.ptr(blk.stats), count, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(nbt),
@@ -1027,7 +1028,7 @@ class ConvNetBase:
             local = float(blk.N * blk.OH * blk.OW)
             count = local
             if sync is not None:
-                count = sync.allreduce_stats(blk.red, count)
+                count = sync.allreduce_stats(blk.red, count, site=(blk.spec['bnkey'], 'b'))
             bk = blk.spec['bnkey']
             # (count / local = number of ranks whose sums are in `red`: the parameter gradients are formed from the global sums
             # and must come out world times smaller, see srvp_hip.h)
@@ -1061,17 +1062,29 @@ class ConvNetBase:
     # pointer or layout changes) and one multi-tensor zero for the accumulators -- ~140 tiny launches per step otherwise
     @staticmethod
     def _job_table(jobs, dev, cache, src_is_tensor):
+        """Device-resident job tables of one network: 'tiles' (jobs the lean tile kernels take: srvp_pack_job_tiles > 0) and 'multi'
+        (the rest: fp32 parity mode, odd channel counts), each (table, njobs, workgroups) or None."""
         key = tuple((s.data_ptr() if src_is_tensor else s, d if src_is_tensor else d.data_ptr(), pd.layout) for s, d, pd in jobs)
         if cache.get('key') != key:
-            arr = (L.PackJob * len(jobs))()
-            mx = 0
-            for i, (s, d, pd) in enumerate(jobs):
-                arr[i].src = s.data_ptr() if src_is_tensor else s
-                arr[i].dst = d if src_is_tensor else d.data_ptr()
-                arr[i].d = pd
-                mx += L.load().srvp_pack_job_wgs(pd.ntaps * pd.J * pd.K)      # total workgroups of the multi launch
-            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-            cache.update(key=key, table=raw.to(dev), n=len(jobs), mx=mx, keep=[t for j in jobs for t in j[:2] if torch.is_tensor(t)])
+            lib = L.load()
+            parts = {'tiles': [], 'multi': []}
+            for s, d, pd in jobs:
+                nt = int(lib.srvp_pack_job_tiles(C.byref(pd), 1 if src_is_tensor else 0)) if PACK_TILES else 0
+                parts['tiles' if nt > 0 and len(parts['tiles']) < 256 else 'multi'].append((s, d, pd, nt))
+            cache.update(key=key, keep=[t for j in jobs for t in j[:2] if torch.is_tensor(t)])
+            for name, part in parts.items():
+                cache[name] = None
+                if not part:
+                    continue
+                arr = (L.PackJob * len(part))()
+                mx = 0
+                for i, (s, d, pd, nt) in enumerate(part):
+                    arr[i].src = s.data_ptr() if src_is_tensor else s
+                    arr[i].dst = d if src_is_tensor else d.data_ptr()
+                    arr[i].d = pd
+                    mx += nt if name == 'tiles' else lib.srvp_pack_job_wgs(pd.ntaps * pd.J * pd.K)
+                raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+                cache[name] = (raw.to(dev), len(part), mx)
         return cache
 
     def pack_weights(self, params, st):
@@ -1079,7 +1092,10 @@ class ConvNetBase:
         if not jobs:
             return
         c = self._job_table(jobs, self.dev, self.__dict__.setdefault('_pack_cache', {}), False)
-        L.call('srvp_pack_weight_multi', L.ptr(c['table']), c['n'], c['mx'], st)
+        if c['tiles']:
+            L.call('srvp_pack_weight_tiles', L.ptr(c['tiles'][0]), c['tiles'][1], c['tiles'][2], st)
+        if c['multi']:
+            L.call('srvp_pack_weight_multi', L.ptr(c['multi'][0]), c['multi'][1], c['multi'][2], st)
 
     def unpack_wgrads(self, grads, st):
         f32_out = getattr(self, '_f32_out', lambda: False)()       # (decoder) the image-side layer accumulates into grads directly
@@ -1088,7 +1104,10 @@ class ConvNetBase:
         if not jobs:
             return
         c = self._job_table(jobs, self.dev, self.__dict__.setdefault('_unpack_cache', {}), True)
-        L.call('srvp_unpack_wgrad_multi', L.ptr(c['table']), c['n'], c['mx'], st)
+        if c['tiles']:
+            L.call('srvp_unpack_wgrad_tiles', L.ptr(c['tiles'][0]), c['tiles'][1], c['tiles'][2], st)
+        if c['multi']:
+            L.call('srvp_unpack_wgrad_multi', L.ptr(c['multi'][0]), c['multi'][1], c['multi'][2], st)
 
     def _fuse_bn_reduce(self):
         """Pairs (producer P, consumer Q) where Q is a plain 3x3 stride-1 block reading P's activated output at the same resolution

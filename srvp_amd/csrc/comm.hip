@@ -125,7 +125,13 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(double* buf, int n,
         }
     }
     __syncthreads();
-    if (bad) { if (threadIdx.x == 0 && k.err) *k.err = 1; return; }
+    if (bad) {
+        // local-only sums must never be consumed as if they were global ones: poison the result (the loss turns NaN at once) and
+        // raise the error word the host polls once per step
+        for (int i = threadIdx.x; i < n; i += blockDim.x) buf[i] = __longlong_as_double(0x7ff8000000000000ll);
+        if (threadIdx.x == 0 && k.err) *k.err = 1;
+        return;
+    }
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         double tot = 0.;
         for (int p = 0; p < k.world; ++p)

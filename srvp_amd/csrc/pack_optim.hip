@@ -21,7 +21,7 @@ struct PackArgs {
     int kc_total, kc_off;         // layout 1: K chunks per tap of the destination (0 = K/64) and first chunk of this job
 };
 
-__device__ __forceinline__ int real_index(int i, int seg0_pad, int seg0_real, int seg1_real) {
+__host__ __device__ __forceinline__ int real_index(int i, int seg0_pad, int seg0_real, int seg1_real) {
     if (i < seg0_pad) return i < seg0_real ? i : -1;
     int i1 = i - seg0_pad;
     return i1 < seg1_real ? seg0_real + i1 : -1;
@@ -85,7 +85,7 @@ __device__ __forceinline__ void job_args(const srvp_pack_job& j, PackArgs& a) {
 // = (j, eight consecutive k), lanes along j.  The fp32 tensor keeps its taps innermost, so an item's reads / read-modify-writes
 // are runs of `source taps` consecutive floats (re-touched over the tap loop: L1/L2 hits) instead of 4-byte accesses 36
 // bytes apart, and the packed side moves as whole 16-byte (pack) / 32-byte (unpack) vectors.
-__device__ __forceinline__ bool vec_ok(const srvp_pack_desc& d) {
+__host__ __device__ __forceinline__ bool vec_ok(const srvp_pack_desc& d) {
     if (d.K % 8 != 0 || d.dst_f32) return false;
     for (int t = 0; t < d.ntaps; ++t)
         if (d.tap_set[t] == 0 ? (d.tap_off[t] < 0 || d.tap_off[t] >= 16) : (d.tap_set[t] >> 16) != 0) return false;
@@ -137,7 +137,7 @@ __device__ __forceinline__ const srvp_pack_job* locate_job(const srvp_pack_job* 
 // lines per wave instruction there and sustains 0.3-0.8 TB/s); the packed side moves as 16- / 32-byte pieces; the transposition
 // between the two happens in LDS.  Same values and the same summation order as the paths above.
 constexpr int PT_OUT = 8, PT_INN = 64;
-__device__ __forceinline__ bool tile_ok(const srvp_pack_desc& d, int& TS, bool& inner_k) {
+__host__ __device__ __forceinline__ bool tile_ok(const srvp_pack_desc& d, int& TS, bool& inner_k) {
     if (!vec_ok(d)) return false;
     inner_k = d.sk < d.sj;
     const long long ts = inner_k ? d.sk : d.sj;
@@ -148,7 +148,7 @@ __device__ __forceinline__ bool tile_ok(const srvp_pack_desc& d, int& TS, bool& 
     return (inner_k ? d.K : d.J) % 8 == 0;
 }
 // padded (outer, inner) -> element offset of tap 0 in the fp32 tensor, or -1 (channel padding)
-__device__ __forceinline__ long long tile_src_base(const srvp_pack_desc& d, bool inner_k, int po, int pi) {
+__host__ __device__ __forceinline__ long long tile_src_base(const srvp_pack_desc& d, bool inner_k, int po, int pi) {
     const int pj = inner_k ? po : pi, pk = inner_k ? pi : po;
     if (pj >= d.J || pk >= d.K) return -1;
     const int jr = real_index(pj, d.J0, d.J0r, d.J1r), kr = real_index(pk, d.K0, d.K0r, d.K1r);
@@ -285,6 +285,208 @@ __device__ void unpack_job_tiled(const srvp_pack_job& j, unsigned wg, unsigned n
             }
 #pragma unroll
             for (int u = 0; u < LU; ++u) if (ga[u] >= 0) dst[ga[u]] = v[u];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Lean tile kernels (round 4).  Measured per job in isolation (tools/pack_time.py, PER_JOB=1): on the kernels above EVERY job, from
+// 0.04 M to 4 M elements, took the same 21 us (pack) / 39 us (unpack) -- the time of ONE workgroup's dependent chain (job lookup,
+// descriptor fields from global memory, two or three rounds of loads, tap tables read inside the loops), at 2-3 workgroups per CU
+// (164 VGPRs / 32 KB of LDS), so a whole network cost (workgroups / resident workgroups) x that chain: 95 + 236 us forward,
+// 130 + 190 us backward, whatever the access pattern.  Here: one workgroup per SMALL tile (18.5 KB of LDS, <= 64 VGPRs: 8 workgroups
+// per CU), the job descriptor copied into LDS once, every global load of the tile in flight at once (16-byte loads wherever the
+// fp32 run is contiguous), tap tables read from LDS.
+//   pack   tile = JT j x 16 k x all taps (JT = 32, or 16 for 4x4 kernels): per packed tap one (half) MFMA fragment of 64 (32) lanes
+//          x 16 bytes in the fragment-major layout; fp32 side: JT (16) contiguous runs of 16 TS (JT TS) floats
+//   unpack tile = JT j x 32 k x all taps (JT = 16 / 8): packed fp32 gradient rows of 128 bytes; fp32 side: runs of 32 TS (JT TS)
+// Same values and summation order as pack_one / unpack_one (tests/test_gpu_blocks.py: byte-equal on whole networks).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int LT_FLOATS = 4640;
+struct LeanGeo { int TS, JT, KT; bool inner_k; };
+__host__ __device__ inline bool lean_geo(const srvp_pack_desc& d, bool unpack, LeanGeo& g) {
+    if (!tile_ok(d, g.TS, g.inner_k)) return false;
+    if (!unpack) { g.JT = g.TS <= 9 ? 32 : 16; g.KT = 16; }
+    else { g.JT = g.TS <= 9 ? 16 : 8; g.KT = 32; }
+    if (d.J % g.JT != 0 || d.K % g.KT != 0 || d.dst_f32) return false;
+    const int OUTN = g.inner_k ? g.JT : g.KT, INN = g.inner_k ? g.KT : g.JT;
+    if ((INN * g.TS) % 4 != 0 || OUTN * (INN * g.TS + 1) > LT_FLOATS) return false;
+    return (long long)(d.J / g.JT) * (d.K / g.KT) < (1ll << 24);
+}
+__host__ __device__ inline int lean_tiles(const srvp_pack_desc& d, bool unpack) {
+    LeanGeo g;
+    return lean_geo(d, unpack, g) ? (d.J / g.JT) * (d.K / g.KT) : 0;
+}
+
+template <bool UNPACK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void pack_lean_kernel(const srvp_pack_job* __restrict__ jobs, int njobs) {
+    __shared__ float lds[LT_FLOATS];
+    __shared__ unsigned s_n[256];
+    __shared__ srvp_pack_job sj;
+    __shared__ int s_job;
+    __shared__ unsigned s_tile;
+    // ---- blockIdx.x -> (job, tile): all job sizes in one parallel round, scanned from LDS
+    for (int i = threadIdx.x; i < njobs; i += 256) s_n[i] = (unsigned)lean_tiles(jobs[i].d, UNPACK);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned w = blockIdx.x;
+        int found = -1;
+        for (int i = 0; i < njobs; ++i) {
+            if (w < s_n[i]) { found = i; break; }
+            w -= s_n[i];
+        }
+        s_job = found; s_tile = w;
+    }
+    __syncthreads();
+    if (s_job < 0) return;
+    {
+        const unsigned* gp = reinterpret_cast<const unsigned*>(jobs + s_job);
+        unsigned* lp = reinterpret_cast<unsigned*>(&sj);
+        if (threadIdx.x < sizeof(srvp_pack_job) / 4) lp[threadIdx.x] = gp[threadIdx.x];
+    }
+    __syncthreads();
+    const srvp_pack_desc& d = sj.d;
+    LeanGeo g;
+    lean_geo(d, UNPACK, g);
+    const int TS = g.TS, JT = g.JT, KT = g.KT;
+    const bool inner_k = g.inner_k;
+    const int tj = d.J / JT;
+    const int tile = (int)s_tile;
+    const int j0 = (tile % tj) * JT, k0 = (tile / tj) * KT;
+    const int o0 = inner_k ? j0 : k0, i0 = inner_k ? k0 : j0;
+    const int OUTN = inner_k ? JT : KT, INN = inner_k ? KT : JT;
+    const int run = INN * TS, pitch = run + 1, total = OUTN * run;
+    const unsigned r_run = (unsigned)(((1ull << 32) + run - 1) / run), r_ts = (unsigned)(((1ull << 32) + TS - 1) / TS);
+    const int ntaps = d.ntaps;
+    static_assert(sizeof(srvp_pack_job) / 4 <= 256 && sizeof(srvp_pack_job) % 4 == 0, "descriptor copy");
+    constexpr int LU = 5;                                  // 16-byte units per thread: total / 4 <= 1160 <= 5 * 256
+    if constexpr (!UNPACK) {
+        const float* __restrict__ src = (const float*)sj.src;
+        bf16_t* __restrict__ dst = (bf16_t*)sj.dst;
+        f32x4_t v[LU];
+        int la[LU];
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int e = (threadIdx.x + u * 256) * 4;
+            la[u] = -1; v[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (e < total) {
+                const int o = (int)__umulhi((unsigned)e, r_run), rem = e - o * run;
+                la[u] = o * pitch + rem;
+                const int ia = (int)__umulhi((unsigned)rem, r_ts), tpa = rem - ia * TS;
+                const int ib = (int)__umulhi((unsigned)(rem + 3), r_ts), tpb = rem + 3 - ib * TS;
+                const long long ba = tile_src_base(d, inner_k, o0 + o, i0 + ia), bb = tile_src_base(d, inner_k, o0 + o, i0 + ib);
+                if (ba >= 0 && bb >= 0 && bb + tpb == ba + tpa + 3 && ((ba + tpa) & 3) == 0) {
+                    v[u] = *reinterpret_cast<const f32x4_t*>(src + ba + tpa);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int i = (int)__umulhi((unsigned)(rem + c), r_ts), tp = rem + c - i * TS;
+                        const long long b = tile_src_base(d, inner_k, o0 + o, i0 + i);
+                        if (b >= 0) v[u][c] = src[b + tp];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LU; ++u)
+            if (la[u] >= 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) lds[la[u] + c] = v[u][c];
+            }
+        __syncthreads();
+        // packed items (tap, k half, j): consecutive threads = consecutive j = consecutive 16-byte pieces of a fragment
+        for (int it = threadIdx.x; it < ntaps * 2 * JT; it += 256) {
+            const int t = it / (2 * JT), r = it - t * (2 * JT), kh = r / JT, jl = r - kh * JT;
+            const int off = d.tap_off[t], set = d.tap_set[t];
+            float o8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float* cell = inner_k ? lds + jl * pitch + (kh * 8 + e) * TS : lds + (kh * 8 + e) * pitch + jl * TS;
+                if (set == 0) o8[e] = cell[off];
+                else {
+                    // every tap of the cell in flight, then the fp32 sum in ascending tap order (a + 0.f == a exactly)
+                    float w[16];
+#pragma unroll
+                    for (int sidx = 0; sidx < 16; ++sidx) w[sidx] = sidx < TS ? cell[sidx] : 0.f;
+                    float a = 0.f;
+#pragma unroll
+                    for (int sidx = 0; sidx < 16; ++sidx) a += ((set >> sidx) & 1) ? w[sidx] : 0.f;
+                    o8[e] = a;
+                }
+            }
+            *reinterpret_cast<u32x4_t*>(dst + packed_off(d, t, j0 + jl, k0 + kh * 8)) = pack8(o8);
+        }
+    } else {
+        const float* __restrict__ src = (const float*)sj.src;       // packed fp32 gradient [t][J][K] (tap-major)
+        float* __restrict__ dst = (float*)sj.dst;
+        unsigned need = 0;
+        for (int t = 0; t < ntaps; ++t) need |= d.tap_set[t] ? (unsigned)d.tap_set[t] : 1u << d.tap_off[t];
+        const unsigned full = (1u << TS) - 1u;
+        // the flat side's current values: in flight while the packed taps are summed
+        f32x4_t v[LU];
+        long long ga[LU];          // >= 0: one 16-byte read-modify-write at ga; -2: element by element; -1: nothing
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int e = (threadIdx.x + u * 256) * 4;
+            ga[u] = -1; v[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (e < total) {
+                const int o = (int)__umulhi((unsigned)e, r_run), rem = e - o * run;
+                const int ia = (int)__umulhi((unsigned)rem, r_ts), tpa = rem - ia * TS;
+                const int ib = (int)__umulhi((unsigned)(rem + 3), r_ts), tpb = rem + 3 - ib * TS;
+                const long long ba = tile_src_base(d, inner_k, o0 + o, i0 + ia), bb = tile_src_base(d, inner_k, o0 + o, i0 + ib);
+                if (need == full && ba >= 0 && bb >= 0 && bb + tpb == ba + tpa + 3 && ((ba + tpa) & 3) == 0) {
+                    ga[u] = ba + tpa;
+                    v[u] = *reinterpret_cast<const f32x4_t*>(dst + ga[u]);
+                } else ga[u] = -2;
+            }
+        }
+        for (int e = threadIdx.x; e < OUTN * pitch; e += 256) lds[e] = 0.f;
+        __syncthreads();
+        // item = (j, four consecutive k): owns its LDS cells; packed taps in ascending order (= unpack_one's summation order)
+        const int nk4 = KT / 4;
+        for (int it = threadIdx.x; it < JT * nk4; it += 256) {
+            const int k4 = it % nk4, jl = it / nk4;
+            const float* sp = src + ((long long)(j0 + jl)) * d.K + k0 + k4 * 4;
+            const long long tstride = (long long)d.J * d.K;
+            for (int t0 = 0; t0 < ntaps; t0 += 4) {
+                f32x4_t pv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    pv[q] = t0 + q < ntaps ? *reinterpret_cast<const f32x4_t*>(sp + (t0 + q) * tstride) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (t0 + q >= ntaps) break;
+                    const unsigned m = d.tap_set[t0 + q] ? (unsigned)d.tap_set[t0 + q] : 1u << d.tap_off[t0 + q];
+                    for (int sidx = 0; sidx < TS; ++sidx)
+                        if ((m >> sidx) & 1) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float* cell = inner_k ? lds + jl * pitch + (k4 * 4 + e) * TS : lds + (k4 * 4 + e) * pitch + jl * TS;
+                                cell[sidx] += pv[q][e];
+                            }
+                        }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int e = (threadIdx.x + u * 256) * 4;
+            if (ga[u] >= 0) {
+                const int o = (int)__umulhi((unsigned)e, r_run), rem = e - o * run;
+                f32x4_t w = v[u];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) w[c] += lds[o * pitch + rem + c];
+                *reinterpret_cast<f32x4_t*>(dst + ga[u]) = w;
+            } else if (ga[u] == -2) {
+                const int o = (int)__umulhi((unsigned)e, r_run), rem = e - o * run;
+                for (int c = 0; c < 4; ++c) {
+                    const int i = (int)__umulhi((unsigned)(rem + c), r_ts), tp = rem + c - i * TS;
+                    if (!((need >> tp) & 1)) continue;
+                    const long long b = tile_src_base(d, inner_k, o0 + o, i0 + i);
+                    if (b >= 0) dst[b + tp] += lds[o * pitch + rem + c];
+                }
+            }
         }
     }
 }
@@ -626,6 +828,22 @@ extern "C" int srvp_unpack_wgrad_multi(const srvp_pack_job* jobs_dev, int njobs,
 }
 
 extern "C" int srvp_pack_job_wgs(int64_t total) { return pack_job_wgs(total); }
+
+// Lean tile kernels: `jobs_dev` holds ONLY jobs with srvp_pack_job_tiles(...) > 0 (the caller sends the others through the multi
+// launches above); total_tiles = the sum of their tile counts, njobs <= 256.
+extern "C" int srvp_pack_job_tiles(const srvp_pack_desc* d, int unpack) { return d ? lean_tiles(*d, unpack != 0) : 0; }
+extern "C" int srvp_pack_weight_tiles(const srvp_pack_job* jobs_dev, int njobs, int64_t total_tiles, void* stream) {
+    SRVP_REQUIRE(jobs_dev && njobs > 0 && njobs <= 256 && total_tiles > 0 && total_tiles < (1ll << 31), "srvp_pack_weight_tiles: bad args (at most 256 jobs)");
+    hipLaunchKernelGGL(pack_lean_kernel<false>, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
+    SRVP_CHECK_LAUNCH("srvp_pack_weight_tiles");
+    return SRVP_OK;
+}
+extern "C" int srvp_unpack_wgrad_tiles(const srvp_pack_job* jobs_dev, int njobs, int64_t total_tiles, void* stream) {
+    SRVP_REQUIRE(jobs_dev && njobs > 0 && njobs <= 256 && total_tiles > 0 && total_tiles < (1ll << 31), "srvp_unpack_wgrad_tiles: bad args (at most 256 jobs)");
+    hipLaunchKernelGGL(pack_lean_kernel<true>, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
+    SRVP_CHECK_LAUNCH("srvp_unpack_wgrad_tiles");
+    return SRVP_OK;
+}
 
 extern "C" int srvp_skip_grad_reduce(const void* dcat, int cstride, int coff, int C, int HW, int T, int B, void* dsel,
                                      void* stream) {

@@ -117,9 +117,12 @@ class PeerStats:
         self.err = torch.zeros(1, dtype=torch.int32, device='cuda')
         self.slot_of, self.uses = {}, {}
 
-    def allreduce(self, t):
+    def allreduce(self, t, site=None):
+        """`site`: the call site's identity, the same on every rank whatever its allocation history -- (BatchNorm layer key,
+        direction), fixed by the model definition; training plans of different batch sizes share the slot of a layer (they run in
+        the same order on every rank).  Without one the tensor's address stands in (self-test only)."""
         assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float64 and t.numel() <= self.NMAX
-        key = t.data_ptr()
+        key = site if site is not None else t.data_ptr()
         slot = self.slot_of.setdefault(key, len(self.slot_of))
         if slot >= self.SLOTS:
             raise L.SrvpHipError('peer statistics exchange: more call sites than slots')
@@ -131,7 +134,7 @@ class PeerStats:
     def check(self):
         """(synchronises) raises if a collective gave up waiting for a peer."""
         if int(self.err.item()) != 0:
-            raise L.SrvpHipError('peer statistics exchange: a rank waited 5 s for a peer that never published its sums')
+            raise L.SrvpHipError('peer statistics exchange: a rank gave up waiting for a peer that never published its sums')
 
     def self_test(self):
         want = self.world * (self.world + 1) / 2
@@ -219,11 +222,12 @@ class Sync:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         return int(flag.item()) == 1
 
-    def allreduce_stats(self, t, count):
-        """In-place sum of a small fp64 statistics tensor over ranks; returns the global element count."""
+    def allreduce_stats(self, t, count, site=None):
+        """In-place sum of a small fp64 statistics tensor over ranks; returns the global element count.  `site` names the call site
+        (BatchNorm key, direction) for the transports that keep per-call-site state."""
         if self.sync_bn and (self.world > 1 or self.force):
             if self.peer is not None:
-                self.peer.allreduce(t)
+                self.peer.allreduce(t, site)
             elif self.native_stats is not None:
                 self.native_stats.allreduce(t)
             else:
@@ -251,8 +255,8 @@ class Sync:
             host = self._peer_err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
             self._peer_err_event = None
         if self._peer_err_event is not None and self._peer_err_event.query() and int(host[0]) != 0:
-            raise L.SrvpHipError('peer statistics exchange: a rank waited 5 s for a peer that never published its sums '
-                                 '(results since then are invalid); set SRVP_COMM=rccl')
+            raise L.SrvpHipError('peer statistics exchange: a rank gave up waiting for a peer that never published its sums '
+                                 '(the sums of that collective were replaced by NaN); set SRVP_COMM=rccl')
         host.copy_(self.peer.err, non_blocking=True)
         self._peer_err_event = torch.cuda.Event()
         self._peer_err_event.record()
@@ -283,6 +287,13 @@ class Sync:
                 h.wait()
             self.handles = []
             flat_g.mul_(1.0 / self.world)     # DDP averages gradients over ranks
+
+    def after_rank0_phase(self):
+        """Called by EVERY rank at an iteration where rank 0 alone did something long (validation, checkpoint writes; reference
+        train.py:355-366 has no barrier there, an RCCL all-reduce simply blocks until rank 0 arrives).  The peer exchange waits on the
+        device with a deadline instead, so the ranks meet on the host first."""
+        if self.peer is not None and self.world > 1:
+            dist.barrier(group=self.group)
 
     def broadcast(self, t):
         if self.native_grads is not None:

@@ -318,6 +318,10 @@ def main(opt):
                         torch.save(model.state_dict(), os.path.join(opt.save_path, f'model_{itr}.pt'))
                         save_train_state(os.path.join(opt.save_path, 'train_state.pt'), model, optimizer, lr_scheduler, itr,
                                          best_val_metric)
+                if sync is not None and (itr % opt.val_interval == 0
+                                         or (opt.chkpt_interval is not None and itr % opt.chkpt_interval == 0)):
+                    sync.after_rank0_phase()       # (no-op unless the statistics exchange waits on the device with a deadline)
+                if local_rank == 0:
                     if itr % 50 == 0 or itr == 1:
                         print(f'itr {itr}: loss {loss:.3f} nll {nll:.3f} kl_y_0 {kl_y_0:.4f} kl_z {kl_z:.4f} '
                               f'val {val_metric} best {best_val_metric}', flush=True)

@@ -526,17 +526,43 @@ gw = torch.randn(*wshape, generator=g).to(dev)
 net = ConvNetBase(); net.dev = dev
 jobs = blk.unpack_jobs(gw)
 c = net._job_table(jobs, dev, dict(), True)
-L.call('srvp_unpack_wgrad_multi', L.ptr(c['table']), c['n'], c['mx'], L.stream())
+if c['tiles']:
+    L.call('srvp_unpack_wgrad_tiles', L.ptr(c['tiles'][0]), c['tiles'][1], c['tiles'][2], L.stream())
+if c['multi']:
+    L.call('srvp_unpack_wgrad_multi', L.ptr(c['multi'][0]), c['multi'][1], c['multi'][2], L.stream())
 torch.cuda.synchronize()
 torch.save(gw.cpu(), sys.argv[1])
 """
     outs = []
-    for mode in ('2', '0'):
-        path = os.path.join(os.environ.get('TMPDIR', '/tmp'), f'unpack_{mode}_{kind}_{cin}_{cout}_{k}_{int(split)}.pt')
-        r = subprocess.run([sys.executable, '-c', code, path], env=dict(os.environ, SRVP_PACK_TILED=mode), capture_output=True, text=True, timeout=300)
+    for tiles, mode in (('1', '2'), ('0', '2'), ('0', '0')):      # lean tile kernel / 8 x 64 LDS-tiled multi path / item-per-thread multi path
+        path = os.path.join(os.environ.get('TMPDIR', '/tmp'), f'unpack_{tiles}{mode}_{kind}_{cin}_{cout}_{k}_{int(split)}.pt')
+        r = subprocess.run([sys.executable, '-c', code, path], env=dict(os.environ, SRVP_PACK_TILES=tiles, SRVP_PACK_TILED=mode), capture_output=True,
+                           text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(torch.load(path))
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])
+
+
+@pytest.mark.parametrize('config', ['bair', 'smmnist'])
+def test_big_tile_pack_unpack_equal_item_path(config):
+    """The lean tile kernels (srvp_pack_weight_tiles / srvp_unpack_wgrad_tiles, the default for every eligible job) write exactly the
+    bytes the item-per-thread multi paths write, for every job of a whole network at full width: VGG (3x3, folded sub-pixel tap sets,
+    hoisted skip halves, fragment-major and tap-major layouts, space-to-depth phase jobs) and DCGAN (4x4 kernels, IOHW)."""
+    import subprocess, sys, os, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ('1', '0'):
+        r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'pack_time.py'), config], env=dict(os.environ, SRVP_PACK_TILES=mode, SRVP_PACK_TILED='0'),
+                           capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res['1']['dec_jobs']['tiles'] and not res['0']['dec_jobs']['tiles'], res
+    for k in ('enc_pack_digest', 'dec_pack_digest', 'enc_unpack_digest', 'dec_unpack_digest'):
+        assert res['1'][k] == res['0'][k], (k, res)
+    rep = os.path.join(root, 'gpurun_out', 'parity_report.jsonl')
+    os.makedirs(os.path.dirname(rep), exist_ok=True)
+    with open(rep, 'a') as f:
+        f.write(json.dumps(dict(test='pack_unpack_us', config=config, **{f'{k}_{m}': res[m][k] for m in res for k in res[m] if k.endswith('_us')})) + '\n')
 
 
 @pytest.mark.parametrize('nc,k,s,p', [(3, 3, 1, 1), (1, 4, 2, 1), (3, 4, 2, 1)])
