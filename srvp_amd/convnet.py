@@ -19,6 +19,7 @@ from . import _lib as L
 CP = 32                      # channel padding granule
 SUBPIX = os.environ.get('SRVP_SUBPIX', '1') != '0'
 S2D = os.environ.get('SRVP_SUBPIX_S2D', '1') != '0'
+WGRAD_HALO2 = os.environ.get('SRVP_WGRAD_HALO2', '1') != '0'  # sub-pixel weight gradients: one 16-tap launch, two phases per workgroup on the halo kernel
 PACK_TILES = os.environ.get('SRVP_PACK_TILES', '1') != '0'      # 0: every pack / unpack job through the multi kernels (A/B)
 BN_FUSED_FINALIZE = os.environ.get('SRVP_BN_FUSED_FINALIZE', '1') != '0'    # bn_finalize / bn_bwd_finalize folded into bn_act / bn_bwd_apply
 # encoder weight gradients on the second stream when the batch is small (<= this many frames): grids of 100-600 workgroups do not
@@ -813,12 +814,13 @@ class Block:
 
     def _wgrad_s2d(self):
         """Weight gradient of a sub-pixel block from its space-to-depth output gradient; entries (a*2+b)*4 + u*2+v of dw.
-        cout = 64: four 4-tap HALO launches, one per output phase (dout = the phase's channel slice, taps = that phase's folded
-        offsets).  Wider layers: the halo kernel is LDS-DMA bound with only 4 taps per staged tile (measured 0.55-0.60 vs
-        0.50-0.52 ms), so ONE 16-tap launch of the per-tap kernel, tap t reading the slice of phase t / 4 at unit stride."""
+        ONE 16-tap launch, tap t reading the slice of phase t / 4 at unit stride: the halo kernel takes it with two phases per workgroup
+        (round 4: wgrad_halo_kernel<.., 8, 2>; low-resolution grids narrower than 8 columns stay on the per-tap kernel).
+        SRVP_WGRAD_HALO2=0 (round 3): cout = 64: four 4-tap HALO launches, one per output phase; wider layers: the 4-tap halo kernel is
+        LDS-DMA bound (measured 0.55-0.60 vs 0.50-0.52 ms), so the 16-tap launch runs on the per-tap kernel."""
         f0 = self.srcs[0]
         out = []
-        if self.cout > 64:
+        if self.cout > 64 or WGRAD_HALO2:
             ent = [(a, b, u, v) for a in (0, 1) for b in (0, 1) for u in (0, 1) for v in (0, 1)]
             d = L.WgradDesc()
             d.src0, d.C0, d.H0p, d.W0p, d.ups0 = L.ptr(f0.t), f0.C, f0.Hp, f0.Wp, 0

@@ -425,16 +425,23 @@ struct WgradHaloK {
     int lgTW, RH, PW, Ppix, lg_nxb, lg_nyb, ntiles, oo;   // oo: border offset of dout (ooy = oox)
 };
 
-template <bool UPS, int BJ, int NTAPS = 9>
+template <bool UPS, int BJ, int NTAPS = 9, int NX = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_halo_kernel(const WgradHaloK p) {
     // BJ = 64: wave = (cout tile, cin tile), all 9 taps.  BJ = 32 (image-side layer, Cout padded to 32): wave = (cin tile,
     // tap group 0-4 / 5-8); the second group computes one duplicate tap that is not written back.
     // NTAPS = 4 (BJ = 64): one phase of a sub-pixel upsample convolution -- dout is a channel slice of the space-to-depth
     // gradient, the four taps are that phase's offsets inside the same 3x3 window.
-    constexpr int NT = 256, NBUF = 4, BC = 64;
+    // NTAPS = 8, NX = 2 (round 4): TWO phases of such a block per workgroup -- both phases' 64-channel slices of the space-to-depth
+    // gradient are staged beside ONE input patch (the 16 (phase, folded tap) products all read the same 3x3 window of it), taps 0-3 use
+    // slice 0 and taps 4-7 slice 1: 16 MFMAs per wave and 20 KB stage (the 9-tap kernel: 18 per 16 KB; one phase: 8 per 16 KB, which
+    // was LDS-DMA bound).  blockIdx carries the phase pair; 3-deep ring so that two workgroups still share a CU.
+    constexpr int NT = 256, NBUF = NX == 2 ? 3 : 4, BC = 64;
     constexpr int NTW = BJ == 64 ? NTAPS : 5;            // taps per wave
+    constexpr int NTOT = NX == 2 ? 16 : NTAPS;           // taps of the launch (dy / dx entries, dw slabs)
+    static_assert(NX == 1 || (BJ == 64 && NTAPS == 8 && !UPS), "two-slice variant: 8 taps, 64 x 64 tiles");
     constexpr int XROW = BJ * 2;                         // bytes per dout pixel row
-    constexpr int XBYTES = 32 * XROW;                    // [32 px][BJ ch]
+    constexpr int XTILE = 32 * XROW;                     // [32 px][BJ ch]
+    constexpr int XBYTES = NX * XTILE;
     constexpr int YPIECES = 3 * NT;                      // 96 px * 8 chunks
     constexpr int YBYTES = YPIECES * 16;                 // 12 KiB
     constexpr int STAGE = XBYTES + YBYTES;
@@ -445,11 +452,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     const WgradK& a = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int jt = BJ == 64 ? (wid >> 1) : 0, ct = wid & 1;
-    const int tap0 = BJ == 64 ? 0 : (wid >> 1) * 5;
     const int tc_n = a.C0 / BC, tj_n = a.Cout / BJ;
     int b = (int)xcd_remap(blockIdx.x, gridDim.x);
     const int tc = b % tc_n; b /= tc_n;
     const int tj = b % tj_n; b /= tj_n;
+    int pp = 0;                                          // phase pair (NX = 2)
+    if constexpr (NX == 2) { pp = b & 1; b >>= 1; }
+    const int tap0 = NX == 2 ? pp * 8 : (BJ == 64 ? 0 : (wid >> 1) * 5);
     const int split = b;
     const int j0 = tj * BJ, c0 = tc * BC;
     const int per = (p.ntiles + a.splitk - 1) / a.splitk;
@@ -491,10 +500,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         const int n = tau >> (p.lg_nxb + p.lg_nyb);
         const int y0 = yb * p.RH, x0 = xb << p.lgTW;
         const int ns = a.map0 ? maps[n] : n;             // LDS copy: a global load here would sit in the DMA's vmcnt queue
-        const unsigned xbase = (((unsigned)n * a.DHp + y0 + p.oo) * a.DWp + x0 + p.oo) * a.dcs + a.dco + j0;
+        const unsigned xbase = (((unsigned)n * a.DHp + y0 + p.oo) * a.DWp + x0 + p.oo) * a.dcs + a.dco + (NX == 2 ? 2 * pp * a.Cout : 0) + j0;
         const unsigned ybase = (((unsigned)ns * a.H0p + (y0 >> ups)) * a.W0p + (x0 >> ups)) * a.C0 + c0;
         unsigned char* sb = lds + (size_t)buf * STAGE;
         __builtin_amdgcn_global_load_lds((gptr_t)(a.dout + xbase + xlane), (lptr_t)(sb + (BJ == 64 ? wid : (wid & 1)) * 1024), 16, 0, 0);
+        if constexpr (NX == 2)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.dout + xbase + a.Cout + xlane), (lptr_t)(sb + XTILE + wid * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             if (i < ny)
@@ -533,7 +544,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     unsigned toff[NTW][NAD];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-        const int tg = (tap0 + t) > NTAPS - 1 ? NTAPS - 1 : tap0 + t;
+        const int tg = (tap0 + t) > NTOT - 1 ? NTOT - 1 : tap0 + t;
         const int dy = (int)((a.dy_bits >> (4 * tg)) & 15), dx = (int)((a.dx_bits >> (4 * tg)) & 15);
         if constexpr (!UPS) {
             const unsigned P0 = (unsigned)((ty0 + dy) * PW + tx0 + dx) << 7, P1 = (unsigned)((ty1 + dy) * PW + tx0 + dx) << 7;
@@ -555,10 +566,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     for (int s = 0; s < nsteps; ++s) {
         if (s + NBUF - 2 < nsteps) {
             // tile s has landed when only the NBUF-2 younger stages ((1 + ny) DMAs each) are outstanding
-            if (ny == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NBUF - 2)) : "memory");
-            else if (ny == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (NBUF - 2)) : "memory");
-            else if (ny == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NBUF - 2)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * (NBUF - 2)) : "memory");
+            if (ny == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NX + 3) * (NBUF - 2)) : "memory");
+            else if (ny == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NX + 2) * (NBUF - 2)) : "memory");
+            else if (ny == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NX + 1) * (NBUF - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NX * (NBUF - 2)) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -566,13 +577,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         asm volatile("" ::: "memory");
         if (s + NBUF - 1 < nsteps) stage(s + NBUF - 1, (s + NBUF - 1) % NBUF);
         const unsigned bb = lds_base + (unsigned)(s % NBUF) * (unsigned)STAGE;
-        bf16x8_t xf[2];
-        {
+        bf16x8_t xf[NX][2];
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
             s16x4_t a0, a1, b0, b1;
-            tr_read_tile<4 * XROW, 16 * XROW>(bb + xoff, a0, a1, b0, b1);
+            tr_read_tile<4 * XROW, 16 * XROW>(bb + xoff + q * XTILE, a0, a1, b0, b1);
             s16x8_t v0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
             s16x8_t v1 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-            xf[0] = __builtin_bit_cast(bf16x8_t, v0); xf[1] = __builtin_bit_cast(bf16x8_t, v1);
+            xf[q][0] = __builtin_bit_cast(bf16x8_t, v0); xf[q][1] = __builtin_bit_cast(bf16x8_t, v1);
         }
         // software pipeline over the taps: the four transpose reads of tap t+1 are issued before the MFMAs of tap t (LDS
         // returns in order, so lgkmcnt(4) = "tap t has landed"); the waits carry the fragment registers as operands so
@@ -614,15 +626,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             }
             s16x8_t v0 = {y0[c][0], y0[c][1], y0[c][2], y0[c][3], y1[c][0], y1[c][1], y1[c][2], y1[c][3]};
             s16x8_t v1 = {y2[c][0], y2[c][1], y2[c][2], y2[c][3], y3[c][0], y3[c][1], y3[c][2], y3[c][3]};
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], __builtin_bit_cast(bf16x8_t, v0), acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[1], __builtin_bit_cast(bf16x8_t, v1), acc[t], 0, 0, 0);
+            constexpr int XS = NX == 2 ? 4 : 1 << 30;     // taps per dout slice
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[t / XS][0], __builtin_bit_cast(bf16x8_t, v0), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[t / XS][1], __builtin_bit_cast(bf16x8_t, v1), acc[t], 0, 0, 0);
         }
     }
 
     const int lcol = lane & 31, lhalf = lane >> 5;
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-        if (tap0 + t > NTAPS - 1) break;
+        if (tap0 + t > NTOT - 1) break;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int jj = j0 + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
@@ -645,8 +658,12 @@ static int try_launch_halo(const srvp_wgrad_desc* d, const WgradK& k, hipStream_
     static int four_max = -1;
     if (four_max < 0) { const char* e = getenv("SRVP_WGRAD_HALO4_MAXC"); four_max = e ? atoi(e) : 64; }
     const bool four = d->ntaps == 4 && d->Cout % 64 == 0 && d->Cout <= four_max && !d->ups0;
-    if ((d->ntaps != 9 && !four) || d->si != 1 || d->so != 1 || d->C1 != 0 || d->C0 % 64 || (d->Cout % 64 && d->Cout != 32)) return SRVP_OK;
-    if ((!four && (d->dout_cstride || d->dout_coff)) || d->dout_phase_taps) return SRVP_OK;
+    // all 16 (phase, folded tap) gradients of a sub-pixel block in one launch, two phases per workgroup (SRVP_WGRAD_HALO2, default on)
+    static int halo2 = -1;
+    if (halo2 < 0) { const char* e = getenv("SRVP_WGRAD_HALO2"); halo2 = e ? atoi(e) : 1; }
+    const bool two = halo2 && d->ntaps == 16 && d->dout_phase_taps == 4 && d->Cout % 64 == 0 && !d->ups0 && d->dout_cstride == 4 * d->Cout;
+    if ((d->ntaps != 9 && !four && !two) || d->si != 1 || d->so != 1 || d->C1 != 0 || d->C0 % 64 || (d->Cout % 64 && d->Cout != 32)) return SRVP_OK;
+    if ((!four && !two && (d->dout_cstride || d->dout_coff)) || (d->dout_phase_taps && !two)) return SRVP_OK;
     for (int t = 0; t < d->ntaps; ++t)
         if (d->dy[t] < 0 || d->dy[t] > 2 || d->dx[t] < 0 || d->dx[t] > 2 || d->ooy[t] != d->ooy[0] || d->oox[t] != d->ooy[0]) return SRVP_OK;
     const int OH = d->OH, OW = d->OW, ups = d->ups0 ? 1 : 0;
@@ -667,7 +684,7 @@ static int try_launch_halo(const srvp_wgrad_desc* d, const WgradK& k, hipStream_
     h.ntiles = d->N * (OH / h.RH) * (OW / TW);
     h.oo = d->ooy[0];
     const int bj = d->Cout == 32 ? 32 : 64;
-    const int pairs = (d->Cout / bj) * (d->C0 / 64);
+    const int pairs = (d->Cout / bj) * (d->C0 / 64) * (two ? 2 : 1);      // (two: x phase pairs)
     // workgroups per launch the split-K aims at: every split pays 9 x 64 x 64 fp32 atomics, amortised over its K steps -- 512 is
     // the measured best at 2304 frames (43.35 vs 44.1 / 44.4 ms per step for 384 / 256), 320 at 288 frames (10.70 vs 10.98 ms)
     static int target_env = -2;
@@ -677,6 +694,12 @@ static int try_launch_halo(const srvp_wgrad_desc* d, const WgradK& k, hipStream_
     if (splitk > h.ntiles / 8) splitk = h.ntiles / 8 > 0 ? h.ntiles / 8 : 1;
     h.a.splitk = splitk;
     const long long blocks = (long long)pairs * splitk;
+    if (two) {
+        hipLaunchKernelGGL((wgrad_halo_kernel<false, 64, 8, 2>), dim3((unsigned)blocks), dim3(256), 0, st, h);
+        SRVP_CHECK_LAUNCH("srvp_wgrad_mfma(halo, 2 x 8 taps)");
+        done = true;
+        return SRVP_OK;
+    }
     if (four) {
         hipLaunchKernelGGL((wgrad_halo_kernel<false, 64, 4>), dim3((unsigned)blocks), dim3(256), 0, st, h);
         SRVP_CHECK_LAUNCH("srvp_wgrad_mfma(halo, 4 taps)");
