@@ -94,6 +94,13 @@ typedef struct {
      * i.e. exactly what srvp_bn_bwd_reduce (da_mode 0) computes from the stored dA and raw -- one read of dA and one launch less
      * per layer.  bnr_coef: fp32 [4][Cout] = scale, shift, mean, invstd of that layer. */
     const void* bnr_raw; const float* bnr_coef; double* bnr_red;
+    /* Inference (eval-mode BatchNorm, conv.py:103-104 with running statistics): ep_coef != NULL folds the block's normalisation and
+     * activation into this launch's epilogue -- dst receives  act( ep_coef[c] * acc + ep_coef[Cout + c] )  (scale, shift of output
+     * channel c; ep_act = ACT_* id) computed from the fp32 accumulators (after add_f32) and rounded to bf16 once, written where the
+     * consumer reads it: dst is an activation tensor [N][DHp + 2 ep_border][DWp + 2 ep_border][Cdst] whose interior the launch
+     * addresses through DHp / DWp / so / ooy / oox as usual (add_f32 keeps the unbordered geometry).  No raw tensor, no srvp_bn_act
+     * pass.  bf16 launches without stats / dst_is_f32 / out_f32 / splitk. */
+    const float* ep_coef; int32_t ep_act, ep_border;
 } srvp_conv_desc;
 int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
 /* 1 (default): 3x3 stride-1 single-source convolutions run on the halo-tiled kernel (input patch staged in LDS once

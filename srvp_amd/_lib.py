@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
                 ('out_f32', c_vp), ('out_nc', c_i32), ('out_sigmoid', c_i32),
                 ('map0', c_vp), ('dst_is_f32', c_i32), ('add_f32', c_vp), ('add_mod', c_i32), ('wt_fragmajor', c_i32),
                 ('tap_phase_chunks', c_i32), ('elem_f32', c_i32), ('splitk', c_i32), ('f32_quad', c_i32),
-                ('bnr_raw', c_vp), ('bnr_coef', c_vp), ('bnr_red', c_vp)]
+                ('bnr_raw', c_vp), ('bnr_coef', c_vp), ('bnr_red', c_vp), ('ep_coef', c_vp), ('ep_act', c_i32), ('ep_border', c_i32)]
 
 
 class WgradDesc(C.Structure):

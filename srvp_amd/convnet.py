@@ -20,6 +20,7 @@ CP = 32                      # channel padding granule
 SUBPIX = os.environ.get('SRVP_SUBPIX', '1') != '0'
 S2D = os.environ.get('SRVP_SUBPIX_S2D', '1') != '0'
 WGRAD_HALO2 = os.environ.get('SRVP_WGRAD_HALO2', '1') != '0'  # sub-pixel weight gradients: one 16-tap launch, two phases per workgroup on the halo kernel
+EVAL_FOLD = os.environ.get('SRVP_EVAL_FOLD', '1') != '0'      # inference: eval-mode BatchNorm + activation in the conv epilogue (no raw tensor, no bn_act pass)
 PACK_TILES = os.environ.get('SRVP_PACK_TILES', '1') != '0'      # 0: every pack / unpack job through the multi kernels (A/B)
 BN_FUSED_FINALIZE = os.environ.get('SRVP_BN_FUSED_FINALIZE', '1') != '0'    # bn_finalize / bn_bwd_finalize folded into bn_act / bn_bwd_apply
 # encoder weight gradients on the second stream when the batch is small (<= this many frames): grids of 100-600 workgroups do not
@@ -951,6 +952,34 @@ class Block:
 class ConvNetBase:
     """Shared launch helpers."""
 
+    def _fold_eval_bn(self, blk):
+        """Inference dataflow (reference conv.py:103-104 in eval mode: BatchNorm with running statistics is a per-channel affine map):
+        the block's forward launches apply scale / shift / activation to their fp32 accumulators and write the ACTIVATED output where
+        the consumer reads it (srvp_conv_desc.ep_*) -- no raw tensor, no srvp_bn_act pass (19 % of the kernel time of a long-horizon
+        rollout in round 3).  Plain 3x3 blocks (incl. hoisted-skip and sub-pixel forms) and transposed 4x4 stride-2 blocks."""
+        blk._ep = False
+        if not (EVAL_FOLD and not blk.training and not blk.f32 and blk.role == 'mfma' and blk.has_bn and blk.out is not None
+                and blk.pool is None and blk.geom in ('same', 'up') and not getattr(blk.out, 's2d', False)
+                and blk.out.C == blk.cout and getattr(blk, '_fwd_fin', None) is None):
+            return
+        o = blk.out
+        descs = blk._fwd[1:] if blk.split else blk._fwd          # (split: the first launch writes the fp32 hoisted skip half S)
+        for d in descs:
+            assert d.Cout == blk.cout and not d.dst_is_f32 and not d.out_f32
+            assert d.DHp == blk.OH and d.DWp == blk.OW and d.cdst_off == 0
+            d.dst, d.Cdst = L.ptr(o.t), o.C
+            d.stats, d.stat_mod = None, 1
+            d.ep_coef, d.ep_act, d.ep_border = L.ptr(blk.coef), blk.act, o.b
+        blk.__dict__.pop('_fwd_arr', None)
+        blk._ep = True
+
+    def _eval_coeffs(self, blk, params, st):
+        """scale / shift of an eval-mode BatchNorm from its running statistics (recomputed per forward: the statistics are written by
+        kernels through raw pointers, so no tensor version tells whether they changed; a 6 us launch off the critical chain)."""
+        bk = blk.spec['bnkey']
+        g, b, rm, rv = params[bk + '.weight'], params[bk + '.bias'], params[bk + '.running_mean'], params[bk + '.running_var']
+        L.call('srvp_bn_eval_coeffs', L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(blk.coef[0]), L.ptr(blk.coef[1]), blk.cout, blk.cout_r, BN_EPS, st)
+
     def _bn_forward(self, blk, params, st, sync, keep=None):
         N, C_ = blk.N, blk.cout
         scale, shift, mean, invstd = (blk.coef[i] for i in range(4))
@@ -989,6 +1018,19 @@ class ConvNetBase:
             L.call('srvp_conv_in_fwd_f32' if blk.f32 else 'srvp_conv_in_fwd', L.ptr(x), L.ptr(w), L.ptr(blk.raw),
                    L.ptr(blk.stats) if (blk.has_bn and blk.training) else None,
                    blk.N, blk.cin_r[0], 64, 64, blk.cout, blk.cout_r, blk.k, blk.s, blk.p, st)
+        elif getattr(blk, '_ep', False):
+            skip_s = blk.split and getattr(self, '_skips_done', False)
+            if blk.subpix:
+                if blk.split and not skip_s:
+                    L.call('srvp_conv_mfma', C.byref(blk._fwd[0]), st)
+                arr = blk.__dict__.get('_fwd_arr')
+                if arr is None:
+                    arr = blk._fwd_arr = (L.ConvDesc * 4)(*blk._fwd[-4:])
+                L.call('srvp_conv_mfma_multi', arr, 4, st)
+            else:
+                for d in (blk._fwd[1:] if skip_s else blk._fwd):
+                    L.call('srvp_conv_mfma', C.byref(d), st)
+            return                                   # (activated output written by the launches above)
         elif blk.subpix:
             # [conv_s(skip) when split], then the four output phases as one grid
             for d in blk._fwd[:-4]:
@@ -1299,6 +1341,8 @@ class DecoderNet(ConvNetBase):
             if training:
                 blk._dg = blk.dgrad_descs()
                 blk._wg = blk.wgrad_desc()
+            else:
+                self._fold_eval_bn(blk)
         self._fuse_bn_reduce()
         ob = self.blocks[-1]
         self.nc = ob.cout_r
@@ -1324,6 +1368,9 @@ class DecoderNet(ConvNetBase):
             L.call('srvp_pad_f32' if self.f32 else 'srvp_cast_f32_bf16', L.ptr(z_f32), L.ptr(self.z.t), self.N, z_f32.shape[1], self.z.C, st)
         if self.training:
             self.zero_forward_accumulators()
+        for blk in self.blocks[:-1]:
+            if getattr(blk, '_ep', False):           # inference: every folded block's coefficients up front, off the conv chain
+                self._eval_coeffs(blk, params, st)
         for blk in self.blocks[:-1]:
             self._block_forward(blk, params, st, sync)
         self._skips_done = False

@@ -36,6 +36,7 @@ struct ConvK {
     int splitk;                // > 1 (generic kernel, fp32 destination): blockIdx.y walks its share of the K steps into slab blockIdx.y
     long long slab;            // elements per split-K slab
     const bf16_t* bnr_raw; const float* bnr_coef; double* bnr_red;     // fused BatchNorm-backward reduction of the producer (srvp_hip.h)
+    const float* ep_coef; int ep_act, ep_border;                       // eval-mode BatchNorm + activation in the epilogue (srvp_hip.h)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -208,6 +209,30 @@ __device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[TM][TN], const Con
         }
         return;
     }
+    if (a.ep_coef) {
+        // inference: y = act(scale * acc + shift) straight from the fp32 accumulators (srvp_conv_desc.ep_*)
+        float sc[TN], sh[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = n0 + wn * (TN * 32) + j * 32 + lcol;
+            sc[j] = a.ep_coef[c]; sh[j] = a.ep_coef[a.Cout + c];
+        }
+        if (a.ep_act == ACT_LRELU) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float v = __builtin_fmaf(acc[i][j][r], sc[j], sh[j]); acc[i][j][r] = v > 0.f ? v : LRELU_SLOPE * v; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(__builtin_fmaf(acc[i][j][r], sc[j], sh[j]), a.ep_act);
+        }
+    }
     bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);     // [BM][LDC], reuses the A/B buffers (all waves are past the loop)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -236,8 +261,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[TM][TN], const Con
     static_assert(NT % CCH == 0 && (BM * CCH) % NT == 0, "copy-out tiling");
     constexpr int RSTEP = NT / CCH, ITER = BM * CCH / NT, G = ITER % 4 == 0 ? 4 : (ITER % 2 == 0 ? 2 : 1);
     const int ch = tid % CCH, row0 = tid / CCH;
-    const int so = a.so, ooy = a.ooy, oox = a.oox, DWp = a.DWp, Cdst = a.Cdst;
-    const size_t img = (size_t)a.DHp * DWp * Cdst;
+    // (ep_coef launches: dst is the consumer's activation tensor with an ep_border-pixel zero border around the DHp x DWp interior)
+    const int eb = a.ep_coef ? a.ep_border : 0;
+    const int so = a.so, ooy = a.ooy + eb, oox = a.oox + eb, DWp = a.DWp + 2 * eb, Cdst = a.Cdst;
+    const size_t img = (size_t)(a.DHp + 2 * eb) * DWp * Cdst;
     bf16_t* dbase = a.dst + a.cdst_off + n0 + ch * 8;
     const bf16_t* cbase = Cs + row0 * LDC + ch * 8;
     constexpr bool BNR_FITS = RSTEP * BN * 2 * 4 <= BM * LDC * 2;     // (all 256-pixel variants; the launcher sends nothing else here)
@@ -520,6 +547,7 @@ static int fill_convk(const srvp_conv_desc* d, ConvK& k) {
     k.out_f32 = d->out_f32; k.out_nc = d->out_nc; k.out_sigmoid = d->out_sigmoid;
     k.map0 = d->map0; k.dst_is_f32 = d->dst_is_f32; k.add_f32 = d->add_f32; k.add_mod = d->add_mod;
     k.bnr_raw = (const bf16_t*)d->bnr_raw; k.bnr_coef = d->bnr_coef; k.bnr_red = d->bnr_red;
+    k.ep_coef = d->ep_coef; k.ep_act = d->ep_act; k.ep_border = d->ep_border;
     return SRVP_OK;
 }
 
@@ -905,6 +933,8 @@ extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
                                  d->oox == 0 && d->cdst_off == 0 && d->Cdst == d->Cout && d->DHp == d->OH && d->DWp == d->OW && halo_variant(d) >= 256 &&
                                  (long long)d->N * d->OH * d->OW * d->Cout < (1ll << 32)),
                  "srvp_conv_mfma: bnr_red (fused BatchNorm-backward reduction) needs a plain bf16 data-gradient launch on the halo kernel");
+    SRVP_REQUIRE(!d->ep_coef || (!d->elem_f32 && !d->stats && !d->dst_is_f32 && !d->out_f32 && d->splitk <= 1 && !d->bnr_red && d->ep_act >= 0 && d->ep_act <= 4 && d->ep_border >= 0 && d->ep_border <= 1),
+                 "srvp_conv_mfma: ep_coef (eval-mode BatchNorm epilogue) needs a plain bf16 forward launch without statistics");
     if (d->elem_f32) return srvp_conv_f32_launch(d, st);
     SRVP_REQUIRE((long long)d->N * d->H0p * d->W0p * d->C0 < (1ll << 32) && (d->C1 == 0 || d->map1 || (long long)d->N * d->H1p * d->W1p * d->C1 < (1ll << 32)),
                  "srvp_conv_mfma: source tensors must have fewer than 2^32 elements");
