@@ -8,7 +8,8 @@ fixtures under tests/golden/.  The fixtures are data only; the oracle (oracle/sr
 are both checked against them.  /root/reference does not exist on the GPU box, so this script is never run there.
 
     python tests/make_golden.py            # regenerate every fixture
-    python tests/make_golden.py --full     # only the full-width fixtures; --dense: only the remove_intermediate=False ones
+    python tests/make_golden.py --full     # only the full-width fixtures; --dense: only the remove_intermediate=False ones;
+                                           # --roll2: add the well-conditioned 53-frame leg to the config-5 fixture
 """
 import argparse
 import os
@@ -487,6 +488,57 @@ def gen_dense(name, spec, srvp):
     return tuple(o[0].shape)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Second long-horizon leg of config 5: the 53-frame prediction from a WELL-CONDITIONED state, so that every
+# one of the 53 frames can be held to a tight tolerance.  At the recipe's res_gain = 1.2 the untrained residual MLP expands |y| by
+# ~1.35x per frame (7 -> 3e5 over the horizon) and with it every arithmetic difference; here: same seed, init(res_gain = 0.8)
+# (|y| 7 -> 46, the reference's own fp32 vs float64 runs agree to 3e-7 at EVERY frame), BatchNorm running statistics settled by
+# three training-mode forwards of the reference (stored in the fixture), and the output layer's weight scaled by 30 so that the
+# decoded frames of this untrained network span 0.39 .. 0.68 and move by up to 1.4e-2 per frame instead of sitting at 0.5.
+ROLL2 = {'full_c5_human_vgg': dict(nt_cond=8, nt=53, res_gain=0.8, out_scale=30.0, settle=3)}
+
+
+def roll2_state(model, ro, T, B, nc):
+    """The three training-mode forwards that settle the BatchNorm statistics + the output-layer scaling (reference model)."""
+    model.train()
+    xs = torch.from_numpy(synth_video(T, B, nc, seed=323))
+    with torch.no_grad():
+        for i in range(ro['settle']):
+            torch.manual_seed(100 + i)
+            model(xs, T, dt=0.5)
+        model.state_dict()['decoder.conv.3.1.weight'].mul_(ro['out_scale'])
+    model.eval()
+
+
+def gen_roll2(name, spec, ro, srvp):
+    torch.set_num_threads(8)
+    ctor, T, B, n_euler = spec['ctor'], spec['T'], spec['B'], spec['n_euler']
+    cfg_keys = ['nx', 'nc', 'nf', 'nhx', 'ny', 'nz', 'skipco', 'nt_inf', 'nh_inf', 'nlayers_inf', 'nh_res', 'nlayers_res', 'archi']
+    cfg = dict(zip(cfg_keys, ctor))
+    path = os.path.join(GOLDEN, name + '.npz')
+    old = np.load(path, allow_pickle=False)
+    out = {k: old[k] for k in old.files if not k.startswith('roll2.')}
+    torch.manual_seed(1)
+    model = srvp.StochasticLatentResidualVideoPredictor(*ctor)
+    model.init(res_gain=ro['res_gain'])
+    roll2_state(model, ro, T, B, cfg['nc'])
+    for k, v in model.state_dict().items():
+        if k.endswith(('running_mean', 'running_var', 'num_batches_tracked')):
+            out['roll2.bn.' + k] = v.detach().numpy().copy()
+    out['roll2.sd.checksums'] = np.array([[v.double().sum().item(), v.double().abs().sum().item()] for v in model.state_dict().values()])
+    xr = torch.from_numpy(synth_video(ro['nt_cond'], B, cfg['nc'], seed=322))
+    with torch.no_grad(), Tape() as tape:
+        o = model(xr, ro['nt'], dt=1 / n_euler)
+    ev = tape_arrays(tape, cfg, False)
+    out.update({k.replace('tape.', 'roll2.tape.'): v for k, v in ev.items()})
+    out['roll2.y'] = o[1].numpy()
+    out['roll2.x_'] = frame_samples(o[0]).numpy()
+    out['roll2.cfg'] = np.array([ro['nt_cond'], ro['nt']])
+    out['roll2.recipe'] = np.array([ro['res_gain'], ro['out_scale'], ro['settle']], np.float64)
+    np.savez_compressed(path, **out)
+    return float(o[1][-1].norm()), float(o[0].min()), float(o[0].max())
+
+
 DENSE = ['tiny_vgg_nc3_skip1_e2', 'tiny_dcgan_nc1_skip0_e2']
 
 
@@ -497,10 +549,16 @@ def main():
         for name in DENSE:
             print(f'dense_{name}: frames', gen_dense(name, TINY[name], srvp), flush=True)
         return
+    if '--roll2' in sys.argv:                              # only the second long-horizon leg, added to the existing full-width fixture
+        for name, ro in ROLL2.items():
+            print(f'{name} roll2: |y_52|, min / max decoded frame', gen_roll2(name, FULL[name], ro, srvp), flush=True)
+        return
     if '--full' in sys.argv:                               # only the full-width fixtures (minutes of CPU time)
         for name, spec in FULL.items():
             loss = gen_full(name, spec, srvp, ref_train, helper)
             print(f'{name}: loss {loss:.6f}', flush=True)
+            if name in ROLL2:
+                gen_roll2(name, spec, ROLL2[name], srvp)
         return
     for name, spec in TINY.items():
         loss = gen_one(name, spec, srvp, ref_train, helper)

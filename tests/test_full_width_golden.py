@@ -103,8 +103,76 @@ def test_oracle_vs_full_width_reference_fixture(name):
         check_rollout(fx, o[1], o[0], 1e-6)
 
 
+def roll2_model(fx):
+    """The well-conditioned long-horizon state of tests/make_golden.py (ROLL2): same-seed weights at init(res_gain = 0.8), the
+    reference's settled BatchNorm statistics from the fixture, output-layer weight x 30; checked against the reference's checksums."""
+    import srvp_amd
+    rg, out_scale, _ = (float(v) for v in fx.z['roll2.recipe'])
+    torch.manual_seed(1)
+    m = srvp_amd.StochasticLatentResidualVideoPredictor(*fx.ctor)
+    m.init(res_gain=rg)
+    sd = m.state_dict()
+    with torch.no_grad():
+        for k in fx.z.files:
+            if k.startswith('roll2.bn.'):
+                sd[k[len('roll2.bn.'):]].copy_(fx.t(k))
+        sd['decoder.conv.3.1.weight'].mul_(out_scale)
+    cs = np.array([[v.double().sum().item(), v.double().abs().sum().item()] for v in m.state_dict().values()])
+    assert np.allclose(cs, fx.z['roll2.sd.checksums'], rtol=1e-5, atol=1e-5)
+    nt_cond, nt = (int(v) for v in fx.z['roll2.cfg'])
+    xr = torch.from_numpy(synth_video(nt_cond, fx.meta['B'], fx.ctor[1], seed=322))
+    return m, xr, nt
+
+
+def check_rollout2(fx, y, x_, tol_y, tol_x, what):
+    """EVERY one of the 53 frames at ONE tolerance (no growth with t): latent states relative, decoded-frame samples absolute."""
+    yr, xr = fx.t('roll2.y'), fx.t('roll2.x_')
+    xs = frame_samples(x_.detach().float().cpu())
+    ey = [rel_l2(y[t], yr[t]) for t in range(yr.shape[0])]
+    ex = [(xs[t] - xr[t]).abs().max().item() for t in range(yr.shape[0])]
+    try:
+        from test_gpu_parity_gate import report
+        report(test='c5_rollout_53_frames_well_conditioned', what=what, max_rel_y=max(ey), max_abs_x=max(ex), y_last=ey[-1], x_last=ex[-1])
+    except Exception:
+        pass
+    assert max(ey) <= tol_y, (what, 'y', int(np.argmax(ey)), max(ey))
+    assert max(ex) <= tol_x, (what, 'x_', int(np.argmax(ex)), max(ex))
+    # the leg is not degenerate: the decoded frames span a range and move over the horizon
+    assert xr.max() - xr.min() > 0.2 and (xr[-1] - xr[8]).abs().max() > 0.02
+
+
+def test_oracle_vs_c5_rollout_every_frame():
+    """Config 5's reason to exist is the 53-frame horizon (reference test.py:237-246): the oracle reproduces the reference's prediction
+    from the well-conditioned state at 1e-5 (latent states, relative) / 1e-5 (decoded frames) at every frame."""
+    from oracle import srvp_oracle as O
+    fx = Full('full_c5_human_vgg')
+    m, xr, nt = roll2_model(fx)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        o = O.forward(sd, O.make_cfg(*fx.ctor), xr, nt, fx.meta['n_euler'], fx.tape('roll2.tape.'), training=False)
+    check_rollout2(fx, o[1], o[0], 1e-5, 1e-5, 'oracle')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_hip_c5_rollout_every_frame(precision):
+    """The HIP path on the same leg, EVERY frame at one tolerance (VERDICT r3 item 6 asked for <= 1e-3 / <= 3e-2): fp32 mode 2e-5
+    (latent states, relative) / 1e-5 (decoded frames) -- measured 2.3e-6 / 5.4e-7 --, production bf16 1e-3 / 5e-3 -- measured
+    1.5e-4 / 1.3e-3.  No tolerance grows with the frame index."""
+    fx = Full('full_c5_human_vgg')
+    m, xr, nt = roll2_model(fx)
+    m = m.cuda().eval().set_precision(precision)
+    o = m(xr.cuda(), nt, dt=1 / fx.meta['n_euler'], tape=fx.tape('roll2.tape.'))
+    if precision == 'fp32':
+        check_rollout2(fx, o[1], o[0], 2e-5, 1e-5, 'hip fp32')
+    else:
+        check_rollout2(fx, o[1], o[0], 1e-3, 5e-3, 'hip bf16')
+
+
 def check_rollout(fx, y, x_, eps0):
-    """53-frame prediction at res_gain = 1.2: the untrained residual MLP expands |y| by ~1.3x per frame, and so it expands any
+    """(The documented ILL-CONDITIONED leg; the every-frame check is check_rollout2 on the well-conditioned leg above.)
+    53-frame prediction at res_gain = 1.2: the untrained residual MLP expands |y| by ~1.3x per frame, and so it expands any
     arithmetic difference: the fp32 reference run twice with different summation orders agrees to eps0 * 1.35^t at frame t.
     The latent states are therefore held to a tolerance that grows at that rate, the decoded frames (saturating sigmoid of
     logits that scale with |y|) to the matching absolute band."""
