@@ -103,6 +103,13 @@ typedef struct {
     const float* ep_coef; int32_t ep_act, ep_border;
 } srvp_conv_desc;
 int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
+/* Image-side OUTPUT layer of the VGG decoder (conv.py:353 + 273-274: ConvTranspose2d(64 -> nc <= 3, 3x3, stride 1, pad 1) + sigmoid) as a
+ * streaming kernel (csrc/conv_out.hip): act = bf16 [N][66][66][64] (1-pixel zero border), wt_tapmajor = bf16 [9][32][64] (srvp_pack_desc
+ * layout 0 of the block's forward weights, Cout padded to 32), out = fp32 (N, Cout_real, 64, 64).  One persistent workgroup per CU walks
+ * whole images with a rolling LDS window of input rows: every activation byte crosses HBM -> LDS once.  srvp_conv_out_eligible: 1 if
+ * the geometry is the one this kernel covers (SRVP_CONV_OUT_STREAM=0 switches it off: the layer then runs through srvp_conv_mfma). */
+int srvp_conv_out_eligible(int C0, int H, int W, int Cout_real, int k, int s, int p);
+int srvp_conv_out_fwd(const void* act, const void* wt_tapmajor, float* out, int N, int Cout_real, int sigmoid, void* stream);
 /* 1 (default): 3x3 stride-1 single-source convolutions run on the halo-tiled kernel (input patch staged in LDS once
  * per channel chunk, taps = LDS offsets); 0: every convolution on the generic tap-gather kernel.  Same results, bit for bit. */
 int srvp_conv_set_halo(int on);

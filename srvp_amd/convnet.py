@@ -372,12 +372,21 @@ class Block:
         self.pf = _pack_desc(order_f, co_p, self.ctot, osegs, isegs, sj_f, sk_f)
         self.pd = _pack_desc(order_d, self.ctot, co_p, isegs, osegs, sk_f, sj_f)
         self.pu = _pack_desc(nat, co_p, self.ctot, osegs, isegs, sj_f, sk_f)
+        # image-side output layer on the streaming kernel (csrc/conv_out.hip): a tap-major copy [9][32][64] of its forward weights
+        self.stream_out = bool(self.role == 'out' and self.geom == 'sameT' and not self.f32 and len(self.srcs) == 1 and co_p == 32 and
+                               L.load().srvp_conv_out_eligible(self.ctot, self.OH, self.OW, co_r, self.k, self.s, self.p))
+        if self.stream_out:
+            self.pf_o = _pack_desc(order_f, co_p, self.ctot, osegs, isegs, sj_f, sk_f)
+            self.pf_o.layout = 0
+            self.wt_o = torch.empty(kk, co_p, self.ctot, dtype=self.adt, device=dev)
         self.wt_f = torch.empty(kk, co_p, self.ctot, dtype=self.adt, device=dev)
         self.wt_d = torch.empty(kk, self.ctot, co_p, dtype=self.adt, device=dev) if self.training else None
 
     def pack_jobs(self, w):
         """[(fp32 source pointer, packed destination tensor, pack descriptor)] of this block's weight buffers."""
         jobs = [(L.ptr(w), self.wt_f, d) for d in self.pf_ph] if self.s2d_in else [(L.ptr(w), self.wt_f, self.pf)]
+        if getattr(self, 'stream_out', False):
+            jobs.append((L.ptr(w), self.wt_o, self.pf_o))
         if self.wt_d is not None and self.s2d:
             jobs += [(L.ptr(w), self.wt_d, d) for d in self.pd_ph]
         elif self.wt_d is not None:
@@ -398,6 +407,8 @@ class Block:
     def pack(self, w, st):
         for d in (self.pf_ph if self.s2d_in else [self.pf]):
             L.call('srvp_pack_weight', L.ptr(w), L.ptr(self.wt_f), C.byref(d), st)
+        if getattr(self, 'stream_out', False):
+            L.call('srvp_pack_weight', L.ptr(w), L.ptr(self.wt_o), C.byref(self.pf_o), st)
         if self.wt_d is not None and self.s2d:
             for d in self.pd_ph:
                 L.call('srvp_pack_weight', L.ptr(w), L.ptr(self.wt_d), C.byref(d), st)
@@ -1374,8 +1385,13 @@ class DecoderNet(ConvNetBase):
         for blk in self.blocks[:-1]:
             self._block_forward(blk, params, st, sync)
         self._skips_done = False
-        # image-side output layer: MFMA conv with Cout padded to 32, sigmoid + fp32 frame store in the epilogue
-        for d in self.blocks[-1]._fwd:
+        ob = self.blocks[-1]
+        if getattr(ob, 'stream_out', False):
+            # image-side output layer on the streaming kernel: rolling LDS row window, packed-bf16 dot products, sigmoid + fp32 frames
+            L.call('srvp_conv_out_fwd', L.ptr(ob.srcs[0].t), L.ptr(ob.wt_o), L.ptr(self.x_out), self.N, ob.cout_r, 1, st)
+            return self.x_out
+        # (other geometries: MFMA conv with Cout padded to 32, sigmoid + fp32 frame store in the epilogue)
+        for d in ob._fwd:
             L.call('srvp_conv_mfma', C.byref(d), st)
         return self.x_out
 
