@@ -15,6 +15,7 @@
 #include "../../include/srvp_hip.h"
 
 int srvp_conv_f32_launch(const srvp_conv_desc* d, hipStream_t st);     // conv_f32.hip (precision = 'fp32' parity mode)
+int srvp_conv_stream64_launch(const srvp_conv_desc* d, hipStream_t st, int* taken);     // conv_stream.hip (64 -> 64 channels at 64x64: streaming kernel)
 
 namespace {
 
@@ -938,6 +939,11 @@ extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
     if (d->elem_f32) return srvp_conv_f32_launch(d, st);
     SRVP_REQUIRE((long long)d->N * d->H0p * d->W0p * d->C0 < (1ll << 32) && (d->C1 == 0 || d->map1 || (long long)d->N * d->H1p * d->W1p * d->C1 < (1ll << 32)),
                  "srvp_conv_mfma: source tensors must have fewer than 2^32 elements");
+    {
+        int taken = 0;
+        if (int rc = srvp_conv_stream64_launch(d, st, &taken)) return rc;
+        if (taken) return SRVP_OK;
+    }
     if (const int v = halo_variant(d)) return launch_halo_any(d, 1, v, st);
     SRVP_REQUIRE(d->tap_phase_chunks == 0, "srvp_conv_mfma: tap_phase_chunks launches run on the halo kernel only, and this descriptor is not eligible for it");
     const bool k64 = (d->C0 % 64 == 0) && (d->C1 % 64 == 0);

@@ -99,7 +99,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // when only the younger groups' pieces are outstanding (9 per group for wave 0, 8 for the others)
         if (b + 3 <= b1) stage(b + 3);
         const int younger = (b + 3 <= b1 ? b + 3 : b1) - (b + 1);
-        if (younger >= 2) { if (wid == 0) __builtin_amdgcn_s_waitcnt(0x4F70 | 2); else __builtin_amdgcn_s_waitcnt(0x4F70); }       // vmcnt(18) / vmcnt(16)
+        // (+ 4 from the second band on: the previous band's four frame stores were issued after group b + 1 -- vmcnt counts stores too
+        // and retires in order, so a count without them makes every band wait for the store acknowledgements)
+        if (b > b0) {
+            if (younger >= 2) { if (wid == 0) __builtin_amdgcn_s_waitcnt(0x4F70 | 6); else __builtin_amdgcn_s_waitcnt(0x4F70 | 4); }   // vmcnt(22) / (20)
+            else if (younger == 1) { if (wid == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | 13); else __builtin_amdgcn_s_waitcnt(0x0F70 | 12); }
+            else __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+        } else if (younger >= 2) { if (wid == 0) __builtin_amdgcn_s_waitcnt(0x4F70 | 2); else __builtin_amdgcn_s_waitcnt(0x4F70); }     // vmcnt(18) / (16)
         else if (younger == 1) { if (wid == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | 9); else __builtin_amdgcn_s_waitcnt(0x0F70 | 8); }
         else __builtin_amdgcn_s_waitcnt(0x0F70);
         __builtin_amdgcn_s_barrier();
