@@ -243,6 +243,8 @@ int srvp_conv_in_fwd(const float* x, const float* w, void* raw, double* stats,
  * producer's BatchNorm-backward sums accumulated in the same launch: bnr_raw / bnr_coef / bnr_red as in srvp_conv_desc.bnr_*. */
 int srvp_conv_in_fwd_bnr(const float* x, const float* w, void* raw, int N, int Cin, int H, int W, int Cout, int Cout_real, int k, int s,
                          int p, const void* bnr_raw, const float* bnr_coef, double* bnr_red, void* stream);
+/* 1 if srvp_conv_in_fwd_bnr serves this shape (3x3 stride 1 on 64x64 frames, Cout 32 / 64, MFMA image-side kernels enabled) */
+int srvp_conv_in_fwd_bnr_ok(int Cin, int H, int W, int Cout, int k, int s, int p);
 int srvp_conv_in_wgrad(const float* x, const void* draw, float* dw,
                        int N, int Cin, int H, int W, int Cout, int Cout_real, int k, int s, int p, void* stream);
 /* fp32 parity mode: raw / draw are fp32 NHWC tensors (direct fp32 kernels: an fmaf chain in (ci, kh, kw) order) */
@@ -389,6 +391,10 @@ typedef struct {
 int srvp_rollout_fwd(const srvp_rollout_desc* d, void* stream);
 /* bytes of fused_ws the persistent kernels need for this chain, 0 if it must run unfused (dimensions / LDS budget / mode) */
 int64_t srvp_rollout_fused_ws_bytes(const srvp_rollout_desc* d);
+/* Cluster-barrier timeouts of the persistent latent kernels since the library was loaded (a cluster whose workgroups were not
+ * co-resident gives up after a bounded spin and leaves garbage behind): copied to pinned host memory in stream order; the host polls
+ * it every few steps and raises if it is non-zero. */
+int srvp_cluster_timeouts_read(unsigned* host_word, void* stream);
 typedef struct {
     srvp_rollout_desc f;
     const float* d_y_all;                  /* [nsteps+1][B][ny] gradient wrt every stored state (zeros where unused) */

@@ -108,6 +108,7 @@ _SIGS = {
     'srvp_bn_bwd_apply': ([C.POINTER(BnBwdDesc), c_vp, c_vp, c_i32, c_vp], c_i32),
     'srvp_conv_in_fwd': ([c_vp, c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp], c_i32),
     'srvp_conv_in_fwd_bnr': ([c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp, c_vp, c_vp, c_vp], c_i32),
+    'srvp_conv_in_fwd_bnr_ok': ([c_i32] * 7, c_i32),
     'srvp_conv_in_wgrad': ([c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp], c_i32),
     'srvp_conv_in_fwd_f32': ([c_vp, c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp], c_i32),
     'srvp_conv_in_wgrad_f32': ([c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp], c_i32),
@@ -117,6 +118,7 @@ _SIGS = {
     'srvp_pack_weight_multi': ([c_vp, c_i32, c_i64, c_vp], c_i32),
     'srvp_unpack_wgrad_multi': ([c_vp, c_i32, c_i64, c_vp], c_i32),
     'srvp_pack_job_wgs': ([c_i64], c_i32),
+    'srvp_cluster_timeouts_read': ([c_vp, c_vp], c_i32),
     'srvp_pack_job_tiles': ([C.POINTER(PackDesc), c_i32], c_i32),
     'srvp_conv_out_eligible': ([c_i32] * 7, c_i32),
     'srvp_conv_out_fwd': ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),

@@ -1453,7 +1453,8 @@ class DecoderNet(ConvNetBase):
                 on_side(lambda s_: self._out_wgrad_f32(grads, s_))
             prod = self.blocks[-2] if len(self.blocks) > 1 else None
             fuse = (BN_FUSED_REDUCE and not self.f32 and prod is not None and prod.out is ob.srcs[0] and prod.has_bn and prod.act == L.ACT_LRELU
-                    and (ob.k, ob.s, ob.p) == (3, 1, 1) and tuple(prod.raw.shape) == tuple(ob.dcat.shape))
+                    and (ob.k, ob.s, ob.p) == (3, 1, 1) and tuple(prod.raw.shape) == tuple(ob.dcat.shape)
+                    and bool(L.load().srvp_conv_in_fwd_bnr_ok(ob.cout_r, 64, 64, ob.ctot, ob.k, ob.s, ob.p)))
             if fuse:
                 # ... with the BatchNorm-backward sums of the producer block accumulated in the same launch (_fuse_bn_reduce)
                 L.call('srvp_conv_in_fwd_bnr', L.ptr(self.dpre_f32), L.ptr(params[ob.spec['key'] + '.weight']), L.ptr(ob.dcat), self.N, ob.cout_r, 64, 64,

@@ -50,6 +50,10 @@ __device__ __forceinline__ int sw(int k, int c) { return (k >> 1) * 64 + ((((k &
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Timeouts of the bounded spin below, over the lifetime of the library (the per-launch counter blocks are wiped by the next launch):
+// the host reads it through srvp_cluster_timeouts_read once in a while and refuses to go on if it is non-zero.
+__device__ unsigned g_cluster_timeouts = 0;
+
 __device__ __forceinline__ void cluster_barrier(unsigned* cnt, unsigned target) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's agent-scope stores have been acknowledged
     __syncthreads();
@@ -61,7 +65,11 @@ __device__ __forceinline__ void cluster_barrier(unsigned* cnt, unsigned target) 
         unsigned spins = 0;
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 25)) { __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (++spins > (1u << 25)) {
+                __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&g_cluster_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
         }
     }
     __syncthreads();
@@ -819,5 +827,14 @@ extern "C" int srvp_lstm_bwd_fused(const float* dh_out, const float* w_hh, const
         hipLaunchKernelGGL(kern, dim3(8 * cpx * k.G), dim3(256), lds, st, k);
     }
     SRVP_CHECK_LAUNCH("srvp_lstm_bwd_fused");
+    return SRVP_OK;
+}
+
+// Number of cluster-barrier timeouts since the library was loaded (0 = every persistent latent kernel -- fused rollout forward / backward,
+// LSTM forward / backward -- ran with its workgroups co-resident), copied to `host_word` (pinned host memory) in stream order.
+extern "C" int srvp_cluster_timeouts_read(unsigned* host_word, void* stream) {
+    SRVP_REQUIRE(host_word, "srvp_cluster_timeouts_read: null pointer");
+    hipError_t e = hipMemcpyFromSymbolAsync(host_word, HIP_SYMBOL(g_cluster_timeouts), sizeof(unsigned), 0, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_cluster_timeouts_read: %s", hipGetErrorString(e));
     return SRVP_OK;
 }

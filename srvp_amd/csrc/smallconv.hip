@@ -663,6 +663,10 @@ extern "C" int srvp_conv_in_fwd(const float* x, const float* w, void* raw, doubl
 
 // srvp_conv_in_fwd as the data gradient of the image-side OUTPUT layer (x = gradient frames, w = the ConvTranspose weight read as
 // (O, I, k, k), raw = dA of the producer block) with that block's BatchNorm-backward sums fused in (see srvp_conv_desc.bnr_*)
+// 1 if srvp_conv_in_fwd_bnr serves this shape (the MFMA image-side kernel: SRVP_CONV_IN_MFMA switch included) -- the host asks before it
+// drops the producer's separate srvp_bn_bwd_reduce launch
+extern "C" int srvp_conv_in_fwd_bnr_ok(int Cin, int H, int W, int Cout, int k, int s, int p) { return in_mfma_ok(Cin, H, W, Cout, k, s, p) && s == 1 && k == 3 ? 1 : 0; }
+
 extern "C" int srvp_conv_in_fwd_bnr(const float* x, const float* w, void* raw, int N, int Cin, int H, int W, int Cout, int Cout_real, int k, int s,
                                     int p, const void* bnr_raw, const float* bnr_coef, double* bnr_red, void* stream) {
     SRVP_REQUIRE(x && w && raw && bnr_raw && bnr_coef && bnr_red, "srvp_conv_in_fwd_bnr: null pointer");

@@ -82,6 +82,27 @@ def fused_step(model, x, opt, tape=None):
     return acc
 
 
+def _poll_cluster_timeouts(model, every=32):
+    """Every `every` steps (and on the first): the library's count of cluster-barrier timeouts in the persistent latent kernels, as it
+    stood when it was last copied -- no extra host sync: the word is read back in stream order into pinned memory and looked at one
+    poll later.  Non-zero = some launch ran with workgroups that were not co-resident and left garbage behind: stop, do not train on it."""
+    n = model.__dict__.get('_ct_step', 0)
+    model.__dict__['_ct_step'] = n + 1
+    if n % every:
+        return
+    host = model.__dict__.get('_ct_host')
+    if host is None:
+        host = model.__dict__['_ct_host'] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        model.__dict__['_ct_event'] = None
+    ev = model.__dict__['_ct_event']
+    if ev is not None and ev.query() and int(host[0]) != 0:
+        raise L.SrvpHipError(f'{int(host[0])} cluster-barrier timeout(s) in the persistent latent kernels (workgroups of a cluster were not '
+                             'co-resident): results since then are invalid; set SRVP_ROLLOUT_FUSED=0 SRVP_LSTM_BWD_FUSED=0')
+    L.call('srvp_cluster_timeouts_read', host.data_ptr(), L.stream())
+    ev = model.__dict__['_ct_event'] = torch.cuda.Event()
+    ev.record()
+
+
 def train(forward_fn, optimizer, scaler, batch, device, opt):
     """
     One optimisation step (reference train.py:49-129): returns (loss, nll, kl_y_0, kl_z) as python floats, all
@@ -101,6 +122,7 @@ def train(forward_fn, optimizer, scaler, batch, device, opt):
     n = x.shape[1]
     acc = fused_step(model, x, opt)
     optimizer.step()
+    _poll_cluster_timeouts(model)
     model._elbo_event.synchronize()                     # the step's single host sync: waits for the forward + ELBO only
     nll, kl_y_0, kl_z, l2 = model._elbo_host.tolist()
     loss = nll + opt.beta_y * kl_y_0 + opt.beta_z * kl_z
@@ -283,6 +305,9 @@ def main(opt):
         gen = getattr(train_loader, 'gen', None)
         if gen is not None and hasattr(gen, 'counter'):
             gen.counter = itr          # device Moving-MNIST generator: batch k is a function of (seed, k) -- continue the same data stream
+        vgen = getattr(val_loader, 'gen', None) if val_loader is not None else None
+        if vgen is not None and hasattr(vgen, 'counter'):
+            vgen.counter = (itr // opt.val_interval) * opt.n_iter_test      # ... and the validation stream where the validations so far left it
     # the plans / descriptor tables built by the first steps are long-lived: keep them out of the cyclic collector's generations
     # (a full collection over them is a ~90 ms host stall, several steps' worth at the small configurations)
     import gc
