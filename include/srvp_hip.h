@@ -395,6 +395,19 @@ int64_t srvp_rollout_fused_ws_bytes(const srvp_rollout_desc* d);
  * co-resident gives up after a bounded spin and leaves garbage behind): copied to pinned host memory in stream order; the host polls
  * it every few steps and raises if it is non-zero. */
 int srvp_cluster_timeouts_read(unsigned* host_word, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Deterministic mode of the fp32 parity mode (elem_f32 launches): the reference's CPU path is bit-reproducible run to run; with this
+ * switch on, so is the parity mode.  Every cross-workgroup sum that is otherwise formed with atomics in arrival order -- the
+ * BatchNorm-backward sums, the image-side weight gradient, the latent weight gradients (single split), the ELBO accumulators (single
+ * workgroup) -- is formed in a fixed order; the BatchNorm FORWARD statistics are not taken in the convolution epilogues (pass
+ * stats = NULL) but by srvp_bn_stats_f32_det from the stored fp32 raw output (= the accumulators).  `workspace`: >= 8 MiB of device
+ * memory owned by the caller for the per-workgroup partial sums; all launches from one stream while the mode is on.  Process-wide.
+ * ------------------------------------------------------------------------------------------------ */
+int srvp_set_deterministic(int on, void* workspace, int64_t workspace_bytes);
+int srvp_get_deterministic(void);
+/* stats[0][c] += sum_r raw[r][c], stats[1][c] += sum_r raw[r][c]^2 over the rows of an fp32 tensor [rows][C], fp64, fixed order */
+int srvp_bn_stats_f32_det(const float* raw, int64_t rows, int C, double* stats, void* stream);
 typedef struct {
     srvp_rollout_desc f;
     const float* d_y_all;                  /* [nsteps+1][B][ny] gradient wrt every stored state (zeros where unused) */

@@ -119,6 +119,9 @@ _SIGS = {
     'srvp_unpack_wgrad_multi': ([c_vp, c_i32, c_i64, c_vp], c_i32),
     'srvp_pack_job_wgs': ([c_i64], c_i32),
     'srvp_cluster_timeouts_read': ([c_vp, c_vp], c_i32),
+    'srvp_set_deterministic': ([c_i32, c_vp, c_i64], c_i32),
+    'srvp_get_deterministic': ([], c_i32),
+    'srvp_bn_stats_f32_det': ([c_vp, c_i64, c_i32, c_vp, c_vp], c_i32),
     'srvp_pack_job_tiles': ([C.POINTER(PackDesc), c_i32], c_i32),
     'srvp_conv_out_eligible': ([c_i32] * 7, c_i32),
     'srvp_conv_out_fwd': ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),

@@ -20,6 +20,7 @@ CP = 32                      # channel padding granule
 SUBPIX = os.environ.get('SRVP_SUBPIX', '1') != '0'
 S2D = os.environ.get('SRVP_SUBPIX_S2D', '1') != '0'
 WGRAD_HALO2 = os.environ.get('SRVP_WGRAD_HALO2', '1') != '0'  # sub-pixel weight gradients: one 16-tap launch, two phases per workgroup on the halo kernel
+DETERMINISTIC = False       # set by model.set_deterministic (fp32 parity mode only): fixed-order BatchNorm statistics / weight-gradient sums
 EVAL_FOLD = os.environ.get('SRVP_EVAL_FOLD', '1') != '0'      # inference: eval-mode BatchNorm + activation in the conv epilogue (no raw tensor, no bn_act pass)
 PACK_TILES = os.environ.get('SRVP_PACK_TILES', '1') != '0'      # 0: every pack / unpack job through the multi kernels (A/B)
 BN_FUSED_FINALIZE = os.environ.get('SRVP_BN_FUSED_FINALIZE', '1') != '0'    # bn_finalize / bn_bwd_finalize folded into bn_act / bn_bwd_apply
@@ -501,7 +502,7 @@ class Block:
         d.si, d.wt, d.Cout = 1, L.ptr(self.wt_f), self.cout
         d.N, d.OH, d.OW = self.N, self.OH, self.OW
         d.dst, d.DHp, d.DWp, d.so, d.ooy, d.oox, d.Cdst, d.cdst_off = L.ptr(self.raw), self.OH, self.OW, 1, 0, 0, self.cout, 0
-        use_stats = self.has_bn and self.training
+        use_stats = self.has_bn and self.training and not (DETERMINISTIC and self.f32)     # (deterministic mode: srvp_bn_stats_f32_det on the stored raw output)
         d.stats, d.stat_mod = (L.ptr(self.stats) if use_stats else None), self.cout
         d.out_f32, d.out_nc, d.out_sigmoid = None, 0, 0
         d.wt_fragmajor, d.elem_f32 = 1, 0
@@ -525,7 +526,7 @@ class Block:
     def _fwd_descs_raw(self):
         k, N = self.k, self.N
         out = []
-        use_stats = self.has_bn and self.training
+        use_stats = self.has_bn and self.training and not (DETERMINISTIC and self.f32)     # (deterministic mode: srvp_bn_stats_f32_det on the stored raw output)
         b_in = self.srcs[0].b
         frame_out = self.role == 'out'
         dst_ptr = None if frame_out else L.ptr(self.raw)
@@ -957,6 +958,8 @@ class Block:
         tiles = (self.cout // bj) * (ctot // bc) * d.ntaps
         chunks = (M + 31) // 32
         d.splitk = int(max(1, min((1024 + tiles - 1) // tiles, chunks // 4 if chunks >= 4 else 1)))
+        if DETERMINISTIC and self.f32:
+            d.splitk = 1          # one workgroup per weight tile: a single atomic per element, nothing arrives in a varying order
         return d
 
 
@@ -1005,6 +1008,9 @@ class ConvNetBase:
             rm, rv, nbt = params[bk + '.running_mean'], params[bk + '.running_var'], params.get(bk + '.num_batches_tracked')
             if blk.training:
                 count = float(N * blk.OH * blk.OW)
+                if DETERMINISTIC and blk.f32:
+                    # the statistics in a fixed summation order, from the stored fp32 raw output (= the accumulators, unrounded)
+                    L.call('srvp_bn_stats_f32_det', L.ptr(blk.raw), blk.raw.numel() // C_, C_, L.ptr(blk.stats), st)
                 if sync is not None:
                     count = sync.allreduce_stats(blk.stats, count, site=(bk, 'f'))
                 blk.count = count
@@ -1027,7 +1033,7 @@ class ConvNetBase:
         if blk.role == 'in':
             w = params[blk.spec['key'] + '.weight']
             L.call('srvp_conv_in_fwd_f32' if blk.f32 else 'srvp_conv_in_fwd', L.ptr(x), L.ptr(w), L.ptr(blk.raw),
-                   L.ptr(blk.stats) if (blk.has_bn and blk.training) else None,
+                   L.ptr(blk.stats) if (blk.has_bn and blk.training and not (DETERMINISTIC and blk.f32)) else None,
                    blk.N, blk.cin_r[0], 64, 64, blk.cout, blk.cout_r, blk.k, blk.s, blk.p, st)
         elif getattr(blk, '_ep', False):
             skip_s = blk.split and getattr(self, '_skips_done', False)

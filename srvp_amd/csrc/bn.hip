@@ -180,6 +180,7 @@ struct BnBwdK {
     int N, H, W, C;
     void* tsum; int tsum_T;        // apply: also write the sum over the T time steps of each sample (frames are t*B + b)
     int s2d;                         // apply: draw is written space-to-depth [N][H/2+2][W/2+2][4C] (border 1)
+    int det;                         // reduce: `red` is the slab [workgroup][2][C] of the deterministic two-launch form
 };
 
 // element offset of pixel (n, y, x), channel group cg in the gradient tensor `draw`
@@ -436,7 +437,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdK a, doub
         double s = 0.;
         for (int l = 0; l < PPB; ++l) s += sred[l * CG + c][k];
         int ch = c * 8 + (k & 7);
-        atomicAdd(red + (k >> 3) * a.C + ch, s);
+        if (a.det) red[(size_t)blockIdx.x * 2 * a.C + (k >> 3) * a.C + ch] = s;       // (every workgroup writes all 2 C values)
+        else atomicAdd(red + (k >> 3) * a.C + ch, s);
     }
 }
 
@@ -777,13 +779,24 @@ extern "C" int srvp_bn_bwd_reduce(const srvp_bnbwd_desc* d, double* red, void* s
     // leaves fewer than 64 workgroups (the 1x1 encoder output: 3 workgroups walked 2304 rows in 100 us of dependent loads)
     int rows = k.da_mode == 2 ? 16 : 64;
     while (rows > 4 && P / ((long long)PPB * rows) < 64) rows /= 2;
-    const dim3 g(grid_for(P, PPB * rows));
+    dim3 g(grid_for(P, PPB * rows));
     const bool lr = k.act_kind == ACT_LRELU;
+    double* red_out = red;
+    k.det = 0;
+    if (g_srvp_det && d->elem_f32) {
+        // deterministic mode: at most 256 workgroups (the kernel strides over the pixels), partial sums into the workspace, added up in
+        // workgroup order by a second launch
+        SRVP_REQUIRE(g_srvp_det_ws && 256ll * 2 * k.C * 8 <= g_srvp_det_ws_bytes, "srvp_bn_bwd_reduce: deterministic workspace too small");
+        if (g.x > 256) g.x = 256;
+        k.det = 1;
+        red = (double*)g_srvp_det_ws;
+    }
     if (d->elem_f32) {
         auto kern = k.da_mode == 0 ? (lr ? bn_bwd_reduce_kernel<float, 0, ACT_LRELU> : bn_bwd_reduce_kernel<float, 0, -1>)
                   : k.da_mode == 1 ? (lr ? bn_bwd_reduce_kernel<float, 1, ACT_LRELU> : bn_bwd_reduce_kernel<float, 1, -1>)
                                    : (lr ? bn_bwd_reduce_kernel<float, 2, ACT_LRELU> : bn_bwd_reduce_kernel<float, 2, -1>);
         hipLaunchKernelGGL(kern, g, dim3(256), 0, (hipStream_t)stream, k, red);
+        if (k.det) hipLaunchKernelGGL(det_sum_kernel<double>, dim3((2 * k.C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)red, (int)g.x, 2 * k.C, red_out);
         SRVP_CHECK_LAUNCH("srvp_bn_bwd_reduce(f32)");
         return SRVP_OK;
     }

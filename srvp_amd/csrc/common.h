@@ -117,6 +117,22 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// ---- deterministic mode (srvp_set_deterministic / SRVP_DETERMINISTIC=1; precision = 'fp32' only): every cross-workgroup sum that the
+// default build forms with atomics in arrival order is formed in a FIXED order instead -- workgroups write their partial sums into
+// slab[workgroup][n] of a caller-provided workspace and a second tiny launch adds them up in workgroup order -- or by a single
+// workgroup / a single split (one atomic per destination element onto a value that only stream order precedes).
+extern int g_srvp_det;                 // util.hip
+extern void* g_srvp_det_ws;            // caller-owned device workspace
+extern long long g_srvp_det_ws_bytes;
+template <class T>
+__global__ void det_sum_kernel(const T* __restrict__ slab, int nwg, int n, T* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    T acc = 0;
+    for (int w = 0; w < nwg; ++w) acc += slab[(size_t)w * n + i];
+    dst[i] += acc;
+}
+
 // ---- error reporting across the C ABI (no exceptions cross it) ----
 void srvp_set_error(const char* fmt, ...);
 #define SRVP_CHECK_LAUNCH(name)                                                         \

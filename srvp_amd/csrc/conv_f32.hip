@@ -266,7 +266,7 @@ int srvp_wgrad_f32_launch(const srvp_wgrad_desc* d, hipStream_t st) {
     const long long tiles = (long long)d->ntaps * (d->Cout / 32) * ((d->C0 + d->C1) / 32);
     long long sk = (2048 + tiles - 1) / tiles;          // enough workgroups to fill the chip
     if (sk > nchunks) sk = nchunks;
-    if (sk < 1) sk = 1;
+    if (sk < 1 || g_srvp_det) sk = 1;                   // deterministic mode: one workgroup per weight tile = one atomic per element
     k.splitk = (int)sk;
     const long long blocks = tiles * sk;
     SRVP_REQUIRE(blocks > 0 && blocks < (1ll << 31), "srvp_wgrad_mfma(fp32): bad grid %lld", blocks);

@@ -203,7 +203,7 @@ int gemm(hipStream_t st, const float* A, long long a_rs, long long a_cs, const f
         int splits = (int)((768 + tiles - 1) / tiles);
         const int maxs = (K + 63) / 64;
         if (splits > maxs) splits = maxs;
-        if (splits < 1) splits = 1;
+        if (splits < 1 || g_srvp_det) splits = 1;           // deterministic mode: one split = one atomic per element, onto what stream order left there
         int kper = ((K + splits - 1) / splits + 31) / 32 * 32;
         splits = (K + kper - 1) / kper;
         const dim3 grid((N + 63) / 64, (M + 63) / 64, splits);
@@ -214,7 +214,8 @@ int gemm(hipStream_t st, const float* A, long long a_rs, long long a_cs, const f
         return SRVP_OK;
     }
     if (colsum) {                                          // (small K: the column sums as their own launch)
-        hipLaunchKernelGGL(colsum_kernel, dim3((M + 63) / 64, (K + 127) / 128), dim3(256), 0, st, A, a_cs, colsum, K, M, 128);
+        const int rpb_c = g_srvp_det ? K : 128;           // (deterministic mode: one row slice per column block)
+        hipLaunchKernelGGL(colsum_kernel, dim3((M + 63) / 64, (K + rpb_c - 1) / rpb_c), dim3(256), 0, st, A, a_cs, colsum, K, M, rpb_c);
     }
     GemmArgs g{A, a_rs, a_cs, B, b_rs, b_cs, bias, C, c_rs, mask, mask_rs, M, N, K, act, accumulate, alpha};
     dim3 grid((N + 31) / 32, (M + 31) / 32);
@@ -593,7 +594,7 @@ extern "C" int srvp_colsum_f32(const float* A, int64_t a_rs, float* out, int M, 
         hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * N, (hipStream_t)stream);
         SRVP_REQUIRE(e == hipSuccess, "srvp_colsum_f32: memset failed");
     }
-    const int rpb = 128;
+    const int rpb = g_srvp_det ? (M > 0 ? M : 1) : 128;
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, A, (long long)a_rs,
                        out, M, N, rpb);
     SRVP_CHECK_LAUNCH("srvp_colsum_f32");

@@ -85,8 +85,9 @@ __device__ __forceinline__ void job_args(const srvp_pack_job& j, PackArgs& a) {
 // = (j, eight consecutive k), lanes along j.  The fp32 tensor keeps its taps innermost, so an item's reads / read-modify-writes
 // are runs of `source taps` consecutive floats (re-touched over the tap loop: L1/L2 hits) instead of 4-byte accesses 36
 // bytes apart, and the packed side moves as whole 16-byte (pack) / 32-byte (unpack) vectors.
-__host__ __device__ __forceinline__ bool vec_ok(const srvp_pack_desc& d) {
-    if (d.K % 8 != 0 || d.dst_f32) return false;
+// (dst_f32 describes the PACKED WEIGHT tensor of a pack job; an unpack job reads the fp32 gradient whatever it says: ignore_f32)
+__host__ __device__ __forceinline__ bool vec_ok(const srvp_pack_desc& d, bool ignore_f32 = false) {
+    if (d.K % 8 != 0 || (d.dst_f32 && !ignore_f32)) return false;
     for (int t = 0; t < d.ntaps; ++t)
         if (d.tap_set[t] == 0 ? (d.tap_off[t] < 0 || d.tap_off[t] >= 16) : (d.tap_set[t] >> 16) != 0) return false;
     return true;
@@ -137,8 +138,8 @@ __device__ __forceinline__ const srvp_pack_job* locate_job(const srvp_pack_job* 
 // lines per wave instruction there and sustains 0.3-0.8 TB/s); the packed side moves as 16- / 32-byte pieces; the transposition
 // between the two happens in LDS.  Same values and the same summation order as the paths above.
 constexpr int PT_OUT = 8, PT_INN = 64;
-__host__ __device__ __forceinline__ bool tile_ok(const srvp_pack_desc& d, int& TS, bool& inner_k) {
-    if (!vec_ok(d)) return false;
+__host__ __device__ __forceinline__ bool tile_ok(const srvp_pack_desc& d, int& TS, bool& inner_k, bool ignore_f32 = false) {
+    if (!vec_ok(d, ignore_f32)) return false;
     inner_k = d.sk < d.sj;
     const long long ts = inner_k ? d.sk : d.sj;
     if (ts < 1 || ts > 16) return false;
@@ -305,10 +306,10 @@ __device__ void unpack_job_tiled(const srvp_pack_job& j, unsigned wg, unsigned n
 constexpr int LT_FLOATS = 4640;
 struct LeanGeo { int TS, JT, KT; bool inner_k; };
 __host__ __device__ inline bool lean_geo(const srvp_pack_desc& d, bool unpack, LeanGeo& g) {
-    if (!tile_ok(d, g.TS, g.inner_k)) return false;
+    if (!tile_ok(d, g.TS, g.inner_k, unpack)) return false;
     if (!unpack) { g.JT = g.TS <= 9 ? 32 : 16; g.KT = 16; }
     else { g.JT = g.TS <= 9 ? 16 : 8; g.KT = 32; }
-    if (d.J % g.JT != 0 || d.K % g.KT != 0 || d.dst_f32) return false;
+    if (d.J % g.JT != 0 || d.K % g.KT != 0 || (d.dst_f32 && !unpack)) return false;
     const int OUTN = g.inner_k ? g.JT : g.KT, INN = g.inner_k ? g.KT : g.JT;
     if ((INN * g.TS) % 4 != 0 || OUTN * (INN * g.TS + 1) > LT_FLOATS) return false;
     return (long long)(d.J / g.JT) * (d.K / g.KT) < (1ll << 24);
@@ -565,8 +566,8 @@ __global__ __launch_bounds__(256) void unpack_multi_kernel(const srvp_pack_job* 
     const srvp_pack_desc& d = j.d;
     __shared__ float tile_lds[PT_OUT * (PT_INN * 16 + 1)];
     int TS; bool inner_k;
-    if ((g_pack_tiled & 2) && tile_ok(d, TS, inner_k)) { unpack_job_tiled(j, wg, nwg, TS, inner_k, tile_lds); return; }
-    if (!vec_ok(d)) {
+    if ((g_pack_tiled & 2) && tile_ok(d, TS, inner_k, true)) { unpack_job_tiled(j, wg, nwg, TS, inner_k, tile_lds); return; }
+    if (!vec_ok(d, true)) {
         PackArgs a;
         job_args(j, a);
         const long long total = (long long)a.ntaps * a.J * a.K;
@@ -778,6 +779,8 @@ inline unsigned capped_grid(long long items, int per_block, int cap) {
     if (b < 1) b = 1;
     return (unsigned)b;
 }
+// the ELBO reductions (one fp64 atomic per workgroup onto the accumulator): a single workgroup in deterministic mode
+inline unsigned elbo_grid(long long items, int per_block, int cap) { return g_srvp_det ? 1u : capped_grid(items, per_block, cap); }
 
 }  // namespace
 
@@ -869,7 +872,7 @@ extern "C" int srvp_nll(const float* x_, const float* x, float* d_x_, int64_t n,
     SRVP_REQUIRE(x_ && x && out && scale > 0.f, "srvp_nll: bad args");
     const float inv2s2 = 1.f / (2.f * scale * scale);
     const float logc = logf(scale) + 0.91893853320467274f;
-    hipLaunchKernelGGL(nll_kernel, dim3(capped_grid(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, x_, x, d_x_, (long long)n,
+    hipLaunchKernelGGL(nll_kernel, dim3(elbo_grid(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, x_, x, d_x_, (long long)n,
                        inv2s2, logc, gscale / (scale * scale), out);
     SRVP_CHECK_LAUNCH("srvp_nll");
     return SRVP_OK;
@@ -879,7 +882,7 @@ extern "C" int srvp_kl(const float* q, const float* p, float* dq, float* dp, int
                        void* stream) {
     SRVP_REQUIRE(q && out, "srvp_kl: bad args");
     if (rows * d <= 0) return SRVP_OK;
-    hipLaunchKernelGGL(kl_kernel, dim3(capped_grid(rows * d, 256, 1024)), dim3(256), 0, (hipStream_t)stream, q, p, dq, dp,
+    hipLaunchKernelGGL(kl_kernel, dim3(elbo_grid(rows * d, 256, 1024)), dim3(256), 0, (hipStream_t)stream, q, p, dq, dp,
                        (long long)rows, d, gscale, out);
     SRVP_CHECK_LAUNCH("srvp_kl");
     return SRVP_OK;
@@ -888,7 +891,7 @@ extern "C" int srvp_kl(const float* q, const float* p, float* dq, float* dp, int
 extern "C" int srvp_l2rows(const float* res, float* d_res, int64_t rows, int d, float gscale, double* out, void* stream) {
     SRVP_REQUIRE(res && out, "srvp_l2rows: bad args");
     if (rows <= 0) return SRVP_OK;
-    hipLaunchKernelGGL(l2rows_kernel, dim3(capped_grid(rows, 4, 1024)), dim3(256), 0, (hipStream_t)stream, res, d_res,
+    hipLaunchKernelGGL(l2rows_kernel, dim3(elbo_grid(rows, 4, 1024)), dim3(256), 0, (hipStream_t)stream, res, d_res,
                        (long long)rows, d, gscale, out);
     SRVP_CHECK_LAUNCH("srvp_l2rows");
     return SRVP_OK;

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restric
 template <class E, int K>
 __global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restrict__ x, const E* __restrict__ draw,
                                                            float* dw, int N, int Cin, int H, int W, int Cout, int Cout_real,
-                                                           int s, int p, int OH, int OW, long long pix_per_stream) {
+                                                           int s, int p, int OH, int OW, long long pix_per_stream, float* det_slab) {
     constexpr int KK = K * K;
     extern __shared__ float part[];                 // [streams-1][G][8*KK]
     const int CG = Cout / 8;
@@ -145,7 +145,10 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restr
             int co = cg * 8 + e;
             if (co < Cout_real)
 #pragma unroll
-                for (int t = 0; t < KK; ++t) atomicAdd(dw + ((size_t)co * Cin + ci) * KK + t, acc[e][t]);
+                for (int t = 0; t < KK; ++t) {
+                    if (det_slab) det_slab[(size_t)blockIdx.x * Cout_real * Cin * KK + ((size_t)co * Cin + ci) * KK + t] = acc[e][t];    // (deterministic mode)
+                    else atomicAdd(dw + ((size_t)co * Cin + ci) * KK + t, acc[e][t]);
+                }
         }
     }
 }
@@ -620,12 +623,21 @@ int conv_in_wgrad_valu(const float* x, const void* draw, float* dw, int N, int C
     if (pps < 16) { pps = 16; blocks = (P + pps * SPB - 1) / (pps * SPB); }
     const size_t sh = (size_t)(SPB > 1 ? SPB - 1 : 1) * G * 8 * k * k * sizeof(float);
     SRVP_REQUIRE(sh <= 160 * 1024, "srvp_conv_in_wgrad: LDS budget");
+    float* slab = nullptr;
+    const int n_dw = Cout_real * Cin * k * k;
+    if (g_srvp_det && El<E>::is_f32) {
+        // deterministic mode: at most 256 workgroups, their partial gradients into the workspace, summed in workgroup order afterwards
+        SRVP_REQUIRE(g_srvp_det_ws && 256ll * n_dw * 4 <= g_srvp_det_ws_bytes, "srvp_conv_in_wgrad: deterministic workspace too small");
+        if (blocks > 256) { blocks = 256; pps = (P + blocks * SPB - 1) / (blocks * SPB); }
+        slab = (float*)g_srvp_det_ws;
+    }
     if (k == 3)
         hipLaunchKernelGGL((conv_in_wgrad_kernel<E, 3>), dim3((unsigned)blocks), dim3(256), sh, (hipStream_t)stream, x,
-                           (const E*)draw, dw, N, Cin, H, W, Cout, Cout_real, s, p, OH, OW, pps);
+                           (const E*)draw, dw, N, Cin, H, W, Cout, Cout_real, s, p, OH, OW, pps, slab);
     else
         hipLaunchKernelGGL((conv_in_wgrad_kernel<E, 4>), dim3((unsigned)blocks), dim3(256), sh, (hipStream_t)stream, x,
-                           (const E*)draw, dw, N, Cin, H, W, Cout, Cout_real, s, p, OH, OW, pps);
+                           (const E*)draw, dw, N, Cin, H, W, Cout, Cout_real, s, p, OH, OW, pps, slab);
+    if (slab) hipLaunchKernelGGL(det_sum_kernel<float>, dim3((n_dw + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)slab, (int)blocks, n_dw, dw);
     SRVP_CHECK_LAUNCH("srvp_conv_in_wgrad");
     return SRVP_OK;
 }

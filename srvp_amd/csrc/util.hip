@@ -4,6 +4,9 @@
 #include <stdarg.h>
 
 static thread_local char g_err[512] = "";
+int g_srvp_det = 0;
+void* g_srvp_det_ws = nullptr;
+long long g_srvp_det_ws_bytes = 0;
 void srvp_set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -287,5 +290,62 @@ extern "C" int srvp_splitk_finish(const float* parts, int splitk, int64_t slab_e
     hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, parts, splitk,
                        (long long)slab_elems, (long long)M, C, (bf16_t*)dst, stats, stat_mod, rpb);
     SRVP_CHECK_LAUNCH("srvp_splitk_finish");
+    return SRVP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Deterministic mode (fp32 parity mode only).  The workspace (>= 8 MiB of device memory, caller-owned) holds the
+// per-workgroup partial sums of the two-launch reductions; launches must come from ONE stream while the mode is on.
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int srvp_set_deterministic(int on, void* workspace, int64_t workspace_bytes) {
+    SRVP_REQUIRE(!on || (workspace && workspace_bytes >= (8ll << 20)), "srvp_set_deterministic: needs a device workspace of at least 8 MiB");
+    g_srvp_det = on ? 1 : 0;
+    g_srvp_det_ws = on ? workspace : nullptr;
+    g_srvp_det_ws_bytes = on ? workspace_bytes : 0;
+    return SRVP_OK;
+}
+extern "C" int srvp_get_deterministic(void) { return g_srvp_det; }
+
+namespace {
+// BatchNorm batch statistics of an fp32 tensor [rows][C] in a fixed order: workgroup w walks rows [w * chunk, ...) sequentially, thread =
+// (row lane, channel); the row lanes are added in lane order, the workgroups by det_sum_kernel.  slab: [nwg][2][C] doubles.
+__global__ __launch_bounds__(256) void bn_stats_det_kernel(const float* __restrict__ raw, long long rows, int C, long long chunk, double* __restrict__ slab) {
+    __shared__ double part[256][2];
+    const int Cb = C < 256 ? C : 256, L = 256 / Cb;            // channels per pass, row lanes
+    const int cl = threadIdx.x % Cb, lane = threadIdx.x / Cb;
+    const long long r0 = (long long)blockIdx.x * chunk;
+    long long r1 = r0 + chunk; if (r1 > rows) r1 = rows;
+    for (int c0 = 0; c0 < C; c0 += Cb) {
+        const int c = c0 + cl;
+        double s1 = 0., s2 = 0.;
+        if (lane < L && c < C)
+            for (long long r = r0 + lane; r < r1; r += L) { const double v = (double)raw[r * C + c]; s1 += v; s2 += v * v; }
+        part[threadIdx.x][0] = s1; part[threadIdx.x][1] = s2;
+        __syncthreads();
+        if (lane == 0 && c < C) {
+            double t1 = 0., t2 = 0.;
+            for (int l = 0; l < L; ++l) { t1 += part[l * Cb + cl][0]; t2 += part[l * Cb + cl][1]; }
+            slab[((size_t)blockIdx.x * 2 + 0) * C + c] = t1;
+            slab[((size_t)blockIdx.x * 2 + 1) * C + c] = t2;
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+// stats[0][c] += sum over rows of raw[r][c], stats[1][c] += sum of squares (fp64, fixed summation order): what the convolution
+// epilogues add with atomics, recomputed from the stored fp32 raw output (= the accumulators, unrounded, in fp32 mode)
+extern "C" int srvp_bn_stats_f32_det(const float* raw, int64_t rows, int C, double* stats, void* stream) {
+    SRVP_REQUIRE(raw && stats && rows > 0 && C > 0 && C <= 4096, "srvp_bn_stats_f32_det: bad args");
+    SRVP_REQUIRE(g_srvp_det && g_srvp_det_ws, "srvp_bn_stats_f32_det: deterministic mode is off (srvp_set_deterministic)");
+    int nwg = 256;
+    if (rows < 4 * nwg) nwg = (int)((rows + 3) / 4);
+    while ((long long)nwg * 2 * C * 8 > g_srvp_det_ws_bytes && nwg > 1) nwg /= 2;
+    const long long chunk = (rows + nwg - 1) / nwg;
+    nwg = (int)((rows + chunk - 1) / chunk);
+    double* slab = (double*)g_srvp_det_ws;
+    hipLaunchKernelGGL(bn_stats_det_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, raw, (long long)rows, C, chunk, slab);
+    hipLaunchKernelGGL(det_sum_kernel<double>, dim3((2 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)slab, nwg, 2 * C, stats);
+    SRVP_CHECK_LAUNCH("srvp_bn_stats_f32_det");
     return SRVP_OK;
 }

@@ -189,6 +189,36 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             self._pack_version = None
         return self
 
+    def set_deterministic(self, on=True):
+        """Bit-reproducible runs of the fp32 parity mode (SRVP_DETERMINISTIC=1 switches it on at construction): every
+        cross-workgroup sum that is normally formed with atomics in arrival order -- BatchNorm statistics, BatchNorm-backward sums,
+        split-K weight gradients, the image-side weight gradient, the latent weight gradients, the ELBO accumulators -- is formed in a
+        fixed order instead (csrc/common.h), and everything is issued on ONE stream.  Process-wide (the library holds the switch and
+        the 8 MiB workspace of the two-launch reductions); the production bf16 path keeps its atomics and is refused here."""
+        from . import convnet as _cn
+        global OVERLAP_WGRAD, OVERLAP_SKIP, OVERLAP_PACK
+        if on:
+            if self.precision != 'fp32':
+                raise ValueError("deterministic mode covers precision = 'fp32' only: call set_precision('fp32') first")
+            if self.__dict__.get('_det_saved') is None:
+                self.__dict__['_det_saved'] = (OVERLAP_WGRAD, OVERLAP_SKIP, OVERLAP_PACK, _cn.ENC_WGRAD_SIDE_MAXN)
+            ws = self.__dict__.get('_det_ws')
+            if ws is None or ws.device != self._device():
+                ws = self.__dict__['_det_ws'] = torch.zeros(8 << 20, dtype=torch.uint8, device=self._device())
+            L.call('srvp_set_deterministic', 1, L.ptr(ws), ws.numel())
+            OVERLAP_WGRAD, OVERLAP_SKIP, OVERLAP_PACK, _cn.ENC_WGRAD_SIDE_MAXN = False, False, False, 0
+        else:
+            L.call('srvp_set_deterministic', 0, None, 0)
+            saved = self.__dict__.get('_det_saved')
+            if saved is not None:
+                OVERLAP_WGRAD, OVERLAP_SKIP, OVERLAP_PACK, _cn.ENC_WGRAD_SIDE_MAXN = saved
+                self.__dict__['_det_saved'] = None
+        _cn.DETERMINISTIC = bool(on)
+        self.deterministic = bool(on)
+        self._plans = {}
+        self._pack_version = None
+        return self
+
     # ------------------------------------------------------------------------------------------------ plumbing
     def _cfg(self):
         return dict(nx=self.nx, nc=self.nc, nf=self.nf, nhx=self.nhx, ny=self.ny, nz=self.nz, skipco=self.skipco,
@@ -258,6 +288,8 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         on B*S (video, sample) rows -- row s*B + b -- sharing the B skip tensors / hoisted skip halves through the image maps.
         S_lat > S: the latent path carries S_lat samples per video at once (its chains are latency-bound: 800 rows cost what 160
         do) while the decoder, whose activations set the memory footprint, works through them S at a time."""
+        if os.environ.get('SRVP_DETERMINISTIC') == '1' and not getattr(self, 'deterministic', False) and self.precision == 'fp32':
+            self.set_deterministic(True)                  # (the environment switch: applies once the model sits on its device)
         f32 = self.precision == 'fp32'
         S_lat = S if S_lat is None else S_lat
         key = (T, B, nt, n_euler, training, str(self._device()) + ('/fp32' if f32 else '')) + ((S,) if S > 1 or S_lat > 1 else ()) + ((S_lat,) if S_lat != S else ())

@@ -25,7 +25,7 @@ CTOR = (64, 1, 16, 32, 8, 8, True, 2, 32, 3, 64, 4, 'vgg')      # reduced width,
 HP = dict(obs_scale=0.2, beta_y=1.0, beta_z=1.0, l2_res=1.0)
 
 
-def _run(precision, data, val, report):
+def _run(precision, data, val, report, steps=STEPS, deterministic=False, return_params=False):
     import srvp_amd
     from srvp_amd.train import fused_step
     from srvp_amd import metrics as M
@@ -34,11 +34,17 @@ def _run(precision, data, val, report):
     model = srvp_amd.StochasticLatentResidualVideoPredictor(*CTOR)
     model.init(1.2)
     model.to(dev).train().set_precision(precision)
+    if deterministic:
+        model.set_deterministic(True)
     optim = srvp_amd.FusedAdam(model, lr=3e-4)                           # the recipes' learning rate (args.py: --lr 3e-4)
     opt = srvp_amd.DotDict(dict(n_euler_steps=NE, **HP))
     g = torch.Generator().manual_seed(99)
     losses = []
-    for it in range(STEPS):
+    import time
+    t_start = None
+    for it in range(steps):
+        if it == 5:
+            torch.cuda.synchronize(); t_start = time.perf_counter()
         idx = torch.randperm(data.shape[1], generator=g)[:B]
         x = data[:, idx].contiguous().to(dev)
         tape = dict(t_skip=torch.randint(T, (B,), generator=g),
@@ -58,6 +64,13 @@ def _run(precision, data, val, report):
     with torch.no_grad():
         x_ = model(val[:nt_cond].to(dev), T, 1 / NE, tape=tape)[0]
         psnr = M.psnr(x_, val.to(dev))[nt_cond:].mean().item()
+    if return_params:
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t_start) / max(1, steps - 5) * 1e3 if t_start is not None else float('nan')
+        flat = model._flat[0].detach().clone().cpu()
+        if deterministic:
+            model.set_deterministic(False)
+        return losses, psnr, flat, x_.detach().cpu(), ms
     return losses, psnr
 
 
@@ -88,3 +101,31 @@ def test_bf16_trains_like_fp32_over_300_steps():
     assert max(rel_sm) <= 1e-2, max(rel_sm)
     assert abs(p16 - p32) <= 0.6, (p16, p32, p32b)
     assert abs(p32b - p32) <= 0.4, (p32, p32b)
+
+
+def test_fp32_deterministic_mode_is_bit_reproducible():
+    """the reference's CPU path is bit-reproducible run to run; the parity mode is too once
+    model.set_deterministic(True) (or SRVP_DETERMINISTIC=1) replaces every arrival-order atomic sum by a fixed-order one (BatchNorm
+    statistics from the stored fp32 raw output, two-launch BatchNorm-backward / image-side weight-gradient sums, single-split weight
+    gradients, single-workgroup ELBO accumulators, one stream).  Two identical 300-step training runs: EVERY loss, the final
+    parameters and the validation frames are bit-equal.  The default fp32 mode on the same run is reported beside it (it differs from
+    run to run in the last bits and from the deterministic mode by summation order only)."""
+    from make_golden import synth_video
+    from test_gpu_parity_gate import report
+    data = torch.from_numpy(synth_video(T, 64, 1, seed=11))
+    val = torch.from_numpy(synth_video(T, 16, 1, seed=12))
+    n, nd = STEPS, 60                                  # the 300 steps of the trajectory test above, twice; the default mode beside it on 60
+    a = _run('fp32', data, val, report, steps=n, deterministic=True, return_params=True)
+    b = _run('fp32', data, val, report, steps=n, deterministic=True, return_params=True)
+    c = _run('fp32', data, val, report, steps=nd, deterministic=False, return_params=True)
+    d = _run('fp32', data, val, report, steps=nd, deterministic=False, return_params=True)
+    scale = max(a[0]) - min(a[0])
+    report(test='deterministic_fp32', steps=n, ms_per_step_deterministic=a[4], ms_per_step_default=c[4],
+           max_loss_diff_det_vs_det=max(abs(x - y) for x, y in zip(a[0], b[0])),
+           max_rel_loss_diff_default_vs_default=max(abs(x - y) for x, y in zip(c[0], d[0])) / scale,
+           max_rel_loss_diff_det_vs_default=max(abs(x - y) for x, y in zip(a[0], c[0])) / scale,
+           params_equal_det=bool(torch.equal(a[2], b[2])), params_equal_default=bool(torch.equal(c[2], d[2])))
+    assert a[0] == b[0], [(i, x, y) for i, (x, y) in enumerate(zip(a[0], b[0])) if x != y][:3]
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and a[1] == b[1]
+    # same algorithm, another summation order: the deterministic run stays inside the band two default runs span
+    assert max(abs(x - y) for x, y in zip(a[0], c[0])) / scale <= 2e-2
