@@ -113,6 +113,10 @@ int srvp_conv_out_fwd(const void* act, const void* wt_tapmajor, float* out, int 
 /* 1 (default): 3x3 stride-1 single-source convolutions run on the halo-tiled kernel (input patch staged in LDS once
  * per channel chunk, taps = LDS offsets); 0: every convolution on the generic tap-gather kernel.  Same results, bit for bit. */
 int srvp_conv_set_halo(int on);
+/* 1 (default): 3x3 stride-1 64 -> 64 channel launches on 64x64 images (N >= 96, plain bf16 destination, optional stats / bnr_*) run on the
+ * streaming kernel (csrc/conv_stream.hip: persistent workgroup per CU, rolling LDS row window, register-resident weights); 0: on the
+ * tile kernels.  Same results up to fp32 summation order. */
+int srvp_conv_set_stream64(int on);
 /* 1 if this descriptor will run on the halo-tiled kernel, which wants its weights fragment-major (pack layout 1) */
 int srvp_conv_wants_fragmajor(const srvp_conv_desc* d);
 /* 0, or the pixel-tile size (>= 256: eligible for bnr_red) of the halo-tiled kernel variant this descriptor will run on */

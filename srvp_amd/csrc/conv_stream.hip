@@ -258,15 +258,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 }  // namespace
 
+static int g_stream64 = -1;      // -1: SRVP_CONV_STREAM64 env (default 1)
+// A/B switch (tests): 1 = 64 -> 64 channel 64x64 launches on the streaming kernel (default), 0 = on the tile kernels.  Same results up to
+// fp32 summation order.
+extern "C" int srvp_conv_set_stream64(int on) { g_stream64 = on ? 1 : 0; return SRVP_OK; }
+
 // Called by srvp_conv_mfma before the tile kernels: *taken = 1 if this launch was handled here.
 int srvp_conv_stream64_launch(const srvp_conv_desc* d, hipStream_t st, int* taken) {
     *taken = 0;
-    static int on = -1, minN = 0;
-    if (on < 0) {
-        const char* e = getenv("SRVP_CONV_STREAM64"); on = e ? atoi(e) : 1;
-        const char* m = getenv("SRVP_CONV_STREAM64_MIN_N"); minN = m ? atoi(m) : 96;
-    }
-    if (!on || d->elem_f32 || d->splitk > 1 || d->C1 != 0 || d->C0 != 64 || d->Cout != 64 || d->ntaps != 9 || d->si != 1 || d->so != 1 || d->ooy != 0 ||
+    static int minN = -1;
+    if (g_stream64 < 0) { const char* e = getenv("SRVP_CONV_STREAM64"); g_stream64 = e ? atoi(e) : 1; }
+    if (minN < 0) { const char* m = getenv("SRVP_CONV_STREAM64_MIN_N"); minN = m ? atoi(m) : 96; }
+    if (!g_stream64 || d->elem_f32 || d->splitk > 1 || d->C1 != 0 || d->C0 != 64 || d->Cout != 64 || d->ntaps != 9 || d->si != 1 || d->so != 1 || d->ooy != 0 ||
         d->oox != 0 || d->ups0 || d->map0 || d->add_f32 || d->dst_is_f32 || d->out_f32 || d->tap_phase_chunks || d->ep_coef || d->wt_fragmajor != 1 ||
         d->OH != 64 || d->OW != 64 || d->H0p != 66 || d->W0p != 66 || d->DHp != 64 || d->DWp != 64 || d->Cdst != 64 || d->cdst_off != 0 || d->f32_quad ||
         (d->stats && d->stat_mod != 64) || d->N < minN || !d->dst)

@@ -260,6 +260,83 @@ def test_conv_halo_split_skip(monkeypatch):
     assert rel_err(blk.raw.permute(0, 3, 1, 2).float().cpu(), ref) < 2 ** -7
 
 
+@pytest.mark.parametrize('N', [96, 300, 1030])
+def test_conv_stream64_matches_tile_kernel(N):
+    """csrc/conv_stream.hip (64 -> 64 channels at 64x64: persistent workgroups, rolling LDS row window, register-resident weights) against
+    the tile kernels on the same launches: forward with BatchNorm statistics, and the data gradient with the producer's fused
+    BatchNorm-backward sums (srvp_conv_desc.bnr_*).  Same products, another fp32 summation order: outputs agree to a bf16 ulp on a few
+    elements, the statistics to 1e-6.  N = 96 / 300 / 1030 frames: quarter / quarter / whole images per work item."""
+    from srvp_amd import _lib as L
+    from srvp_amd.convnet import Block
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(17)
+    f0 = make_feat(N, 64, 64, 64, dev, g)
+    spec = dict(kind='conv', key='w', bnkey='bn', cin=64, cout=64, k=3, s=1, p=1, act='leaky_relu')
+    blk = Block(spec, 'mfma', [f0], False, N, dev, True)
+    blk._fwd, blk._dg = blk.fwd_descs(), blk.dgrad_descs()
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(dev)
+    st = L.stream()
+    blk.pack(w, st)
+    blk.draw[:, 1:-1, 1:-1, :].copy_((torch.randn(N, 64, 64, 64, generator=g) * 0.5).to(torch.bfloat16))
+    # a producer layer for the fused reduction: its raw output and coefficients
+    praw = (torch.randn(N, 64, 64, 64, generator=g)).to(torch.bfloat16).to(dev)
+    coef = torch.stack([torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3, torch.randn(64, generator=g) * 0.1,
+                        torch.rand(64, generator=g) + 0.5]).to(dev).contiguous()
+    d = blk._dg[0]
+    res = {}
+    try:
+        for on in (1, 0):
+            L.call('srvp_conv_set_stream64', on)
+            red = torch.zeros(2, 64, dtype=torch.float64, device=dev)
+            d.bnr_raw, d.bnr_coef, d.bnr_red = L.ptr(praw), L.ptr(coef), L.ptr(red)
+            blk.raw.fill_(7.0); blk.dcat.fill_(7.0); blk.stats.zero_()
+            L.call('srvp_conv_mfma', C.byref(blk._fwd[0]), st)
+            L.call('srvp_conv_mfma', C.byref(d), st)
+            torch.cuda.synchronize()
+            res[on] = (blk.raw.float().clone(), blk.dcat.float().clone(), blk.stats.clone(), red.clone())
+    finally:
+        L.call('srvp_conv_set_stream64', 1)
+        d.bnr_raw, d.bnr_coef, d.bnr_red = None, None, None
+    for i, name in ((0, 'raw'), (1, 'dcat')):
+        a, b = res[1][i], res[0][i]
+        diff = (a - b).abs()
+        assert diff.max().item() <= 2 ** -7 * max(1.0, b.abs().max().item()), name           # at most one bf16 ulp
+        assert (diff > 0).float().mean().item() < 5e-3, (name, (diff > 0).float().mean().item())
+    # (the fused sums see the data gradient as stored: the few elements that round the other way move them at the 1e-5 level)
+    assert rel_err(res[1][2], res[0][2]) < 1e-6 and rel_err(res[1][3], res[0][3]) < 2e-4
+    # and against torch on the bf16-rounded operands (forward)
+    ref = F.conv2d(feat_nchw(f0)[:4], bf(w.cpu()), None, 1, 1)
+    assert rel_err(res[1][0][:4].permute(0, 3, 1, 2).cpu(), ref) < 2 ** -7
+
+
+@pytest.mark.parametrize('N,nc', [(5, 3), (300, 3), (700, 1), (1100, 3)])
+def test_conv_out_stream_matches_tile_kernel(N, nc):
+    """csrc/conv_out.hip (image-side output layer, 64 -> nc channels + sigmoid on a rolling LDS window, 16x16x32 MFMA) against the padded
+    32-column tile kernel: fp32 frames within 2e-6."""
+    from srvp_amd import _lib as L
+    from srvp_amd.convnet import Block
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(23)
+    f0 = make_feat(N, 64, 64, 64, dev, g)
+    spec = dict(kind='convT', key='w', bnkey=None, cin=64, cout=nc, k=3, s=1, p=1, act='sigmoid')
+    blk = Block(spec, 'out', [f0], False, N, dev, False)
+    assert blk.stream_out
+    blk._fwd = blk.fwd_descs()
+    w = (torch.randn(64, nc, 3, 3, generator=g) * 0.1).to(dev)
+    st = L.stream()
+    blk.pack(w, st)
+    for d in blk._fwd:
+        L.call('srvp_conv_mfma', C.byref(d), st)
+    torch.cuda.synchronize()
+    ref = blk.x_out.clone()
+    blk.x_out.fill_(7.0)
+    L.call('srvp_conv_out_fwd', L.ptr(f0.t), L.ptr(blk.wt_o), L.ptr(blk.x_out), N, nc, 1, st)
+    torch.cuda.synchronize()
+    assert (blk.x_out - ref).abs().max().item() < 2e-6
+    t = torch.sigmoid(F.conv_transpose2d(feat_nchw(f0)[:3], bf(w.cpu()), None, 1, 1))
+    assert (blk.x_out[:3].cpu() - t).abs().max().item() < 1e-5
+
+
 SPLIT_CASES = [
     # c0r (low-res main input, upsampled x2), c1r (skip), Hs, cout, T, B
     (512, 512, 4, 512, 3, 2),       # decoder.conv.0.0: 1024 -> 512 @ 8x8 (split skip half + sub-pixel main half)
