@@ -15,7 +15,8 @@
 #include "../../include/srvp_hip.h"
 
 int srvp_conv_f32_launch(const srvp_conv_desc* d, hipStream_t st);     // conv_f32.hip (precision = 'fp32' parity mode)
-int srvp_conv_stream64_launch(const srvp_conv_desc* d, hipStream_t st, int* taken);     // conv_stream.hip (64 -> 64 channels at 64x64: streaming kernel)
+int srvp_conv_stream64_launch(const srvp_conv_desc* d, hipStream_t st, int* taken);
+int srvp_conv_stream_sub64_launch(const srvp_conv_desc* d, int n, hipStream_t st, int* taken);   // (four sub-pixel phases at 64 channels)     // conv_stream.hip (64 -> 64 channels at 64x64: streaming kernel)
 
 namespace {
 
@@ -905,6 +906,11 @@ extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
 // a sub-pixel upsample conv); otherwise simply n launches.
 extern "C" int srvp_conv_mfma_multi(const srvp_conv_desc* d, int n, void* stream) {
     SRVP_REQUIRE(d && n >= 1, "srvp_conv_mfma_multi: bad args");
+    {
+        int taken = 0;
+        if (int rc = srvp_conv_stream_sub64_launch(d, n, (hipStream_t)stream, &taken)) return rc;
+        if (taken) return SRVP_OK;
+    }
     bool same = n <= 4;
     const int v = halo_variant(d);
     for (int i = 1; i < n && same; ++i)

@@ -256,6 +256,184 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Sub-pixel stage entry at 64 channels (decoder.conv.3.0, reference module/conv.py:331-349 + srvp.py:222-223): nearest x2 upsample + 3x3
+// conv of the 32x32 main input, evaluated as four output phases with 2x2 folded taps (DESIGN "Sub-pixel form"), plus the hoisted skip
+// half S[sample] (fp32) in the accumulators, BatchNorm statistics, bf16 raw output at 64x64.  K = 4 x 64 per output pixel: on the tile
+// kernel the launch was all prologue / epilogue (0.82 ms at 2304 frames; HBM floor 0.33 ms), and its largest stream was the S tile:
+// 64 KB of fp32 per 256 output pixels, re-read for every frame.
+// Here a work item is (sample b, band of four output rows): the band's S values are loaded ONCE into 64 registers per lane and
+// seed the accumulators of all T frames t * B + b of that sample (2.4 GB of L2 reads -> 0.2 GB); per frame the item needs four
+// low-resolution input rows (17 KB by LDS-DMA, double-buffered: the rows of frame t + 1 arrive under the arithmetic of frame t) and
+// writes one contiguous 32 KB run of the raw tensor.  Wave w = (32 output channels nt, column phase b): its 2 row phases x 4 taps x 4
+// sixteen-channel slices = 32 weight fragments stay in 128 registers; an input fragment (32 low-resolution pixels of row R at column
+// offset b + v) is read once and feeds every (row phase a, tap row u, output row) combination with y + a + u = R: 32 reads, 64 MFMAs
+// per frame and wave.  Same products as the four phase launches of the tile kernel; fp32 summation order differs.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int UW = 32, UPW = 34, UROWB = UPW * 128;           // low-resolution padded row: 34 pixels x 64 channels x 2 bytes
+constexpr int UGROUP_B = 4 * UROWB;                           // the four input rows of a band
+constexpr int USLOTS = 4 * UPW * 8;                           // 1088 sixteen-byte pieces = 4.25 x 256
+
+struct SubK {
+    const bf16_t* src; const bf16_t* wt; bf16_t* dst; const float* S; double* stats;
+    int N, B;                  // frames t * B + b, samples
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_stream_sub64_kernel(const SubK a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[2 * UGROUP_B];
+    __shared__ __attribute__((aligned(16))) bf16_t cs[SBAND_PX * SLDC];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nt = wid & 1, bph = wid >> 1;                   // 32 output channels, column phase of this wave
+    const int lcol = lane & 31, lhalf = lane >> 5;
+    unsigned soff[5];
+    bool svalid[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int q = i * 256 + tid;
+        svalid[i] = q < USLOTS;
+        const int qq = svalid[i] ? q : 0;
+        const int r = qq / (UPW * 8), rem = qq - r * (UPW * 8), px = rem >> 3, s = rem & 7;
+        soff[i] = (unsigned)(((r * UPW + px) * 64) + ((s ^ (px & 7)) * 8));
+    }
+    // weight fragments: [row phase a][tap u * 2 + v][slice kk]; packed tap index (a * 2 + bph) * 4 + u * 2 + v, fragment-major
+    bf16x8_t wf[2][4][4];
+    {
+        const bf16_t* wl = a.wt + (size_t)nt * 512 + lane * 8;
+#pragma unroll
+        for (int ap = 0; ap < 2; ++ap)
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    wf[ap][tp][kk] = *reinterpret_cast<const bf16x8_t*>(wl + (size_t)((((ap * 2 + bph) * 4 + tp) * 4 + kk) * 2) * 512);
+#pragma unroll
+        for (int ap = 0; ap < 2; ++ap)
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) asm volatile("" : "+v"(wf[ap][tp][kk]));
+    }
+    const unsigned ring_base = (unsigned)(uintptr_t)ring;
+    unsigned swz[2][4];                                       // column offset bph + v, slice kk: pixel byte offset + swizzled chunk
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int px = lcol + bph + v;
+            swz[v][kk] = (unsigned)(px * 128) + ((((unsigned)(kk * 2 + lhalf)) ^ (unsigned)(px & 7)) << 4);
+        }
+    const int cch = tid & 7;
+    const int T = a.N / a.B;
+    double d1 = 0., d2 = 0.;
+    for (int item = blockIdx.x; item < a.B * 16; item += gridDim.x) {
+        const int b = item >> 4, band = item & 15;            // output rows 4 band .. + 3 = low-resolution rows 2 band, 2 band + 1
+        // ---- the hoisted skip half of this band: tile m = yl * 2 + ap (output row 4 band + 2 yl + ap), this lane's 16 pixels x its channel
+        f32x16_t sreg[4];
+        {
+            const float* sp = a.S + ((size_t)b * 64 + 4 * band) * 64 * 64 + nt * 32 + lcol;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int xl = (i & 3) + 8 * (i >> 2) + 4 * lhalf;
+                    sreg[m][i] = sp[((size_t)((m >> 1) * 2 + (m & 1)) * 64 + 2 * xl + bph) * 64];
+                }
+        }
+        auto stage = [&](int t, int buf) {
+            const bf16_t* src = a.src + ((size_t)(t * a.B + b) * UPW + 2 * band) * UPW * 64;
+            unsigned char* dst = ring + buf * UGROUP_B;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const unsigned o = svalid[i] ? soff[i] : 0u;
+                if (i != 4 || wid == 0)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(src + o), (lptr_t)(dst + ((size_t)i * 256 + wid * 64) * 16), 16, 0, 0);
+            }
+        };
+        __syncthreads();                                       // previous item: every wave is past its last ring / staging access
+        stage(0, 0);
+        for (int t = 0; t < T; ++t) {
+            __builtin_amdgcn_s_barrier();                      // every wave is done with frame t - 1 (the other ring buffer, the staging tile)
+            asm volatile("" ::: "memory");
+            if (t + 1 < T) {
+                stage(t + 1, (t + 1) & 1);
+                if (wid == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | 5); else __builtin_amdgcn_s_waitcnt(0x0F70 | 4);      // frame t's rows landed
+            } else {
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            f32x16_t acc[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = sreg[m];
+            constexpr int NSTEP = 4 * 2 * 4, PF = 3;           // (input row R, column offset v, slice kk)
+            u32x4_t fa[PF + 1];
+            const unsigned bufb = ring_base + (unsigned)((t & 1) * UGROUP_B);
+            auto issue = [&](int k, u32x4_t& v) {
+                const int R = k >> 3, cv = (k >> 2) & 1, kk = k & 3;
+                const unsigned a0 = bufb + (unsigned)(R * UROWB) + swz[cv][kk];
+                asm volatile("ds_read_b128 %0, %1" : "=&v"(v) : "v"(a0) : "memory");
+            };
+            auto mac = [&](int k, const u32x4_t& v) {
+                const int R = k >> 3, cv = (k >> 2) & 1, kk = k & 3;
+                const bf16x8_t af = __builtin_bit_cast(bf16x8_t, v);
+#pragma unroll
+                for (int yl = 0; yl < 2; ++yl)
+#pragma unroll
+                    for (int ap = 0; ap < 2; ++ap) {
+                        const int u = R - yl - ap;             // padded input row (2 band + yl) + ap + u = 2 band + R
+                        if (u < 0 || u > 1) continue;
+                        acc[yl * 2 + ap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wf[ap][u * 2 + cv][kk], acc[yl * 2 + ap], 0, 0, 0);
+                    }
+            };
+#pragma unroll
+            for (int k = 0; k < PF; ++k) issue(k, fa[k]);
+#pragma unroll
+            for (int k = 0; k < NSTEP; ++k) {
+                u32x4_t& cur = fa[k % (PF + 1)];
+                if (k + PF < NSTEP) issue(k + PF, fa[(k + PF) % (PF + 1)]);
+                const int younger = (k + PF < NSTEP ? k + PF : NSTEP - 1) - k;
+                if (younger >= 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(cur)::"memory");
+                else if (younger == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(cur)::"memory");
+                else if (younger == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(cur)::"memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur)::"memory");
+                mac(k, cur);
+            }
+            if (a.stats) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { const float v = acc[m][i]; s1 += v; s2 += v * v; }
+                d1 += (double)s1; d2 += (double)s2;
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int xl = (i & 3) + 8 * (i >> 2) + 4 * lhalf;
+                    const int pix = m * SW + 2 * xl + bph;     // (tile m = output row 4 band + m)
+                    cs[pix * SLDC + nt * 32 + lcol] = f2bf(acc[m][i]);
+                }
+            __syncthreads();
+            bf16_t* ob = a.dst + ((size_t)(t * a.B + b) * SW + 4 * band) * SW * 64;
+            u32x4_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const u32x4_t*>(cs + (i * 32 + (tid >> 3)) * SLDC + cch * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4_t*>(ob + (size_t)(i * 256 + tid) * 8) = v[i];
+        }
+    }
+    if (a.stats) {                                             // one atomic pair per channel, wave and WORKGROUP (all its items)
+        d1 += __shfl_xor(d1, 32);
+        d2 += __shfl_xor(d2, 32);
+        if (lhalf == 0) {
+            atomicAdd(a.stats + nt * 32 + lcol, d1);
+            atomicAdd(a.stats + 64 + nt * 32 + lcol, d2);
+        }
+    }
+}
+
 }  // namespace
 
 static int g_stream64 = -1;      // -1: SRVP_CONV_STREAM64 env (default 1)
@@ -295,6 +473,41 @@ int srvp_conv_stream64_launch(const srvp_conv_desc* d, hipStream_t st, int* take
     if (d->bnr_red) hipLaunchKernelGGL(conv_stream64_kernel<true>, g, b, 0, st, k);
     else hipLaunchKernelGGL(conv_stream64_kernel<false>, g, b, 0, st, k);
     SRVP_CHECK_LAUNCH("srvp_conv_mfma(stream64)");
+    *taken = 1;
+    return SRVP_OK;
+}
+
+// Called by srvp_conv_mfma_multi: the four phase launches of a 64-channel sub-pixel stage entry with a hoisted skip half as ONE streaming
+// launch (*taken = 1), if they are exactly that.
+int srvp_conv_stream_sub64_launch(const srvp_conv_desc* d, int n, hipStream_t st, int* taken) {
+    *taken = 0;
+    static int on = -1, minN = -1;
+    if (on < 0) { const char* e = getenv("SRVP_CONV_STREAM_SUB64"); on = e ? atoi(e) : 1; }
+    if (minN < 0) { const char* m = getenv("SRVP_CONV_STREAM64_MIN_N"); minN = m ? atoi(m) : 96; }
+    if (!on || g_stream64 == 0 || n != 4) return SRVP_OK;
+    const srvp_conv_desc& d0 = d[0];
+    if (d0.N < minN || !d0.add_f32 || d0.add_mod <= 0 || d0.N % d0.add_mod != 0 || !d0.dst) return SRVP_OK;
+    for (int ph = 0; ph < 4; ++ph) {
+        const srvp_conv_desc& p = d[ph];
+        const int ap = ph >> 1, bp = ph & 1;
+        if (p.elem_f32 || p.splitk > 1 || p.C1 != 0 || p.C0 != 64 || p.Cout != 64 || p.ntaps != 4 || p.si != 1 || p.so != 2 || p.ooy != ap || p.oox != bp ||
+            p.ups0 || p.map0 || p.dst_is_f32 || p.out_f32 || p.tap_phase_chunks || p.ep_coef || p.bnr_red || p.wt_fragmajor != 1 || p.f32_quad ||
+            p.OH != 32 || p.OW != 32 || p.H0p != 34 || p.W0p != 34 || p.DHp != 64 || p.DWp != 64 || p.Cdst != 64 || p.cdst_off != 0 ||
+            p.N != d0.N || p.src0 != d0.src0 || p.dst != d0.dst || p.add_f32 != d0.add_f32 || p.add_mod != d0.add_mod || p.stats != d0.stats ||
+            (p.stats && p.stat_mod != 64) || (const char*)p.wt != (const char*)d0.wt + (size_t)ph * 4 * 64 * 64 * 2)
+            return SRVP_OK;
+        for (int u = 0; u < 2; ++u)
+            for (int v = 0; v < 2; ++v)
+                if (p.dy[u * 2 + v] != ap + u || p.dx[u * 2 + v] != bp + v) return SRVP_OK;
+    }
+    static int ncu = 0;
+    if (!ncu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; if (ncu <= 0) ncu = 256; }
+    SubK k{};
+    k.src = (const bf16_t*)d0.src0; k.wt = (const bf16_t*)d0.wt; k.dst = (bf16_t*)d0.dst; k.S = d0.add_f32; k.stats = d0.stats;
+    k.N = d0.N; k.B = d0.add_mod;
+    const long long items = (long long)k.B * 16;
+    hipLaunchKernelGGL(conv_stream_sub64_kernel, dim3((unsigned)(items < ncu ? items : ncu)), dim3(256), 0, st, k);
+    SRVP_CHECK_LAUNCH("srvp_conv_mfma_multi(stream sub64)");
     *taken = 1;
     return SRVP_OK;
 }

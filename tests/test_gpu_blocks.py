@@ -309,6 +309,49 @@ def test_conv_stream64_matches_tile_kernel(N):
     assert rel_err(res[1][0][:4].permute(0, 3, 1, 2).cpu(), ref) < 2 ** -7
 
 
+@pytest.mark.parametrize('T,B', [(12, 8), (6, 40)])
+def test_conv_stream_sub64_matches_tile_kernel(T, B):
+    """csrc/conv_stream.hip, sub-pixel stage entry at 64 channels (decoder.conv.3.0 forward: four output phases + hoisted skip half +
+    statistics as ONE streaming launch, the fp32 skip tile held in registers across the T frames of a sample) against the four phase
+    launches of the tile kernel: raw output within a bf16 ulp on a few elements, statistics to 1e-6; and against torch."""
+    from srvp_amd import _lib as L
+    from srvp_amd.convnet import Block
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(29)
+    N = T * B
+    f0 = make_feat(N, 32, 32, 64, dev, g)
+    f1 = make_feat(B + 2, 64, 64, 64, dev, g)
+    sel = torch.tensor([(3 * b + 1) % (B + 2) for b in range(B)], dtype=torch.int32, device=dev)
+    smap = sel.repeat(T)
+    spec = dict(kind='conv', key='w', bnkey='bn', cin=128, cout=64, k=3, s=1, p=1, act='leaky_relu')
+    blk = Block(spec, 'mfma', [f0, f1], True, N, dev, True, skip_map=smap, skip_sel=sel)
+    assert blk.split and blk.subpix
+    blk._fwd = blk.fwd_descs()
+    w = (torch.randn(64, 128, 3, 3, generator=g) * 0.05).to(dev)
+    st = L.stream()
+    blk.pack(w, st)
+    L.call('srvp_conv_mfma', C.byref(blk._fwd[0]), st)                   # conv_s(skip) -> S
+    arr = (L.ConvDesc * 4)(*blk._fwd[-4:])
+    res = {}
+    try:
+        for on in (1, 0):
+            L.call('srvp_conv_set_stream64', on)
+            blk.raw.fill_(7.0); blk.stats.zero_()
+            L.call('srvp_conv_mfma_multi', arr, 4, st)
+            torch.cuda.synchronize()
+            res[on] = (blk.raw.float().clone(), blk.stats.clone())
+    finally:
+        L.call('srvp_conv_set_stream64', 1)
+    diff = (res[1][0] - res[0][0]).abs()
+    assert diff.max().item() <= 2 ** -7 * max(1.0, res[0][0].abs().max().item())
+    assert (diff > 0).float().mean().item() < 5e-3, (diff > 0).float().mean().item()
+    assert rel_err(res[1][1], res[0][1]) < 1e-6
+    x0 = F.interpolate(feat_nchw(f0)[:2], scale_factor=2, mode='nearest')
+    xin = torch.cat([x0, feat_nchw(f1)[smap[:2].cpu().long()]], 1)
+    ref = F.conv2d(xin, bf(w.cpu()), None, 1, 1)
+    assert rel_err(res[1][0][:2].permute(0, 3, 1, 2).cpu(), ref) < 2 ** -7
+
+
 @pytest.mark.parametrize('N,nc', [(5, 3), (300, 3), (700, 1), (1100, 3)])
 def test_conv_out_stream_matches_tile_kernel(N, nc):
     """csrc/conv_out.hip (image-side output layer, 64 -> nc channels + sigmoid on a rolling LDS window, 16x16x32 MFMA) against the padded
