@@ -278,6 +278,8 @@ constexpr int USLOTS = 4 * UPW * 8;                           // 1088 sixteen-by
 struct SubK {
     const bf16_t* src; const bf16_t* wt; bf16_t* dst; const float* S; double* stats;
     int N, B;                  // frames t * B + b, samples
+    int TS;                    // a (sample, band)'s T frames are shared out over TS work items (few samples: inference)
+    const float* ep_coef; int ep_border;       // inference: LeakyReLU(scale * acc + shift) into a tensor with an ep_border-pixel border (srvp_conv_desc.ep_*)
 };
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_stream_sub64_kernel(const SubK a) {
@@ -326,8 +328,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int cch = tid & 7;
     const int T = a.N / a.B;
     double d1 = 0., d2 = 0.;
-    for (int item = blockIdx.x; item < a.B * 16; item += gridDim.x) {
+    const float ep_sc = a.ep_coef ? a.ep_coef[nt * 32 + lcol] : 1.f, ep_sh = a.ep_coef ? a.ep_coef[64 + nt * 32 + lcol] : 0.f;
+    const int Tper = (T + a.TS - 1) / a.TS;
+    for (int item0 = blockIdx.x; item0 < a.B * 16 * a.TS; item0 += gridDim.x) {
+        const int ts = item0 % a.TS, item = item0 / a.TS;
         const int b = item >> 4, band = item & 15;            // output rows 4 band .. + 3 = low-resolution rows 2 band, 2 band + 1
+        const int t_lo = ts * Tper, t_hi = t_lo + Tper < T ? t_lo + Tper : T;
+        if (t_lo >= t_hi) continue;
         // ---- the hoisted skip half of this band: tile m = yl * 2 + ap (output row 4 band + 2 yl + ap), this lane's 16 pixels x its channel
         f32x16_t sreg[4];
         {
@@ -351,11 +358,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         };
         __syncthreads();                                       // previous item: every wave is past its last ring / staging access
-        stage(0, 0);
-        for (int t = 0; t < T; ++t) {
+        stage(t_lo, t_lo & 1);
+        for (int t = t_lo; t < t_hi; ++t) {
             __builtin_amdgcn_s_barrier();                      // every wave is done with frame t - 1 (the other ring buffer, the staging tile)
             asm volatile("" ::: "memory");
-            if (t + 1 < T) {
+            if (t + 1 < t_hi) {
                 stage(t + 1, (t + 1) & 1);
                 if (wid == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | 5); else __builtin_amdgcn_s_waitcnt(0x0F70 | 4);      // frame t's rows landed
             } else {
@@ -407,6 +414,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     for (int i = 0; i < 16; ++i) { const float v = acc[m][i]; s1 += v; s2 += v * v; }
                 d1 += (double)s1; d2 += (double)s2;
             }
+            if (a.ep_coef) {                                   // inference: eval-mode BatchNorm + LeakyReLU from the fp32 accumulators
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { const float v = __builtin_fmaf(acc[m][i], ep_sc, ep_sh); acc[m][i] = v > 0.f ? v : LRELU_SLOPE * v; }
+            }
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -416,12 +429,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     cs[pix * SLDC + nt * 32 + lcol] = f2bf(acc[m][i]);
                 }
             __syncthreads();
-            bf16_t* ob = a.dst + ((size_t)(t * a.B + b) * SW + 4 * band) * SW * 64;
+            // copy-out: piece i * 256 + tid = (output row i >> 1 of the band, column (i & 1) * 32 + tid / 8, chunk tid & 7); without a
+            // border the band is one contiguous 32 KB run
+            const int eb = a.ep_coef ? a.ep_border : 0, PW2 = SW + 2 * eb;
+            bf16_t* ob = a.dst + (((size_t)(t * a.B + b) * PW2 + 4 * band + eb) * PW2 + eb) * 64 + cch * 8;
             u32x4_t v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const u32x4_t*>(cs + (i * 32 + (tid >> 3)) * SLDC + cch * 8);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4_t*>(ob + (size_t)(i * 256 + tid) * 8) = v[i];
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4_t*>(ob + ((size_t)(i >> 1) * PW2 + (i & 1) * 32 + (tid >> 3)) * 64) = v[i];
         }
     }
     if (a.stats) {                                             // one atomic pair per channel, wave and WORKGROUP (all its items)
@@ -491,7 +507,8 @@ int srvp_conv_stream_sub64_launch(const srvp_conv_desc* d, int n, hipStream_t st
         const srvp_conv_desc& p = d[ph];
         const int ap = ph >> 1, bp = ph & 1;
         if (p.elem_f32 || p.splitk > 1 || p.C1 != 0 || p.C0 != 64 || p.Cout != 64 || p.ntaps != 4 || p.si != 1 || p.so != 2 || p.ooy != ap || p.oox != bp ||
-            p.ups0 || p.map0 || p.dst_is_f32 || p.out_f32 || p.tap_phase_chunks || p.ep_coef || p.bnr_red || p.wt_fragmajor != 1 || p.f32_quad ||
+            p.ups0 || p.map0 || p.dst_is_f32 || p.out_f32 || p.tap_phase_chunks || p.bnr_red || p.wt_fragmajor != 1 || p.f32_quad ||
+            p.ep_coef != d0.ep_coef || (p.ep_coef && (p.ep_act != ACT_LRELU || p.ep_border != d0.ep_border || p.ep_border < 0 || p.ep_border > 1 || p.stats)) ||
             p.OH != 32 || p.OW != 32 || p.H0p != 34 || p.W0p != 34 || p.DHp != 64 || p.DWp != 64 || p.Cdst != 64 || p.cdst_off != 0 ||
             p.N != d0.N || p.src0 != d0.src0 || p.dst != d0.dst || p.add_f32 != d0.add_f32 || p.add_mod != d0.add_mod || p.stats != d0.stats ||
             (p.stats && p.stat_mod != 64) || (const char*)p.wt != (const char*)d0.wt + (size_t)ph * 4 * 64 * 64 * 2)
@@ -504,8 +521,11 @@ int srvp_conv_stream_sub64_launch(const srvp_conv_desc* d, int n, hipStream_t st
     if (!ncu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; if (ncu <= 0) ncu = 256; }
     SubK k{};
     k.src = (const bf16_t*)d0.src0; k.wt = (const bf16_t*)d0.wt; k.dst = (bf16_t*)d0.dst; k.S = d0.add_f32; k.stats = d0.stats;
-    k.N = d0.N; k.B = d0.add_mod;
-    const long long items = (long long)k.B * 16;
+    k.N = d0.N; k.B = d0.add_mod; k.ep_coef = d0.ep_coef; k.ep_border = d0.ep_border;
+    const int T = k.N / k.B;
+    k.TS = 1;
+    while ((long long)k.B * 16 * k.TS < 2ll * ncu && T / (2 * k.TS) >= 4) k.TS *= 2;      // few samples: share a (sample, band)'s frames out
+    const long long items = (long long)k.B * 16 * k.TS;
     hipLaunchKernelGGL(conv_stream_sub64_kernel, dim3((unsigned)(items < ncu ? items : ncu)), dim3(256), 0, st, k);
     SRVP_CHECK_LAUNCH("srvp_conv_mfma_multi(stream sub64)");
     *taken = 1;
