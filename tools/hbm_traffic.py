@@ -28,7 +28,8 @@ for k, v in agg.items():
     rd, rd32 = v.get('TCC_EA0_RDREQ_sum', 0), v.get('TCC_EA0_RDREQ_32B_sum', 0)
     wr, wr64 = v.get('TCC_EA0_WRREQ_sum', 0), v.get('TCC_EA0_WRREQ_64B_sum', 0)
     out[k] = dict(launches=cnt[k], read_bytes=rd32 * 32 + (rd - rd32) * 128, write_bytes=wr64 * 64 + (wr - wr64) * 32)
-conv = [v for k, v in out.items() if 'conv_halo_kernel' in k or 'conv_mfma_kernel' in k]
+# the launches behind srvp_conv_mfma / srvp_conv_mfma_multi: tile kernels + (round 4) the streaming kernels of the 64-channel 64x64 layers
+conv = [v for k, v in out.items() if any(n in k for n in ('conv_halo_kernel', 'conv_mfma_kernel', 'conv_stream64_kernel', 'conv_stream_sub64_kernel'))]
 summary = dict(
     source='rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum (own pass)',
     srvp_conv_mfma=dict(launches=sum(v['launches'] for v in conv),
