@@ -117,6 +117,9 @@ int srvp_conv_set_halo(int on);
  * streaming kernel (csrc/conv_stream.hip: persistent workgroup per CU, rolling LDS row window, register-resident weights); 0: on the
  * tile kernels.  Same results up to fp32 summation order. */
 int srvp_conv_set_stream64(int on);
+/* 1 (default; env SRVP_CONV_IN_STREAM): srvp_conv_in_fwd / srvp_conv_in_fwd_bnr serve 3x3 stride-1 layers with 64 output channels on 64x64
+ * frames through the streaming kernel of csrc/conv_in_stream.hip; 0: through the 128-pixel tile kernel (exact fp32 MFMA).  A/B switch of the tests. */
+int srvp_conv_set_in_stream(int on);
 /* 1 if this descriptor will run on the halo-tiled kernel, which wants its weights fragment-major (pack layout 1) */
 int srvp_conv_wants_fragmajor(const srvp_conv_desc* d);
 /* 0, or the pixel-tile size (>= 256: eligible for bnr_red) of the halo-tiled kernel variant this descriptor will run on */

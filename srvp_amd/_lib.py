@@ -124,6 +124,7 @@ _SIGS = {
     'srvp_bn_stats_f32_det': ([c_vp, c_i64, c_i32, c_vp, c_vp], c_i32),
     'srvp_pack_job_tiles': ([C.POINTER(PackDesc), c_i32], c_i32),
     'srvp_conv_set_stream64': ([c_i32], c_i32),
+    'srvp_conv_set_in_stream': ([c_i32], c_i32),
     'srvp_conv_out_eligible': ([c_i32] * 7, c_i32),
     'srvp_conv_out_fwd': ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_pack_weight_tiles': ([c_vp, c_i32, c_i64, c_vp], c_i32),

@@ -594,6 +594,10 @@ static bool in_mfma_ok(int Cin, int H, int W, int Cout, int k, int s, int p) {
 
 }  // namespace
 
+// conv_in_stream.hip (3x3 stride 1, 64 output channels: streaming kernel)
+int srvp_conv_in_stream_launch(const float* x, const float* w, bf16_t* raw, double* stats, int N, int Cin, int Cout, int Cout_real,
+                               const bf16_t* bnr_raw, const float* bnr_coef, double* bnr_red, hipStream_t st, int* taken);
+
 namespace {
 template <class E>
 int conv_in_fwd_valu(const float* x, const float* w, void* raw, double* stats, int N, int Cin, int H, int W, int Cout, int Cout_real,
@@ -663,6 +667,11 @@ extern "C" int srvp_conv_in_fwd(const float* x, const float* w, void* raw, doubl
     SRVP_REQUIRE(Cin >= 1 && Cin <= MAXC && k <= MAXK && Cout % 8 == 0 && Cout / 8 <= 256, "srvp_conv_in_fwd: unsupported shape");
     if (in_mfma_ok(Cin, H, W, Cout, k, s, p)) {
         hipStream_t st = (hipStream_t)stream;
+        if (k == 3 && s == 1) {
+            int taken = 0;
+            if (int rc = srvp_conv_in_stream_launch(x, w, (bf16_t*)raw, stats, N, Cin, Cout, Cout_real, nullptr, nullptr, nullptr, st, &taken)) return rc;
+            if (taken) { SRVP_CHECK_LAUNCH("srvp_conv_in_fwd(stream)"); return SRVP_OK; }
+        }
         if (k == 3 && Cin == 3) launch_in_fwd<3, 1, 3>(x, w, (bf16_t*)raw, stats, N, Cout, Cout_real, st);
         else if (k == 3) launch_in_fwd<3, 1, 1>(x, w, (bf16_t*)raw, stats, N, Cout, Cout_real, st);
         else if (Cin == 3) launch_in_fwd<4, 2, 3>(x, w, (bf16_t*)raw, stats, N, Cout, Cout_real, st);
@@ -684,6 +693,11 @@ extern "C" int srvp_conv_in_fwd_bnr(const float* x, const float* w, void* raw, i
     SRVP_REQUIRE(x && w && raw && bnr_raw && bnr_coef && bnr_red, "srvp_conv_in_fwd_bnr: null pointer");
     SRVP_REQUIRE(in_mfma_ok(Cin, H, W, Cout, k, s, p) && s == 1 && k == 3, "srvp_conv_in_fwd_bnr: shape not served by the MFMA image-side kernel (3x3 stride 1, 64x64, Cout 32 / 64)");
     hipStream_t st = (hipStream_t)stream;
+    {
+        int taken = 0;
+        if (int rc = srvp_conv_in_stream_launch(x, w, (bf16_t*)raw, nullptr, N, Cin, Cout, Cout_real, (const bf16_t*)bnr_raw, bnr_coef, bnr_red, st, &taken)) return rc;
+        if (taken) { SRVP_CHECK_LAUNCH("srvp_conv_in_fwd_bnr(stream)"); return SRVP_OK; }
+    }
     if (Cin == 3) launch_in_fwd<3, 1, 3>(x, w, (bf16_t*)raw, nullptr, N, Cout, Cout_real, st, (const bf16_t*)bnr_raw, bnr_coef, bnr_red);
     else launch_in_fwd<3, 1, 1>(x, w, (bf16_t*)raw, nullptr, N, Cout, Cout_real, st, (const bf16_t*)bnr_raw, bnr_coef, bnr_red);
     SRVP_CHECK_LAUNCH("srvp_conv_in_fwd_bnr");

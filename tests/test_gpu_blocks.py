@@ -309,6 +309,79 @@ def test_conv_stream64_matches_tile_kernel(N):
     assert rel_err(res[1][0][:4].permute(0, 3, 1, 2).cpu(), ref) < 2 ** -7
 
 
+@pytest.mark.parametrize('N,nc', [(5, 3), (600, 3), (1100, 3), (37, 1)])
+def test_conv_in_stream_matches_tile_kernel(N, nc):
+    """csrc/conv_in_stream.hip (image-side 3x3 layer, nc -> 64 channels on 64x64 fp32 frames: persistent workgroup per CU, frame records of bf16
+    high + low parts, weights split the same way and register-resident, stores straight from the accumulators) against the exact-fp32 tile
+    kernel on the same launches: the plain forward with BatchNorm statistics (encoder.conv.0.0) and the data gradient of the output layer with
+    the producer's fused BatchNorm-backward sums (srvp_conv_in_fwd_bnr).  The split drops terms of 2^-16 relative size: the stored bf16
+    outputs differ from the exact kernel's by one ulp on a few elements per thousand.  N = 5 / 37, 600, 1100 frames: quarter, half, whole
+    frames per work item."""
+    from srvp_amd import _lib as L
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(41)
+    x = torch.rand(N, nc, 64, 64, generator=g)
+    x[0, :, :2] = torch.randn(nc, 2, 64, generator=g) * 3.0          # (gradient frames are signed)
+    w = torch.randn(64, nc, 3, 3, generator=g) * 0.2
+    xd, wd = x.to(dev), w.to(dev)
+    praw = torch.randn(N, 64, 64, 64, generator=g).to(torch.bfloat16).to(dev)
+    coef = torch.stack([torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3, torch.randn(64, generator=g) * 0.1,
+                        torch.rand(64, generator=g) + 0.5]).to(dev).contiguous()
+    coef[0, ::5] *= -1.0
+    st = L.stream()
+    res = {}
+    try:
+        for on in (1, 0):
+            L.call('srvp_conv_set_in_stream', on)
+            raw = torch.full((N, 64, 64, 64), 7.0, dtype=torch.bfloat16, device=dev)
+            stats = torch.zeros(2, 64, dtype=torch.float64, device=dev)
+            L.call('srvp_conv_in_fwd', L.ptr(xd), L.ptr(wd), L.ptr(raw), L.ptr(stats), N, nc, 64, 64, 64, 64, 3, 1, 1, st)
+            raw2 = torch.full((N, 64, 64, 64), 7.0, dtype=torch.bfloat16, device=dev)
+            red = torch.zeros(2, 64, dtype=torch.float64, device=dev)
+            L.call('srvp_conv_in_fwd_bnr', L.ptr(xd), L.ptr(wd), L.ptr(raw2), N, nc, 64, 64, 64, 64, 3, 1, 1, L.ptr(praw), L.ptr(coef), L.ptr(red), st)
+            torch.cuda.synchronize()
+            res[on] = (raw.float(), stats.clone(), raw2.float(), red.clone())
+    finally:
+        L.call('srvp_conv_set_in_stream', 1)
+    for i in (0, 2):
+        a, b = res[1][i], res[0][i]
+        diff = (a - b).abs()
+        assert diff.max().item() <= 2 ** -7 * max(1.0, b.abs().max().item()), i           # at most one bf16 ulp
+        assert (diff > 0).float().mean().item() < 5e-3, (i, (diff > 0).float().mean().item())
+    assert torch.equal(res[1][0], res[1][2])                                              # the two launches compute the same output
+    assert rel_err(res[1][1], res[0][1]) < 2e-5                                           # (the 2^-17 split residue is systematic)
+    # (the fused sums see the data gradient as stored: the few elements that round the other way move them at the 1e-5 level)
+    assert rel_err(res[1][3], res[0][3]) < 2e-4
+    # against torch in fp32 on the first frames, before the bf16 rounding matters: the statistics of one frame
+    ref = F.conv2d(x[:2].double(), w.double(), None, 1, 1)
+    assert rel_err(res[1][0][:2].permute(0, 3, 1, 2).cpu().double(), ref) < 2 ** -8
+    if N <= 40:
+        full = F.conv2d(x.double(), w.double(), None, 1, 1)
+        assert rel_err(res[1][1][0].cpu(), full.sum(dim=(0, 2, 3))) < 1e-5
+        assert rel_err(res[1][1][1].cpu(), (full ** 2).sum(dim=(0, 2, 3))) < 1e-5
+        # the activation gate of the fused sums is a per-channel threshold on the producer's bf16 value there (fmaf(raw, scale, shift) > 0 in the
+        # tile kernel): operands with few mantissa bits make both kernels' outputs exact and equal, the producer's values sit within +- 3 bf16
+        # steps of -shift / scale, so one wrong gate would move a sum by 1e-3 of its size
+        x2 = (torch.randint(-8, 9, (N, nc, 64, 64), generator=g).float() / 8).to(dev)
+        w2 = (torch.randint(-4, 5, (64, nc, 3, 3), generator=g).float() / 4).to(dev)
+        t0 = (-coef[1] / coef[0]).to(torch.bfloat16).float()
+        ulp = torch.maximum(t0.abs(), torch.tensor(1e-30, device=dev)) * 2.0 ** -7
+        praw2 = (t0 + ulp * torch.randint(-3, 4, (N, 64, 64, 64), generator=g).float().to(dev)).to(torch.bfloat16)
+        out = {}
+        try:
+            for on in (1, 0):
+                L.call('srvp_conv_set_in_stream', on)
+                raw2 = torch.empty(N, 64, 64, 64, dtype=torch.bfloat16, device=dev)
+                red = torch.zeros(2, 64, dtype=torch.float64, device=dev)
+                L.call('srvp_conv_in_fwd_bnr', L.ptr(x2), L.ptr(w2), L.ptr(raw2), N, nc, 64, 64, 64, 64, 3, 1, 1, L.ptr(praw2), L.ptr(coef), L.ptr(red), st)
+                torch.cuda.synchronize()
+                out[on] = (raw2.float(), red.clone())
+        finally:
+            L.call('srvp_conv_set_in_stream', 1)
+        assert torch.equal(out[1][0], out[0][0])
+        assert rel_err(out[1][1], out[0][1]) < 2e-6, rel_err(out[1][1], out[0][1])
+
+
 @pytest.mark.parametrize('T,B', [(12, 8), (6, 40)])
 def test_conv_stream_sub64_matches_tile_kernel(T, B):
     """csrc/conv_stream.hip, sub-pixel stage entry at 64 channels (decoder.conv.3.0 forward: four output phases + hoisted skip half +

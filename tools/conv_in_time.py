@@ -19,7 +19,16 @@ def t(fn, reps=10):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-print('conv_in_fwd  %.3f ms' % t(lambda: L.call('srvp_conv_in_fwd', L.ptr(x), L.ptr(w), L.ptr(raw), L.ptr(stats), N, 3, 64, 64, 64, 64, 3, 1, 1, st)))
+N = int(os.environ.get('N', N))
+praw = torch.randn(N, 64, 64, 64, device=dev).to(torch.bfloat16)
+coef = torch.stack([torch.rand(64) + 0.5, torch.randn(64) * 0.3, torch.randn(64) * 0.1, torch.rand(64) + 0.5]).to(dev).contiguous()
+red = torch.zeros(2, 64, dtype=torch.float64, device=dev)
+for on in (1, 0):
+    L.call('srvp_conv_set_in_stream', on)
+    print('in_stream=%d  conv_in_fwd  %.3f ms' % (on, t(lambda: L.call('srvp_conv_in_fwd', L.ptr(x), L.ptr(w), L.ptr(raw), L.ptr(stats), N, 3, 64, 64, 64, 64, 3, 1, 1, st))))
+    print('in_stream=%d  conv_in_fwd_bnr  %.3f ms' % (on, t(lambda: L.call('srvp_conv_in_fwd_bnr', L.ptr(x), L.ptr(w), L.ptr(raw), N, 3, 64, 64, 64, 64, 3, 1, 1,
+                                                                          L.ptr(praw), L.ptr(coef), L.ptr(red), st))))
+L.call('srvp_conv_set_in_stream', 1)
 print('conv_in_wgrad %.3f ms' % t(lambda: L.call('srvp_conv_in_wgrad', L.ptr(x), L.ptr(draw), L.ptr(dw), N, 3, 64, 64, 64, 64, 3, 1, 1, st)))
 # accuracy of the weight gradient against a float64 reference (small N so that the CPU reference is quick)
 N2 = 8
