@@ -1,0 +1,28 @@
+"""Host enqueue time per training step vs GPU time per step (is the step launch-bound?): B = env B (default 24), headline architecture."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import srvp_amd
+from srvp_amd.train import train
+import bench
+cfg = bench.CONFIGS[os.environ.get('CFG', 'bair')]
+B = int(os.environ.get('B', 24)); T = cfg['T']
+dev = torch.device('cuda', 0)
+torch.manual_seed(1)
+model = srvp_amd.StochasticLatentResidualVideoPredictor(*cfg['ctor'])
+model.init(res_gain=cfg['res_gain'])
+model.to(dev).train()
+optim = srvp_amd.FusedAdam(model, lr=3e-4)
+opt = srvp_amd.DotDict(dict(n_euler_steps=cfg['n_euler'], obs_scale=cfg['obs_scale'], beta_y=1.0, beta_z=cfg['beta_z'], l2_res=1.0))
+x = torch.rand(T, B, cfg['ctor'][0] if False else 3, 64, 64).to(dev) if cfg is bench.CONFIGS['bair'] else None
+for _ in range(8):
+    train(model, optim, None, x, dev, opt)
+torch.cuda.synchronize()
+K = 40
+t0 = time.perf_counter()
+for _ in range(K):
+    train(model, optim, None, x, dev, opt)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f'B={B}: host enqueue {1e3 * (t1 - t0) / K:.2f} ms/step, with GPU {1e3 * (t2 - t0) / K:.2f} ms/step')

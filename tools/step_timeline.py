@@ -63,3 +63,10 @@ if side:
     print(f'last kernel before adam: main queue ends at {last_main:.1f}, second queue at {max(S(r) + D(r) for r in side):.1f}')
 small = [D(r) for r in step if r['Queue_Id'] == main and D(r) < 10]
 print(f'kernels < 10 us on the main queue: {len(small)} ({sum(small):.1f} us)')
+
+if len(sys.argv) > 2 and sys.argv[2] == '--list':
+    import re
+    print('every launch of the step: queue, start us, duration us, kernel')
+    for r in step:
+        nm = re.sub(r'\(anonymous namespace\)::|void |at::native::', '', r['Kernel_Name'])[:90]
+        print(f"  q{'M' if r['Queue_Id'] == main else 'S'} {S(r):9.1f} {D(r):8.1f}  {nm}")
