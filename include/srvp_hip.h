@@ -195,7 +195,13 @@ int srvp_bn_finalize_act(const void* raw, const double* stats, double count, con
                          float* running_mean, float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
                          float* mean, float* invstd, int C_real, float eps, float momentum, int act, int N, int H, int W, int C,
                          void* dst, int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep_frames,
-                         int elem_f32, int dst_s2d, void* stream);
+                         void* raw_pool, int elem_f32, int dst_s2d, void* stream);
+/* raw_pool (with dst_pool; may be NULL): [N][H/2][W/2][C], unbordered, element type of raw -- the RAW value at the position each pooled
+ * activation was taken from (first maximum in scan order, torch's tie rule).  It is what lets the BatchNorm-backward sums of a pooled
+ * layer ride the consumer's data-gradient launch: that launch writes the pooled gradient dA_p, only the arg-max position of a window
+ * receives it, so  sum g = sum dA_p * f'(scale * raw_pool + shift)  and likewise the second sum -- srvp_conv_desc.bnr_raw = raw_pool
+ * -- instead of a pass that re-derives the arg-max from four raw pixels per window (srvp_bn_bwd_reduce da_mode 2).  The skip-connection
+ * gradient of such a layer (da2) is added by srvp_bn_bwd_reduce with da_mode 3. */
 /* dst_s2d = 1: `dst` is written SPACE-TO-DEPTH, [N][H/2+2][W/2+2][4C] with a 1-pixel zero border -- pixel (y, x) at position (y/2, x/2),
  * channel group (y&1)*2 + (x&1) -- the layout a 4x4 stride-2 consumer (DCGAN encoder, conv.py:174-179) convolves as a 2x2-tap-per-phase
  * stride-1 halo convolution (srvp_conv_desc.tap_phase_chunks); no pooling then.  srvp_bn_act_s2d: the same store for the two-launch /
@@ -211,7 +217,9 @@ int srvp_bn_act_s2d(const void* raw, const float* scale, const float* shift, int
 typedef struct {
     const void* raw; const void* act; int32_t act_border;   /* act: padded activated tensor (mode 2 only) */
     const float* scale; const float* shift; const float* mean; const float* invstd; int32_t act_kind;
-    const void* da; int32_t da_mode, da_cstride, da_coff, da_border; int32_t da_is_f32;
+    const void* da; int32_t da_mode, da_cstride, da_coff, da_border; int32_t da_is_f32;   /* da_mode 3 (srvp_bn_bwd_reduce only): the pooled consumer's
+                                                             * term is accumulated elsewhere (raw_pool above): only the da2 term is summed -- N = the number of da2 rows,
+                                                             * da2_idx[j] = the FRAME row j belongs to (the inverse map of modes 0-2), `da` unused */
     const void* da2; const int32_t* da2_idx;                /* da2: compact [B][H][W][C]; da2_idx[n] = row or -1 */
     int32_t N, H, W, C;
     void* tsum; int32_t tsum_T;                             /* apply only: bf16 [N/T][H+2b][W+2b][C] = sum over the T time steps (frames

@@ -100,7 +100,7 @@ _SIGS = {
     'srvp_bn_act_keep': ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp], c_i32),
     'srvp_bn_act_keep_f32': ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp], c_i32),
     'srvp_bn_finalize_act': ([c_vp, c_vp, c_f64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_f32, c_i32, c_i32, c_i32, c_i32,
-                             c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp], c_i32),
+                             c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp], c_i32),
     'srvp_bn_act_s2d': ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp], c_i32),
     'srvp_bn_bwd_finalize_apply': ([C.POINTER(BnBwdDesc), c_vp, c_f64, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_i32, c_vp], c_i32),
     'srvp_bn_bwd_reduce': ([C.POINTER(BnBwdDesc), c_vp, c_vp], c_i32),

@@ -34,6 +34,7 @@ BN_FUSED_REDUCE = os.environ.get('SRVP_BN_FUSED_REDUCE', '1') != '0'
 # the decoder's data-gradient chain: the MFMA-bound weight gradients then run beside the HBM-bound BatchNorm passes of the blocks below
 # (measured, same box: 41.70 vs 41.21 ms per step at 192 sequences with / without, 8.88 vs 8.86 at 24: off)
 DEC_WGRAD_EARLY = os.environ.get('SRVP_DEC_WGRAD_EARLY', '0') != '0'
+POOL_FUSED_REDUCE = os.environ.get('SRVP_POOL_FUSED_REDUCE', '1') != '0'    # 0: pooled layers keep their own BatchNorm-backward reduction pass
 S_QUAD = os.environ.get('SRVP_S_QUAD', '1') != '0'        # hoisted skip half stored pixel-quad-major (16-byte loads in the consumers)
 SPLITK = int(os.environ.get('SRVP_CONV_SPLITK', '16'))    # tiny-M long-K launches: K steps shared over this many workgroups
 # Sub-pixel form of "nearest x2 upsample, then 3x3 conv" (conv.py:331-349): output phase a in {0,1} of a row pair reads
@@ -1017,6 +1018,7 @@ class ConvNetBase:
                 if BN_FUSED_FINALIZE:
                     L.call('srvp_bn_finalize_act', L.ptr(blk.raw), L.ptr(blk.stats), count, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(nbt),
                            L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), blk.cout_r, BN_EPS, BN_MOMENTUM, *act_args,
+                           L.ptr(getattr(blk, 'raw_pool', None)) if pool is not None else None,
                            1 if blk.f32 else 0, 1 if (out is not None and out.s2d) else 0, st)
                     return
                 L.call('srvp_bn_finalize', L.ptr(blk.stats), count, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(nbt),
@@ -1086,6 +1088,12 @@ class ConvNetBase:
         if blk.has_bn:
             if not getattr(blk, '_reduce_fused', False):       # (else: accumulated by the consumer's data-gradient launch, _fuse_bn_reduce)
                 L.call('srvp_bn_bwd_reduce', C.byref(d), L.ptr(blk.red), st)
+            elif d.da_mode == 2 and da.get('da2') is not None:
+                # pooled layer whose arg-max terms rode the consumer's data-gradient launch (raw_pool): the skip-connection gradient of its
+                # B selected frames is the only term left -- both sums are linear in the gradient
+                d3 = self._bnbwd_desc(blk, da)
+                d3.da_mode, d3.N, d3.da2_idx = 3, da['da2'].shape[0], L.ptr(da['da2_sel'])     # rows of da2 and the frame each belongs to
+                L.call('srvp_bn_bwd_reduce', C.byref(d3), L.ptr(blk.red), st)
             local = float(blk.N * blk.OH * blk.OW)
             count = local
             if sync is not None:
@@ -1186,7 +1194,24 @@ class ConvNetBase:
             if (q.ups or q.subpix) and not (q.subpix and q.s2d):
                 continue
             p = next((b for b in self.blocks if b.out is not None and b.out is q.srcs[0]), None)
-            if p is None or not p.has_bn or p.act != L.ACT_LRELU or p.spec.get('skip_out') is not None or p.pool is not None:
+            if p is None:
+                # a POOLED producer (round 4): its forward stores the raw value at every window's arg-max (raw_pool, srvp_bn_finalize_act), the
+                # pooled gradient q writes lands on exactly that position, so q's launch accumulates the sums from (dA_pooled, raw_pool) as for
+                # a same-resolution pair -- the VALU-bound pass that re-derived the arg-max from four raw pixels per window (1.7 ms per step over
+                # the four VGG stages) is gone; a skip-connection gradient on top is added by a da_mode 3 reduction of its B frames
+                pp = next((b for b in self.blocks if b.pool is not None and b.pool is q.srcs[0]), None)
+                if (pp is None or not POOL_FUSED_REDUCE or not BN_FUSED_FINALIZE or not pp.has_bn or pp.act != L.ACT_LRELU or (q.ups or q.subpix)
+                        or len(q._dg) != 1):
+                    continue
+                d = q._dg[0]
+                shape = (pp.N, pp.OH // 2, pp.OW // 2, pp.cout)
+                if shape != tuple(q.dcat.shape) or d.Cout != pp.cout or int(lib.srvp_conv_runs_on_halo(C.byref(d))) < 256:
+                    continue
+                pp.raw_pool = torch.empty(shape, dtype=pp.adt, device=self.dev)
+                d.bnr_raw, d.bnr_coef, d.bnr_red = L.ptr(pp.raw_pool), L.ptr(pp.coef), L.ptr(pp.red)
+                pp._reduce_fused = True
+                continue
+            if not p.has_bn or p.act != L.ACT_LRELU or p.spec.get('skip_out') is not None or p.pool is not None:
                 continue
             d = q._dg[0]
             if tuple(p.raw.shape) != tuple(q.dcat.shape) or d.Cout != p.cout or int(lib.srvp_conv_runs_on_halo(C.byref(d))) < 256:
@@ -1306,7 +1331,9 @@ class EncoderNet(ConvNetBase):
                 unpacked = True
             sk = blk.spec['skip_out']
             if sk is not None and skip_grads and (3 - sk) in skip_grads:
-                da['da2'], da['da2_idx'] = skip_grads[3 - sk]
+                sg = skip_grads[3 - sk]
+                da['da2'], da['da2_idx'] = sg[0], sg[1]
+                da['da2_sel'] = sg[2] if len(sg) > 2 else None                   # sample -> frame (the inverse of da2_idx)
             self._bn_backward(blk, params, grads, da, st, sync)
             if blk.role == 'in':
                 w = blk.spec['key'] + '.weight'

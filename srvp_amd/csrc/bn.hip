@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const E* __restrict__ raw, 
                                                      const float* __restrict__ shift, int act, int N, int H, int W, int C,
                                                      E* __restrict__ dst, int db, E* __restrict__ dpool, int pb,
                                                      float* __restrict__ dst_f32, const int* __restrict__ keep, const BnFin fin,
-                                                     const int dst_s2d) {
+                                                     const int dst_s2d, E* __restrict__ rawpool) {
     if (ACT >= 0) act = ACT;
     const int CG = C / 8;
     const int PPB = blockDim.x / CG;             // (pooled) pixels handled in parallel by one workgroup
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const E* __restrict__ raw, 
 #pragma unroll
             for (int j = 0; j < R; ++j)
                 El<E>::ld8_nt(raw + (((size_t)n * H + y * R + i) * W + x * R + j) * C + cg * 8, v[i * R + j]);
-        float mx[8];
+        float mx[8], rsel[8];
 #pragma unroll
         for (int i = 0; i < R; ++i)
 #pragma unroll
@@ -159,12 +159,20 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const E* __restrict__ raw, 
                 if (POOL) {
                     // pooled values are taken from the activations as stored (bf16-rounded: what the consumer of `dst` sees)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float fr = El<E>::rnd(f[e]); mx[e] = (i == 0 && j == 0) ? fr : fmaxf(mx[e], fr); }
+                    for (int e = 0; e < 8; ++e) {
+                        // (strictly greater replaces: torch's first-max tie rule, the one the backward routes the gradient by; rsel = the RAW
+                        // value at that position -- srvp_bn_finalize_act's raw_pool, what the fused backward reduction of a pooled layer reads)
+                        const float fr = El<E>::rnd(f[e]);
+                        const bool take = (i == 0 && j == 0) || fr > mx[e];
+                        mx[e] = take ? fr : mx[e];
+                        rsel[e] = take ? v[i * R + j][e] : rsel[e];
+                    }
                 }
             }
         if (POOL) {
             size_t poff = (((size_t)n * (OH + 2 * pb) + y + pb) * (OW + 2 * pb) + x + pb) * C + cg * 8;
             El<E>::st8(dpool + poff, mx);
+            if (rawpool) El<E>::st8(rawpool + (((size_t)n * OH + y) * OW + x) * C + cg * 8, rsel);
         }
     }
 }
@@ -345,7 +353,38 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdK a, doub
             sc[e] = a.scale[cg * 8 + e]; sh[e] = a.shift[cg * 8 + e];
             mu[e] = a.mean ? a.mean[cg * 8 + e] : 0.f; is[e] = a.invstd ? a.invstd[cg * 8 + e] : 0.f;
         }
-        if constexpr (MODE == 2) {
+        if constexpr (MODE == 3) {
+            // pooled consumer whose own gradient is reduced ELSEWHERE (da_mode 3: the consumer's data-gradient launch carries raw_pool and
+            // accumulates the arg-max terms, srvp_conv_desc.bnr_*): only the frames that also receive a skip-connection gradient are walked
+            // here -- a.N of them, row j of da2 belongs to frame da2_idx[j] -- every pixel with the da2 term alone (both sums are linear in
+            // the gradient).  Four pixels per thread and iteration, all eight loads up front.
+            const unsigned P = (unsigned)a.N * a.H * a.W, stride = gridDim.x * PPB;
+            const unsigned hw = (unsigned)a.H * a.W;
+            constexpr int U = 4;
+            for (unsigned p = blockIdx.x * (PPB * U) + pl; p < P; p += U * stride) {
+                float rv[U][8], uv[U][8];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const unsigned pu = p + u * PPB;
+                    ok[u] = pu < P;
+                    const unsigned pc = ok[u] ? pu : 0u;
+                    const unsigned j = pc / hw, px = pc - j * hw;
+                    const int n = a.da2_idx[j];
+                    El<E>::ld8_nt((const E*)a.raw + ((size_t)n * hw + px) * a.C + cg * 8, rv[u]);
+                    El<E>::ld8_nt((const E*)a.da2 + (size_t)pc * a.C + cg * 8, uv[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float m = ok[u] ? 1.f : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float g = m * uv[u][e] * act_bwd(rv[u][e] * sc[e] + sh[e], ACT >= 0 ? ACT : a.act_kind);
+                        s1[e] += g; s2[e] += g * (rv[u][e] - mu[e]) * is[e];
+                    }
+                }
+            }
+        } else if constexpr (MODE == 2) {
             // pooled: one thread per 2x2 window (window activations and the pooled gradient are read once)
             // (one window per iteration: this loop is VALU-bound -- the four activations of a window are recomputed, rounded and
             // arg-max-routed, ~800 instructions per 80 bytes -- and two windows in flight only cost occupancy: 477 -> 613 us)
@@ -711,7 +750,7 @@ namespace {
 template <class E>
 int bn_act_launch(const void* raw, const float* scale, const float* shift, int act, int N, int H, int W, int C, void* dst,
                   int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep, void* stream,
-                  const BnFin fin = BnFin{}, int dst_s2d = 0) {
+                  const BnFin fin = BnFin{}, int dst_s2d = 0, void* raw_pool = nullptr) {
     SRVP_REQUIRE(!dst_s2d || (dst && !dst_pool && H % 2 == 0 && W % 2 == 0), "srvp_bn_act: a space-to-depth destination needs even H, W and no pooling");
     SRVP_REQUIRE(raw && scale && shift && C % 8 == 0, "srvp_bn_act: bad args");
     hipStream_t st = (hipStream_t)stream;
@@ -721,13 +760,13 @@ int bn_act_launch(const void* raw, const float* scale, const float* shift, int a
         SRVP_REQUIRE(C / 8 <= 256 && (long long)N * H * W < (1ll << 31), "srvp_bn_act: C=%d / size unsupported", C);
         auto kern = act == ACT_LRELU ? bn_act_kernel<E, true, ACT_LRELU> : bn_act_kernel<E, true, -1>;
         hipLaunchKernelGGL(kern, dim3(grid_for(total, (256 / (C / 8)) * 2)), dim3(256), 0, st, (const E*)raw, scale, shift,
-                           act, N, H, W, C, (E*)dst, dst_border, (E*)dst_pool, pool_border, dst_f32, (const int*)keep, fin, dst_s2d);
+                           act, N, H, W, C, (E*)dst, dst_border, (E*)dst_pool, pool_border, dst_f32, (const int*)keep, fin, dst_s2d, (E*)raw_pool);
     } else {
         long long total = (long long)N * H * W;
         SRVP_REQUIRE(C / 8 <= 256 && total < (1ll << 31), "srvp_bn_act: C=%d / size unsupported", C);
         auto kern = act == ACT_LRELU ? bn_act_kernel<E, false, ACT_LRELU> : bn_act_kernel<E, false, -1>;
         hipLaunchKernelGGL(kern, dim3(grid_for(total, (256 / (C / 8)) * 4)), dim3(256), 0, st, (const E*)raw, scale, shift,
-                           act, N, H, W, C, (E*)dst, dst_border, (E*)nullptr, 0, dst_f32, (const int*)nullptr, fin, dst_s2d);
+                           act, N, H, W, C, (E*)dst, dst_border, (E*)nullptr, 0, dst_f32, (const int*)nullptr, fin, dst_s2d, (E*)nullptr);
     }
     SRVP_CHECK_LAUNCH("srvp_bn_act");
     return SRVP_OK;
@@ -748,12 +787,13 @@ extern "C" int srvp_bn_act_keep_f32(const void* raw, const float* scale, const f
 extern "C" int srvp_bn_finalize_act(const void* raw, const double* stats, double count, const float* gamma, const float* beta,
                                     float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift, float* mean,
                                     float* invstd, int C_real, float eps, float momentum, int act, int N, int H, int W, int C, void* dst,
-                                    int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep, int elem_f32,
-                                    int dst_s2d, void* stream) {
+                                    int dst_border, void* dst_pool, int pool_border, float* dst_f32, const int32_t* keep, void* raw_pool,
+                                    int elem_f32, int dst_s2d, void* stream) {
     SRVP_REQUIRE(stats && scale && shift && mean && invstd && C > 0 && C <= BN_MAX_C && count > 0, "srvp_bn_finalize_act: bad args");
+    SRVP_REQUIRE(!raw_pool || dst_pool, "srvp_bn_finalize_act: raw_pool needs dst_pool");
     BnFin fin{stats, count, gamma, beta, running_mean, running_var, (long long*)nbt, scale, shift, mean, invstd, C_real, eps, momentum};
-    if (elem_f32) return bn_act_launch<float>(raw, scale, shift, act, N, H, W, C, dst, dst_border, dst_pool, pool_border, dst_f32, keep, stream, fin, dst_s2d);
-    return bn_act_launch<bf16_t>(raw, scale, shift, act, N, H, W, C, dst, dst_border, dst_pool, pool_border, dst_f32, keep, stream, fin, dst_s2d);
+    if (elem_f32) return bn_act_launch<float>(raw, scale, shift, act, N, H, W, C, dst, dst_border, dst_pool, pool_border, dst_f32, keep, stream, fin, dst_s2d, raw_pool);
+    return bn_act_launch<bf16_t>(raw, scale, shift, act, N, H, W, C, dst, dst_border, dst_pool, pool_border, dst_f32, keep, stream, fin, dst_s2d, raw_pool);
 }
 // srvp_bn_act_keep with a space-to-depth destination (eval mode / separate-finalize path of a block whose consumer is a 4x4 stride-2 conv)
 extern "C" int srvp_bn_act_s2d(const void* raw, const float* scale, const float* shift, int act, int N, int H, int W, int C, void* dst,
@@ -774,6 +814,7 @@ extern "C" int srvp_bn_bwd_reduce(const srvp_bnbwd_desc* d, double* red, void* s
     const int CG = k.C / 8, PPB = 256 / CG;
     long long P = (long long)k.N * k.H * k.W;
     SRVP_REQUIRE(P < (1ll << 31), "srvp_bn_bwd_reduce: too many pixels");
+    SRVP_REQUIRE(k.da_mode != 3 || (k.da2 && k.da2_idx && !d->elem_f32), "srvp_bn_bwd_reduce: da_mode 3 (skip-gradient term only) needs da2, da2_idx (row -> frame), bf16 tensors");
     if (k.da_mode == 2) P /= 4;
     // >= 64 pixel rows per thread slot: the 2C fp64 atomics per workgroup must stay small beside its streaming work -- unless that
     // leaves fewer than 64 workgroups (the 1x1 encoder output: 3 workgroups walked 2304 rows in 100 us of dependent loads)
@@ -802,6 +843,7 @@ extern "C" int srvp_bn_bwd_reduce(const srvp_bnbwd_desc* d, double* red, void* s
     }
     auto kern = k.da_mode == 0 ? (lr ? bn_bwd_reduce_kernel<bf16_t, 0, ACT_LRELU> : bn_bwd_reduce_kernel<bf16_t, 0, -1>)
               : k.da_mode == 1 ? (lr ? bn_bwd_reduce_kernel<bf16_t, 1, ACT_LRELU> : bn_bwd_reduce_kernel<bf16_t, 1, -1>)
+              : k.da_mode == 3 ? (lr ? bn_bwd_reduce_kernel<bf16_t, 3, ACT_LRELU> : bn_bwd_reduce_kernel<bf16_t, 3, -1>)
                                : (lr ? bn_bwd_reduce_kernel<bf16_t, 2, ACT_LRELU> : bn_bwd_reduce_kernel<bf16_t, 2, -1>);
     hipLaunchKernelGGL(kern, g, dim3(256), 0, (hipStream_t)stream, k, red);
     SRVP_CHECK_LAUNCH("srvp_bn_bwd_reduce");

@@ -16,6 +16,8 @@
 // set 1 = (w_hi | w_hi | 0) meets (x_hi | x_lo), set 2 = (w_lo | 0 | 0) meets x_hi: w x = w_hi x_hi + w_hi x_lo + w_lo x_hi, relative
 // error 2^-16 per product, accumulated in fp32 -- two orders below the bf16 rounding of the stored output (the precision = 'fp32'
 // parity mode keeps the exact direct kernels).  20 MFMAs of 8 passes per 32 pixels x 64 channels instead of 28 of 16 passes.
+// nc = 1 (KTH, Moving MNIST): the record holds (x1, x2, x3, x1, x2, x1) -- three bf16 terms = all 24 bits -- against the weights' (w1, w1, w1,
+// w2, w2, w3): every product term down to 2^-24 in one weight set, i.e. fp32-exact products in 10 MFMAs.
 // Output channels are PERMUTED over the MFMA rows so that a lane ends up with 16 consecutive channels of one pixel: it rounds them and
 // stores 32 contiguous bytes straight from registers (no LDS staging, no barrier in the pixel loop), and the BatchNorm sums are plain
 // per-lane register accumulators over the whole launch (one double atomic per channel and workgroup at the end).
@@ -32,6 +34,11 @@ constexpr int REC_BYTES = PWI * PWI * 16;                   // 69 696: [66][66] 
 
 __device__ __forceinline__ unsigned short bf_hi(float v) { return f2bf(v); }
 __device__ __forceinline__ unsigned short bf_lo(float v) { return f2bf(v - bf2f(f2bf(v))); }
+// three bf16 terms = all 24 significant bits of an fp32 value (the subtractions are exact)
+__device__ __forceinline__ void bf_split3(float v, unsigned short (&t)[3]) {
+    t[0] = f2bf(v); const float r1 = v - bf2f(t[0]);
+    t[1] = f2bf(r1); t[2] = f2bf(r1 - bf2f(t[1]));
+}
 
 struct InStreamK {
     const float* x;          // (N, CIN, 64, 64) fp32 frames
@@ -67,8 +74,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int ci = i % CIN;
                 const bool ok = tap < 9 && co < a.Cout_real;
                 const float wv = ok ? a.w[((size_t)co * CIN + ci) * 9 + (tap < 9 ? tap : 0)] : 0.f;
-                v1[i] = i < 2 * CIN ? bf_hi(wv) : (unsigned short)0;
-                v2[i] = i < CIN ? bf_lo(wv) : (unsigned short)0;
+                if constexpr (CIN == 1) {
+                    // one channel: the record has room for (x1, x2, x3, x1, x2, x1) against (w1, w1, w1, w2, w2, w3) -- every product term down to
+                    // 2^-24 in ONE weight set: fp32-exact products, fp32 accumulation
+                    unsigned short t3[3];
+                    bf_split3(wv, t3);
+                    v1[i] = i < 3 ? t3[0] : (i < 5 ? t3[1] : (i == 5 ? t3[2] : (unsigned short)0));
+                    v2[i] = 0;
+                } else {
+                    v1[i] = i < 2 * CIN ? bf_hi(wv) : (unsigned short)0;
+                    v2[i] = i < CIN ? bf_lo(wv) : (unsigned short)0;
+                }
             }
             u32x4_t p1, p2;
             p1.x = v1[0] | ((unsigned)v1[1] << 16); p1.y = v1[2] | ((unsigned)v1[3] << 16); p1.z = v1[4] | ((unsigned)v1[5] << 16); p1.w = v1[6] | ((unsigned)v1[7] << 16);
@@ -148,15 +164,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // ---- staging -> records: one pixel per thread and round (three conflict-free 4-byte reads, one 16-byte write)
         for (int q = tid; q < nrow * IW; q += 512) {
             const int r = q >> 6, xx = q & 63;
-            unsigned short hv[CIN], lv[CIN];
-#pragma unroll
-            for (int c = 0; c < CIN; ++c) {
-                const float v = stg[(c * nrow + r) * IW + xx];
-                hv[c] = bf_hi(v); lv[c] = bf_lo(v);
-            }
             unsigned short sl[8];
+            if constexpr (CIN == 1) {
+                unsigned short t3[3];
+                bf_split3(stg[r * IW + xx], t3);
+                sl[0] = t3[0]; sl[1] = t3[1]; sl[2] = t3[2]; sl[3] = t3[0]; sl[4] = t3[1]; sl[5] = t3[0]; sl[6] = 0; sl[7] = 0;
+            } else {
+                unsigned short hv[CIN], lv[CIN];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) sl[i] = i < CIN ? hv[i % CIN] : (i < 2 * CIN ? lv[i % CIN] : (unsigned short)0);
+                for (int c = 0; c < CIN; ++c) {
+                    const float v = stg[(c * nrow + r) * IW + xx];
+                    hv[c] = bf_hi(v); lv[c] = bf_lo(v);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sl[i] = i < CIN ? hv[i % CIN] : (i < 2 * CIN ? lv[i % CIN] : (unsigned short)0);
+            }
             u32x4_t pr;
             pr.x = sl[0] | ((unsigned)sl[1] << 16); pr.y = sl[2] | ((unsigned)sl[3] << 16); pr.z = sl[4] | ((unsigned)sl[5] << 16); pr.w = sl[6] | ((unsigned)sl[7] << 16);
             *reinterpret_cast<u32x4_t*>(rec + ((size_t)(lo + r + 1) * PWI + xx + 1) * 16) = pr;
@@ -191,7 +213,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                     const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, fb[t][s]);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], bf, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][1], bf, acc, 0, 0, 0);
+                    if constexpr (CIN != 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][1], bf, acc, 0, 0, 0);
                 }
                 if (t == 0) {
 #pragma unroll

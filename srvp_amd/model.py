@@ -534,7 +534,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             skip_grads = {}
             idx = pl['skip_idx']                                   # frame -> sample whose skip connection it feeds, or -1 (forward)
             for stage, dsel in dec.skip_grads(nt, B, st).items():
-                skip_grads[stage] = (dsel, idx)
+                skip_grads[stage] = (dsel, idx, pl['skip_sel_t'])     # gradient rows, frame -> row (or -1), row -> frame
         nhp = cpad(self.nhx)
         if nhp != self.nhx:
             d_hx_p = torch.zeros(T * B, nhp, dtype=torch.float32, device=d_hx.device)

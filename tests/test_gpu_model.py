@@ -712,7 +712,73 @@ def test_fused_bn_backward_reduction_equals_separate_pass(B):
                         assert err < 1e-5, (p.spec['key'], err)
     finally:
         convnet.BN_FUSED_REDUCE = old
-    assert fused_layers[True] >= 12 and fused_layers[False] == 0, fused_layers     # 6 encoder + 5 + 4 (sub-pixel consumers) decoder layers
+    assert fused_layers[True] >= 12 and fused_layers[False] == 0, fused_layers     # 6 encoder (+ pooled stages) + 5 + 4 (sub-pixel consumers) decoder layers
     assert torch.allclose(grads[True][1], grads[False][1], rtol=1e-12)              # the forward is the same code
+    worst = max(((grads[True][0][k] - grads[False][0][k]).norm() / (grads[False][0][k].norm() + 1e-30)).item() for k in grads[True][0])
+    assert worst < 5e-2, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B', [3, 8])
+def test_pooled_bn_backward_reduction_rides_the_consumer(B):
+    """Pooled VGG stages (conv.py:204-222): the forward stores the raw value at every window's arg-max (srvp_bn_finalize_act raw_pool), the
+    consumer's data-gradient launch accumulates the BatchNorm-backward sums from (pooled dA, raw_pool) in its epilogue, and the skip-connection
+    gradient of the B selected frames is added by a da_mode 3 reduction.  Sharp: after a training step, the separate pass (da_mode 2: arg-max
+    re-derived from four raw pixels per window, + da2) run on the tensors the step left behind gives the same two sums per channel to 1e-5.
+    End to end: the step with SRVP_POOL_FUSED_REDUCE off gives the same loss and the same gradients within the band a 1-ulp change of a
+    BatchNorm coefficient opens on an untrained bf16 network."""
+    import ctypes as C
+    import srvp_amd
+    from srvp_amd import convnet, _lib as L
+    from srvp_amd.train import fused_step
+    dev = torch.device('cuda')
+    ctor = (64, 3, 64, 128, 50, 50, True, 2, 256, 3, 512, 4, 'vgg')
+    T, ne = 4, 2
+    g = torch.Generator().manual_seed(33)
+    x = torch.rand(T, B, 3, 64, 64, generator=g).to(dev)
+    tape = dict(t_skip=torch.randint(T, (B,), generator=g), t_w=torch.stack([torch.randperm(T, generator=g)[:2] for _ in range(B)], 1),
+                eps_y0=torch.randn(B, 50, generator=g), eps_z=torch.randn(T - 1, B, 50, generator=g))
+    opt = srvp_amd.DotDict(dict(n_euler_steps=ne, obs_scale=0.5, beta_y=1.0, beta_z=1.0, l2_res=1.0))
+    grads, npooled = {}, {}
+    old = convnet.POOL_FUSED_REDUCE
+    try:
+        for mode in (True, False):
+            convnet.POOL_FUSED_REDUCE = mode
+            torch.manual_seed(1)
+            m = srvp_amd.StochasticLatentResidualVideoPredictor(*ctor)
+            m.init(1.41)
+            m.to(dev).train()
+            o = srvp_amd.FusedAdam(m, lr=1e-3)
+            o.zero_grad()
+            acc = fused_step(m, x, opt, tape=tape)
+            torch.cuda.synchronize()
+            grads[mode] = ({k: p.grad.detach().clone() for k, p in m.named_parameters()}, acc.cpu())
+            pl = m._last_plan
+            enc, dec = pl['enc'], pl['dec']
+            pooled = [b for b in enc.blocks if b.pool is not None and getattr(b, '_reduce_fused', False)]
+            npooled[mode] = len(pooled)
+            if mode:
+                sk = {stage: (dsel, pl['skip_idx']) for stage, dsel in dec.skip_grads(T, B, L.stream()).items()}
+                for p in pooled:
+                    q = next(b for b in enc.blocks if b.srcs and b.srcs[0] is p.pool)
+                    assert p.raw_pool is not None and tuple(p.raw_pool.shape) == tuple(q.dcat.shape)
+                    da = dict(t=q.dcat, mode=2, cstride=q.dcat_c, coff=0, border=0)
+                    if p.spec['skip_out'] is not None:
+                        da['da2'], da['da2_idx'] = sk[3 - p.spec['skip_out']]
+                    d = enc._bnbwd_desc(p, da)
+                    ref = torch.zeros_like(p.red)
+                    L.call('srvp_bn_bwd_reduce', C.byref(d), L.ptr(ref), L.stream())
+                    torch.cuda.synchronize()
+                    err = ((p.red - ref).abs().max() / (ref.abs().max() + 1e-30)).item()
+                    assert err < 1e-5, (p.spec['key'], err)
+                    # and raw_pool is the raw value behind every pooled activation
+                    sc, sh = p.coef[0].float(), p.coef[1].float()
+                    a = torch.nn.functional.leaky_relu(p.raw_pool.float() * sc + sh, 0.2).to(torch.bfloat16).float()
+                    diff = (a - p.pool.interior().float()).abs()              # (the kernel's fused multiply-add vs two roundings here: a bf16 ulp, rarely)
+                    assert (diff > 0).float().mean().item() < 1e-3 and diff.max().item() <= 2 ** -7 * max(1.0, a.abs().max().item()), p.spec['key']
+    finally:
+        convnet.POOL_FUSED_REDUCE = old
+    assert npooled[True] >= 3 and npooled[False] == 0, npooled          # the 64x64, 32x32 and 16x16 stages (the 8x8 stage feeds the 4x4 -> 1x1 split-K launch)
+    assert torch.allclose(grads[True][1], grads[False][1], rtol=1e-12)   # the forward computes the same values
     worst = max(((grads[True][0][k] - grads[False][0][k]).norm() / (grads[False][0][k].norm() + 1e-30)).item() for k in grads[True][0])
     assert worst < 5e-2, worst
