@@ -309,6 +309,8 @@ int srvp_conv_in_stream_launch(const float* x, const float* w, bf16_t* raw, doub
     *taken = 0;
     if (g_in_stream < 0) { const char* e = getenv("SRVP_CONV_IN_STREAM"); g_in_stream = e ? atoi(e) : 1; }
     if (!g_in_stream || Cout != 64 || (Cin != 1 && Cin != 3) || N < 1) return SRVP_OK;
+    // 16-byte LDS-DMA pieces of the frames, 16-byte stores / loads of the NHWC tensors: anything less aligned stays on the tile kernel
+    if ((((uintptr_t)x) | ((uintptr_t)raw) | ((uintptr_t)bnr_raw)) & 15) return SRVP_OK;
     static int ncu = 0;
     if (!ncu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; if (ncu <= 0) ncu = 256; }
     InStreamK a;
