@@ -1333,7 +1333,16 @@ class EncoderNet(ConvNetBase):
             if sk is not None and skip_grads and (3 - sk) in skip_grads:
                 sg = skip_grads[3 - sk]
                 da['da2'], da['da2_idx'] = sg[0], sg[1]
-                da['da2_sel'] = sg[2] if len(sg) > 2 else None                   # sample -> frame (the inverse of da2_idx)
+                if len(sg) > 2:
+                    da['da2_sel'] = sg[2]                                        # row -> frame (the inverse of da2_idx)
+                else:
+                    # (a caller that hands over the frame -> row map only: invert it here, a few tiny launches off the hot path)
+                    inv = getattr(self, '_da2_sel', None)
+                    if inv is None or inv.numel() != sg[0].shape[0]:
+                        inv = self._da2_sel = torch.zeros(sg[0].shape[0], dtype=torch.int32, device=self.dev)
+                    fr = torch.nonzero(sg[1] >= 0).flatten()
+                    inv[sg[1][fr].long()] = fr.to(torch.int32)
+                    da['da2_sel'] = inv
             self._bn_backward(blk, params, grads, da, st, sync)
             if blk.role == 'in':
                 w = blk.spec['key'] + '.weight'

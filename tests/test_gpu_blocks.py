@@ -634,9 +634,10 @@ def test_bn_act_fwd_bwd(mode, C_):
     coef2 = torch.zeros(4, Cp, device=dev)
     out2 = Feat(N, H, H, C_, dev)
     pool2 = Feat(N, H // 2, H // 2, C_, dev) if mode == 'pool' else None
+    rawp = torch.zeros(N, H // 2, H // 2, Cp, dtype=torch.bfloat16, device=dev) if mode == 'pool' else None    # raw value behind every pooled activation
     L.call('srvp_bn_finalize_act', L.ptr(raw), L.ptr(stats), cnt, L.ptr(gamma), L.ptr(beta), L.ptr(rm2), L.ptr(rv2), L.ptr(nbt2),
            L.ptr(coef2[0]), L.ptr(coef2[1]), L.ptr(coef2[2]), L.ptr(coef2[3]), C_, BN_EPS, BN_MOMENTUM, L.ACT_LRELU, N, H, H, Cp,
-           L.ptr(out2.t), 1, L.ptr(pool2.t) if pool2 else None, 1, None, None, 0, 0, st)
+           L.ptr(out2.t), 1, L.ptr(pool2.t) if pool2 else None, 1, None, None, L.ptr(rawp) if pool2 else None, 0, 0, st)
     draw2 = torch.zeros_like(draw)
     bcoef2 = torch.zeros(3, Cp, device=dev)
     dgamma2, dbeta2 = torch.zeros(C_, device=dev), torch.zeros(C_, device=dev)
@@ -644,6 +645,13 @@ def test_bn_act_fwd_bwd(mode, C_):
     torch.cuda.synchronize()
     assert torch.equal(out2.t, out.t) and torch.equal(coef2, coef) and torch.equal(rm2, rm) and torch.equal(rv2, rv) and int(nbt2) == 1
     assert pool is None or torch.equal(pool2.t, pool.t)
+    if pool2 is not None:
+        # raw_pool: activating it again gives the pooled tensor, and it is one of the window's four raw values
+        a4 = F.leaky_relu(rawp[..., :C_].float() * coef2[0, :C_] + coef2[1, :C_], 0.2).to(torch.bfloat16).float()
+        diff = (a4 - pool2.interior().float()).abs()
+        assert (diff > 0).float().mean().item() < 2e-3 and diff.max().item() <= 2 ** -7 * max(1.0, a4.abs().max().item())
+        win = raw[..., :C_].view(N, H // 2, 2, H // 2, 2, C_).permute(0, 1, 3, 5, 2, 4).reshape(N, H // 2, H // 2, C_, 4)
+        assert bool((win == rawp[..., :C_].unsqueeze(-1)).any(-1).all())
     assert torch.equal(draw2, draw) and torch.equal(bcoef2, bcoef) and torch.equal(dgamma2, dgamma) and torch.equal(dbeta2, dbeta)
     del keep
 

@@ -304,6 +304,11 @@ def test_conv_backward_teacher_forced(name):
             if blk.pool is not None:
                 f = blk.pool
                 put_nhwc(f.t[:, f.b:f.b + f.H, f.b:f.b + f.W, :], torch.nn.functional.max_pool2d(e['out'], 2, 2).cuda())
+                if getattr(blk, 'raw_pool', None) is not None:
+                    # the raw value behind every pooled activation (srvp_bn_finalize_act raw_pool: first maximum of the stored activations)
+                    ob = e['out'].to(torch.bfloat16).float()
+                    _, ix = torch.nn.functional.max_pool2d(ob, 2, 2, return_indices=True)
+                    put_nhwc(blk.raw_pool, e['raw'].to(torch.bfloat16).float().flatten(2).gather(2, ix.flatten(2)).view_as(ix).cuda())
             if blk.role == 'out':
                 blk.x_out.copy_(torch.sigmoid(e['out']).cuda())
     # ---- HIP backward of decoder and encoder on the oracle's gradients
