@@ -13,8 +13,8 @@
 // LOW parts (x = hi + lo + O(2^-17 x)), zero-padded to 8 slots.  A record IS the 8-value k group a lane of v_mfma_f32_32x32x16_bf16
 // holds, so one ds_read_b128 per lane is the operand for two taps of 32 pixels (lanes 0-31: tap 2s, lanes 32-63: tap 2s + 1), five
 // reads per 32-pixel tile.  The WEIGHTS are the stationary M operand, split the same way and held in registers for the whole launch:
-// set 1 = (w_hi | w_hi | 0) meets (x_hi | x_lo), set 2 = (w_lo | 0 | 0) meets x_hi: w x = w_hi x_hi + w_hi x_lo + w_lo x_hi, relative
-// error 2^-16 per product, accumulated in fp32 -- two orders below the bf16 rounding of the stored output (the precision = 'fp32'
+// set 1 = (w_hi | w_hi | 0) and set 2 = (w_lo | w_lo | 0) meet (x_hi | x_lo): w x = (w_hi + w_lo)(x_hi + x_lo), relative
+// error 2^-17 per product (what two bf16 terms leave of each operand), accumulated in fp32 -- two orders below the bf16 rounding of the stored output (the precision = 'fp32'
 // parity mode keeps the exact direct kernels).  20 MFMAs of 8 passes per 32 pixels x 64 channels instead of 28 of 16 passes.
 // nc = 1 (KTH, Moving MNIST): the record holds (x1, x2, x3, x1, x2, x1) -- three bf16 terms = all 24 bits -- against the weights' (w1, w1, w1,
 // w2, w2, w3): every product term down to 2^-24 in one weight set, i.e. fp32-exact products in 10 MFMAs.
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     v2[i] = 0;
                 } else {
                     v1[i] = i < 2 * CIN ? bf_hi(wv) : (unsigned short)0;
-                    v2[i] = i < CIN ? bf_lo(wv) : (unsigned short)0;
+                    v2[i] = i < 2 * CIN ? bf_lo(wv) : (unsigned short)0;       // (w_lo x_lo rides along for free)
                 }
             }
             u32x4_t p1, p2;
