@@ -50,6 +50,7 @@ def _to_dev(v, dev):
 
 
 OVERLAP_WGRAD = os.environ.get('SRVP_OVERLAP_WGRAD', '1') != '0'
+LATENT_WGRAD_STREAM = os.environ.get('SRVP_LATENT_WGRAD_STREAM', '1') != '0'    # the latent networks' weight gradients on a stream of their own
 OVERLAP_SKIP = os.environ.get('SRVP_OVERLAP_SKIP', '1') == '1'
 SKIP_LATE = os.environ.get('SRVP_SKIP_LATE', '1') == '1'        # hoisted skip convs under the rollout kernel (1) / under the inference chain (0)
 OVERLAP_PACK = os.environ.get('SRVP_OVERLAP_PACK', '1') == '1'    # decoder weight packing on the second stream, under the encoder
@@ -543,11 +544,19 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             d_hx_p = d_hx
         enc.backward(pl['x'].view(T * B, *pl['x'].shape[2:]), d_hx_p, skip_grads, params, grads, st, self.sync,
                      side=self._side_stream if overlap else None)
+        lat_stream = None
         if deferred:
-            # the latent networks' weight gradients feed nothing but the optimizer: second stream, behind the encoder's (enqueued last so
-            # that the encoder backward's main-stream launches are not held up on the host)
-            with torch.cuda.stream(self._side_stream):
-                self._side_stream.wait_event(ev_lat)
+            # the latent networks' weight gradients feed nothing but the optimizer.  ~25 small launches (a few workgroups each): on the second
+            # stream they sat BEHIND the encoder's weight gradients and ran as the step's tail, 0.3 ms after the main stream's last kernel;
+            # on a stream of their own (SRVP_LATENT_WGRAD_STREAM=0: the second stream) they run as soon as the latent backward is done,
+            # beside everything else.  Enqueued last so that the encoder backward's main-stream launches are not held up on the host.
+            lat_stream = self._side_stream
+            if LATENT_WGRAD_STREAM:
+                if getattr(self, '_lat_stream', None) is None:
+                    self._lat_stream = torch.cuda.Stream()
+                lat_stream = self._lat_stream
+            with torch.cuda.stream(lat_stream):
+                lat_stream.wait_event(ev_lat)
                 s2 = L.stream()
                 for fn in deferred:
                     fn(s2)
@@ -556,6 +565,10 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             side_done = torch.cuda.Event()
             side_done.record(self._side_stream)
             torch.cuda.current_stream().wait_event(side_done)
+            if lat_stream is not None and lat_stream is not self._side_stream:
+                lat_done = torch.cuda.Event()
+                lat_done.record(lat_stream)
+                torch.cuda.current_stream().wait_event(lat_done)
         if self.sync is not None:
             self.sync.grads_ready('all', self)
 
