@@ -1088,12 +1088,10 @@ class ConvNetBase:
         if blk.has_bn:
             if not getattr(blk, '_reduce_fused', False):       # (else: accumulated by the consumer's data-gradient launch, _fuse_bn_reduce)
                 L.call('srvp_bn_bwd_reduce', C.byref(d), L.ptr(blk.red), st)
-            elif d.da_mode == 2 and da.get('da2') is not None:
+            elif d.da_mode == 2 and da.get('da2') is not None and not da.get('da2_reduced'):
                 # pooled layer whose arg-max terms rode the consumer's data-gradient launch (raw_pool): the skip-connection gradient of its
                 # B selected frames is the only term left -- both sums are linear in the gradient
-                d3 = self._bnbwd_desc(blk, da)
-                d3.da_mode, d3.N, d3.da2_idx = 3, da['da2'].shape[0], L.ptr(da['da2_sel'])     # rows of da2 and the frame each belongs to
-                L.call('srvp_bn_bwd_reduce', C.byref(d3), L.ptr(blk.red), st)
+                self._skip_reduce(blk, da, st)
             local = float(blk.N * blk.OH * blk.OW)
             count = local
             if sync is not None:
@@ -1310,16 +1308,56 @@ class EncoderNet(ConvNetBase):
             self._block_forward(blk, params, st, sync, x=x, keep=keep)
         return self.blocks[-1].out_f32[:, :self.nh_r]
 
-    def backward(self, x, d_hx, skip_grads, params, grads, st, sync=None, side=None):
+    def _skip_term(self, blk, sg):
+        """da entries for the skip-connection gradient sg = (rows bf16 [B][H][W][C], frame -> row int32 [N][, row -> frame int32 [B]])"""
+        out = dict(da2=sg[0], da2_idx=sg[1])
+        if len(sg) > 2:
+            out['da2_sel'] = sg[2]                                       # row -> frame (the inverse of da2_idx)
+        else:
+            # (a caller that hands over the frame -> row map only: invert it here, a few tiny launches off the hot path)
+            inv = getattr(self, '_da2_sel', None)
+            if inv is None or inv.numel() != sg[0].shape[0]:
+                inv = self._da2_sel = torch.zeros(sg[0].shape[0], dtype=torch.int32, device=self.dev)
+            fr = torch.nonzero(sg[1] >= 0).flatten()
+            inv[sg[1][fr].long()] = fr.to(torch.int32)
+            out['da2_sel'] = inv
+        return out
+
+    def _skip_reduce(self, blk, da, st):
+        """srvp_bn_bwd_reduce da_mode 3: the skip-connection term of a pooled stage whose arg-max terms ride its consumer's data gradient"""
+        d3 = self._bnbwd_desc(blk, da)
+        d3.da_mode, d3.N, d3.da2_idx = 3, da['da2'].shape[0], L.ptr(da['da2_sel'])     # rows of da2 and the frame each belongs to
+        L.call('srvp_bn_bwd_reduce', C.byref(d3), L.ptr(blk.red), st)
+
+    def backward(self, x, d_hx, skip_grads, params, grads, st, sync=None, side=None, aux=None):
         """
         d_hx: fp32 [N][nh_padded] gradient of the encoder output; skip_grads: {stage: (dsel bf16 [B][H][W][C], idx int32 [N])}
         side (a torch stream, optional): the unpacking of the MFMA layers' weight gradients runs there, under the image-side layer's
         backward (its BatchNorm passes and weight gradient, ~1 ms that needs none of it); the caller joins the stream afterwards.
+        aux (a torch stream, optional): the skip-connection terms of the pooled stages' BatchNorm-backward sums (da_mode 3) are formed
+        there at once -- everything they read exists when this function is entered -- instead of in line on the main stream, where each
+        of these 40 us reductions waited 0.25-0.33 ms for workgroup slots beside the second stream's weight gradients.
         """
         nb = len(self.blocks)
         self.zero_backward_accumulators()
         da = dict(t=d_hx, mode=0, cstride=d_hx.shape[1], coff=0, border=0, f32=True)
         unpacked = False
+        skip_red = None
+        if aux is not None and skip_grads:
+            todo = [(i, b) for i, b in enumerate(self.blocks) if b.pool is not None and getattr(b, '_reduce_fused', False)
+                    and b.has_bn and b.spec['skip_out'] is not None and (3 - b.spec['skip_out']) in skip_grads and i + 1 < nb]
+            if todo:
+                ev = torch.cuda.Event()
+                ev.record()                                               # accumulators cleared, skip gradients written
+                with torch.cuda.stream(aux):
+                    aux.wait_event(ev)
+                    for i, b in todo:
+                        q = self.blocks[i + 1]
+                        self._skip_reduce(b, dict(t=q.dcat, mode=2, cstride=q.dcat_c, coff=0, border=0,
+                                                  **self._skip_term(b, skip_grads[3 - b.spec['skip_out']])), L.stream())
+                    skip_red = torch.cuda.Event()
+                    skip_red.record()
+                self._skip_red_blocks = {id(b) for _, b in todo}
         for i in range(nb - 1, -1, -1):
             blk = self.blocks[i]
             if blk.role == 'in' and side is not None and nb > 1:
@@ -1331,18 +1369,10 @@ class EncoderNet(ConvNetBase):
                 unpacked = True
             sk = blk.spec['skip_out']
             if sk is not None and skip_grads and (3 - sk) in skip_grads:
-                sg = skip_grads[3 - sk]
-                da['da2'], da['da2_idx'] = sg[0], sg[1]
-                if len(sg) > 2:
-                    da['da2_sel'] = sg[2]                                        # row -> frame (the inverse of da2_idx)
-                else:
-                    # (a caller that hands over the frame -> row map only: invert it here, a few tiny launches off the hot path)
-                    inv = getattr(self, '_da2_sel', None)
-                    if inv is None or inv.numel() != sg[0].shape[0]:
-                        inv = self._da2_sel = torch.zeros(sg[0].shape[0], dtype=torch.int32, device=self.dev)
-                    fr = torch.nonzero(sg[1] >= 0).flatten()
-                    inv[sg[1][fr].long()] = fr.to(torch.int32)
-                    da['da2_sel'] = inv
+                da.update(self._skip_term(blk, skip_grads[3 - sk]))
+                if skip_red is not None and id(blk) in self._skip_red_blocks:
+                    torch.cuda.current_stream().wait_event(skip_red)      # (its da_mode 3 term was accumulated on `aux`)
+                    da['da2_reduced'] = True
             self._bn_backward(blk, params, grads, da, st, sync)
             if blk.role == 'in':
                 w = blk.spec['key'] + '.weight'

@@ -50,6 +50,7 @@ def _to_dev(v, dev):
 
 
 OVERLAP_WGRAD = os.environ.get('SRVP_OVERLAP_WGRAD', '1') != '0'
+SKIP_REDUCE_AUX = os.environ.get('SRVP_SKIP_REDUCE_AUX', '1') != '0'      # 0: the pooled stages' skip-gradient reductions in line on the main stream
 LATENT_WGRAD_STREAM = os.environ.get('SRVP_LATENT_WGRAD_STREAM', '1') != '0'    # the latent networks' weight gradients on a stream of their own
 OVERLAP_SKIP = os.environ.get('SRVP_OVERLAP_SKIP', '1') == '1'
 SKIP_LATE = os.environ.get('SRVP_SKIP_LATE', '1') == '1'        # hoisted skip convs under the rollout kernel (1) / under the inference chain (0)
@@ -542,8 +543,13 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             d_hx_p[:, :self.nhx] = d_hx
         else:
             d_hx_p = d_hx
+        aux = None
+        if overlap and LATENT_WGRAD_STREAM and SKIP_REDUCE_AUX:
+            if getattr(self, '_lat_stream', None) is None:
+                self._lat_stream = torch.cuda.Stream()
+            aux = self._lat_stream
         enc.backward(pl['x'].view(T * B, *pl['x'].shape[2:]), d_hx_p, skip_grads, params, grads, st, self.sync,
-                     side=self._side_stream if overlap else None)
+                     side=self._side_stream if overlap else None, aux=aux)
         lat_stream = None
         if deferred:
             # the latent networks' weight gradients feed nothing but the optimizer.  ~25 small launches (a few workgroups each): on the second
