@@ -189,8 +189,10 @@ class LatentNet:
             nq = min(T - 1, self.F)
             linear_fwd(st, self.hz[B:(nq + 1) * B], params['q_z.weight'], params['q_z.bias'], self.q_z.view(-1, 2 * nz)[:nq * B])
 
-    def generate(self, y0, n_data, params, eps_z, st):
-        """srvp.py:325-413 (remove_intermediate=True); the LSTM/q_z part must have run if n_data > 1."""
+    def generate(self, y0, n_data, params, eps_z, st, pz_stream=None):
+        """srvp.py:325-413 (remove_intermediate=True); the LSTM/q_z part must have run if n_data > 1.
+        pz_stream (torch stream, optional; training): the batched prior MLP p_z(y_t) -- it feeds the KL term only, not the decoder -- runs
+        there behind the rollout; self.pz_done is the event its readers wait for (None when it ran in line)."""
         if self.S > 0:
             self._rd = self._rollout_desc(params, n_data, eps_z, y0)
             # training (every frame has data): z always comes from the posterior, so the prior MLP p_z(y_t) only feeds the KL
@@ -206,15 +208,28 @@ class LatentNet:
                         ws = self._fused_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
                     self._rd.fused_ws, self._rd.fused_ws_bytes = L.ptr(ws), need
             L.call('srvp_rollout_fwd', C.byref(self._rd), st)
+            self.pz_done = None
             if self.pz_ext:
                 B, F, nlr, ny, nz, nhr = self.B, self.F, self.nl_res, self.cfg['ny'], self.cfg['nz'], self.cfg['nh_res']
-                cur = self._pz_in
-                cur.view(F, B, ny).copy_(self.y_all[0:self.S:self.ne])      # states at the frame starts as contiguous rows
-                for l, k in enumerate(mlp_keys('p_z', nlr)):
-                    last = l == nlr - 1
-                    out = self.p_z.view(F * B, 2 * nz) if last else self.hid_pz[l].view(F * B, nhr)
-                    linear_fwd(st, cur, params[k + '.weight'], params[k + '.bias'], out, L.ACT_NONE if last else L.ACT_RELU)
-                    cur = out
+
+                def prior(s_):
+                    cur = self._pz_in
+                    cur.view(F, B, ny).copy_(self.y_all[0:self.S:self.ne])      # states at the frame starts as contiguous rows
+                    for l, k in enumerate(mlp_keys('p_z', nlr)):
+                        last = l == nlr - 1
+                        out = self.p_z.view(F * B, 2 * nz) if last else self.hid_pz[l].view(F * B, nhr)
+                        linear_fwd(s_, cur, params[k + '.weight'], params[k + '.bias'], out, L.ACT_NONE if last else L.ACT_RELU)
+                        cur = out
+                if pz_stream is None:
+                    prior(st)
+                else:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    with torch.cuda.stream(pz_stream):
+                        pz_stream.wait_event(ev)
+                        prior(L.stream())
+                        self.pz_done = torch.cuda.Event()
+                        self.pz_done.record()
         else:
             self.y_all[0].copy_(y0)
         y = self.y_all[::self.ne]

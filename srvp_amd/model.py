@@ -50,6 +50,7 @@ def _to_dev(v, dev):
 
 
 OVERLAP_WGRAD = os.environ.get('SRVP_OVERLAP_WGRAD', '1') != '0'
+PZ_AUX = os.environ.get('SRVP_PZ_AUX', '1') != '0'                       # 0: the batched prior MLP of a training forward in line
 SKIP_REDUCE_AUX = os.environ.get('SRVP_SKIP_REDUCE_AUX', '1') != '0'      # 0: the pooled stages' skip-gradient reductions in line on the main stream
 LATENT_WGRAD_STREAM = os.environ.get('SRVP_LATENT_WGRAD_STREAM', '1') != '0'    # the latent networks' weight gradients on a stream of their own
 OVERLAP_SKIP = os.environ.get('SRVP_OVERLAP_SKIP', '1') == '1'
@@ -425,7 +426,14 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             # launch on nh/32 x batch-tiles CUs that leaves the rest of the chip idle for 0.5 ms).  Issued earlier -- under the
             # inference MLPs and the LSTM chain -- their big workgroups starved those small dependent kernels (15 -> 60-80 us each)
             s_done = skips_on_side()
-        y, z, qz, pz, res = lat.generate(y0, T, params, tape['eps_z'], st)
+        # (training: the prior MLP over the stored states feeds the KL term only -- on the auxiliary stream, under the decoder, instead of
+        # 0.12 ms of small dependent launches between the rollout and the decoder; SRVP_PZ_AUX=0: in line)
+        pz_stream = None
+        if training and PZ_AUX and OVERLAP_WGRAD:
+            if getattr(self, '_lat_stream', None) is None:
+                self._lat_stream = torch.cuda.Stream()
+            pz_stream = self._lat_stream
+        y, z, qz, pz, res = lat.generate(y0, T, params, tape['eps_z'], st, pz_stream=pz_stream)
         if s_done is not None:
             torch.cuda.current_stream().wait_event(s_done)
         if pack_done is not None:
@@ -433,6 +441,8 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         # decoder input rows [w[b] | y[t][b]] (srvp.py:216-221) assembled by the library from w and the stored states y_all[t * n_euler]
         x_flat = dec.forward(None, params, st, self.sync if training else None,
                              latent=(w, lat.y_all, lat.ne * B * self.ny, nt, B, self.nh_inf, self.ny))
+        if getattr(lat, 'pz_done', None) is not None:
+            torch.cuda.current_stream().wait_event(lat.pz_done)          # p_z is read (KL term, callers) from here on
         x_ = x_flat.view(nt, B, *x_flat.shape[1:])
         pl['hx'], pl['x'] = hx, x
         self._last_plan = pl
