@@ -262,6 +262,14 @@ int srvp_conv_in_fwd_bnr(const float* x, const float* w, void* raw, int N, int C
 int srvp_conv_in_fwd_bnr_ok(int Cin, int H, int W, int Cout, int k, int s, int p);
 int srvp_conv_in_wgrad(const float* x, const void* draw, float* dw,
                        int N, int Cin, int H, int W, int Cout, int Cout_real, int k, int s, int p, void* stream);
+/* srvp_bn_bwd_finalize_apply + srvp_conv_in_wgrad of the FIRST block (conv.py:200) as one launch: the gradient wrt the block's pre-BatchNorm
+ * output feeds nothing but this weight gradient (there is no data gradient wrt the frames), so it is formed on the way into LDS from dA and
+ * raw and never stored.  d as for srvp_bn_bwd_finalize_apply (da_mode 0, bf16, LeakyReLU, unbordered 64-channel dA of 64x64 frames, scale /
+ * shift / mean / invstd the rows of one [4][64] tensor); red / count / dgamma / dbeta / coef / C_real / param_grad_scale as there.
+ * srvp_conv_in_wgrad_bn_ok: 1 if the descriptor and shape are served (SRVP_IN_WGRAD_BN=0 switches it off). */
+int srvp_conv_in_wgrad_bn_ok(const srvp_bnbwd_desc* d, int Cin, int H, int W, int Cout, int k, int s, int p);
+int srvp_conv_in_wgrad_bn(const float* x, const srvp_bnbwd_desc* d, const double* red, double count, float* dgamma, float* dbeta,
+                          float* coef, int C_real, float param_grad_scale, float* dw, int N, int Cin, int Cout_real, void* stream);
 /* fp32 parity mode: raw / draw are fp32 NHWC tensors (direct fp32 kernels: an fmaf chain in (ci, kh, kw) order) */
 int srvp_conv_in_fwd_f32(const float* x, const float* w, void* raw, double* stats,
                          int N, int Cin, int H, int W, int Cout, int Cout_real, int k, int s, int p, void* stream);

@@ -104,6 +104,8 @@ _SIGS = {
     'srvp_bn_act_s2d': ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp], c_i32),
     'srvp_bn_bwd_finalize_apply': ([C.POINTER(BnBwdDesc), c_vp, c_f64, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_i32, c_vp], c_i32),
     'srvp_bn_bwd_reduce': ([C.POINTER(BnBwdDesc), c_vp, c_vp], c_i32),
+    'srvp_conv_in_wgrad_bn_ok': ([C.POINTER(BnBwdDesc), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32], c_i32),
+    'srvp_conv_in_wgrad_bn': ([c_vp, C.POINTER(BnBwdDesc), c_vp, c_f64, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_bn_bwd_finalize': ([c_vp, c_f64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp], c_i32),
     'srvp_bn_bwd_apply': ([C.POINTER(BnBwdDesc), c_vp, c_vp, c_i32, c_vp], c_i32),
     'srvp_conv_in_fwd': ([c_vp, c_vp, c_vp, c_vp] + [c_i32] * 9 + [c_vp], c_i32),

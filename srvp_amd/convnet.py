@@ -34,6 +34,7 @@ BN_FUSED_REDUCE = os.environ.get('SRVP_BN_FUSED_REDUCE', '1') != '0'
 # the decoder's data-gradient chain: the MFMA-bound weight gradients then run beside the HBM-bound BatchNorm passes of the blocks below
 # (measured, same box: 41.70 vs 41.21 ms per step at 192 sequences with / without, 8.88 vs 8.86 at 24: off)
 DEC_WGRAD_EARLY = os.environ.get('SRVP_DEC_WGRAD_EARLY', '0') != '0'
+IN_WGRAD_BN = os.environ.get('SRVP_IN_WGRAD_BN', '1') != '0'                # 0: the first block's output gradient is written and read back by its weight gradient
 POOL_FUSED_REDUCE = os.environ.get('SRVP_POOL_FUSED_REDUCE', '1') != '0'    # 0: pooled layers keep their own BatchNorm-backward reduction pass
 S_QUAD = os.environ.get('SRVP_S_QUAD', '1') != '0'        # hoisted skip half stored pixel-quad-major (16-byte loads in the consumers)
 SPLITK = int(os.environ.get('SRVP_CONV_SPLITK', '16'))    # tiny-M long-K launches: K steps shared over this many workgroups
@@ -1080,8 +1081,10 @@ class ConvNetBase:
         d.N, d.H, d.W, d.C = blk.N, blk.OH, blk.OW, blk.cout
         return d
 
-    def _bn_backward(self, blk, params, grads, da, st, sync):
-        """da: dict(t, mode, cstride, coff, border, f32, da2, da2_idx).  Produces blk.draw (and BN param grads)."""
+    def _bn_backward(self, blk, params, grads, da, st, sync, in_wgrad=None):
+        """da: dict(t, mode, cstride, coff, border, f32, da2, da2_idx).  Produces blk.draw (and BN param grads).
+        in_wgrad = (x, dw) (the image-side first block): where the library serves it, the block's weight gradient is formed in the same
+        launch from dA and raw and blk.draw is NOT written (srvp_conv_in_wgrad_bn); returns True then."""
         d = self._bnbwd_desc(blk, da)
         if blk.split and blk.draw_b == 1:
             d.tsum, d.tsum_T = L.ptr(blk.draw_sum), blk.N // blk.B      # time-summed gradient for the hoisted skip half
@@ -1100,6 +1103,11 @@ class ConvNetBase:
             # (count / local = number of ranks whose sums are in `red`: the parameter gradients are formed from the global sums
             # and must come out world times smaller, see srvp_hip.h)
             if BN_FUSED_FINALIZE:
+                if (in_wgrad is not None and IN_WGRAD_BN and not blk.f32
+                        and L.load().srvp_conv_in_wgrad_bn_ok(C.byref(d), blk.cin_r[0], 64, 64, blk.cout, blk.k, blk.s, blk.p)):
+                    L.call('srvp_conv_in_wgrad_bn', L.ptr(in_wgrad[0]), C.byref(d), L.ptr(blk.red), count, L.ptr(grads[bk + '.weight']),
+                           L.ptr(grads[bk + '.bias']), L.ptr(blk.bcoef), blk.cout_r, local / count, L.ptr(in_wgrad[1]), blk.N, blk.cin_r[0], blk.cout_r, st)
+                    return True
                 L.call('srvp_bn_bwd_finalize_apply', C.byref(d), L.ptr(blk.red), count, L.ptr(grads[bk + '.weight']), L.ptr(grads[bk + '.bias']),
                        L.ptr(blk.bcoef), blk.cout_r, local / count, L.ptr(blk.draw), blk.draw_b, st)
                 return
@@ -1373,12 +1381,14 @@ class EncoderNet(ConvNetBase):
                 if skip_red is not None and id(blk) in self._skip_red_blocks:
                     torch.cuda.current_stream().wait_event(skip_red)      # (its da_mode 3 term was accumulated on `aux`)
                     da['da2_reduced'] = True
-            self._bn_backward(blk, params, grads, da, st, sync)
             if blk.role == 'in':
                 w = blk.spec['key'] + '.weight'
+                if self._bn_backward(blk, params, grads, da, st, sync, in_wgrad=(x, grads[w])):
+                    continue
                 L.call('srvp_conv_in_wgrad_f32' if blk.f32 else 'srvp_conv_in_wgrad', L.ptr(x), L.ptr(blk.draw), L.ptr(grads[w]), blk.N, blk.cin_r[0], 64, 64,
                        blk.cout, blk.cout_r, blk.k, blk.s, blk.p, st)
             else:
+                self._bn_backward(blk, params, grads, da, st, sync)
                 if side is not None and self.N <= ENC_WGRAD_SIDE_MAXN:
                     ev = torch.cuda.Event()
                     ev.record()

@@ -439,9 +439,23 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_mfma_kernel(const float* __
 // instead of 2 (v_mfma_f32_32x32x2_f32 made this HBM-sized layer MFMA-bound: 0.60 ms against 1.2 GB of traffic).
 // A = draw^T: the draw tile is staged TRANSPOSED in LDS, [cout][pixel], 16-byte pixel chunks XOR-swizzled by
 // (cout & 7) ^ (cout >> 3 & 7) -- conflict-free for the transposing 2-byte stores and for the ds_read_b128 fragment reads.
-template <int KS, int S, int CIN, int NTL>
+// FUSE (srvp_conv_in_wgrad_bn): the output gradient of the first block is consumed by NOTHING but this weight gradient (there is no data
+// gradient wrt the frames), so it is never written: the tile is formed on the way into LDS from the block's dA and raw output --
+// draw = k1 g + k2 + k3 raw, g = dA lrelu'(scale raw + shift), rounded to bf16 as srvp_bn_bwd_apply stores it -- with the coefficients
+// derived per workgroup from the BatchNorm-backward sums exactly as srvp_bn_bwd_finalize does (workgroup 0 adds dgamma / dbeta).  One
+// read of (dA, raw) instead of apply's read of both + write of draw + this kernel's read of draw: 4.8 -> 2.4 GB at 2304 frames, at the
+// very end of the step where nothing else is left to overlap it.
+struct InWgradBn {
+    const bf16_t* da; const bf16_t* raw;                   // [N][OH][OW][Cout], unbordered
+    const double* red; double count;                       // BatchNorm-backward sums [2][Cout] (all-reduced), element count
+    const float* coef4;                                    // [4][Cout] scale, shift, mean, inverse std
+    float* dgamma; float* dbeta; float* bcoef;             // parameter gradients (+=), [3][Cout] k1 k2 k3 (may be null)
+    int C_real; float pscale;
+};
+template <int KS, int S, int CIN, int NTL, bool FUSE = false>
 __global__ __launch_bounds__(256) void conv_in_wgrad_mfma3_kernel(const float* __restrict__ x, const bf16_t* __restrict__ draw,
-                                                                  float* dw, int N, int Cout, int Cout_real, int tiles_per_wg) {
+                                                                  float* dw, int N, int Cout, int Cout_real, int tiles_per_wg,
+                                                                  const InWgradBn fb = InWgradBn{}) {
     typedef InGeom<KS, S, CIN> Gm;
     static_assert(Gm::OW % 8 == 0, "eight consecutive pixels of a K group lie in one output row");
     constexpr int KT = (Gm::K + 31) / 32;
@@ -473,7 +487,32 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_mfma3_kernel(const float* _
     // both operands of tile i+1 are fetched into registers while tile i is computed
     constexpr int NP = (CIN * Gm::PH * Gm::PWp + 255) / 256, ND = 128 * 8 / 256;      // ND: 16-byte draw pieces per thread (Cout <= 64)
     float pv[NP];
-    u32x4_t dv[ND];
+    u32x4_t dv[ND], rv[FUSE ? ND : 1];
+    // FUSE: this thread's eight channels (256 % cch == 0: the chunk index is the same for all its pieces) and their coefficients
+    float fsc[8], fsh[8], fk1[8], fk2[8], fk3[8];
+    if constexpr (FUSE) {
+        const int C = Cout, c0 = (tid % cch) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            fsc[e] = fb.coef4[c]; fsh[e] = fb.coef4[C + c];
+            fk1[e] = fk2[e] = fk3[e] = 0.f;
+            if (c < fb.C_real) {
+                // (the fp64 expressions of bn_bwd_finalize_kernel)
+                const double sg = fb.red[c], sgx = fb.red[C + c];
+                const double mg = sg / fb.count, mgx = sgx / fb.count;
+                const double k1 = fb.coef4[c];
+                const double k3 = -k1 * mgx * fb.coef4[3 * C + c];
+                const double k2 = -k1 * mg - k3 * fb.coef4[2 * C + c];
+                fk1[e] = (float)k1; fk2[e] = (float)k2; fk3[e] = (float)k3;
+                if (blockIdx.x == 0 && tid < cch) {
+                    if (fb.dgamma) fb.dgamma[c] += (float)(sgx * fb.pscale);
+                    if (fb.dbeta) fb.dbeta[c] += (float)(sg * fb.pscale);
+                }
+            }
+            if (blockIdx.x == 0 && tid < cch && fb.bcoef) { fb.bcoef[c] = fk1[e]; fb.bcoef[C + c] = fk2[e]; fb.bcoef[2 * C + c] = fk3[e]; }
+        }
+    }
     auto fetch_draw = [&](long long tile) {
         const int n = (int)(tile / Gm::TPI), tin = (int)(tile % Gm::TPI);
 #pragma unroll
@@ -482,7 +521,13 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_mfma3_kernel(const float* _
             if (q >= 128 * cch) continue;
             const int row = q / cch, ch = q % cch;
             const int oy = tin * Gm::TR + row / Gm::OW, ox = row % Gm::OW;
-            dv[u] = *reinterpret_cast<const u32x4_t*>(draw + (((size_t)n * (Gm::OH + 2) + oy + 1) * (Gm::OW + 2) + ox + 1) * Cout + ch * 8);
+            if constexpr (FUSE) {
+                const size_t o = (((size_t)n * Gm::OH + oy) * Gm::OW + ox) * Cout + ch * 8;
+                dv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(fb.da + o));
+                rv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(fb.raw + o));
+            } else {
+                dv[u] = *reinterpret_cast<const u32x4_t*>(draw + (((size_t)n * (Gm::OH + 2) + oy + 1) * (Gm::OW + 2) + ox + 1) * Cout + ch * 8);
+            }
         }
     };
     if (t0 < ntiles) { in_fetch_patch<KS, S, CIN, NP>(x, pv, (int)(t0 / Gm::TPI), (int)(t0 % Gm::TPI)); fetch_draw(t0); }
@@ -496,6 +541,17 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_mfma3_kernel(const float* _
             const int q = tid + u * 256;
             if (q >= 128 * cch) continue;
             const int row = q / cch, ch = q % cch;
+            if constexpr (FUSE) {
+                float d8[8], r8[8];
+                unpack8(dv[u], d8);
+                unpack8(rv[u], r8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float g = d8[e] * (r8[e] * fsc[e] + fsh[e] > 0.f ? 1.f : LRELU_SLOPE);
+                    d8[e] = fk1[e] * g + fk2[e] + fk3[e] * r8[e];
+                }
+                dv[u].x = pack2bf(d8[0], d8[1]); dv[u].y = pack2bf(d8[2], d8[3]); dv[u].z = pack2bf(d8[4], d8[5]); dv[u].w = pack2bf(d8[6], d8[7]);
+            }
             const unsigned short* h = reinterpret_cast<const unsigned short*>(&dv[u]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -585,6 +641,13 @@ static void launch_in_wgrad(const float* x, const bf16_t* draw, float* dw, int N
         hipLaunchKernelGGL((conv_in_wgrad_mfma_kernel<KS, S, CIN, 2>), grid, dim3(256), 0, st, x, draw, dw, N, Cout, Cout_real, tpw);
     else
         hipLaunchKernelGGL((conv_in_wgrad_mfma_kernel<KS, S, CIN, 1>), grid, dim3(256), 0, st, x, draw, dw, N, Cout, Cout_real, tpw);
+}
+template <int CIN>
+static void launch_in_wgrad_bn(const float* x, float* dw, int N, int Cout, int Cout_real, const InWgradBn& fb, hipStream_t st) {
+    const long long ntiles = (long long)N * InGeom<3, 1, CIN>::TPI;
+    const int tpw = ntiles >= 32768 ? 16 : (ntiles >= 16 ? 2 : 1);
+    const dim3 grid((unsigned)((ntiles + tpw - 1) / tpw));
+    hipLaunchKernelGGL((conv_in_wgrad_mfma3_kernel<3, 1, CIN, 2, true>), grid, dim3(256), 0, st, x, (const bf16_t*)nullptr, dw, N, Cout, Cout_real, tpw, fb);
 }
 static bool in_mfma_ok(int Cin, int H, int W, int Cout, int k, int s, int p) {
     static int on = -1;
@@ -701,6 +764,32 @@ extern "C" int srvp_conv_in_fwd_bnr(const float* x, const float* w, void* raw, i
     if (Cin == 3) launch_in_fwd<3, 1, 3>(x, w, (bf16_t*)raw, nullptr, N, Cout, Cout_real, st, (const bf16_t*)bnr_raw, bnr_coef, bnr_red);
     else launch_in_fwd<3, 1, 1>(x, w, (bf16_t*)raw, nullptr, N, Cout, Cout_real, st, (const bf16_t*)bnr_raw, bnr_coef, bnr_red);
     SRVP_CHECK_LAUNCH("srvp_conv_in_fwd_bnr");
+    return SRVP_OK;
+}
+
+// srvp_bn_bwd_finalize_apply + srvp_conv_in_wgrad of the FIRST block in one launch (see InWgradBn): d describes the block's BatchNorm
+// backward as for srvp_bn_bwd_finalize_apply (da_mode 0, bf16, LeakyReLU, unbordered same-size dA, no da2 / tsum); the gradient wrt the
+// block's pre-BatchNorm output is never stored.  srvp_conv_in_wgrad_bn_ok: 1 if this shape / descriptor is served.
+extern "C" int srvp_conv_in_wgrad_bn_ok(const srvp_bnbwd_desc* d, int Cin, int H, int W, int Cout, int k, int s, int p) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SRVP_IN_WGRAD_BN"); on = e ? atoi(e) : 1; }
+    return on && d && in_mfma_ok(Cin, H, W, Cout, k, s, p) && k == 3 && s == 1 && Cout == 64 && d->C == 64 && d->H == 64 && d->W == 64 &&
+           d->da_mode == 0 && !d->da_is_f32 && !d->elem_f32 && !d->da2 && !d->tsum && !d->draw_s2d && d->da_border == 0 && d->da_coff == 0 &&
+           d->da_cstride == 64 && d->act_kind == ACT_LRELU && d->mean && d->invstd &&
+           (((uintptr_t)d->da | (uintptr_t)d->raw) & 15) == 0 ? 1 : 0;
+}
+extern "C" int srvp_conv_in_wgrad_bn(const float* x, const srvp_bnbwd_desc* d, const double* red, double count, float* dgamma, float* dbeta,
+                                     float* coef, int C_real, float param_grad_scale, float* dw, int N, int Cin, int Cout_real, void* stream) {
+    SRVP_REQUIRE(x && d && red && dw && count > 0, "srvp_conv_in_wgrad_bn: null pointer / count");
+    SRVP_REQUIRE(srvp_conv_in_wgrad_bn_ok(d, Cin, 64, 64, 64, 3, 1, 1) && d->N == N, "srvp_conv_in_wgrad_bn: descriptor / shape not served (ask srvp_conv_in_wgrad_bn_ok)");
+    // scale, shift, mean, invstd must be the four rows of ONE [4][64] tensor (they are: srvp_bn_finalize writes them so)
+    SRVP_REQUIRE(d->shift == d->scale + 64 && d->mean == d->scale + 128 && d->invstd == d->scale + 192, "srvp_conv_in_wgrad_bn: coefficients must be one [4][64] tensor");
+    InWgradBn fb;
+    fb.da = (const bf16_t*)d->da; fb.raw = (const bf16_t*)d->raw; fb.red = red; fb.count = count; fb.coef4 = d->scale;
+    fb.dgamma = dgamma; fb.dbeta = dbeta; fb.bcoef = coef; fb.C_real = C_real; fb.pscale = param_grad_scale;
+    if (Cin == 3) launch_in_wgrad_bn<3>(x, dw, N, 64, Cout_real, fb, (hipStream_t)stream);
+    else launch_in_wgrad_bn<1>(x, dw, N, 64, Cout_real, fb, (hipStream_t)stream);
+    SRVP_CHECK_LAUNCH("srvp_conv_in_wgrad_bn");
     return SRVP_OK;
 }
 

@@ -787,3 +787,48 @@ def test_pooled_bn_backward_reduction_rides_the_consumer(B):
     assert torch.allclose(grads[True][1], grads[False][1], rtol=1e-12)   # the forward computes the same values
     worst = max(((grads[True][0][k] - grads[False][0][k]).norm() / (grads[False][0][k].norm() + 1e-30)).item() for k in grads[True][0])
     assert worst < 5e-2, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nc', [3, 1])
+def test_first_block_weight_gradient_without_stored_output_gradient(nc):
+    """srvp_conv_in_wgrad_bn: the first block's BatchNorm-backward apply and its weight gradient as one launch -- the gradient wrt the
+    block's pre-BatchNorm output feeds nothing else, so it is formed on the way into LDS from dA and raw and never stored -- against the
+    two launches (srvp_bn_bwd_finalize_apply writing it, srvp_conv_in_wgrad reading it back).  Same expressions, same bf16 rounding of the
+    gradient tile, same MFMA schedule: the first block's weight / BatchNorm gradients agree to 1e-5, every other gradient is untouched."""
+    import srvp_amd
+    from srvp_amd import convnet
+    from srvp_amd.train import fused_step
+    dev = torch.device('cuda')
+    ctor = (64, nc, 64, 128, 50, 50, True, 2, 256, 3, 512, 4, 'vgg')
+    T, B, ne = 4, 6, 2
+    g = torch.Generator().manual_seed(35)
+    x = torch.rand(T, B, nc, 64, 64, generator=g).to(dev)
+    tape = dict(t_skip=torch.randint(T, (B,), generator=g), t_w=torch.stack([torch.randperm(T, generator=g)[:2] for _ in range(B)], 1),
+                eps_y0=torch.randn(B, 50, generator=g), eps_z=torch.randn(T - 1, B, 50, generator=g))
+    opt = srvp_amd.DotDict(dict(n_euler_steps=ne, obs_scale=0.5, beta_y=1.0, beta_z=1.0, l2_res=1.0))
+    grads = {}
+    old = convnet.IN_WGRAD_BN
+    try:
+        for mode in (True, False):
+            convnet.IN_WGRAD_BN = mode
+            torch.manual_seed(1)
+            m = srvp_amd.StochasticLatentResidualVideoPredictor(*ctor)
+            m.init(1.41)
+            m.to(dev).train()
+            o = srvp_amd.FusedAdam(m, lr=1e-3)
+            o.zero_grad()
+            fused_step(m, x, opt, tape=tape)
+            torch.cuda.synchronize()
+            grads[mode] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    finally:
+        convnet.IN_WGRAD_BN = old
+    first = [k for k in grads[True] if k.startswith('encoder.conv.0.0.')]
+    assert len(first) == 3, first                                       # conv weight, BatchNorm weight and bias
+    for k in grads[True]:
+        err = ((grads[True][k] - grads[False][k]).norm() / (grads[False][k].norm() + 1e-30)).item()
+        if k in first:
+            assert err < 1e-5, (k, err)
+        else:
+            # (everything else is computed by the same launches in both runs; fp64 / fp32 atomics in another order)
+            assert err < 2e-3, (k, err)
