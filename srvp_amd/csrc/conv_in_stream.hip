@@ -297,6 +297,253 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The fused-sum variant with the producer's raw rows in an LDS RING (round 4, second form).  Measured on the kernel above: arithmetic
+// alone 0.29 ms, + the raw loads 0.43, + the stores instead 0.42, both 0.78 -- a persistent 8-wave workgroup with its raw values in
+// registers one row ahead has <= 32 KB of reads in flight per CU, half of what 4.5 TB/s x the loaded latency ask for.  Here an item is
+// HALF a frame (quarter for few frames), which shrinks the records to 34 rows (36 KB) and the staging area to 26 KB and leaves room for
+// three 32 KB ring slots: the four raw rows of iteration j + 2 are requested by LDS-DMA (no registers) while iteration j computes, 64 KB
+// in flight per CU.  A slot is lane-linear with the 16-byte channel chunk XOR-swizzled by the pixel on the SOURCE side, so that the
+// epilogue's reads (one pixel per lane, two chunks) are conflict-free.  vmcnt is counted by hand per iteration: it retires in order and
+// counts the four stores of every row.
+constexpr int RG_ROWS = 34;                                   // record rows of an item: 32 + halo
+constexpr int RG_REC = RG_ROWS * PWI * 16;                    // 35 904
+constexpr int RG_SLOT = 4 * IW * 128;                         // four raw rows: 32 768 bytes
+constexpr int RG_NSLOT = 3;
+
+template <int CIN>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_in_bnr_ring_kernel(const InStreamK a) {
+    __shared__ __attribute__((aligned(16))) unsigned char rec[RG_REC];
+    __shared__ __attribute__((aligned(16))) float stg[CIN * RG_ROWS * IW];
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[RG_NSLOT * RG_SLOT];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lcol = lane & 31, kg = lane >> 5;
+    const int jw = wid & 1, g = wid >> 1;
+    for (int i = tid; i < RG_REC / 16; i += 512) reinterpret_cast<u32x4_t*>(rec)[i] = u32x4_t{0u, 0u, 0u, 0u};
+    // ---- weights (as in conv_in_stream_kernel)
+    bf16x8_t wf[5][2];
+    {
+        const int R = lcol, co = 32 * jw + 16 * ((R >> 2) & 1) + (R & 3) + 4 * (R >> 3);
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const int tap = 2 * s + kg;
+            unsigned short v1[8], v2[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ci = i % CIN;
+                const bool ok = tap < 9 && co < a.Cout_real;
+                const float wv = ok ? a.w[((size_t)co * CIN + ci) * 9 + (tap < 9 ? tap : 0)] : 0.f;
+                if constexpr (CIN == 1) {
+                    unsigned short t3[3];
+                    bf_split3(wv, t3);
+                    v1[i] = i < 3 ? t3[0] : (i < 5 ? t3[1] : (i == 5 ? t3[2] : (unsigned short)0));
+                    v2[i] = 0;
+                } else {
+                    v1[i] = i < 2 * CIN ? bf_hi(wv) : (unsigned short)0;
+                    v2[i] = i < 2 * CIN ? bf_lo(wv) : (unsigned short)0;
+                }
+            }
+            u32x4_t p1, p2;
+            p1.x = v1[0] | ((unsigned)v1[1] << 16); p1.y = v1[2] | ((unsigned)v1[3] << 16); p1.z = v1[4] | ((unsigned)v1[5] << 16); p1.w = v1[6] | ((unsigned)v1[7] << 16);
+            p2.x = v2[0] | ((unsigned)v2[1] << 16); p2.y = v2[2] | ((unsigned)v2[3] << 16); p2.z = v2[4] | ((unsigned)v2[5] << 16); p2.w = v2[6] | ((unsigned)v2[7] << 16);
+            wf[s][0] = __builtin_bit_cast(bf16x8_t, p1);
+            wf[s][1] = __builtin_bit_cast(bf16x8_t, p2);
+        }
+#pragma unroll
+        for (int s = 0; s < 5; ++s) { asm volatile("" : "+v"(wf[s][0])); asm volatile("" : "+v"(wf[s][1])); }
+    }
+    unsigned tapoff[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int tap = 2 * s + kg < 9 ? 2 * s + kg : 8;
+        tapoff[s] = (unsigned)(((tap / 3) * PWI + tap % 3) * 16);
+    }
+    const int c0 = 32 * jw + 16 * kg;
+    float s1[16], s2[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s1[e] = s2[e] = 0.f;
+    float thr[16];
+    bool neg[16];
+    {
+        auto ord = [](float f) { int o = __builtin_bit_cast(int, f); return o < 0 ? (int)(0x80000000u - (unsigned)o) : o; };
+        auto unord = [](int o) { return __builtin_bit_cast(float, o < 0 ? (int)(0x80000000u - (unsigned)o) : o); };
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float sc = a.bnr_coef[c0 + e], sh = a.bnr_coef[64 + c0 + e];
+            neg[e] = sc < 0.f;
+            if (!(sc > 0.f) && !(sc < 0.f)) { thr[e] = sh > 0.f ? -__builtin_huge_valf() : __builtin_huge_valf(); continue; }
+            const float as = fabsf(sc);
+            int o = ord(bf2f(f2bf(-sh / as))) & ~0xFFFF;
+            const int omax = ord(bf2f((unsigned short)0x7F7F)), omin = -omax;
+            o = o > omax ? omax : (o < omin ? omin : o);
+            for (int it = 0; it < 6 && o > omin && fmaf(unord(o), as, sh) > 0.f; ++it) o -= 0x10000;
+            for (int it = 0; it < 6 && o < omax && !(fmaf(unord(o + 0x10000), as, sh) > 0.f); ++it) o += 0x10000;
+            thr[e] = neg[e] ? unord(ord(-unord(o)) - 0x10000) : unord(o);
+        }
+    }
+    const int NR = IW / a.P, n_it = NR / 4;                  // P in {2, 4}: 8 or 4 iterations of four rows (one per row group g)
+    const int nitems = a.N * a.P;
+    const unsigned rec_base = (unsigned)(uintptr_t)rec, ring_base = (unsigned)(uintptr_t)ring;
+    auto dma = [&](int item) {
+        const int n = item / a.P, R0 = (item - n * a.P) * NR;
+        const int lo = R0 > 0 ? R0 - 1 : 0, hi = R0 + NR < IW ? R0 + NR : IW - 1;
+        const int per_plane = (hi - lo + 1) * 16, total = per_plane * CIN;
+        const float* src = a.x + ((size_t)n * CIN * IW + lo) * IW;
+        for (int c = wid * 64; c < total; c += 512) {
+            const int cc = c + lane;
+            if (cc < total) {
+                const int pl = cc / per_plane, wi = cc - pl * per_plane;
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)pl * IW * IW + wi * 4), (lptr_t)(stg + (size_t)c * 4), 16, 0, 0);
+            }
+        }
+    };
+    // ring piece of this thread inside a row: pixel tid >> 3, LDS chunk position tid & 7 holds source chunk (tid & 7) ^ (pixel & 7)
+    const unsigned poff = (unsigned)((tid >> 3) * 64 + (((tid & 7) ^ ((tid >> 3) & 7)) * 8));
+    auto ringD = [&](const bf16_t* frame, int R0, int j) {       // rows R0 + 4 j .. + 3 of the producer's raw tensor into slot j % 3
+        unsigned char* dst = ring + (j % RG_NSLOT) * RG_SLOT;
+        const bf16_t* src = frame + (size_t)(R0 + 4 * j) * IW * 64 + poff;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)k * IW * 64), (lptr_t)(dst + ((size_t)k * 512 + wid * 64) * 16), 16, 0, 0);
+    };
+    int item = blockIdx.x;
+    if (item < nitems) dma(item);
+    for (; item < nitems; item += gridDim.x) {
+        const int n = item / a.P, R0 = (item - n * a.P) * NR;
+        const int lo = R0 > 0 ? R0 - 1 : 0, hi = R0 + NR < IW ? R0 + NR : IW - 1;
+        const int nrow = hi - lo + 1;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): staging pieces landed, every store / ring piece of the previous item retired
+        __syncthreads();
+        // ---- staging -> records; record row of frame row Y: Y - R0 + 1 (halo above = 0, below = NR + 1; outside the frame: zero)
+        for (int q = tid; q < nrow * IW; q += 512) {
+            const int r = q >> 6, xx = q & 63;
+            unsigned short sl[8];
+            if constexpr (CIN == 1) {
+                unsigned short t3[3];
+                bf_split3(stg[r * IW + xx], t3);
+                sl[0] = t3[0]; sl[1] = t3[1]; sl[2] = t3[2]; sl[3] = t3[0]; sl[4] = t3[1]; sl[5] = t3[0]; sl[6] = 0; sl[7] = 0;
+            } else {
+                unsigned short hv[CIN], lv[CIN];
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) {
+                    const float v = stg[(c * nrow + r) * IW + xx];
+                    hv[c] = bf_hi(v); lv[c] = bf_lo(v);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sl[i] = i < CIN ? hv[i % CIN] : (i < 2 * CIN ? lv[i % CIN] : (unsigned short)0);
+            }
+            u32x4_t pr;
+            pr.x = sl[0] | ((unsigned)sl[1] << 16); pr.y = sl[2] | ((unsigned)sl[3] << 16); pr.z = sl[4] | ((unsigned)sl[5] << 16); pr.w = sl[6] | ((unsigned)sl[7] << 16);
+            *reinterpret_cast<u32x4_t*>(rec + ((size_t)(lo + r - R0 + 1) * PWI + xx + 1) * 16) = pr;
+        }
+        if (tid < IW) {
+            const u32x4_t z = u32x4_t{0u, 0u, 0u, 0u};
+            if (R0 == 0) *reinterpret_cast<u32x4_t*>(rec + ((size_t)tid + 1) * 16) = z;
+            if (R0 + NR == IW) *reinterpret_cast<u32x4_t*>(rec + ((size_t)(NR + 1) * PWI + tid + 1) * 16) = z;
+        }
+        __syncthreads();
+        if (item + (int)gridDim.x < nitems) dma(item + gridDim.x);
+        const bf16_t* frame = a.bnr_raw + (size_t)n * IW * IW * 64;
+        ringD(frame, R0, 0);
+        if (n_it > 1) ringD(frame, R0, 1);
+        bf16_t* obase = a.raw + (size_t)n * IW * IW * 64 + c0;
+        for (int j = 0; j < n_it; ++j) {
+            // ring rows of iteration j: issued two iterations ago; younger operations of this wave: the stores of rows j - 2 and j - 1 (four
+            // each) and the ring pieces of iteration j + 1 (four)
+            const int younger = (j >= 2 ? 4 : 0) + (j >= 1 ? 4 : 0) + (j + 1 < n_it ? 4 : 0);
+            if (younger == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                    // everybody's pieces; and every wave is past row j - 1 (slot (j + 2) % 3 is free)
+            asm volatile("" ::: "memory");
+            if (j + 2 < n_it) ringD(frame, R0, j + 2);
+            const int y = R0 + 4 * j + g;
+            const unsigned rb = rec_base + (unsigned)((((y - R0) * PWI) + lcol) * 16);
+            const unsigned sb = ring_base + (unsigned)((j % RG_NSLOT) * RG_SLOT + g * 512 * 16);
+            u32x4_t fb[2][5], rw[2][2];
+#pragma unroll
+            for (int s = 0; s < 5; ++s) asm volatile("ds_read_b128 %0, %1" : "=&v"(fb[0][s]) : "v"(rb + tapoff[s]) : "memory");
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned px = (unsigned)(32 * t + lcol), ck = (unsigned)(c0 / 8 + h);
+                    asm volatile("ds_read_b128 %0, %1" : "=&v"(rw[t][h]) : "v"(sb + ((px * 8 + (ck ^ (px & 7))) << 4)) : "memory");
+                }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x16_t acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 5; ++s) {
+                    // LDS returns in order.  tile 0: the four ring reads and 4 - s operand reads are younger; tile 1: 4 - s operand reads
+                    if (t == 0) {
+                        switch (8 - s) {
+                            case 8: asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fb[t][s])::"memory"); break;
+                            case 7: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(fb[t][s])::"memory"); break;
+                            case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fb[t][s])::"memory"); break;
+                            case 5: asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fb[t][s])::"memory"); break;
+                            default: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fb[t][s])::"memory"); break;
+                        }
+                    } else {
+                        switch (4 - s) {
+                            case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fb[t][s])::"memory"); break;
+                            case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fb[t][s])::"memory"); break;
+                            case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fb[t][s])::"memory"); break;
+                            case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fb[t][s])::"memory"); break;
+                            default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[t][s])::"memory"); break;
+                        }
+                    }
+                    const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, fb[t][s]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], bf, acc, 0, 0, 0);
+                    if constexpr (CIN != 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][1], bf, acc, 0, 0, 0);
+                }
+                if (t == 0) {
+#pragma unroll
+                    for (int s = 0; s < 5; ++s) asm volatile("ds_read_b128 %0, %1" : "=&v"(fb[1][s]) : "v"(rb + 512u + tapoff[s]) : "memory");
+                    // the ring reads are older than these five
+                    asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(rw[0][0]), "+v"(rw[0][1]), "+v"(rw[1][0]), "+v"(rw[1][1])::"memory");
+                }
+                u32x4_t o0, o1;
+                o0.x = pack2bf(acc[0], acc[1]); o0.y = pack2bf(acc[2], acc[3]); o0.z = pack2bf(acc[4], acc[5]); o0.w = pack2bf(acc[6], acc[7]);
+                o1.x = pack2bf(acc[8], acc[9]); o1.y = pack2bf(acc[10], acc[11]); o1.z = pack2bf(acc[12], acc[13]); o1.w = pack2bf(acc[14], acc[15]);
+                u32x4_t* op = reinterpret_cast<u32x4_t*>(obase + ((size_t)y * IW + 32 * t + lcol) * 64);
+                op[0] = o0; op[1] = o1;
+                float da[16], rv[16];
+                unpack8(o0, da); unpack8(o1, da + 8);
+                unpack8(rw[t][0], rv); unpack8(rw[t][1], rv + 8);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float gg = da[e] * (((rv[e] > thr[e]) != neg[e]) ? 1.f : LRELU_SLOPE);
+                    s1[e] += gg; s2[e] = fmaf(gg, rv[e], s2[e]);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(stg);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float u = s1[e], v = s2[e];
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) { u += __shfl_xor(u, m); v += __shfl_xor(v, m); }
+        if (lcol == 0) { red[(g * 64 + c0 + e) * 2] = (double)u; red[(g * 64 + c0 + e) * 2 + 1] = (double)v; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double t1 = 0., t2 = 0.;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { t1 += red[(r * 64 + tid) * 2]; t2 += red[(r * 64 + tid) * 2 + 1]; }
+        const double mu = a.bnr_coef[128 + tid], is = a.bnr_coef[192 + tid];
+        atomicAdd(a.bnr_red + tid, t1);
+        atomicAdd(a.bnr_red + 64 + tid, is * (t2 - mu * t1));
+    }
+}
+
 int g_in_stream = -1;
 
 }  // namespace
@@ -319,7 +566,16 @@ int srvp_conv_in_stream_launch(const float* x, const float* w, bf16_t* raw, doub
     a.P = N >= 4 * ncu ? 1 : (N >= 2 * ncu ? 2 : 4);
     const long long items = (long long)N * a.P;
     const dim3 grid((unsigned)(items < ncu ? items : ncu)), blk(512);
-    if (bnr_red) {
+    static int ring_on = -1;
+    if (ring_on < 0) { const char* e = getenv("SRVP_CONV_IN_BNR_RING"); ring_on = e ? atoi(e) : 1; }
+    if (bnr_red && ring_on) {
+        // the raw rows of the producer in an LDS ring: items are half frames (quarter frames when there are few)
+        a.P = N >= 2 * ncu ? 2 : 4;
+        const long long it2 = (long long)N * a.P;
+        const dim3 grid2((unsigned)(it2 < ncu ? it2 : ncu));
+        if (Cin == 3) hipLaunchKernelGGL((conv_in_bnr_ring_kernel<3>), grid2, blk, 0, st, a);
+        else hipLaunchKernelGGL((conv_in_bnr_ring_kernel<1>), grid2, blk, 0, st, a);
+    } else if (bnr_red) {
         if (Cin == 3) hipLaunchKernelGGL((conv_in_stream_kernel<3, true>), grid, blk, 0, st, a);
         else hipLaunchKernelGGL((conv_in_stream_kernel<1, true>), grid, blk, 0, st, a);
     } else {
