@@ -129,7 +129,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 // groups <= b + 1 have landed when only what was issued after group b + 1 is outstanding: this group's 9 (8) pieces and,
                 // from the second band on, the 8 stores of the previous band's copy-out (vmcnt counts stores too and retires in order:
                 // a count that excluded them made every band wait for the store acknowledgements)
-                if (b > b0) { if (wid == 0) __builtin_amdgcn_s_waitcnt(0x4F70 | 1); else __builtin_amdgcn_s_waitcnt(0x4F70); }   // vmcnt(17) / (16)
+                // (BNR: + the previous band's 8 loads of the producer's raw values, issued behind group b + 1 as well)
+                if (b > b0) {
+                    if constexpr (BNR) { if (wid == 0) __builtin_amdgcn_s_waitcnt(0x4F70 | 9); else __builtin_amdgcn_s_waitcnt(0x4F70 | 8); }   // vmcnt(25) / (24)
+                    else { if (wid == 0) __builtin_amdgcn_s_waitcnt(0x4F70 | 1); else __builtin_amdgcn_s_waitcnt(0x4F70); }                  // vmcnt(17) / (16)
+                }
                 else if (wid == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | 9); else __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
             } else {
                 __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -137,6 +141,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const int y0 = b * SGROUP_ROWS;
+            // BNR: the band's eight pieces of the producer's raw output (consumed in the copy-out loop) are requested NOW, so that they
+            // travel under the band's MFMA phase instead of in two exposed rounds of four behind it
+            u32x4_t rwb[BNR ? 8 : 1];
+            if constexpr (BNR) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    rwb[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(rbase + (size_t)y0 * SW * 64 + ((size_t)i * 256 + tid) * 8));
+            }
             f32x16_t acc[SGROUP_ROWS];
 #pragma unroll
             for (int r = 0; r < SGROUP_ROWS; ++r)
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int i = 0; i < 4; ++i) {
                     const int q = (h * 4 + i) * 256 + tid;
                     v[i] = *reinterpret_cast<const u32x4_t*>(cs + (q >> 3) * SLDC + cch * 8);
-                    if constexpr (BNR) rw[i] = *reinterpret_cast<const u32x4_t*>(rbase + (size_t)y0 * SW * 64 + (size_t)q * 8);
+                    if constexpr (BNR) rw[i] = rwb[h * 4 + i];
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
