@@ -285,6 +285,20 @@ __device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[TM][TN], const Con
             csc[e] = a.bnr_coef[c]; csh[e] = a.bnr_coef[Cdst + c]; cmu[e] = a.bnr_coef[2 * Cdst + c]; cis[e] = a.bnr_coef[3 * Cdst + c];
             s1[e] = 0.f; s2[e] = 0.f;
         }
+        // (the raw pieces of group g + 1 are requested before group g is worked on: issued inside their own group they cost every group a
+        // full global-load latency, four times per 128-column tile)
+        auto piece = [&](int gi, size_t& o, bool& k) {
+            const int row = row0 + gi * RSTEP;
+            int n, oy, ox;
+            k = rowmap(row, n, oy, ox);
+            if (!k) { n = 0; oy = 0; ox = 0; }
+            o = (size_t)n * img + (size_t)(unsigned)(((oy * so + ooy) * DWp + ox * so + oox) * Cdst);
+        };
+        u32x4_t rwn[G];
+        size_t offn[G];
+        bool okn[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) { piece(u, offn[u], okn[u]); rwn[u] = *reinterpret_cast<const u32x4_t*>(rbase + offn[u]); }
 #pragma unroll
         for (int g = 0; g < ITER; g += G) {
             u32x4_t v[G], rw[G];
@@ -292,13 +306,12 @@ __device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[TM][TN], const Con
             bool ok[G];
 #pragma unroll
             for (int u = 0; u < G; ++u) {
-                const int row = row0 + (g + u) * RSTEP;
-                int n, oy, ox;
-                ok[u] = rowmap(row, n, oy, ox);
-                if (!ok[u]) { n = 0; oy = 0; ox = 0; }
-                off[u] = (size_t)n * img + (size_t)(unsigned)(((oy * so + ooy) * DWp + ox * so + oox) * Cdst);
-                rw[u] = *reinterpret_cast<const u32x4_t*>(rbase + off[u]);
+                off[u] = offn[u]; ok[u] = okn[u]; rw[u] = rwn[u];
                 v[u] = *reinterpret_cast<const u32x4_t*>(cbase + (g + u) * RSTEP * LDC);
+            }
+            if (g + G < ITER) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) { piece(g + G + u, offn[u], okn[u]); rwn[u] = *reinterpret_cast<const u32x4_t*>(rbase + offn[u]); }
             }
 #pragma unroll
             for (int u = 0; u < G; ++u) {
