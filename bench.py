@@ -322,6 +322,14 @@ def main():
         # the reference's loader hands over uint8 videos (data/base.py:71-84): stacked [B][T][H][W][C] in pinned host memory;
         # srvp_amd.train.train() copies them and finishes the collate (transpose + /255) on the device
         x = (torch.rand(B, T, 64, 64, cfg['ctor'][1], generator=g) * 255).to(torch.uint8).pin_memory()
+    # --h2d u8: the step's input comes through srvp_amd.data.Prefetcher, as in srvp_amd.train.main: the pinned batch of step i + 1 is copied
+    # and collated on a copy stream under step i (SRVP_BENCH_H2D_INLINE=1: the round-3 form, copy + collate in line at the top of the step)
+    feed = None
+    if args.h2d == 'u8' and os.environ.get('SRVP_BENCH_H2D_INLINE') != '1':
+        import itertools
+        from srvp_amd.data import Prefetcher
+        feed = iter(Prefetcher(itertools.repeat(x), dev))
+    batch = (lambda: next(feed)) if feed is not None else (lambda: x)
 
     def barrier():
         torch.cuda.synchronize()
@@ -331,7 +339,7 @@ def main():
 
     loss = None
     for _ in range(args.warmup):
-        loss = train(fwd, optim, None, x, dev, opt)
+        loss = train(fwd, optim, None, batch(), dev, opt)
     # HIP events around the launches of the two dominant kernel classes only (~110 per step), on every EVENT_EVERY-th step of
     # the timed region: each event record is a marker packet in the stream (~1 ms per step if every step carries them; timing
     # all 329 launches costs ~3 ms per step), so the full per-kernel table is taken in an extra untimed pass
@@ -342,7 +350,7 @@ def main():
         # one instrumented step OUTSIDE the timed region: the first timing event of a process costs ~75-100 ms once (the runtime
         # switches the queue to profiling mode), which is 7-10 ms per step of a 10-step run of the short-step configs
         L.PROFILE, L.PROFILE_ONLY = {}, {'srvp_conv_mfma', 'srvp_conv_mfma_multi', 'srvp_wgrad_mfma'}
-        train(fwd, optim, None, x, dev, opt)
+        train(fwd, optim, None, batch(), dev, opt)
         L.PROFILE, L.PROFILE_ONLY = None, None
     # Same garbage-collector treatment as a real run (srvp_amd.train.main: gc.collect(); gc.freeze() after set-up, collector left
     # ON): the long-lived object graph (model, plans, descriptors) moves to the permanent generation, so the collections the
@@ -357,7 +365,7 @@ def main():
         if timing and i % EVENT_EVERY == 0:
             L.PROFILE, L.PROFILE_ONLY = prof, {'srvp_conv_mfma', 'srvp_conv_mfma_multi', 'srvp_wgrad_mfma'}
             n_prof_steps += 1
-        loss = train(fwd, optim, None, x, dev, opt)
+        loss = train(fwd, optim, None, batch(), dev, opt)
         L.PROFILE, L.PROFILE_ONLY = None, None
         if os.environ.get('SRVP_BENCH_TRACE'):
             print(f'step {i} host t={1e3 * (time.perf_counter() - t0):.2f} ms', file=sys.stderr)
@@ -367,12 +375,12 @@ def main():
     if prof is not None and rank == 0:
         L.PROFILE = {}                      # untimed extra pass: every launch
         for _ in range(2):
-            train(fwd, optim, None, x, dev, opt)
+            train(fwd, optim, None, batch(), dev, opt)
         torch.cuda.synchronize()
         table, L.PROFILE = L.PROFILE, None
     elif prof is not None:
         for _ in range(2):
-            train(fwd, optim, None, x, dev, opt)
+            train(fwd, optim, None, batch(), dev, opt)
     # context for `roofline.achieved`: the same launches with NOTHING running beside them.  Since round 3 every weight gradient runs
     # on the second stream, concurrently with the data-gradient / BatchNorm kernels of the main stream (a faster step, and launch
     # durations that include the sharing); two more untimed steps with the second stream switched off give the kernels' own rate.
@@ -383,10 +391,10 @@ def main():
         saved = (_m.OVERLAP_WGRAD, _m.OVERLAP_SKIP, _m.OVERLAP_PACK, _cn.ENC_WGRAD_SIDE_MAXN)
         _m.OVERLAP_WGRAD, _m.OVERLAP_SKIP, _m.OVERLAP_PACK, _cn.ENC_WGRAD_SIDE_MAXN = False, False, False, 0
         try:
-            train(fwd, optim, None, x, dev, opt)
+            train(fwd, optim, None, batch(), dev, opt)
             L.PROFILE, L.PROFILE_ONLY = {}, {'srvp_conv_mfma', 'srvp_conv_mfma_multi', 'srvp_wgrad_mfma'}
             for _ in range(2):
-                train(fwd, optim, None, x, dev, opt)
+                train(fwd, optim, None, batch(), dev, opt)
             torch.cuda.synchronize()
             unshared, L.PROFILE, L.PROFILE_ONLY = L.PROFILE, None, None
         finally:
@@ -413,6 +421,18 @@ def main():
         torch.distributed.all_reduce(ts, op=torch.distributed.ReduceOp.MAX)
         strong = dict(scaling='strong', global_batch=192, per_gpu_batch=Bs, ms_per_step=ts.item() / args.steps * 1e3,
                       value=192 * T * args.steps / ts.item(), unit='frames/s')
+    # ---- N > 1 (or SRVP_FORCE_COLLECTIVES=1): what the exchange itself costs on the transports the step used (every rank takes part): the
+    # transport per exchange, RCCL's own rank count per communicator, the in-stream latency of one statistics all-reduce, the bandwidth of one
+    # 95 MB gradient all-reduce -- so that a scaling curve explains itself (srvp_amd.distributed.Sync.diagnostics)
+    comm_diag = None
+    if sync is not None:
+        try:
+            comm_diag = sync.diagnostics()
+        except Exception as exc:           # a diagnostic must never take the bench line down
+            comm_diag = {'error': str(exc)}
+        wd = model.__dict__.get('_watchdog')
+        if wd is not None:
+            comm_diag['step_watchdog_s'] = wd.timeout_s
     if rank != 0:
         torch.distributed.destroy_process_group()
         return
@@ -426,13 +446,16 @@ def main():
         'data': 'synthetic (uniform random frames, random-init weights)',
         'config': {'workload': cfg['label'], 'per_gpu_batch': B, 'global_batch': B * world, 'seq_len': T,
                    'parallelism': f'dp{world}', 'step': 'forward + ELBO + backward + Adam (reference train.py:49-129)',
-                   'input': 'uint8 host batch, H2D + device collate inside the step' if args.h2d == 'u8' else 'float32 batch resident in HBM',
+                   'input': ('uint8 pinned host batch per step; H2D + device collate ' + ('on a copy stream under the previous step (srvp_amd.data.Prefetcher)' if feed is not None else 'in line at the top of the step'))
+                            if args.h2d == 'u8' else 'float32 batch resident in HBM',
                    'collectives': sync.transport if sync is not None else None},
         'loss': loss[0] if loss else None,
         'model_flops_frac_of_bf16_peak': (3 * fl['fwd_all'] * world * args.steps / dt) / (PEAK_BF16_TFLOPS * 1e12 * world),
     }
     if strong is not None:
         line['strong_scaling'] = strong
+    if comm_diag is not None:
+        line['comm'] = comm_diag
     if prof:
         per = {}
         for name, evs in prof.items():

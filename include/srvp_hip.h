@@ -117,6 +117,10 @@ int srvp_conv_set_halo(int on);
  * streaming kernel (csrc/conv_stream.hip: persistent workgroup per CU, rolling LDS row window, register-resident weights); 0: on the
  * tile kernels.  Same results up to fp32 summation order. */
 int srvp_conv_set_stream64(int on);
+/* Launches taken by the streaming kernels of csrc/conv_stream.hip since the library was loaded (host-side counters, for tests that must
+ * know a case really ran on them): which = 0: 64 -> 64 channel forward / plain data gradient, 1: data gradient with fused BatchNorm-backward
+ * sums (bnr_*), 2: the 64-channel sub-pixel stage entry (srvp_conv_mfma_multi).  -1 for another `which`. */
+long long srvp_conv_stream_count(int which);
 /* 1 (default; env SRVP_CONV_IN_STREAM): srvp_conv_in_fwd / srvp_conv_in_fwd_bnr serve 3x3 stride-1 layers with 64 output channels on 64x64
  * frames through the streaming kernel of csrc/conv_in_stream.hip; 0: through the 128-pixel tile kernel (exact fp32 MFMA).  A/B switch of the tests. */
 int srvp_conv_set_in_stream(int on);
@@ -474,6 +478,9 @@ int srvp_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr,
 int srvp_comm_unique_id(void* id128);
 int srvp_comm_init(const void* id128, int rank, int world, void** comm_out);
 int srvp_comm_destroy(void* comm);
+/* What RCCL reports about a communicator (diagnostics of `bench.py --gpus N`): info3[0] = ncclCommCount, [1] = ncclCommUserRank,
+ * [2] = ncclGetVersion; -1 where the loaded librccl lacks the call. */
+int srvp_comm_info(void* comm, int* info3);
 /* in-place sum over ranks */
 int srvp_allreduce_f64(void* comm, double* buf, int64_t n, void* stream);
 int srvp_allreduce_f32(void* comm, float* buf, int64_t n, void* stream);

@@ -126,6 +126,7 @@ _SIGS = {
     'srvp_bn_stats_f32_det': ([c_vp, c_i64, c_i32, c_vp, c_vp], c_i32),
     'srvp_pack_job_tiles': ([C.POINTER(PackDesc), c_i32], c_i32),
     'srvp_conv_set_stream64': ([c_i32], c_i32),
+    'srvp_conv_stream_count': ([c_i32], c_i64),
     'srvp_conv_set_in_stream': ([c_i32], c_i32),
     'srvp_conv_out_eligible': ([c_i32] * 7, c_i32),
     'srvp_conv_out_fwd': ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
@@ -158,6 +159,7 @@ _SIGS = {
     'srvp_comm_unique_id': ([c_vp], c_i32),
     'srvp_comm_init': ([c_vp, c_i32, c_i32, C.POINTER(c_vp)], c_i32),
     'srvp_comm_destroy': ([c_vp], c_i32),
+    'srvp_comm_info': ([c_vp, C.POINTER(c_i32)], c_i32),
     'srvp_allreduce_f64': ([c_vp, c_vp, c_i64, c_vp], c_i32),
     'srvp_allreduce_f32': ([c_vp, c_vp, c_i64, c_vp], c_i32),
     'srvp_bcast_bytes': ([c_vp, c_vp, c_i64, c_i32, c_vp], c_i32),

@@ -376,7 +376,9 @@ class Block:
         self.pd = _pack_desc(order_d, self.ctot, co_p, isegs, osegs, sk_f, sj_f)
         self.pu = _pack_desc(nat, co_p, self.ctot, osegs, isegs, sj_f, sk_f)
         # image-side output layer on the streaming kernel (csrc/conv_out.hip): a tap-major copy [9][32][64] of its forward weights
+        # (the kernel hardcodes its source: [N][66][66][64] with a 1-pixel border, read at full resolution -- ADVICE r4)
         self.stream_out = bool(self.role == 'out' and self.geom == 'sameT' and not self.f32 and len(self.srcs) == 1 and co_p == 32 and
+                               self.srcs[0].b == 1 and self.srcs[0].C == 64 and not self.ups and not getattr(self.srcs[0], 's2d', False) and
                                L.load().srvp_conv_out_eligible(self.ctot, self.OH, self.OW, co_r, self.k, self.s, self.p))
         if self.stream_out:
             self.pf_o = _pack_desc(order_f, co_p, self.ctot, osegs, isegs, sj_f, sk_f)
@@ -1041,6 +1043,7 @@ class ConvNetBase:
         elif getattr(blk, '_ep', False):
             skip_s = blk.split and getattr(self, '_skips_done', False)
             if blk.subpix:
+                assert len(blk._fwd) == (5 if blk.split else 4), len(blk._fwd)       # [conv_s(skip)] + the four output phases
                 if blk.split and not skip_s:
                     L.call('srvp_conv_mfma', C.byref(blk._fwd[0]), st)
                 arr = blk.__dict__.get('_fwd_arr')

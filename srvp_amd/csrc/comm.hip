@@ -18,6 +18,9 @@ struct Api {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -32,6 +35,9 @@ int load_api() {
     g_api.GetUniqueId = (decltype(g_api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     g_api.CommInitRank = (decltype(g_api.CommInitRank))dlsym(h, "ncclCommInitRank");
     g_api.CommDestroy = (decltype(g_api.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_api.CommCount = (decltype(g_api.CommCount))dlsym(h, "ncclCommCount");            // (the three below are diagnostics: optional)
+    g_api.CommUserRank = (decltype(g_api.CommUserRank))dlsym(h, "ncclCommUserRank");
+    g_api.GetVersion = (decltype(g_api.GetVersion))dlsym(h, "ncclGetVersion");
     g_api.AllReduce = (decltype(g_api.AllReduce))dlsym(h, "ncclAllReduce");
     g_api.Broadcast = (decltype(g_api.Broadcast))dlsym(h, "ncclBroadcast");
     g_api.GetErrorString = (decltype(g_api.GetErrorString))dlsym(h, "ncclGetErrorString");
@@ -70,6 +76,17 @@ extern "C" int srvp_comm_init(const void* id128, int rank, int world, void** com
 extern "C" int srvp_comm_destroy(void* comm) {
     if (!comm || !g_api.lib) return SRVP_OK;
     RCCL_CHECK(g_api.CommDestroy((ncclComm_t)comm), "ncclCommDestroy");
+    return SRVP_OK;
+}
+
+// What RCCL itself reports about a communicator: info[0] = ncclCommCount (ranks), info[1] = ncclCommUserRank, info[2] = ncclGetVersion
+// (-1 where the loaded librccl lacks the call).  bench.py --gpus N prints it, so that a scaling curve explains itself.
+extern "C" int srvp_comm_info(void* comm, int* info3) {
+    SRVP_REQUIRE(comm && info3 && g_api.lib, "srvp_comm_info: bad args / communicator not initialised");
+    info3[0] = info3[1] = info3[2] = -1;
+    if (g_api.CommCount) RCCL_CHECK(g_api.CommCount((ncclComm_t)comm, &info3[0]), "ncclCommCount");
+    if (g_api.CommUserRank) RCCL_CHECK(g_api.CommUserRank((ncclComm_t)comm, &info3[1]), "ncclCommUserRank");
+    if (g_api.GetVersion) RCCL_CHECK(g_api.GetVersion(&info3[2]), "ncclGetVersion");
     return SRVP_OK;
 }
 

@@ -40,6 +40,40 @@ __device__ __forceinline__ void bf_split3(float v, unsigned short (&t)[3]) {
     t[1] = f2bf(r1); t[2] = f2bf(r1 - bf2f(t[1]));
 }
 
+// Sum of each of 16 per-lane values over the 32 lanes of a lane group (lanes 0-31 / 32-63), as a reduce-scatter butterfly: 15 + 1 lane
+// exchanges instead of 16 x 5; afterwards lane lcol holds the total of element rs16_elem(lcol) (both lanes of a pair hold the same one).
+// The array is left zeroed: the per-lane fp32 accumulators of the streaming kernels live for ONE work item (<= 32 values per lane), the
+// totals are widened to double per item (the fp32 accumulation over a whole launch lost precision with N / ncu).
+__device__ __forceinline__ float rs16_flush(float (&a)[16], int lcol) {
+#pragma unroll
+    for (int m = 16, h = 8; h >= 1; m >>= 1, h >>= 1) {
+        const bool up = (lcol & m) != 0;
+#pragma unroll
+        for (int i = 0; i < h; ++i) {
+            const float send = up ? a[i] : a[i + h], keep = up ? a[i + h] : a[i];
+            a[i] = keep + __shfl_xor(send, m);
+        }
+    }
+    const float r = a[0] + __shfl_xor(a[0], 1);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a[e] = 0.f;
+    return r;
+}
+__device__ __forceinline__ int rs16_elem(int lcol) { return (lcol >> 1) & 15; }
+// The same result by 16 x 5 plain xor exchanges: inside conv_in_bnr_ring_kernel the butterfly's selects cost hipcc 100 registers (spills)
+__device__ __forceinline__ float rs16_flush_plain(float (&a)[16], int lcol) {
+    float r = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float u = a[e];
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) u += __shfl_xor(u, m);
+        if (rs16_elem(lcol) == e) r = u;
+        a[e] = 0.f;
+    }
+    return r;
+}
+
 struct InStreamK {
     const float* x;          // (N, CIN, 64, 64) fp32 frames
     const float* w;          // (Cout_real, CIN, 3, 3) fp32
@@ -103,10 +137,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         tapoff[s] = (unsigned)(((tap / 3) * PWI + tap % 3) * 16);
     }
     const int c0 = 32 * jw + 16 * kg;                        // first of this lane's 16 output channels
-    // per-lane sums over the launch: plain forward: sum / sum of squares of the fp32 results; BNR: c1 = sum g, c2 = sum g * raw
+    // per-lane sums over ONE work item: plain forward: sum / sum of squares of the fp32 results; BNR: c1 = sum g, c2 = sum g * raw.
+    // Widened to double per item (rs16_flush): the centring is * (c2 - mean c1) is done in double on the totals.
     float s1[16], s2[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) s1[e] = s2[e] = 0.f;
+    double d1 = 0., d2 = 0.;
     // BNR: the activation gate act'(scale raw + shift) = [fmaf(raw, scale, shift) > 0] as a THRESHOLD on the bf16 value raw -- the predicate
     // is monotone in raw, so there is a bf16 value T with predicate <=> (raw > T) for scale > 0 resp. (raw <= T) for scale < 0; T is found
     // exactly by evaluating the predicate itself on the bf16 neighbours of -shift / scale.  One compare per element, 16 registers less.
@@ -268,25 +304,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         } else {
             for (int y = R0 + g; y < R0 + NR; y += 4) row(y, rwA);
         }
+        // this item's sums over the 32 pixels of the lane group, widened: lane lcol carries channel c0 + rs16_elem(lcol)
+        d1 += (double)rs16_flush(s1, lcol); d2 += (double)rs16_flush(s2, lcol);
     }
-    // ---- sums: over the 32 pixels of the lane group (xor shuffles inside each half), then over the waves of a channel tile through LDS
+    // ---- sums over the waves of a channel tile through LDS
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     double* red = reinterpret_cast<double*>(stg);            // [4 row groups][64 channels][2]
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        float u = s1[e], v = s2[e];
-#pragma unroll
-        for (int m = 1; m < 32; m <<= 1) { u += __shfl_xor(u, m); v += __shfl_xor(v, m); }
-        if (lcol == 0) { red[(g * 64 + c0 + e) * 2] = (double)u; red[(g * 64 + c0 + e) * 2 + 1] = (double)v; }
-    }
+    if (!(lcol & 1)) { red[(g * 64 + c0 + rs16_elem(lcol)) * 2] = d1; red[(g * 64 + c0 + rs16_elem(lcol)) * 2 + 1] = d2; }
     __syncthreads();
     if (tid < 64) {
         double t1 = 0., t2 = 0.;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { t1 += red[(r * 64 + tid) * 2]; t2 += red[(r * 64 + tid) * 2 + 1]; }
         if constexpr (BNR) {
-            // sum g (raw - mean) inv_std = inv_std (sum g raw - mean sum g)
+            // sum g (raw - mean) inv_std = inv_std (sum g raw - mean sum g), in double from the per-item sums
             const double mu = a.bnr_coef[128 + tid], is = a.bnr_coef[192 + tid];
             atomicAdd(a.bnr_red + tid, t1);
             atomicAdd(a.bnr_red + 64 + tid, is * (t2 - mu * t1));
@@ -360,9 +392,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         tapoff[s] = (unsigned)(((tap / 3) * PWI + tap % 3) * 16);
     }
     const int c0 = 32 * jw + 16 * kg;
-    float s1[16], s2[16];
+    float s1[16], s2[16];                                    // per item, widened per item (as in conv_in_stream_kernel)
 #pragma unroll
     for (int e = 0; e < 16; ++e) s1[e] = s2[e] = 0.f;
+    double d1 = 0., d2 = 0.;
     float thr[16];
     bool neg[16];
     {
@@ -522,17 +555,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
+        d1 += (double)rs16_flush_plain(s1, lcol); d2 += (double)rs16_flush_plain(s2, lcol);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     double* red = reinterpret_cast<double*>(stg);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        float u = s1[e], v = s2[e];
-#pragma unroll
-        for (int m = 1; m < 32; m <<= 1) { u += __shfl_xor(u, m); v += __shfl_xor(v, m); }
-        if (lcol == 0) { red[(g * 64 + c0 + e) * 2] = (double)u; red[(g * 64 + c0 + e) * 2 + 1] = (double)v; }
-    }
+    if (!(lcol & 1)) { red[(g * 64 + c0 + rs16_elem(lcol)) * 2] = d1; red[(g * 64 + c0 + rs16_elem(lcol)) * 2 + 1] = d2; }
     __syncthreads();
     if (tid < 64) {
         double t1 = 0., t2 = 0.;

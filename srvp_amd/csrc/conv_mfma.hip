@@ -917,8 +917,18 @@ extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
 
 // n <= 4 launches as one grid when they all run on the same halo kernel variant with the same grid (the output phases of
 // a sub-pixel upsample conv); otherwise simply n launches.
+// ep_coef (eval-mode BatchNorm + activation in the epilogue): the preconditions every kernel that serves it relies on, checked for every
+// descriptor at BOTH entry points (the multi-launch forms took such descriptors unchecked)
+static int check_ep_coef(const srvp_conv_desc* d) {
+    SRVP_REQUIRE(!d->ep_coef || (!d->elem_f32 && !d->stats && !d->dst_is_f32 && !d->out_f32 && d->splitk <= 1 && !d->bnr_red && d->ep_act >= 0 && d->ep_act <= 4 && d->ep_border >= 0 && d->ep_border <= 1),
+                 "srvp_conv_mfma: ep_coef (eval-mode BatchNorm epilogue) needs a plain bf16 forward launch without statistics");
+    return SRVP_OK;
+}
+
 extern "C" int srvp_conv_mfma_multi(const srvp_conv_desc* d, int n, void* stream) {
     SRVP_REQUIRE(d && n >= 1, "srvp_conv_mfma_multi: bad args");
+    for (int i = 0; i < n; ++i)
+        if (int rc = check_ep_coef(d + i)) return rc;
     {
         int taken = 0;
         if (int rc = srvp_conv_stream_sub64_launch(d, n, (hipStream_t)stream, &taken)) return rc;
@@ -953,8 +963,7 @@ extern "C" int srvp_conv_mfma(const srvp_conv_desc* d, void* stream) {
                                  d->oox == 0 && d->cdst_off == 0 && d->Cdst == d->Cout && d->DHp == d->OH && d->DWp == d->OW && halo_variant(d) >= 256 &&
                                  (long long)d->N * d->OH * d->OW * d->Cout < (1ll << 32)),
                  "srvp_conv_mfma: bnr_red (fused BatchNorm-backward reduction) needs a plain bf16 data-gradient launch on the halo kernel");
-    SRVP_REQUIRE(!d->ep_coef || (!d->elem_f32 && !d->stats && !d->dst_is_f32 && !d->out_f32 && d->splitk <= 1 && !d->bnr_red && d->ep_act >= 0 && d->ep_act <= 4 && d->ep_border >= 0 && d->ep_border <= 1),
-                 "srvp_conv_mfma: ep_coef (eval-mode BatchNorm epilogue) needs a plain bf16 forward launch without statistics");
+    if (int rc = check_ep_coef(d)) return rc;
     if (d->elem_f32) return srvp_conv_f32_launch(d, st);
     SRVP_REQUIRE((long long)d->N * d->H0p * d->W0p * d->C0 < (1ll << 32) && (d->C1 == 0 || d->map1 || (long long)d->N * d->H1p * d->W1p * d->C1 < (1ll << 32)),
                  "srvp_conv_mfma: source tensors must have fewer than 2^32 elements");

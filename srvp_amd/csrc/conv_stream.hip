@@ -468,6 +468,11 @@ static int g_stream64 = -1;      // -1: SRVP_CONV_STREAM64 env (default 1)
 // A/B switch (tests): 1 = 64 -> 64 channel 64x64 launches on the streaming kernel (default), 0 = on the tile kernels.  Same results up to
 // fp32 summation order.
 extern "C" int srvp_conv_set_stream64(int on) { g_stream64 = on ? 1 : 0; return SRVP_OK; }
+// launches taken by the streaming kernels since the library was loaded (host counters; tests assert that a case really went through them):
+// which = 0: conv_stream64_kernel<false> (forward / plain data gradient), 1: conv_stream64_kernel<true> (data gradient + fused BatchNorm-backward
+// sums), 2: conv_stream_sub64_kernel
+static long long g_stream_count[3] = {0, 0, 0};
+extern "C" long long srvp_conv_stream_count(int which) { return which >= 0 && which < 3 ? g_stream_count[which] : -1; }
 
 // Called by srvp_conv_mfma before the tile kernels: *taken = 1 if this launch was handled here.
 int srvp_conv_stream64_launch(const srvp_conv_desc* d, hipStream_t st, int* taken) {
@@ -501,6 +506,7 @@ int srvp_conv_stream64_launch(const srvp_conv_desc* d, hipStream_t st, int* take
     if (d->bnr_red) hipLaunchKernelGGL(conv_stream64_kernel<true>, g, b, 0, st, k);
     else hipLaunchKernelGGL(conv_stream64_kernel<false>, g, b, 0, st, k);
     SRVP_CHECK_LAUNCH("srvp_conv_mfma(stream64)");
+    ++g_stream_count[d->bnr_red ? 1 : 0];
     *taken = 1;
     return SRVP_OK;
 }
@@ -540,6 +546,7 @@ int srvp_conv_stream_sub64_launch(const srvp_conv_desc* d, int n, hipStream_t st
     const long long items = (long long)k.B * 16 * k.TS;
     hipLaunchKernelGGL(conv_stream_sub64_kernel, dim3((unsigned)(items < ncu ? items : ncu)), dim3(256), 0, st, k);
     SRVP_CHECK_LAUNCH("srvp_conv_mfma_multi(stream sub64)");
+    ++g_stream_count[2];
     *taken = 1;
     return SRVP_OK;
 }

@@ -53,6 +53,56 @@ def frames_from_u8(u8, device):
     return out
 
 
+class Prefetcher:
+    """Asynchronous input (reference train.py:84,262: `batch.to(device)` at the top of the step, DataLoader(pin_memory=True); SURVEY §2a
+    "async H2D on copy stream"): wraps an iterable of HOST batches -- float32 (T, B, C, H, W), or the stacked uint8 videos of `collate_u8`
+    -- and yields DEVICE batches.  Batch i + 1 is staged (pinned -> HBM copy, and for uint8 the device-side collate) on a copy stream of
+    its own right before batch i is handed out, i.e. under step i; the consumer's stream waits on the staging event, so by the time the
+    step's first kernel needs the frames they are resident and the step pays neither the PCIe transfer nor the collate.
+    Iterables that already yield device tensors (the device Moving-MNIST generator) pass through untouched."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+        self.copy_stream = torch.cuda.Stream(self.device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, batch):
+        if batch.is_cuda:
+            return batch, None
+        if not batch.is_pinned():
+            batch = batch.pin_memory()                       # (an unpinned source would make the copy synchronous)
+        ready = torch.cuda.Event()
+        ready.record()                                       # the staging buffers are allocated after everything queued so far on the consumer
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(ready)
+            x = frames_from_u8(batch, self.device) if batch.dtype == torch.uint8 else batch.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        return (x, batch), ev                                # (the pinned source stays referenced until the copy has been waited for)
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur, ev = nxt
+            try:
+                nxt = self._stage(next(it))                  # batch i + 1 goes out BEFORE step i is queued: it travels under step i
+            except StopIteration:
+                nxt = None
+            if ev is None:
+                yield cur
+                continue
+            x, _src = cur
+            torch.cuda.current_stream().wait_event(ev)
+            x.record_stream(torch.cuda.current_stream())     # allocated on the copy stream, consumed on the compute stream
+            yield x
+
+
 def mnist_digits(data_dir):
     """The 60000 training digits (n, 28, 28) uint8 that reference data/mmnist.py:337-340 takes from torchvision's MNIST,
     read from the raw IDX file torchvision stores under <data_dir>/MNIST/raw (no torchvision, no download here)."""

@@ -72,10 +72,104 @@ class NativeComm:
                 return False
         return True
 
+    def info(self):
+        """What RCCL itself reports about this communicator: dict(ranks=ncclCommCount, rank=ncclCommUserRank, version=ncclGetVersion)."""
+        a = (C.c_int32 * 3)()
+        L.call('srvp_comm_info', self.handle, a)
+        return dict(ranks=int(a[0]), rank=int(a[1]), version=int(a[2]))
+
     def close(self):
         if self.handle:
             L.load().srvp_comm_destroy(self.handle)
             self.handle = C.c_void_p()
+
+
+class StepWatchdog:
+    """a training step that does not complete within `timeout_s` (a collective that never meets its peers, a persistent
+    cluster kernel spinning on workgroups that are not resident) must END the job with the evidence on stderr, on every rank, instead of
+    hanging until a scheduler kills it.  A daemon thread watches the time a step has been in flight (`begin()` on entry of
+    srvp_amd.train.train, `beat()` after the step's host sync); when it is exceeded the thread prints rank, step, the library's last error text, the
+    cluster-timeout word of the persistent latent kernels (read on a stream of its own with a bounded wait: the copy engine still works when
+    a compute queue is stuck), the transports in use -- and leaves with os._exit(EXIT_CODE).  Every rank runs its own: when one rank's
+    collective blocks, its peers block in the same collective and report too.  SRVP_WATCHDOG_S sets the limit (default 30; 0: off); the
+    first step gets `first_s` (plan building, kernel loading, RCCL's lazy channel set-up)."""
+    EXIT_CODE = 17
+
+    def __init__(self, timeout_s=None, first_s=180.0, rank=0, describe=None, on_timeout=None):
+        import threading
+        import time
+        if timeout_s is None:
+            timeout_s = float(os.environ.get('SRVP_WATCHDOG_S', '30'))
+        self.timeout_s, self.first_s, self.rank, self.describe = float(timeout_s), float(first_s), rank, describe
+        self.on_timeout = on_timeout                          # (tests: called instead of os._exit)
+        self._time = time
+        self.step, self.t_begin, self.fired = -1, None, False
+        self._stop = threading.Event()
+        self._thread = None
+        if self.timeout_s > 0:
+            self._thread = threading.Thread(target=self._run, name='srvp-step-watchdog', daemon=True)
+            self._thread.start()
+
+    def begin(self):
+        """A step starts (srvp_amd.train.train on entry): the clock runs until beat().  Time BETWEEN steps (data loading, validation,
+        checkpoint writes on rank 0) is not a step's time and is not counted."""
+        self.t_begin = self._time.monotonic()
+
+    def beat(self):
+        """The step's host sync returned."""
+        self.step += 1
+        self.t_begin = None
+
+    def stop(self):
+        self._stop.set()
+
+    def _limit(self):
+        return self.first_s if self.step < 0 else self.timeout_s
+
+    def _run(self):
+        while not self._stop.wait(0.25):
+            t0 = self.t_begin
+            if t0 is None:
+                continue
+            waited = self._time.monotonic() - t0
+            if waited > self._limit():
+                self.fired = True
+                self.report(waited)
+                if self.on_timeout is not None:
+                    self.on_timeout(self)
+                    return
+                os._exit(self.EXIT_CODE)
+
+    def cluster_timeout_word(self, wait_s=2.0):
+        """The library's count of cluster-barrier timeouts, read on a stream of its own; None if the copy does not come back in time."""
+        try:
+            host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            host[0] = -1
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                L.call('srvp_cluster_timeouts_read', host.data_ptr(), st.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(st)
+            t0 = self._time.monotonic()
+            while not ev.query():
+                if self._time.monotonic() - t0 > wait_s:
+                    return None
+                self._time.sleep(0.01)
+            return int(host[0])
+        except Exception as e:                               # noqa: BLE001 -- a diagnostic must not raise inside the watchdog
+            return f'unreadable ({e})'
+
+    def report(self, waited):
+        import sys
+        try:
+            err = L.load().srvp_last_error().decode()
+        except Exception as e:                               # noqa: BLE001
+            err = f'unreadable ({e})'
+        word = self.cluster_timeout_word() if torch.cuda.is_available() else None
+        what = self.describe() if callable(self.describe) else (self.describe or '')
+        sys.stderr.write(f'[srvp_amd watchdog] rank {self.rank}: step {self.step + 1} has not completed after {waited:.1f} s (limit {self._limit():g} s).  '
+                         f'srvp_last_error: {err!r}; cluster-barrier timeouts: {word}; {what}\n')
+        sys.stderr.flush()
 
 
 class PeerStats:
@@ -214,6 +308,62 @@ class Sync:
             elif made is not None:
                 made.close()
 
+    def describe(self):
+        """One line for logs / the watchdog: world size and the transport of each exchange."""
+        return (f'world {self.world}, statistics: {self.stats_transport()}, gradients: {self.grads_transport()}')
+
+    def stats_transport(self):
+        if self.peer is not None:
+            return 'peer reads of hipIpc slabs (prototype)'
+        return 'rccl, C ABI, in-stream' if self.native_stats is not None else f'torch.distributed ({dist.get_backend(self.stat_group)})'
+
+    def grads_transport(self):
+        return 'rccl, C ABI, in-stream' if self.native_grads is not None else f'torch.distributed ({dist.get_backend(self.group)})'
+
+    def diagnostics(self, stats_channels=512, grad_mb=95, samples=200):
+        """numbers that let a scaling curve explain itself, measured on the transports the step really uses -- called by
+        every rank (collective).  Returns dict(transport per exchange, what RCCL reports about each native communicator, the in-stream
+        latency of ONE SyncBatchNorm statistics all-reduce ([2][C] fp64, `samples` of them back to back behind a dependent kernel each:
+        median / p90 in us), and the algorithm bandwidth of ONE gradient all-reduce of `grad_mb` MB (the VGG model's 23.85 M fp32 gradients
+        are 95 MB): GB/s = bytes / time, bus bandwidth = 2 (n - 1) / n of it)."""
+        d = dict(world=self.world, statistics=self.stats_transport(), gradients=self.grads_transport())
+        if self.native_stats is not None:
+            d['rccl_statistics_comm'] = self.native_stats.info()
+            d['rccl_gradients_comm'] = self.native_grads.info()
+        if not torch.cuda.is_available() or not (self.world > 1 or self.force):
+            return d
+        st = torch.zeros(2, stats_channels, dtype=torch.float64, device='cuda')
+        evs = []
+        for i in range(samples + 20):
+            st.add_(1.0)                                     # the dependent kernel in front (a BatchNorm layer's sums are written just before)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.allreduce_stats(st, 1.0, site=('diagnostics', 'f'))
+            e1.record()
+            st.mul_(1.0 / self.world)
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        us = sorted(a.elapsed_time(b) * 1e3 for a, b in evs[20:])
+        d['statistics_allreduce_us'] = dict(bytes=st.numel() * 8, samples=len(us), median=us[len(us) // 2], p90=us[int(len(us) * 0.9)], min=us[0])
+        n = grad_mb * 1000 * 1000 // 4
+        g = torch.ones(n, dtype=torch.float32, device='cuda')
+        ts = []
+        for i in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if self.native_grads is not None:
+                self.native_grads.allreduce(g)
+            else:
+                dist.all_reduce(g, group=self.group)
+            e1.record()
+            torch.cuda.synchronize()
+            g.fill_(1.0)
+            ts.append(e0.elapsed_time(e1))
+        ms = sorted(ts[1:])[len(ts[1:]) // 2]
+        gbs = n * 4 / (ms * 1e-3) / 1e9
+        d['gradient_allreduce'] = dict(bytes=n * 4, ms=ms, algbw_GBps=gbs, busbw_GBps=gbs * 2 * (self.world - 1) / max(self.world, 1))
+        return d
+
     @staticmethod
     def _agree(ok, group):
         """True iff `ok` on every rank (the decision must be the same everywhere).  On the backend's own device type."""
@@ -318,6 +468,9 @@ class DataParallel(torch.nn.Module):
         super().__init__()
         self.module = module
         module.sync = sync
+        # a step that does not complete ends the job with a report instead of hanging it (StepWatchdog; SRVP_WATCHDOG_S=0: off)
+        if (sync.world > 1 or sync.force) and float(os.environ.get('SRVP_WATCHDOG_S', '30')) > 0:
+            module.__dict__['_watchdog'] = StepWatchdog(rank=dist.get_rank(sync.group) if dist.is_initialized() else 0, describe=sync.describe)
         # same initial parameters / buffers on every rank (DDP broadcasts from rank 0)
         if sync.world > 1 or sync.force:
             module.flatten_parameters_()

@@ -61,6 +61,10 @@ OVERLAP_PACK = os.environ.get('SRVP_OVERLAP_PACK', '1') == '1'    # decoder weig
 SIDE_PRIORITY = os.environ.get('SRVP_SIDE_PRIORITY', 'default')      # 'low' / 'default' / 'high' (A/B switch)
 
 
+# deterministic parity mode: process-wide state shared by the models that are in it (StochasticLatentResidualVideoPredictor.set_deterministic)
+_DET = dict(count=0, saved=None, ws=None)
+
+
 def _make_side_stream():
     """The second stream (weight gradients, weight packing, hoisted skip convolutions: everything off the critical path).
     Measured at three stream priorities (same box, ms per step at 192 sequences / 24 sequences): lowest priority of the device
@@ -197,27 +201,36 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         cross-workgroup sum that is normally formed with atomics in arrival order -- BatchNorm statistics, BatchNorm-backward sums,
         split-K weight gradients, the image-side weight gradient, the latent weight gradients, the ELBO accumulators -- is formed in a
         fixed order instead (csrc/common.h), and everything is issued on ONE stream.  Process-wide (the library holds the switch and
-        the 8 MiB workspace of the two-launch reductions); the production bf16 path keeps its atomics and is refused here."""
+        the 8 MiB workspace of the two-launch reductions); the production bf16 path keeps its atomics and is refused here.
+        The process-wide part (overlap switches, library switch, workspace) is held at MODULE level with a count of the models that are in
+        the mode: it is entered by the first and left by the last (per-instance saves restored the wrong values with two models)."""
         from . import convnet as _cn
         global OVERLAP_WGRAD, OVERLAP_SKIP, OVERLAP_PACK
+        on = bool(on)
+        if on and self.precision != 'fp32':
+            raise ValueError("deterministic mode covers precision = 'fp32' only: call set_precision('fp32') first")
+        was = bool(getattr(self, 'deterministic', False))
+        if on and not was:
+            if _DET['count'] == 0:
+                _DET['saved'] = (OVERLAP_WGRAD, OVERLAP_SKIP, OVERLAP_PACK, _cn.ENC_WGRAD_SIDE_MAXN)
+                OVERLAP_WGRAD, OVERLAP_SKIP, OVERLAP_PACK, _cn.ENC_WGRAD_SIDE_MAXN = False, False, False, 0
+                _cn.DETERMINISTIC = True
+            _DET['count'] += 1
         if on:
-            if self.precision != 'fp32':
-                raise ValueError("deterministic mode covers precision = 'fp32' only: call set_precision('fp32') first")
-            if self.__dict__.get('_det_saved') is None:
-                self.__dict__['_det_saved'] = (OVERLAP_WGRAD, OVERLAP_SKIP, OVERLAP_PACK, _cn.ENC_WGRAD_SIDE_MAXN)
-            ws = self.__dict__.get('_det_ws')
+            ws = _DET['ws']
             if ws is None or ws.device != self._device():
-                ws = self.__dict__['_det_ws'] = torch.zeros(8 << 20, dtype=torch.uint8, device=self._device())
+                ws = _DET['ws'] = torch.zeros(8 << 20, dtype=torch.uint8, device=self._device())
             L.call('srvp_set_deterministic', 1, L.ptr(ws), ws.numel())
-            OVERLAP_WGRAD, OVERLAP_SKIP, OVERLAP_PACK, _cn.ENC_WGRAD_SIDE_MAXN = False, False, False, 0
-        else:
-            L.call('srvp_set_deterministic', 0, None, 0)
-            saved = self.__dict__.get('_det_saved')
-            if saved is not None:
-                OVERLAP_WGRAD, OVERLAP_SKIP, OVERLAP_PACK, _cn.ENC_WGRAD_SIDE_MAXN = saved
-                self.__dict__['_det_saved'] = None
-        _cn.DETERMINISTIC = bool(on)
-        self.deterministic = bool(on)
+        elif was:
+            _DET['count'] -= 1
+            if _DET['count'] == 0:
+                L.call('srvp_set_deterministic', 0, None, 0)
+                OVERLAP_WGRAD, OVERLAP_SKIP, OVERLAP_PACK, _cn.ENC_WGRAD_SIDE_MAXN = _DET['saved']
+                _DET['saved'], _DET['ws'] = None, None
+                _cn.DETERMINISTIC = False
+        if not on:
+            self._det_env_done = True            # an explicit set_deterministic(False) is not undone by SRVP_DETERMINISTIC=1 in _plan
+        self.deterministic = on
         self._plans = {}
         self._pack_version = None
         return self
@@ -291,8 +304,10 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         on B*S (video, sample) rows -- row s*B + b -- sharing the B skip tensors / hoisted skip halves through the image maps.
         S_lat > S: the latent path carries S_lat samples per video at once (its chains are latency-bound: 800 rows cost what 160
         do) while the decoder, whose activations set the memory footprint, works through them S at a time."""
-        if os.environ.get('SRVP_DETERMINISTIC') == '1' and not getattr(self, 'deterministic', False) and self.precision == 'fp32':
-            self.set_deterministic(True)                  # (the environment switch: applies once the model sits on its device)
+        if (os.environ.get('SRVP_DETERMINISTIC') == '1' and not getattr(self, 'deterministic', False) and self.precision == 'fp32'
+                and not getattr(self, '_det_env_done', False)):
+            self._det_env_done = True                     # (the environment switch applies ONCE, when the model first sits on its device)
+            self.set_deterministic(True)
         f32 = self.precision == 'fp32'
         S_lat = S if S_lat is None else S_lat
         key = (T, B, nt, n_euler, training, str(self._device()) + ('/fp32' if f32 else '')) + ((S,) if S > 1 or S_lat > 1 else ()) + ((S_lat,) if S_lat != S else ())

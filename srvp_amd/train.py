@@ -113,6 +113,9 @@ def train(forward_fn, optimizer, scaler, batch, device, opt):
     if model is None:
         raise TypeError('srvp_amd.train.train needs the srvp_amd StochasticLatentResidualVideoPredictor (or a wrapper '
                         'exposing it as .module)')
+    wd = model.__dict__.get('_watchdog')
+    if wd is not None:
+        wd.begin()
     optimizer.zero_grad()
     if batch.dtype == torch.uint8:                     # stacked uint8 videos (data.collate_u8): finish the collate on the GPU
         from .data import frames_from_u8
@@ -124,6 +127,8 @@ def train(forward_fn, optimizer, scaler, batch, device, opt):
     optimizer.step()
     _poll_cluster_timeouts(model)
     model._elbo_event.synchronize()                     # the step's single host sync: waits for the forward + ELBO only
+    if wd is not None:
+        wd.beat()                                       # (distributed.StepWatchdog: a step that never gets here ends the job with a report)
     nll, kl_y_0, kl_z, l2 = model._elbo_host.tolist()
     loss = nll + opt.beta_y * kl_y_0 + opt.beta_z * kl_z
     if opt.l2_res is not None and opt.l2_res > 0:
@@ -319,7 +324,8 @@ def main(opt):
         while not finished:
             if sampler is not None:
                 sampler.set_epoch(opt.seed + itr)
-            for batch in train_loader:
+            # batch i + 1 is copied to the device (and, for uint8 videos, collated there) on a copy stream under step i (data.Prefetcher)
+            for batch in sdata.Prefetcher(train_loader, device):
                 if itr >= opt.n_iter:
                     finished = True
                     break

@@ -246,6 +246,15 @@ FULL = {
     'full_c5_human_vgg': dict(ctor=(64, 3, 64, 128, 50, 50, True, 3, 256, 3, 512, 4, 'vgg'), T=16, B=2, n_euler=2,
                               hp=dict(obs_scale=0.2, beta_y=1.0, beta_z=1.0, l2_res=1.0), res_gain=1.2, lr=3e-4,
                               rollout=dict(nt_cond=8, nt=53)),
+    # round 5: the same three VGG recipes at >= 96 frames, the size from which the product's STREAMING kernels take the 64x64-resolution
+    # layers (csrc/conv_stream.hip: conv_stream64 / conv_stream_sub64 and their fused BatchNorm-backward sums), so that reference-made
+    # numbers pass through them and not only through the tile kernels
+    'full_w3_kth_vgg_b5': dict(ctor=(64, 1, 64, 128, 50, 50, True, 3, 256, 3, 512, 4, 'vgg'), T=20, B=5, n_euler=2,
+                               hp=dict(obs_scale=0.2, beta_y=1.0, beta_z=1.0, l2_res=1.0), res_gain=1.2, lr=3e-4),
+    'full_w4_bair_vgg_b8': dict(ctor=(64, 3, 64, 128, 50, 50, True, 2, 256, 3, 512, 4, 'vgg'), T=12, B=8, n_euler=2,
+                                hp=dict(obs_scale=0.71, beta_y=1.0, beta_z=1.0, l2_res=1.0), res_gain=1.41, lr=3e-4),
+    'full_w5_human_vgg_b6': dict(ctor=(64, 3, 64, 128, 50, 50, True, 3, 256, 3, 512, 4, 'vgg'), T=16, B=6, n_euler=2,
+                                 hp=dict(obs_scale=0.2, beta_y=1.0, beta_z=1.0, l2_res=1.0), res_gain=1.2, lr=3e-4),
 }
 
 
@@ -554,7 +563,10 @@ def main():
             print(f'{name} roll2: |y_52|, min / max decoded frame', gen_roll2(name, FULL[name], ro, srvp), flush=True)
         return
     if '--full' in sys.argv:                               # only the full-width fixtures (minutes of CPU time)
+        only = [a for a in sys.argv[1:] if a.startswith('full_')]     # (optionally: just the named fixtures)
         for name, spec in FULL.items():
+            if only and name not in only:
+                continue
             loss = gen_full(name, spec, srvp, ref_train, helper)
             print(f'{name}: loss {loss:.6f}', flush=True)
             if name in ROLL2:

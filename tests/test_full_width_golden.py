@@ -5,6 +5,8 @@ nt_inf=5), KTH VGG (T=20, nt_inf=3), BAIR VGG (T=12), Human3.6M VGG (T=16, nt_in
 recipe's res_gain = 1.2.  Weights and inputs are re-created from their seeds (checked against the fixture's checksums); the
 fixture pins the ELBO scalars, all latent outputs, strided samples of the decoded frames, and for every parameter gradient
 its norm and its projection on a seeded random direction (full tensors for the small ones).
+Round 5 (`full_w*`): the three VGG recipes again at >= 96 frames (KTH T=20 B=5, BAIR T=12 B=8, Human3.6M T=16 B=6), the size from which the
+product's STREAMING kernels (csrc/conv_stream.hip) take the 64x64-resolution layers -- the GPU test asserts that they did (srvp_conv_stream_count).
 
   * CPU: the oracle against these fixtures (pins the oracle at full width, not only at nf in {4, 8}).
   * GPU: the HIP path in fp32 mode (tight) and in bf16 mode (ELBO band) against the same fixtures.
@@ -203,10 +205,17 @@ def test_hip_vs_full_width_reference_fixture(name, precision):
     m._grads()
     m._flat[1].zero_()
     xg = x.cuda()
+    from srvp_amd import _lib as L
+    cnt = [L.load().srvp_conv_stream_count(i) for i in range(3)]
     outs = m._forward_impl(xg, x.shape[0], ne, fx.tape(), training=True)
     outs_c = [o.clone() for o in outs]
     acc, gr = elbo_terms_and_grads(m, xg, outs, opt)
     m._backward_impl(gr[0], None, None, gr[1], gr[2], gr[3], gr[4])
+    if name.startswith('full_w') and precision == 'bf16':
+        # the >= 96-frame fixtures exist so that reference-made numbers pass through the STREAMING kernels (csrc/conv_stream.hip): forward +
+        # data gradient of the 64 -> 64 channel layer at 64x64, the data gradient with fused BatchNorm-backward sums, the sub-pixel stage entry
+        took = [L.load().srvp_conv_stream_count(i) - cnt[i] for i in range(3)]
+        assert took[0] >= 1 and took[1] >= 1 and took[2] >= 1, took
     nll, kl_y0, kl_z, l2 = acc.cpu().tolist()
     B = x.shape[1]
     loss = (nll + hp['beta_y'] * kl_y0 + hp['beta_z'] * kl_z + hp['l2_res'] * l2) / B
@@ -222,13 +231,31 @@ def test_hip_vs_full_width_reference_fixture(name, precision):
                    e_loss=abs(loss - ref[0]) / abs(ref[0]))
         except Exception:
             pass
-        # measured (rounds 2-3, several boxes): C2 8e-6, C3 2-4e-6, C4 1.1-1.2e-5, C5 2.4e-4 (32 frames at obs_scale 0.2 / res_gain 1.2: the
-        # ill-conditioned point of tests/test_gpu_parity_gate.py::test_elbo_gate_undiluted_recipes_400_frames) -- bounds = measured + 25 %
-        # where the value is stable, x4 where it sits at the rounding-noise floor and moves with the order of the statistics atomics
-        # (round 4: C3 moved from 2-4e-6 to 4.9e-5 when the image-side layer went to the streaming kernel, whose one-channel form is as exact as the
-        # fp32 tile kernel -- 5.5e-5 vs 4.3e-5 of its outputs off the bf16-rounded float64 result -- but rounds OTHER outputs the other way: on these
-        # 40 frames at the recipe's initial weights that is what one realisation of the rounding noise is worth; bound = the north_star 1e-4)
-        bound = {'full_c2_smmnist_dcgan': 4e-5, 'full_c3_kth_vgg': 1e-4, 'full_c4_bair_vgg': 5e-5, 'full_c5_human_vgg': 3e-4}.get(name, 3e-4)
+        # Two classes of recipe.  WELL-CONDITIONED at the initial weights (C2 SM-MNIST, C4 BAIR = the north_star's benchmarked config): measured
+        # 8.9e-6 (30 frames), 1.1-4.1e-5 (24 frames), 1.06e-5 (96 frames) over rounds 2-5 -- bound 5e-5 / the north_star's 1e-4 at 24 frames.
+        # ILL-CONDITIONED at the initial weights (C3 KTH, C5 Human3.6M: obs_scale 0.2, untrained residual MLP at res_gain 1.2 -- |y| grows ~1.3x per
+        # frame): the ELBO error there is one draw of amplified rounding noise, not a property of a kernel.  Measured in round 5
+        # (tools/conv_in_ab.py -> profiles/r05_conv_in_ab.jsonl): the SAME 40-frame KTH fixture reads 9.4e-6 with the image-side tile kernel
+        # and 1.16e-4 with the streaming kernel, while the two kernels' BatchNorm statistics agree to 1.2e-8 (each within 1.2e-8 of float64 sums) and
+        # their raw outputs differ on 6.9e-5 of the elements by one bf16 ulp (both 5-7e-5 off the bf16-rounded float64 convolution): flipping one
+        # rounding in 14 000 moves this ELBO by 1e-4.  400 frames of the same recipes: 1.5e-3 .. 3.4e-3 (KTH), 2.4e-4 (Human) at step 0, and
+        # <= 3.5e-5 at steps 100 / 200 / 300 of training on two seeds (test_gpu_parity_gate.py, profiles/r05_gate_after_training_*.jsonl) -- the
+        # north_star's 1e-4 is asserted THERE for these recipes.  Bounds here = 4 x measured, a regression tripwire only.
+        bound = {'full_c2_smmnist_dcgan': 4e-5, 'full_c4_bair_vgg': 1e-4, 'full_w4_bair_vgg_b8': 5e-5,
+                 'full_c3_kth_vgg': 5e-4, 'full_w3_kth_vgg_b5': 2.2e-3, 'full_c5_human_vgg': 1.2e-3, 'full_w5_human_vgg_b6': 7.5e-4}.get(name, 3e-4)
+        grad_report = {}
+        if name.startswith('full_w'):
+            # parameter gradients of the bf16 path on >= 96 frames against the reference's: the worst norm ratio / projection error over all
+            # tensors (reported; the bound is the one the 400-frame gate of test_gpu_parity_gate.py states relative to the numerics model)
+            names = fx.meta['grad_names']
+            rat = [grads[k].detach().double().norm().item() / max(float(fx.z['grad.norm'][i]), 1e-30) for i, k in enumerate(names)]
+            grad_report = dict(grad_norm_ratio_min=min(rat), grad_norm_ratio_max=max(rat), grad_norm_ratio_median=float(np.median(rat)))
+            try:
+                report(test='full_width_golden_bf16_grads', name=name, **grad_report)
+            except Exception:
+                pass
+            # measured (round 5): norm ratios 0.946 .. 1.082 over all tensors of the three recipes, median 0.998 .. 1.003
+            assert 0.99 < grad_report['grad_norm_ratio_median'] < 1.01 and grad_report['grad_norm_ratio_min'] > 0.9 and grad_report['grad_norm_ratio_max'] < 1.15, grad_report
         assert abs(loss - ref[0]) <= bound * abs(ref[0]), (loss, ref[0], bound)
         assert (frame_samples(outs_c[0].cpu()) - fx.t('train.x_')).abs().max().item() <= 3e-2
         for n, o in zip(OUT_NAMES[1:], outs_c[1:]):

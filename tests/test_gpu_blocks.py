@@ -309,6 +309,108 @@ def test_conv_stream64_matches_tile_kernel(N):
     assert rel_err(res[1][0][:4].permute(0, 3, 1, 2).cpu(), ref) < 2 ** -7
 
 
+def test_conv_stream64_vs_torch_autograd_96_frames():
+    """the streaming kernels are only reached from 96 frames on, so no reference-sized fixture used to pass through
+    them and their data gradient / fused BatchNorm-backward sums were compared with the tile kernels only.  Here conv_stream64_kernel<false>
+    (forward + BatchNorm statistics) and <true> (data gradient + the producer's fused BatchNorm-backward sums) at N = 96 are held directly
+    against torch CPU autograd on ALL frames (reference module/conv.py:200-203: Conv2d(64, 64, 3, 1, 1) -> BatchNorm2d -> LeakyReLU)."""
+    from srvp_amd import _lib as L
+    from srvp_amd.convnet import Block
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(171)
+    N = 96
+    f0 = make_feat(N, 64, 64, 64, dev, g)
+    spec = dict(kind='conv', key='w', bnkey='bn', cin=64, cout=64, k=3, s=1, p=1, act='leaky_relu')
+    blk = Block(spec, 'mfma', [f0], False, N, dev, True)
+    blk._fwd, blk._dg = blk.fwd_descs(), blk.dgrad_descs()
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(dev)
+    st = L.stream()
+    blk.pack(w, st)
+    dr = (torch.randn(N, 64, 64, 64, generator=g) * 0.5).to(torch.bfloat16)
+    blk.draw[:, 1:-1, 1:-1, :].copy_(dr)
+    # the producer layer of the fused reduction: raw output + (scale, shift, mean, inverse std); some negative scales, |mean| up to 3 std
+    praw = (torch.randn(N, 64, 64, 64, generator=g) + torch.randn(64, generator=g) * 2.0).to(torch.bfloat16)
+    coef = torch.stack([torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3, torch.randn(64, generator=g) * 2.0,
+                        torch.rand(64, generator=g) + 0.5]).contiguous()
+    coef[0, ::7] *= -1.0
+    praw_d, coef_d = praw.to(dev), coef.to(dev)
+    red = torch.zeros(2, 64, dtype=torch.float64, device=dev)
+    d = blk._dg[0]
+    try:
+        d.bnr_raw, d.bnr_coef, d.bnr_red = L.ptr(praw_d), L.ptr(coef_d), L.ptr(red)
+        blk.raw.fill_(7.0); blk.dcat.fill_(7.0); blk.stats.zero_()
+        cnt = [L.load().srvp_conv_stream_count(i) for i in (0, 1)]
+        L.call('srvp_conv_mfma', C.byref(blk._fwd[0]), st)
+        L.call('srvp_conv_mfma', C.byref(d), st)
+        torch.cuda.synchronize()
+        assert [L.load().srvp_conv_stream_count(i) for i in (0, 1)] == [cnt[0] + 1, cnt[1] + 1]      # both ran on conv_stream64_kernel
+    finally:
+        d.bnr_raw, d.bnr_coef, d.bnr_red = None, None, None
+    torch.set_num_threads(8)
+    xin = feat_nchw(f0).clone().requires_grad_(True)
+    ref = F.conv2d(xin, bf(w.cpu()), None, 1, 1)
+    raw = blk.raw.permute(0, 3, 1, 2).float().cpu()
+    assert rel_err(raw, ref) < 2 ** -7, rel_err(raw, ref)
+    s1, s2 = ref.double().sum(dim=(0, 2, 3)), (ref.double() ** 2).sum(dim=(0, 2, 3))
+    assert rel_err(blk.stats[0], s1) < 1e-4 * max(1.0, (s2.sqrt().max() / (s1.abs().max() + 1e-9)).item()) and rel_err(blk.stats[1], s2) < 1e-4
+    ref.backward(dr.float().permute(0, 3, 1, 2))
+    dcat = blk.dcat.float().cpu()
+    assert rel_err(dcat.permute(0, 3, 1, 2), xin.grad) < 2 ** -7, rel_err(dcat.permute(0, 3, 1, 2), xin.grad)
+    # fused sums (reference: autograd through BatchNorm + LeakyReLU of the producer): g = dA * act'(scale raw + shift);
+    # red[0] = sum g, red[1] = sum g (raw - mean) inv_std
+    pr = praw.double()
+    gate = torch.where(torch.addcmul(coef[1], praw.float(), coef[0]) > 0, 1.0, 0.2).double()          # fp32 fma, as the kernels evaluate it
+
+    def sums(dA):
+        gg = dA.double() * gate
+        return torch.stack([gg.sum(dim=(0, 1, 2)), (gg * (pr - coef[2].double())).sum(dim=(0, 1, 2)) * coef[3].double()])
+    # (a) from the data gradient AS STORED by the kernel: only the summation differs
+    want = sums(dcat)
+    scale = sums(dcat.abs()).abs()                       # cancellation-free size of each sum
+    assert ((red.cpu() - want).abs() / scale).max().item() < 1e-6, ((red.cpu() - want).abs() / scale).max().item()
+    # (b) from torch's own fp32 data gradient (bf16 rounding of 393 216 elements per channel does not average out below 2^-9 / sqrt(n))
+    want_t = sums(xin.grad.permute(0, 2, 3, 1))
+    assert ((red.cpu() - want_t).abs() / scale).max().item() < 1e-4, ((red.cpu() - want_t).abs() / scale).max().item()
+
+
+def test_conv_stream_sub64_vs_torch_96_frames():
+    """conv_stream_sub64_kernel (decoder.conv.3.0 forward: nearest x2 upsample + concat(skip) + 3x3 conv, reference module/conv.py:270,331-349) at
+    T x B = 12 x 8 = 96 frames against torch CPU on ALL frames, with the BatchNorm statistics."""
+    from srvp_amd import _lib as L
+    from srvp_amd.convnet import Block
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(291)
+    T, B = 12, 8
+    N = T * B
+    f0 = make_feat(N, 32, 32, 64, dev, g)
+    f1 = make_feat(B + 2, 64, 64, 64, dev, g)
+    sel = torch.tensor([(3 * b + 1) % (B + 2) for b in range(B)], dtype=torch.int32, device=dev)
+    smap = sel.repeat(T)
+    spec = dict(kind='conv', key='w', bnkey='bn', cin=128, cout=64, k=3, s=1, p=1, act='leaky_relu')
+    blk = Block(spec, 'mfma', [f0, f1], True, N, dev, True, skip_map=smap, skip_sel=sel)
+    assert blk.split and blk.subpix
+    blk._fwd = blk.fwd_descs()
+    w = (torch.randn(64, 128, 3, 3, generator=g) * 0.05).to(dev)
+    st = L.stream()
+    blk.pack(w, st)
+    L.call('srvp_conv_mfma', C.byref(blk._fwd[0]), st)                   # conv_s(skip) -> S
+    arr = (L.ConvDesc * 4)(*blk._fwd[-4:])
+    blk.raw.fill_(7.0); blk.stats.zero_()
+    cnt = L.load().srvp_conv_stream_count(2)
+    L.call('srvp_conv_mfma_multi', arr, 4, st)
+    torch.cuda.synchronize()
+    assert L.load().srvp_conv_stream_count(2) == cnt + 1                 # ran on conv_stream_sub64_kernel
+    torch.set_num_threads(8)
+    x0 = F.interpolate(feat_nchw(f0), scale_factor=2, mode='nearest')
+    xin = torch.cat([x0, feat_nchw(f1)[smap.cpu().long()]], 1)
+    ref = F.conv2d(xin, bf(w.cpu()), None, 1, 1)
+    raw = blk.raw.permute(0, 3, 1, 2).float().cpu()
+    # (the sub-pixel form rounds the FOLDED weights to bf16: a systematic 2^-9-level difference -- same bounds as test_block_conv_fwd_bwd)
+    assert rel_err(raw, ref) < 2 ** -7, rel_err(raw, ref)
+    s1, s2 = ref.double().sum(dim=(0, 2, 3)), (ref.double() ** 2).sum(dim=(0, 2, 3))
+    assert rel_err(blk.stats[0], s1) < 4e-3 * max(1.0, (s2.sqrt().max() / (s1.abs().max() + 1e-9)).item()) and rel_err(blk.stats[1], s2) < 4e-3
+
+
 @pytest.mark.parametrize('N,nc', [(5, 3), (600, 3), (1100, 3), (37, 1)])
 def test_conv_in_stream_matches_tile_kernel(N, nc):
     """csrc/conv_in_stream.hip (image-side 3x3 layer, nc -> 64 channels on 64x64 fp32 frames: persistent workgroup per CU, frame records of bf16

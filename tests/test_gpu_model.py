@@ -386,6 +386,11 @@ def test_single_rank_collectives(tmp_path):
     l1 = json.loads(dist.stdout.strip().splitlines()[-1])['loss']
     # (not bit-equal: the fp64 statistics atomics retire in a different order from run to run)
     assert abs(l0 - l1) <= 1e-4 * abs(l0), (l0, l1)
+    # the native in-stream RCCL path was the one taken, and the line says what RCCL itself reports about its two communicators
+    c = json.loads(dist.stdout.strip().splitlines()[-1])['comm']
+    assert 'rccl' in c['statistics'] and 'rccl' in c['gradients'], c
+    assert c['rccl_statistics_comm']['ranks'] == 1 and c['rccl_gradients_comm']['ranks'] == 1 and c['rccl_statistics_comm']['version'] > 0, c
+    assert c['statistics_allreduce_us']['samples'] == 200 and c['gradient_allreduce']['algbw_GBps'] > 0, c
 
 
 def test_bench_launches_its_own_ranks():
@@ -411,6 +416,15 @@ def test_bench_launches_its_own_ranks():
     assert 'strong_scaling' in d and d['strong_scaling']['per_gpu_batch'] == 96
     assert abs(d['value'] - 16 * 12 * 3 / (d['ms_per_step'] * 3 / 1e3)) < 1e-6 * d['value']
     assert d['loss'] == d['loss']
+    # the line explains its own scaling: transport per exchange, what RCCL reports per communicator (native path only),
+    # one statistics all-reduce in stream order, one 95 MB gradient all-reduce; and the step watchdog is armed
+    c = d['comm']
+    assert c['world'] == 2 and c['statistics'] and c['gradients'] and 'error' not in c, c
+    assert c['statistics_allreduce_us']['samples'] == 200 and c['statistics_allreduce_us']['median'] > 0
+    assert c['gradient_allreduce']['bytes'] == 95_000_000 and c['gradient_allreduce']['algbw_GBps'] > 0
+    assert c['step_watchdog_s'] == 30.0
+    if 'rccl' in c['statistics']:
+        assert c['rccl_statistics_comm']['ranks'] == 2 and c['rccl_gradients_comm']['ranks'] == 2
 
 
 def test_resume_train_state(tmp_path):

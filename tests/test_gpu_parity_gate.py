@@ -202,26 +202,31 @@ def test_elbo_gate_undiluted_recipes_400_frames(name, nc, T, B):
     assert res['x_maxabs_bf16'] < 3e-2, res
 
 
+@pytest.mark.parametrize('seed', [0, 1])
 @pytest.mark.parametrize('name', ['kth', 'human'])
-def test_elbo_gate_production_precision_once_training_started(name):
-    """north_star "ELBO within 1e-4 relative of the CPU reference" in the BENCHMARKED precision on configs 3 and 5, at a state TRAINING
-    VISITS.  At the initial weights of these recipes bf16 storage is 3.4e-3 / 2.4e-4 off (test above: the untrained
-    residual MLP at res_gain 1.2 is ill-conditioned); that is a property of step 0 only.  tools/gate_after_training.py trains the
+def test_elbo_gate_production_precision_once_training_started(name, seed):
+    """north_star "ELBO within 1e-4 relative of the CPU reference" in the BENCHMARKED precision on configs 3 and 5, at states TRAINING
+    VISITS.  At the initial weights of these recipes bf16 storage is 3.4e-3 / 2.4e-4 off (test above: the
+    untrained residual MLP at res_gain 1.2 is ill-conditioned); that is a property of step 0 only.  tools/gate_after_training.py trains the
     full-width recipe in fp32 parity mode on moving-blob videos and puts the SAME held-out 400-frame batch + noise tape through the
-    HIP path in bf16, in fp32 mode, and through the fp32 CPU oracle: measured (profiles/r04_gate_after_training_*.jsonl)
+    HIP path in bf16, in fp32 mode, and through the fp32 CPU oracle.  Round 4 measured seed 0 (profiles/r04_gate_after_training_*.jsonl)
         KTH       step 0: 3.4e-3   100: 8.3e-6   200: 6.5e-5   300: 2.2e-5
         Human3.6M step 0: 2.3e-4   100: 2.2e-5   200: 4.2e-6   300: 2.0e-5
-    Asserted here after 100 steps: production bf16 <= 1e-4 vs the oracle, fp32 mode <= 1e-5."""
+    and asserted step 100 only.  Asserted now at steps 100, 200 AND 300, on two seeds (held-out batch, noise tape and training videos all
+    change with the seed): production bf16 <= 1e-4 vs the oracle, fp32 mode <= 1e-5 (profiles/r05_gate_after_training_*.jsonl)."""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, 'tools'))
     import gate_after_training as G
-    rows = G.run(name, steps=100, every=100, oracle_at=(100,), log=lambda s: None)
-    first, last = rows[0], rows[-1]
-    report(test='elbo_gate_after_training', recipe=name, step0_bf16_vs_fp32_mode=first['bf16_vs_fp32_mode'], **{k: v for k, v in last.items() if k != 'recipe'})
-    assert last['step'] == 100 and last['loss_oracle'] < 0.0 < first['loss_fp32_mode']            # it did train (the NLL went from +1e5 to -1e5)
-    assert last['fp32_mode_vs_oracle'] <= 1e-5, last
-    assert last['bf16_vs_oracle'] <= 1e-4, last                                                   # north_star, production precision
+    rows = G.run(name, steps=300, every=100, oracle_at=(100, 200, 300), log=lambda s: None, seed=seed)
+    first = rows[0]
+    for row in rows:
+        report(test='elbo_gate_after_training', **row)
+    assert [r['step'] for r in rows] == [0, 100, 200, 300]
+    assert rows[1]['loss_oracle'] < 0.0 < first['loss_fp32_mode']            # it did train (the NLL went from +1e5 to -1e5)
+    for row in rows[1:]:
+        assert row['fp32_mode_vs_oracle'] <= 1e-5, row
+        assert row['bf16_vs_oracle'] <= 1e-4, row                             # north_star, production precision
 
 
 def _settled_full_width_model(nc, nt_inf, gain, seed, x_warm, ne):

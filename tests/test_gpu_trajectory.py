@@ -129,3 +129,40 @@ def test_fp32_deterministic_mode_is_bit_reproducible():
     assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and a[1] == b[1]
     # same algorithm, another summation order: the deterministic run stays inside the band two default runs span
     assert max(abs(x - y) for x, y in zip(a[0], c[0])) / scale <= 2e-2
+
+
+def test_deterministic_mode_is_shared_by_models_and_left_by_the_last():
+    """the process-wide part of the deterministic mode (overlap switches, the library switch and its workspace) is held at module
+    level with a count of the models in the mode -- the second model entering must not save the already-disabled switches, the first one
+    leaving must not switch the library off under the second, and an explicit set_deterministic(False) is not undone by the environment
+    switch."""
+    import srvp_amd
+    from srvp_amd import convnet as cn, model as M
+    dev = torch.device('cuda')
+    ctor = (64, 1, 8, 16, 5, 7, True, 2, 24, 3, 40, 4, 'vgg')
+    before = (M.OVERLAP_WGRAD, M.OVERLAP_SKIP, M.OVERLAP_PACK, cn.ENC_WGRAD_SIDE_MAXN)
+    a = srvp_amd.StochasticLatentResidualVideoPredictor(*ctor).to(dev).train().set_precision('fp32')
+    b = srvp_amd.StochasticLatentResidualVideoPredictor(*ctor).to(dev).train().set_precision('fp32')
+    with pytest.raises(ValueError):
+        srvp_amd.StochasticLatentResidualVideoPredictor(*ctor).to(dev).set_deterministic(True)           # bf16: refused
+    a.set_deterministic(True)
+    b.set_deterministic(True)
+    a.set_deterministic(True)                                   # idempotent
+    assert M._DET['count'] == 2 and cn.DETERMINISTIC and not M.OVERLAP_WGRAD
+    a.set_deterministic(False)
+    assert M._DET['count'] == 1 and cn.DETERMINISTIC and M._DET['ws'] is not None and not M.OVERLAP_WGRAD      # b is still in the mode
+    x = torch.rand(3, 2, 1, 64, 64, device=dev)
+    torch.manual_seed(3)
+    o1 = b(x, 3, 1.0)[0].clone()
+    torch.manual_seed(3)
+    o2 = b(x, 3, 1.0)[0].clone()
+    assert torch.equal(o1, o2)
+    b.set_deterministic(False)
+    assert M._DET['count'] == 0 and not cn.DETERMINISTIC and M._DET['ws'] is None
+    assert (M.OVERLAP_WGRAD, M.OVERLAP_SKIP, M.OVERLAP_PACK, cn.ENC_WGRAD_SIDE_MAXN) == before
+    os.environ['SRVP_DETERMINISTIC'] = '1'
+    try:
+        a(x, 3, 1.0)                                            # explicit off above: the environment switch does not re-enter
+        assert not a.deterministic and M._DET['count'] == 0
+    finally:
+        del os.environ['SRVP_DETERMINISTIC']
