@@ -418,10 +418,22 @@ typedef struct {
 int srvp_rollout_fwd(const srvp_rollout_desc* d, void* stream);
 /* bytes of fused_ws the persistent kernels need for this chain, 0 if it must run unfused (dimensions / LDS budget / mode) */
 int64_t srvp_rollout_fused_ws_bytes(const srvp_rollout_desc* d);
+/* The INFERENCE chain (pz_external = 0: p_z inside the loop, posterior samples while n_data_frames lasts, prior samples afterwards; reference
+ * module/srvp.py:377-405, test.py:237-246) as persistent launches (csrc/rollout_fused.hip rollout_gen_kernel): bytes of fused_ws it needs, 0 if
+ * the chain must run as per-layer launches (dimensions, LDS budget, workgroup placement not round-robin over the XCDs, SRVP_ROLLOUT_GEN_FUSED=0).
+ * srvp_rollout_fwd takes it when fused_ws / fused_ws_bytes hold at least that much; hid_* / inp_all / scratch_* are not touched then. */
+int64_t srvp_rollout_gen_ws_bytes(const srvp_rollout_desc* d);
 /* Cluster-barrier timeouts of the persistent latent kernels since the library was loaded (a cluster whose workgroups were not
  * co-resident gives up after a bounded spin and leaves garbage behind): copied to pinned host memory in stream order; the host polls
  * it every few steps and raises if it is non-zero. */
 int srvp_cluster_timeouts_read(unsigned* host_word, void* stream);
+/* The persistent latent kernels deal the workgroups of a cluster to ONE XCD and VERIFY it per launch (HW_REG_XCC_ID of every member): where it
+ * holds, the exchanged tiles are written with plain stores and stay in that XCD's L2 for the other members' L1-bypassing loads; otherwise
+ * agent-scope write-through stores (csrc/rollout_fused.hip "XCD-LOCAL EXCHANGE").  srvp_cluster_set_xcd_local(0) forces the latter (A/B switch,
+ * default 1 / env SRVP_CLUSTER_XCD_LOCAL; same results bit for bit).  srvp_cluster_stats_read: host_words2[0] = cluster-barrier timeouts,
+ * [1] = clusters that ran XCD-local (summed over launches), since the library was loaded; pinned host memory, stream order. */
+int srvp_cluster_set_xcd_local(int on);
+int srvp_cluster_stats_read(unsigned* host_words2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Deterministic mode of the fp32 parity mode (elem_f32 launches): the reference's CPU path is bit-reproducible run to run; with this

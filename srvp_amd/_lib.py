@@ -121,6 +121,8 @@ _SIGS = {
     'srvp_unpack_wgrad_multi': ([c_vp, c_i32, c_i64, c_vp], c_i32),
     'srvp_pack_job_wgs': ([c_i64], c_i32),
     'srvp_cluster_timeouts_read': ([c_vp, c_vp], c_i32),
+    'srvp_cluster_set_xcd_local': ([c_i32], c_i32),
+    'srvp_cluster_stats_read': ([c_vp, c_vp], c_i32),
     'srvp_set_deterministic': ([c_i32, c_vp, c_i64], c_i32),
     'srvp_get_deterministic': ([], c_i32),
     'srvp_bn_stats_f32_det': ([c_vp, c_i64, c_i32, c_vp, c_vp], c_i32),
@@ -149,6 +151,7 @@ _SIGS = {
     'srvp_lstm_bwd': ([c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_rollout_fwd': ([C.POINTER(RolloutDesc), c_vp], c_i32),
     'srvp_rollout_fused_ws_bytes': ([C.POINTER(RolloutDesc)], c_i64),
+    'srvp_rollout_gen_ws_bytes': ([C.POINTER(RolloutDesc)], c_i64),
     'srvp_rollout_bwd': ([C.POINTER(RolloutBwdDesc), c_vp], c_i32),
     'srvp_nll': ([c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_vp, c_vp], c_i32),
     'srvp_kl': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp], c_i32),

@@ -1453,9 +1453,11 @@ class DecoderNet(ConvNetBase):
                 L.call('srvp_conv_mfma', C.byref(blk._fwd[0]), st)
         self._skips_done = True
 
-    def forward(self, z_f32, params, st, sync=None, latent=None):
+    def forward(self, z_f32, params, st, sync=None, latent=None, coeffs_current=False):
         """z_f32: fp32 [N][nz_real], or None with latent = (w fp32 [B][nh], y fp32 base pointer tensor, y_tstride, nt, B, nh, ny): the rows
-        [w[b] | y[t][b]] are then assembled by the library (srvp.py:216-221) straight into the padded decoder input."""
+        [w[b] | y[t][b]] are then assembled by the library (srvp.py:216-221) straight into the padded decoder input.
+        coeffs_current (inference): the eval-mode BatchNorm coefficients of the folded blocks were formed by an earlier call on the same
+        parameters (the later chunks of one model.sample call) -- not recomputed."""
         if latent is not None:
             w, y, y_ts, nt, B, nh, ny = latent
             assert nt * B == self.N
@@ -1465,7 +1467,7 @@ class DecoderNet(ConvNetBase):
         if self.training:
             self.zero_forward_accumulators()
         for blk in self.blocks[:-1]:
-            if getattr(blk, '_ep', False):           # inference: every folded block's coefficients up front, off the conv chain
+            if getattr(blk, '_ep', False) and not coeffs_current:     # inference: every folded block's coefficients up front, off the conv chain
                 self._eval_coeffs(blk, params, st)
         for blk in self.blocks[:-1]:
             self._block_forward(blk, params, st, sync)

@@ -10,6 +10,7 @@
 
 int srvp_rollout_fused_fwd(const srvp_rollout_desc* d, hipStream_t st);          // rollout_fused.hip
 int srvp_rollout_fused_bwd(const srvp_rollout_bwd_desc* d, hipStream_t st);
+int srvp_rollout_gen_fwd(const srvp_rollout_desc* d, hipStream_t st);            // rollout_fused.hip: the inference chain, p_z inside
 
 namespace {
 
@@ -679,6 +680,11 @@ extern "C" int srvp_rollout_fwd(const srvp_rollout_desc* d, void* stream) {
     const size_t ys = (size_t)B * ny, zs = (size_t)B * nz, hl = (size_t)B * nh;
     const int nin = ny + nz;
     const int F = (d->nsteps + d->n_euler - 1) / d->n_euler;
+    if (!d->pz_external && d->fused_ws) {
+        // generation chain (posterior while data lasts, prior afterwards) as persistent launches: csrc/rollout_fused.hip rollout_gen_kernel
+        const int64_t need = srvp_rollout_gen_ws_bytes(d);
+        if (need > 0 && d->fused_ws_bytes >= need) return srvp_rollout_gen_fwd(d, st);
+    }
     hipError_t e = hipMemcpyAsync(d->y_all, d->y0, sizeof(float) * ys, hipMemcpyDeviceToDevice, st);
     SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd: copy failed");
     if (d->pz_external && d->hid_dyn) {

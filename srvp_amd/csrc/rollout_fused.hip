@@ -34,7 +34,7 @@ struct RollF {
     const float* y0; float* y_all; float* res; float* inp_all; float* hid;
     // backward
     const float* d_y_all; const float* d_res; float* dhid; float* dinp_all; float* d_y0; int dwd;
-    float* part; unsigned* cnt;
+    float* part; unsigned* cnt; int xcd_local;
 };
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -50,9 +50,27 @@ __device__ __forceinline__ int sw(int k, int c) { return (k >> 1) * 64 + ((((k &
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// XCD-LOCAL EXCHANGE (round 5).  The launchers deal the workgroups of a cluster to ONE XCD (locate()); HIP promises nothing about placement, so
+// each launch VERIFIES it: every member ORs the bit of the XCC it really runs on (HW_REG_XCC_ID) into word 2 of the cluster's counter block before
+// the first barrier and reads the mask back after it.  One bit set = all members share one L2: the exchanged tiles are then written with PLAIN
+// stores, which stay in that L2 (write-back), and read by the other members with the same L1-bypassing `sc1` loads as before, now served from
+// the L2 they were written to instead of from memory (sc1 stores are written through AND dropped from the L2: MI355X_MICROARCH.md, "stores of
+// each flavour").  Any other mask: the agent-scope (sc1 write-through) stores of rounds 2-4.  Never a correctness assumption: a decision per
+// launch and per cluster from what the hardware reports.  SRVP_CLUSTER_XCD_LOCAL=0 keeps the write-through stores everywhere (A/B switch).
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 15u;
+}
+__device__ __forceinline__ void st_x(float* p, float v, bool local) {
+    if (local) *p = v; else st_agent(p, v);
+}
+
 // Timeouts of the bounded spin below, over the lifetime of the library (the per-launch counter blocks are wiped by the next launch):
 // the host reads it through srvp_cluster_timeouts_read once in a while and refuses to go on if it is non-zero.
 __device__ unsigned g_cluster_timeouts = 0;
+// clusters (per launch) that found all their members on one XCC and exchanged through its L2 (srvp_cluster_stats_read)
+__device__ unsigned g_cluster_xcd_local = 0;
 
 __device__ __forceinline__ void cluster_barrier(unsigned* cnt, unsigned target) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's agent-scope stores have been acknowledged
@@ -75,8 +93,20 @@ __device__ __forceinline__ void cluster_barrier(unsigned* cnt, unsigned target) 
     __syncthreads();
 }
 
+// see "XCD-LOCAL EXCHANGE" above: announce() before the kernel's first cluster barrier, then agreed() after it (one extra barrier per launch
+// where the kernel has none before its first exchange)
+__device__ __forceinline__ void xcd_announce(unsigned* cnt) {
+    if (threadIdx.x == 0) __hip_atomic_fetch_or(cnt + 2, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool xcd_agreed(const unsigned* cnt, int enabled, bool count_it) {
+    const unsigned m = __hip_atomic_load(cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool ok = enabled && m != 0u && (m & (m - 1u)) == 0u;
+    if (ok && count_it && threadIdx.x == 0) __hip_atomic_fetch_add(&g_cluster_xcd_local, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ok;
+}
+
 // workgroup -> (cluster, member): members of a cluster sit on ONE XCD when workgroups are dealt round-robin to the 8 XCDs
-// (speed only: the exchange then stays inside that XCD's L2)
+// (speed only: the exchange then stays inside that XCD's L2 -- verified per launch, xcd_announce / xcd_agreed)
 __device__ __forceinline__ bool locate(const RollF& a, int& cl, int& g) {
     const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
     cl = x * a.cl_per_xcd + k / a.G;
@@ -161,6 +191,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // read before would be answered with the old line when the producing workgroup sits on another XCD)
     float* part = a.part + (size_t)(a.tile0 + cl) * a.S * a.G * RT * KP0_MAX;
     unsigned target = 0;
+    xcd_announce(cnt);
 
     // ---- one-time: weight slices.  hidden layers l = 1 .. nl-2 into LDS (B[k][c] = W_l[colbase + c][k])
     for (int l = 1; l <= nfull; ++l) {
@@ -209,7 +240,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
     fetch_z(0);
-    __syncthreads();
+    cluster_barrier(cnt, target += a.G);                  // (also the workgroup barrier behind the one-time loads) every member has announced its XCC
+    const bool xl = xcd_agreed(cnt, a.xcd_local, g == 0);
     const int arow_l = 16 * rh + c16;                     // A row of this lane inside the tile
     const int grow = row0 + arow_l < B ? row0 + arow_l : B - 1;
     const size_t hs = (size_t)a.S * B * nh;               // layer stride of hid
@@ -243,7 +275,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const int r = 16 * rh + 4 * q + e;
                 float v = acc[e] + bl;
                 v = v > 0.f ? v : 0.f;
-                if (row0 + r < B) st_agent(hdst + (size_t)(row0 + r) * nh + colbase + cc, v);
+                if (row0 + r < B) st_x(hdst + (size_t)(row0 + r) * nh + colbase + cc, v, xl);
                 if (l == nfull) Hs[r * 33 + cc] = v;
             }
             if (l == nfull) break;
@@ -266,7 +298,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) o = __builtin_amdgcn_mfma_f32_16x16x4f32(hr[4 * jj], wl[u][jj], o, 0, 0, 0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) st_agent(pdst + (16 * trh + 4 * q + e) * NYP_MAX + 16 * ct + c16, o[e]);
+            for (int e = 0; e < 4; ++e) st_x(pdst + (16 * trh + 4 * q + e) * NYP_MAX + 16 * ct + c16, o[e], xl);
         }
         cluster_barrier(cnt, target += a.G);
         // ---- every workgroup: sum the G partials in a fixed order, Euler update of its copy of the state
@@ -325,6 +357,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;
     float* part = a.part + (size_t)(a.tile0 + cl) * a.S * a.G * RT * KP0_MAX;       // fresh slab per step (see the forward kernel)
     unsigned target = 0;
+    xcd_announce(cnt);
     for (int l = 1; l <= nfull; ++l) {
         const float* W = a.W[l];
         float* dst = Wl + (size_t)(l - 1) * nh * CW;
@@ -358,7 +391,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int row = row0 + r < B ? row0 + r : B - 1;
         Dy[idx] = a.d_y_all[((size_t)a.S * B + row) * ny + c];
     }
-    __syncthreads();
+    cluster_barrier(cnt, target += a.G);                  // (workgroup barrier behind the one-time loads + ) every member has announced its XCC
+    const bool xl = xcd_agreed(cnt, a.xcd_local, g == 0);
     const int arow_l = 16 * rh + c16;
     const int grow = row0 + arow_l < B ? row0 + arow_l : B - 1;
     const size_t hs = (size_t)a.S * B * nh;               // layer stride of hid
@@ -420,7 +454,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int e = 0; e < 4; ++e) {
                 const int r = 16 * rh + 4 * q + e;
                 const float v = hm[e] > 0.f ? acc[e] : 0.f;
-                if (row0 + r < B) st_agent(ddst + (size_t)(row0 + r) * dwd + colbase + cc, v);
+                if (row0 + r < B) st_x(ddst + (size_t)(row0 + r) * dwd + colbase + cc, v, xl);
                 if (l == 0) Hs[r * 33 + cc] = v;
             }
             if (l == 0) break;
@@ -443,7 +477,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) o = __builtin_amdgcn_mfma_f32_16x16x4f32(hr[4 * jj], w0b[u][jj], o, 0, 0, 0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) st_agent(pdst + (16 * trh + 4 * q + e) * KP0_MAX + 16 * ct + c16, o[e]);
+            for (int e = 0; e < 4; ++e) st_x(pdst + (16 * trh + 4 * q + e) * KP0_MAX + 16 * ct + c16, o[e], xl);
         }
         // d_y_all[i] of this thread's items (c < ny only), fetched before the barrier wait
         const int nq = a.kp0 / 4;
@@ -491,6 +525,329 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 
+// ------------------------------------------------------------------------------------------------------------ generation chain
+// The INFERENCE rollout (reference module/srvp.py:377-405 with nt > the number of observed frames; test.py:237-246, train.evaluate) as ONE
+// persistent launch per group of row tiles: per frame the prior MLP p_z(y) (srvp.py:383), the sample z ~ posterior while data lasts / prior
+// afterwards (srvp.py:385-391), then the n_euler residual steps with that z (srvp.py:394-400) -- as launches: (nl + 2) + n_euler (nl + 2)
+// dependent micro-kernels per frame (579 GEMM launches for the 53-frame horizon of config 5).  Same decomposition as the training kernels:
+// 32-row tiles, a cluster of nh / 32 workgroups per tile, workgroup g owns hidden columns [32 g, 32 g + 32) of every layer.  The DYNAMICS
+// slices stay in LDS for the whole launch (they are used n_euler times per frame); the LDS has no room for the prior's two 64 KB slices as
+// well, so the prior's hidden layers take their B operand straight from global memory (16 contiguous bytes per lane and MFMA k group: the
+// same 64 KB per workgroup re-read once per frame, L2-resident).  Nothing is saved for a backward pass: the exchanged activation tiles live
+// in one small per-tile buffer per layer that is rewritten every step (a cluster barrier separates any write from the previous reads), which
+// is only safe when every member of the cluster shares one L2 -- the XCD-local exchange, VERIFIED per launch; a launch that finds its
+// cluster spread over several XCCs writes nothing and counts a cluster failure (srvp_cluster_stats_read word 0; the host refuses to go on).
+// The launcher's eligibility test probes the placement once per process, so such a launch is not expected to happen.
+struct GenF {
+    int B, ny, nz, nh, nl, S, ne, G, nin, kp0, nyp, nzp2, F, n_data, ntiles, tile0, cl_per_xcd, xcd_local;
+    float dt;
+    const float* W[MAX_NL]; const float* b[MAX_NL];       // dynamics
+    const float* PW[MAX_NL]; const float* Pb[MAX_NL];     // p_z
+    const float* y0; const float* qz; const float* eps;
+    float* y_all; float* res; float* z; float* pz;
+    float* hbuf; float* part; unsigned* cnt;
+};
+
+__device__ __forceinline__ float softplus_g(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
+
+__device__ __forceinline__ void ld_chunk_plain(f32x4v (&b4)[8], const float* p, int k0, int K) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + 16 * j < K ? k0 + 16 * j : K - 16;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(b4[j]) : "v"(p + k) : "memory");
+    }
+}
+__device__ __forceinline__ void mm_chunk_rr(f32x4v& acc, f32x4v (&a4)[8], f32x4v (&b4)[8], int k0, int K) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (k0 + 16 * j >= K) break;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j][e], b4[j][e], acc, 0, 0, 0);
+    }
+}
+#define WAIT_AB(ba, bb, n) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(ba[0]), "+v"(ba[1]), "+v"(ba[2]), "+v"(ba[3]), "+v"(ba[4]), "+v"(ba[5]), "+v"(ba[6]), "+v"(ba[7]), \
+                                        "+v"(bb[0]), "+v"(bb[1]), "+v"(bb[2]), "+v"(bb[3]), "+v"(bb[4]), "+v"(bb[5]), "+v"(bb[6]), "+v"(bb[7]) :: "memory")
+// acc(16x16) += A(rows from the cluster's exchange buffer: L1-bypassing loads) x B(k-contiguous weight rows from global: plain loads)
+__device__ __forceinline__ void gemm_glob_glob(f32x4v& acc, const float* arow, const float* brow, int K, int q) {
+    const float* pa = arow + 4 * q;
+    const float* pb = brow + 4 * q;
+    for (int k0 = 0; k0 < K; k0 += 256) {
+        f32x4v a0[8], b0[8], a1[8], b1[8];
+        ld_chunk(a0, pa, k0, K); ld_chunk_plain(b0, pb, k0, K); ld_chunk(a1, pa, k0 + 128, K); ld_chunk_plain(b1, pb, k0 + 128, K);
+        WAIT_AB(a0, b0, 16); mm_chunk_rr(acc, a0, b0, k0, K);
+        WAIT_AB(a1, b1, 0); mm_chunk_rr(acc, a1, b1, k0 + 128, K);
+    }
+}
+
+template <int GP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_gen_kernel(const GenF a) {
+    extern __shared__ float lds[];
+    const int xq = blockIdx.x & 7, kblk = blockIdx.x >> 3;
+    const int cl = xq * a.cl_per_xcd + kblk / a.G, g = kblk % a.G;
+    if (cl >= a.ntiles) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int rh = wid >> 1, ch = wid & 1, q = lane >> 4, c16 = lane & 15;
+    const int cc = 16 * ch + c16;
+    const int row0 = (a.tile0 + cl) * RT;
+    const int colbase = g * CW;
+    const int nl = a.nl, nh = a.nh, ny = a.ny, nz = a.nz, nin = a.nin, B = a.B, kp0 = a.kp0;
+    const int nfull = nl - 2;
+    const int ils = kp0 + 1;                              // row stride of the staging tile
+    // LDS: [nfull][nh][32] dynamics slices | Is [32][kp0 + 1] (also the summed prior parameters) | Ys [32][ny] | Zs [32][nz] | Hs [32][33] | biases
+    float* Wl = lds;
+    float* Is = Wl + (size_t)nfull * nh * CW;
+    float* Ys = Is + RT * ils;
+    float* Zs = Ys + RT * ny;
+    float* Hs = Zs + RT * nz;
+    float* Bl = Hs + RT * 33;                             // dynamics: bias of the last layer [ny]
+    float* Bp = Bl + ny;                                  // prior: bias of the last layer [2 nz]
+    unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;
+    float* hbuf = a.hbuf + (size_t)(a.tile0 + cl) * (nfull > 0 ? nfull : 1) * RT * nh;
+    float* part = a.part + (size_t)(a.tile0 + cl) * a.G * RT * KP0_MAX;
+    unsigned target = 0;
+    xcd_announce(cnt);
+    for (int l = 1; l <= nfull; ++l) {
+        const float* W = a.W[l];
+        float* dst = Wl + (size_t)(l - 1) * nh * CW;
+        for (int idx = tid; idx < nh * CW; idx += 256) {
+            const int c = idx / nh, k = idx - c * nh;
+            dst[sw(k, c)] = W[(size_t)(colbase + c) * nh + k];
+        }
+    }
+    // first layers (B fragments in registers): dynamics K = nin, prior K = ny
+    float w0[KP0_MAX / 4], pw0[NYP_MAX / 4];
+#pragma unroll
+    for (int j = 0; j < KP0_MAX / 16; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 16 * j + 4 * q + e;
+            w0[j * 4 + e] = k < nin ? a.W[0][(size_t)(colbase + cc) * nin + k] : 0.f;
+        }
+#pragma unroll
+    for (int j = 0; j < NYP_MAX / 16; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 16 * j + 4 * q + e;
+            pw0[j * 4 + e] = k < ny ? a.PW[0][(size_t)(colbase + cc) * ny + k] : 0.f;
+        }
+    // last layers, split-K over the cluster: tiles t = wid + 4 u -> (row half t & 1, output column tile t >> 1)
+    float wl[2][8], pwl[4][8];
+    const int ntl = 2 * (a.nyp / 16), ntp = 2 * (a.nzp2 / 16);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = wid + 4 * u, col = 16 * (t >> 1) + c16;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+            wl[u][jj] = (t < ntl && col < ny) ? a.W[nl - 1][(size_t)col * nh + colbase + 4 * jj + q] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = wid + 4 * u, col = 16 * (t >> 1) + c16;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+            pwl[u][jj] = (t < ntp && col < 2 * nz) ? a.PW[nl - 1][(size_t)col * nh + colbase + 4 * jj + q] : 0.f;
+    }
+    for (int idx = tid; idx < RT * ny; idx += 256) {
+        const int r = idx / ny, c = idx - r * ny;
+        const int row = row0 + r < B ? row0 + r : B - 1;
+        Ys[idx] = a.y0[(size_t)row * ny + c];
+    }
+    for (int idx = tid; idx < RT * ils; idx += 256) Is[idx] = 0.f;
+    if (tid < ny) Bl[tid] = a.b[nl - 1][tid];
+    if (tid < 2 * nz) Bp[tid] = a.Pb[nl - 1][tid];
+    cluster_barrier(cnt, target += a.G);                  // (workgroup barrier behind the one-time loads + ) every member has announced its XCC
+    if (!xcd_agreed(cnt, a.xcd_local, g == 0)) {
+        // the members do not share one L2: the single-buffer exchange below would read stale lines.  Nothing is written; counted as a cluster
+        // failure (every member takes this branch: the mask is the same for all)
+        if (g == 0 && tid == 0) __hip_atomic_fetch_add(&g_cluster_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int arow_l = 16 * rh + c16;                     // A row of this lane inside the tile
+    const size_t hls = (size_t)RT * nh;                   // layer stride of hbuf
+    const int nq = a.nyp / 4, nq2 = a.nzp2 / 4;
+
+    for (int i = 0; i < a.S; ++i) {
+        const int f = i / a.ne;
+        if (i % a.ne == 0) {
+            // =============================== frame start: p_z(y), then z
+            for (int idx = tid; idx < RT * ny; idx += 256) {
+                const int r = idx / ny, c = idx - r * ny;
+                Is[r * ils + c] = Ys[idx];                // (columns >= ny: the previous z or zeros; their weights are zero)
+            }
+            __syncthreads();
+            f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+            float bl = a.Pb[0][colbase + cc];
+            {
+                const float* ar = Is + arow_l * ils + 4 * q;
+#pragma unroll
+                for (int j = 0; j < NYP_MAX / 16; ++j) {
+                    if (16 * j >= a.nyp) break;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[16 * j + e], pw0[j * 4 + e], acc, 0, 0, 0);
+                }
+            }
+            for (int l = 0; l <= nfull; ++l) {
+                float* hdst = hbuf + (size_t)l * hls;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 16 * rh + 4 * q + e;
+                    float v = acc[e] + bl;
+                    v = v > 0.f ? v : 0.f;
+                    if (l < nfull) hdst[(size_t)r * nh + colbase + cc] = v;
+                    else Hs[r * 33 + cc] = v;
+                }
+                if (l == nfull) break;
+                bl = a.Pb[l + 1][colbase + cc];
+                cluster_barrier(cnt, target += a.G);
+                acc = f32x4v{0.f, 0.f, 0.f, 0.f};
+                gemm_glob_glob(acc, hdst + (size_t)arow_l * nh, a.PW[l + 1] + (size_t)(colbase + cc) * nh, nh, q);
+            }
+            __syncthreads();                              // Hs complete
+            float* pdst = part + (size_t)g * RT * KP0_MAX;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = wid + 4 * u;
+                if (t >= ntp) break;
+                const int trh = t & 1, ct = t >> 1;
+                f32x4v o = {0.f, 0.f, 0.f, 0.f};
+                const float* hr = Hs + (16 * trh + c16) * 33 + q;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) o = __builtin_amdgcn_mfma_f32_16x16x4f32(hr[4 * jj], pwl[u][jj], o, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pdst[(16 * trh + 4 * q + e) * KP0_MAX + 16 * ct + c16] = o[e];
+            }
+            // this frame's noise and (while data lasts) posterior parameters, fetched before the barrier wait
+            const bool posterior = f + 1 < a.n_data;
+            float epsr[NYP_MAX * RT / 256], qlr[NYP_MAX * RT / 256], qsr[NYP_MAX * RT / 256];
+#pragma unroll
+            for (int u = 0; u < NYP_MAX * RT / 256; ++u) {
+                const int idx = tid + 256 * u, r = idx / nz, c = idx - r * nz;
+                const int row = row0 + r < B ? row0 + r : B - 1;
+                const bool ok = idx < RT * nz;
+                epsr[u] = ok ? a.eps[((size_t)f * B + row) * nz + c] : 0.f;
+                qlr[u] = (ok && posterior) ? a.qz[((size_t)f * B + row) * 2 * nz + c] : 0.f;
+                qsr[u] = (ok && posterior) ? a.qz[((size_t)f * B + row) * 2 * nz + nz + c] : 0.f;
+            }
+            cluster_barrier(cnt, target += a.G);
+            // every workgroup: the prior's parameters of its 32 rows = sum of the G partials (fixed order) + bias -> the staging tile
+            for (int it = tid; it < RT * nq2; it += 512) {
+                const int itb = it + 256 < RT * nq2 ? it + 256 : it;
+                f32x4v sv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                sum_slabs2<GP>(sv[0], sv[1], part + (it / nq2) * KP0_MAX + 4 * (it % nq2), part + (itb / nq2) * KP0_MAX + 4 * (itb % nq2), a.G,
+                               (size_t)RT * KP0_MAX);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int item = h ? itb : it;
+                    if (h && itb == it) break;
+                    const int r = item / nq2, c0 = 4 * (item % nq2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c0 + e < 2 * nz) Is[r * ils + c0 + e] = sv[h][e] + Bp[c0 + e];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < NYP_MAX * RT / 256; ++u) {
+                const int idx = tid + 256 * u, r = idx / nz, c = idx - r * nz;
+                if (idx >= RT * nz) break;
+                const float pl = Is[r * ils + c], ps = Is[r * ils + nz + c];
+                const float loc = posterior ? qlr[u] : pl, raw = posterior ? qsr[u] : ps;
+                const float zz = loc + epsr[u] * (softplus_g(raw) + 1e-8f);
+                Zs[idx] = zz;
+                if (g == 0 && row0 + r < B) {
+                    const size_t o = (size_t)f * B + row0 + r;
+                    a.z[o * nz + c] = zz;
+                    a.pz[o * 2 * nz + c] = pl;
+                    a.pz[o * 2 * nz + nz + c] = ps;
+                }
+            }
+            __syncthreads();
+            // the dynamics' input tile [y | z | 0]
+            for (int idx = tid; idx < RT * kp0; idx += 256) {
+                const int r = idx / kp0, k = idx - r * kp0;
+                Is[r * ils + k] = k < ny ? Ys[r * ny + k] : (k < nin ? Zs[r * nz + k - ny] : 0.f);
+            }
+        } else {
+            for (int idx = tid; idx < RT * ny; idx += 256) {
+                const int r = idx / ny, c = idx - r * ny;
+                Is[r * ils + c] = Ys[idx];                // (the z part of the tile stays for the whole frame)
+            }
+        }
+        __syncthreads();
+        // =============================== one residual step (as rollout_fused_fwd_kernel, nothing saved)
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+        float bl = a.b[0][colbase + cc];
+        {
+            const float* ar = Is + arow_l * ils + 4 * q;
+#pragma unroll
+            for (int j = 0; j < KP0_MAX / 16; ++j) {
+                if (16 * j >= kp0) break;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[16 * j + e], w0[j * 4 + e], acc, 0, 0, 0);
+            }
+        }
+        for (int l = 0; l <= nfull; ++l) {
+            float* hdst = hbuf + (size_t)l * hls;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 16 * rh + 4 * q + e;
+                float v = acc[e] + bl;
+                v = v > 0.f ? v : 0.f;
+                if (l < nfull) hdst[(size_t)r * nh + colbase + cc] = v;
+                else Hs[r * 33 + cc] = v;
+            }
+            if (l == nfull) break;
+            bl = a.b[l + 1][colbase + cc];
+            cluster_barrier(cnt, target += a.G);
+            acc = f32x4v{0.f, 0.f, 0.f, 0.f};
+            gemm_glob_lds(acc, hdst + (size_t)arow_l * nh, Wl + (size_t)l * nh * CW, nh, q, cc);
+        }
+        __syncthreads();
+        float* pdst = part + (size_t)g * RT * KP0_MAX;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = wid + 4 * u;
+            if (t >= ntl) break;
+            const int trh = t & 1, ct = t >> 1;
+            f32x4v o = {0.f, 0.f, 0.f, 0.f};
+            const float* hr = Hs + (16 * trh + c16) * 33 + q;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) o = __builtin_amdgcn_mfma_f32_16x16x4f32(hr[4 * jj], wl[u][jj], o, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pdst[(16 * trh + 4 * q + e) * KP0_MAX + 16 * ct + c16] = o[e];
+        }
+        cluster_barrier(cnt, target += a.G);
+        for (int it = tid; it < RT * nq; it += 512) {
+            const int itb = it + 256 < RT * nq ? it + 256 : it;
+            f32x4v sv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            sum_slabs2<GP>(sv[0], sv[1], part + (it / nq) * KP0_MAX + 4 * (it % nq), part + (itb / nq) * KP0_MAX + 4 * (itb % nq), a.G,
+                           (size_t)RT * KP0_MAX);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int item = h ? itb : it;
+                if (h && itb == it) break;
+                const int r = item / nq, c0 = 4 * (item % nq);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = c0 + e;
+                    if (c >= ny) break;
+                    const float rs = a.dt * (sv[h][e] + Bl[c]);
+                    const float yn = Ys[r * ny + c] + rs;
+                    Ys[r * ny + c] = yn;
+                    if (g == 0 && row0 + r < B) {
+                        const size_t o = (size_t)(row0 + r) * ny + c;
+                        a.res[(size_t)i * B * ny + o] = rs;
+                        a.y_all[(size_t)(i + 1) * B * ny + o] = yn;
+                    }
+                }
+            }
+        }
+        // (the next phase's first cluster barrier -- every phase has at least the split-K one -- separates these slab reads from the next
+        // writes of the slabs and of the exchange buffers)
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------ LSTM
 // The posterior LSTM (nn.LSTM(nhx, nh, 1), reference module/srvp.py:132,366) as ONE persistent launch over its T steps, same
 // decomposition: 32-row batch tiles, a cluster of nh / 32 workgroups per tile, workgroup g owns hidden units [32 g, 32 g + 32)
@@ -501,7 +858,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // latency each.)
 struct LstmF {
     int B, nh, T, G, ntiles, tile0, cl_per_xcd;
-    const float* gx; const float* whh; float* h; float* c; float* ga; unsigned* cnt;
+    const float* gx; const float* whh; float* h; float* c; float* ga; unsigned* cnt; int xcd_local;
 };
 
 __device__ __forceinline__ float sigmoid_l(float x) { return 1.f / (1.f + __expf(-x)); }
@@ -525,6 +882,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float cst[4] = {0.f, 0.f, 0.f, 0.f};
     unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;
     const size_t gs = (size_t)a.B * 4 * NH, hs = (size_t)a.B * NH;
+    xcd_announce(cnt);
+    cluster_barrier(cnt, (unsigned)a.G);                   // every member has announced its XCC (XCD-LOCAL EXCHANGE)
+    const bool xl = xcd_agreed(cnt, a.xcd_local, g == 0);
     for (int t = 0; t < a.T; ++t) {
         f32x16_t acc;
 #pragma unroll
@@ -533,7 +893,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             acc[r] = row < a.B ? a.gx[gs * t + (size_t)row * 4 * NH + col] : 0.f;
         }
         if (t > 0) {
-            cluster_barrier(cnt, (unsigned)(t * a.G));     // every member has stored its slice of h_{t-1}
+            cluster_barrier(cnt, (unsigned)((t + 1) * a.G));   // every member has stored its slice of h_{t-1}
             const float* hp = a.h + hs * (t - 1);
             constexpr int NLD = RT * NH / 4 / 256;          // 16-byte pieces per thread (8 at nh = 256): all in flight, one wait
             f32x4v hv[8];
@@ -571,7 +931,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (row0 + rl < a.B) {
                 const size_t o = hs * t + (size_t)(row0 + rl) * NH + g * CW + u;
                 a.c[o] = cst[e];
-                st_agent(a.h + o, og * tanhf(cst[e]));
+                st_x(a.h + o, og * tanhf(cst[e]), xl);
             }
         }
         __syncthreads();                                   // Gs is rewritten by the next step's gates
@@ -587,7 +947,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // into the carry registers.  (As launches: a cell kernel + a GEMM per step, ~18 us of dependent latency each.)
 struct LstmB {
     int B, nh, T, G, ntiles, tile0, cl_per_xcd;
-    const float* dh_out; const float* whh; const float* c; const float* ga; float* dgates; unsigned* cnt;
+    const float* dh_out; const float* whh; const float* c; const float* ga; float* dgates; unsigned* cnt; int xcd_local;
 };
 
 template <int KST>      // nh / 2 MFMA k steps per wave (one gate's nh columns)
@@ -609,6 +969,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;
     const size_t gs = (size_t)a.B * 4 * NH, hs = (size_t)a.B * NH;
     unsigned target = 0;
+    xcd_announce(cnt);
+    cluster_barrier(cnt, target += (unsigned)a.G);         // every member has announced its XCC (XCD-LOCAL EXCHANGE)
+    const bool xl = xcd_agreed(cnt, a.xcd_local, g == 0);
     for (int t = a.T - 1; t >= 0; --t) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -621,10 +984,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float tc = tanhf(a.c[ho]);
             const float dc = dcs[e] + dh * og * (1.f - tc * tc);
             const float cp = t > 0 ? a.c[ho - hs] : 0.f;
-            st_agent(a.dgates + go, dc * gg * ig * (1.f - ig));
-            st_agent(a.dgates + go + NH, dc * cp * fg * (1.f - fg));
-            st_agent(a.dgates + go + 2 * NH, dc * ig * (1.f - gg * gg));
-            st_agent(a.dgates + go + 3 * NH, dh * tc * og * (1.f - og));
+            st_x(a.dgates + go, dc * gg * ig * (1.f - ig), xl);
+            st_x(a.dgates + go + NH, dc * cp * fg * (1.f - fg), xl);
+            st_x(a.dgates + go + 2 * NH, dc * ig * (1.f - gg * gg), xl);
+            st_x(a.dgates + go + 3 * NH, dh * tc * og * (1.f - og), xl);
             dcs[e] = dc * fg;
         }
         if (t == 0) break;
@@ -670,7 +1033,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
-int g_fused = -1, g_ncu = 0;
+// Placement probe (once per process): does block b of a plain launch run on XCC b % 8?  The generation chain needs it for correctness of its
+// buffer reuse (and verifies it again inside every launch); the other persistent kernels only run faster when it holds.
+__global__ void xcc_probe_kernel(unsigned* out) { if (threadIdx.x == 0) out[blockIdx.x] = xcc_id(); }
+int g_placement = -1;        // -1 unknown, 0 no, 1 yes
+bool placement_round_robin() {
+    if (g_placement >= 0) return g_placement == 1;
+    g_placement = 0;
+    const int nb = 256;
+    unsigned* d = nullptr;
+    unsigned h[nb];
+    if (hipMalloc(&d, nb * sizeof(unsigned)) != hipSuccess) return false;
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(nb), dim3(64), 0, 0, d);
+    const bool ok = hipMemcpy(h, d, nb * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    if (!ok) return false;
+    unsigned seen = 0;
+    for (int b = 0; b < 8; ++b) seen |= 1u << (h[b] & 15u);
+    if (__builtin_popcount(seen) != 8) return false;      // (fewer than 8 XCCs visible: another partition mode)
+    for (int b = 0; b < nb; ++b)
+        if (h[b] != h[b & 7]) return false;
+    g_placement = 1;
+    return true;
+}
+
+int g_fused = -1, g_ncu = 0, g_xcd_local = -1;
+int xcd_local_on() {
+    if (g_xcd_local < 0) { const char* e = getenv("SRVP_CLUSTER_XCD_LOCAL"); g_xcd_local = e ? atoi(e) : 1; }
+    return g_xcd_local;
+}
 
 int device_cus() {
     if (!g_ncu) {
@@ -711,7 +1102,7 @@ static int fused_common(const srvp_rollout_desc& f, RollF& k, void* ws) {
     k.nin = f.ny + f.nz; k.kp0 = (k.nin + 15) / 16 * 16; k.nyp = (f.ny + 15) / 16 * 16; k.dt = f.dt;
     for (int l = 0; l < MAX_NL; ++l) { k.W[l] = l < f.nl ? f.dyn_w[l] : nullptr; k.b[l] = l < f.nl ? f.dyn_b[l] : nullptr; }
     const int tiles = (f.B + RT - 1) / RT;
-    k.cnt = (unsigned*)ws;
+    k.cnt = (unsigned*)ws; k.xcd_local = xcd_local_on();
     k.part = (float*)((char*)ws + (size_t)tiles * 256);
     return tiles;
 }
@@ -767,6 +1158,63 @@ int srvp_rollout_fused_bwd(const srvp_rollout_bwd_desc* d, hipStream_t st) {
     return SRVP_OK;
 }
 
+// ---- generation chain (inference: p_z inside the loop).  0 = not eligible (the caller keeps the per-layer launch sequence), else the
+// workspace size in bytes
+extern "C" int64_t srvp_rollout_gen_ws_bytes(const srvp_rollout_desc* d) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SRVP_ROLLOUT_GEN_FUSED"); on = e ? atoi(e) : 1; }
+    if (g_fused < 0) { const char* e = getenv("SRVP_ROLLOUT_FUSED"); g_fused = e ? atoi(e) : 1; }
+    if (!on || !g_fused || !d || !xcd_local_on()) return 0;
+    const int nin = d->ny + d->nz;
+    if (d->nl < 3 || d->nl > MAX_NL || d->nh % CW != 0 || d->nh / CW > 32 || d->nh < 32 || nin > KP0_MAX || d->ny > NYP_MAX || d->nz > NYP_MAX || d->ny > d->nh ||
+        2 * d->nz > KP0_MAX || d->nsteps < 1 || d->n_euler < 1 || d->pz_external) return 0;
+    const int kp0 = (nin + 15) / 16 * 16, nzp2 = (2 * d->nz + 15) / 16 * 16;
+    if (nzp2 > kp0) return 0;                             // the summed prior parameters are staged in the input tile
+    if (!clusters_fit(d->nh / CW)) return 0;
+    const size_t lds = ((size_t)(d->nl - 2) * d->nh * CW + RT * (kp0 + 1) + RT * d->ny + RT * d->nz + RT * 33 + d->ny + 2 * d->nz) * 4;
+    if (lds > 160 * 1024) return 0;
+    if (!placement_round_robin()) return 0;
+    const int64_t tiles = (d->B + RT - 1) / RT;
+    return tiles * 256 + tiles * (int64_t)(d->nl - 2) * RT * d->nh * 4 + tiles * (int64_t)(d->nh / CW) * RT * KP0_MAX * 4;
+}
+
+int srvp_rollout_gen_fwd(const srvp_rollout_desc* d, hipStream_t st) {
+    device_cus();
+    GenF k{};
+    k.B = d->B; k.ny = d->ny; k.nz = d->nz; k.nh = d->nh; k.nl = d->nl; k.S = d->nsteps; k.ne = d->n_euler; k.G = d->nh / CW;
+    k.nin = d->ny + d->nz; k.kp0 = (k.nin + 15) / 16 * 16; k.nyp = (d->ny + 15) / 16 * 16; k.nzp2 = (2 * d->nz + 15) / 16 * 16; k.dt = d->dt;
+    k.F = (d->nsteps + d->n_euler - 1) / d->n_euler; k.n_data = d->n_data_frames; k.xcd_local = xcd_local_on();
+    for (int l = 0; l < MAX_NL; ++l) {
+        k.W[l] = l < d->nl ? d->dyn_w[l] : nullptr; k.b[l] = l < d->nl ? d->dyn_b[l] : nullptr;
+        k.PW[l] = l < d->nl ? d->pz_w[l] : nullptr; k.Pb[l] = l < d->nl ? d->pz_b[l] : nullptr;
+    }
+    k.y0 = d->y0; k.qz = d->q_z_params; k.eps = d->eps_z; k.y_all = d->y_all; k.res = d->res; k.z = d->z; k.pz = d->p_z_params;
+    const int tiles = (d->B + RT - 1) / RT;
+    k.cnt = (unsigned*)d->fused_ws;
+    k.hbuf = (float*)((char*)d->fused_ws + (size_t)tiles * 256);
+    k.part = k.hbuf + (size_t)tiles * (d->nl - 2) * RT * d->nh;
+    SRVP_REQUIRE(k.n_data <= 1 || k.qz, "srvp_rollout_fwd(gen): posterior frames need q_z_params");
+    const size_t lds = ((size_t)(k.nl - 2) * k.nh * CW + RT * (k.kp0 + 1) + RT * k.ny + RT * k.nz + RT * 33 + k.ny + 2 * k.nz) * 4;
+    auto kern = k.G <= 8 ? rollout_gen_kernel<8> : (k.G <= 16 ? rollout_gen_kernel<16> : rollout_gen_kernel<32>);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd(gen): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd(gen): memset failed");
+    e = hipMemcpyAsync(d->y_all, d->y0, sizeof(float) * (size_t)d->B * d->ny, hipMemcpyDeviceToDevice, st);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd(gen): copy failed");
+    // (more tiles than one co-resident launch holds: the groups run one after the other on this stream.  Putting the second group on another
+    // stream under the decoding of the first group's rows was measured in round 5 and is slower: its spinning workgroups hold 144 CUs' worth
+    // of LDS while they become resident one by one, and the decoder's convolutions lose more than the 3.6 ms the overlap hides)
+    int cpx;
+    const int per = clusters_per_launch(k.G, tiles, cpx);
+    for (int t0 = 0; t0 < tiles; t0 += per) {
+        k.tile0 = t0; k.ntiles = tiles - t0 < per ? tiles - t0 : per; k.cl_per_xcd = cpx;
+        hipLaunchKernelGGL(kern, dim3(8 * cpx * k.G), dim3(256), lds, st, k);
+    }
+    SRVP_CHECK_LAUNCH("srvp_rollout_fwd(gen)");
+    return SRVP_OK;
+}
+
 // ---- persistent LSTM forward: 0 = not eligible (the caller keeps srvp_lstm_fwd), else the workspace size in bytes
 extern "C" int64_t srvp_lstm_fused_ws_bytes(int T, int B, int nh) {
     static int on = -1;
@@ -783,7 +1231,7 @@ extern "C" int srvp_lstm_fwd_fused(const float* gates_x, const float* w_hh, floa
     SRVP_REQUIRE(need > 0 && ws_bytes >= need, "srvp_lstm_fwd_fused: shape not eligible or workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)need);
     device_cus();
     LstmF k{};
-    k.B = B; k.nh = nh; k.T = T; k.G = nh / CW; k.gx = gates_x; k.whh = w_hh; k.h = h_out; k.c = c_out; k.ga = gates_act; k.cnt = (unsigned*)ws;
+    k.B = B; k.nh = nh; k.T = T; k.G = nh / CW; k.gx = gates_x; k.whh = w_hh; k.h = h_out; k.c = c_out; k.ga = gates_act; k.cnt = (unsigned*)ws; k.xcd_local = xcd_local_on();
     const int tiles = (B + RT - 1) / RT;
     const size_t lds = ((size_t)RT * (nh + 1) + 4 * RT * 33) * 4;
     auto kern = nh == 256 ? lstm_fused_fwd_kernel<128> : (nh == 128 ? lstm_fused_fwd_kernel<64> : lstm_fused_fwd_kernel<32>);
@@ -811,7 +1259,7 @@ extern "C" int srvp_lstm_bwd_fused(const float* dh_out, const float* w_hh, const
     SRVP_REQUIRE(need > 0 && ws_bytes >= need, "srvp_lstm_bwd_fused: shape not eligible or workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)need);
     device_cus();
     LstmB k{};
-    k.B = B; k.nh = nh; k.T = T; k.G = nh / CW; k.dh_out = dh_out; k.whh = w_hh; k.c = c_out; k.ga = gates_act; k.dgates = dgates; k.cnt = (unsigned*)ws;
+    k.B = B; k.nh = nh; k.T = T; k.G = nh / CW; k.dh_out = dh_out; k.whh = w_hh; k.c = c_out; k.ga = gates_act; k.dgates = dgates; k.cnt = (unsigned*)ws; k.xcd_local = xcd_local_on();
     const int tiles = (B + RT - 1) / RT;
     const size_t lds = ((size_t)RT * (4 * nh + 1) + 4 * RT * 33) * 4;
     SRVP_REQUIRE(lds <= 160 * 1024, "srvp_lstm_bwd_fused: %zu bytes of LDS", lds);
@@ -827,6 +1275,20 @@ extern "C" int srvp_lstm_bwd_fused(const float* dh_out, const float* w_hh, const
         hipLaunchKernelGGL(kern, dim3(8 * cpx * k.G), dim3(256), lds, st, k);
     }
     SRVP_CHECK_LAUNCH("srvp_lstm_bwd_fused");
+    return SRVP_OK;
+}
+
+// A/B switch of the XCD-local exchange of the persistent latent kernels (default 1 / env SRVP_CLUSTER_XCD_LOCAL): 0 = agent-scope write-through
+// stores whatever the placement.  Same results bit for bit (the arithmetic and its order do not change).
+extern "C" int srvp_cluster_set_xcd_local(int on) { g_xcd_local = on ? 1 : 0; return SRVP_OK; }
+// host_words[0] = cluster-barrier timeouts, host_words[1] = clusters (summed over launches) that verified all their members on one XCC and
+// exchanged through its L2, both since the library was loaded; copied to pinned host memory in stream order.
+extern "C" int srvp_cluster_stats_read(unsigned* host_words2, void* stream) {
+    SRVP_REQUIRE(host_words2, "srvp_cluster_stats_read: null pointer");
+    hipError_t e = hipMemcpyFromSymbolAsync(host_words2, HIP_SYMBOL(g_cluster_timeouts), sizeof(unsigned), 0, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_cluster_stats_read: %s", hipGetErrorString(e));
+    e = hipMemcpyFromSymbolAsync(host_words2 + 1, HIP_SYMBOL(g_cluster_xcd_local), sizeof(unsigned), 0, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    SRVP_REQUIRE(e == hipSuccess, "srvp_cluster_stats_read: %s", hipGetErrorString(e));
     return SRVP_OK;
 }
 

@@ -45,6 +45,7 @@ def axpby(st, out, a, x, b=0.0, y=None):
 import os
 PZ_BATCHED = os.environ.get('SRVP_PZ_BATCHED', '1') != '0'
 LSTM_BWD_FUSED = os.environ.get('SRVP_LSTM_BWD_FUSED', '1') != '0'
+ROLLOUT_GEN_FUSED = True      # inference chain (p_z inside the loop) as persistent launches; False: per-layer launch sequence (A/B switch of the tests)
 
 
 def mlp_keys(prefix, n):
@@ -206,6 +207,14 @@ class LatentNet:
                     ws = self.__dict__.get('_fused_ws')
                     if ws is None or ws.numel() < need:
                         ws = self._fused_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
+                    self._rd.fused_ws, self._rd.fused_ws_bytes = L.ptr(ws), need
+            elif not self.training and ROLLOUT_GEN_FUSED:
+                # inference chain (p_z inside the loop): persistent launches where the library takes it (0 = per-layer launch sequence)
+                need = int(L.load().srvp_rollout_gen_ws_bytes(C.byref(self._rd)))
+                if need > 0:
+                    ws = self.__dict__.get('_gen_ws')
+                    if ws is None or ws.numel() < need:
+                        ws = self._gen_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
                     self._rd.fused_ws, self._rd.fused_ws_bytes = L.ptr(ws), need
             L.call('srvp_rollout_fwd', C.byref(self._rd), st)
             self.pz_done = None

@@ -373,6 +373,28 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         tape['eps_z'] = torch.randn(max(nt - 1, 1), B, self.nz, device=dev)
         return tape
 
+    def _poll_cluster(self, every=32):
+        """Every `every` calls (and on the first): the library's count of cluster failures of the persistent latent kernels -- barrier timeouts
+        (workgroups of a cluster not co-resident) or a generation launch that found its cluster spread over several XCCs -- as it stood when it
+        was last copied: no extra host sync, the word is read back in stream order into pinned memory and looked at one poll later.  Non-zero =
+        some launch left garbage behind: stop, do not train on / return it."""
+        n = self.__dict__.get('_ct_step', 0)
+        self.__dict__['_ct_step'] = n + 1
+        if n % every:
+            return
+        host = self.__dict__.get('_ct_host')
+        if host is None:
+            host = self.__dict__['_ct_host'] = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self.__dict__['_ct_event'] = None
+        ev = self.__dict__['_ct_event']
+        if ev is not None and ev.query() and int(host[0]) != 0:
+            raise L.SrvpHipError(f'{int(host[0])} cluster failure(s) in the persistent latent kernels (workgroups of a cluster were not co-resident, or not '
+                                 'on one XCD for the generation chain): results since then are invalid; set SRVP_ROLLOUT_FUSED=0 SRVP_LSTM_FUSED=0 '
+                                 'SRVP_LSTM_BWD_FUSED=0')
+        L.call('srvp_cluster_timeouts_read', host.data_ptr(), L.stream())
+        ev = self.__dict__['_ct_event'] = torch.cuda.Event()
+        ev.record()
+
     # ------------------------------------------------------------------------------------------------ core
     def _forward_impl(self, x, nt, n_euler, tape, training):
         dev = self._require_gpu()
@@ -461,6 +483,8 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         x_ = x_flat.view(nt, B, *x_flat.shape[1:])
         pl['hx'], pl['x'] = hx, x
         self._last_plan = pl
+        if not training:
+            self._poll_cluster(8)                 # (training: srvp_amd.train.train polls once per step)
         return x_, y, z, w, q_y0, qz, pz, res
 
     @torch.no_grad()
@@ -485,6 +509,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             tape = self._draw_tape(T, B * S, nt, False, dev)
         tape = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in tape.items()}
         enc, dec, lat = pl['enc'], pl['dec'], pl['lat']
+        self._last_sample_lat = lat
         x = x.contiguous().float()
         hx = enc.forward(x.view(T * B, *x.shape[2:]), params, st, None).contiguous().view(T, B, self.nhx)
         if self.skipco:
@@ -496,6 +521,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         y0, _ = lat.infer_y(hx_s[:self.nt_inf], params, tape['eps_y0'], st)
         lat.posterior(hx_s, params, st)
         lat.generate(y0, T, params, tape['eps_z'], st)
+        self._poll_cluster(8)
         if Sd == S:
             x_flat = dec.forward(None, params, st, None, latent=(w, lat.y_all, lat.ne * B * S * self.ny, nt, B * S, self.nh_inf, self.ny))
             return x_flat.view(nt, S, B, *x_flat.shape[1:]).clone()
@@ -504,7 +530,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             # the last chunk is decoded at the common size (one decoder plan per evaluation shape), re-using the final samples
             s0 = min(s0, S - Sd)
             x_flat = dec.forward(None, params, st, None, latent=(w[s0 * B:], lat.y_all[:, s0 * B:], lat.ne * B * S * self.ny, nt, B * Sd,
-                                                                  self.nh_inf, self.ny))
+                                                                  self.nh_inf, self.ny), coeffs_current=s0 > 0)
             out[:, s0:s0 + Sd] = x_flat.view(nt, Sd, B, *x_flat.shape[1:])
         return out
 

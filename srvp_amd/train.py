@@ -83,24 +83,8 @@ def fused_step(model, x, opt, tape=None):
 
 
 def _poll_cluster_timeouts(model, every=32):
-    """Every `every` steps (and on the first): the library's count of cluster-barrier timeouts in the persistent latent kernels, as it
-    stood when it was last copied -- no extra host sync: the word is read back in stream order into pinned memory and looked at one
-    poll later.  Non-zero = some launch ran with workgroups that were not co-resident and left garbage behind: stop, do not train on it."""
-    n = model.__dict__.get('_ct_step', 0)
-    model.__dict__['_ct_step'] = n + 1
-    if n % every:
-        return
-    host = model.__dict__.get('_ct_host')
-    if host is None:
-        host = model.__dict__['_ct_host'] = torch.zeros(1, dtype=torch.int32).pin_memory()
-        model.__dict__['_ct_event'] = None
-    ev = model.__dict__['_ct_event']
-    if ev is not None and ev.query() and int(host[0]) != 0:
-        raise L.SrvpHipError(f'{int(host[0])} cluster-barrier timeout(s) in the persistent latent kernels (workgroups of a cluster were not '
-                             'co-resident): results since then are invalid; set SRVP_ROLLOUT_FUSED=0 SRVP_LSTM_BWD_FUSED=0')
-    L.call('srvp_cluster_timeouts_read', host.data_ptr(), L.stream())
-    ev = model.__dict__['_ct_event'] = torch.cuda.Event()
-    ev.record()
+    """Every `every` steps (and on the first): the library's count of cluster failures in the persistent latent kernels (model._poll_cluster)."""
+    model._poll_cluster(every)
 
 
 def train(forward_fn, optimizer, scaler, batch, device, opt):

@@ -258,3 +258,66 @@ def test_persistent_lstm_forward(T, B, nh):
         assert rel_l2(h, href) < 2e-6 and rel_l2(c, cref) < 2e-6, (fused, rel_l2(h, href), rel_l2(c, cref))
     assert rel_l2(outs[1][2], outs[0][2]) < 2e-6
     assert (gxd.cpu() == gx).all()                                     # the fused entry point leaves gates_x untouched
+
+
+# (B, T observed frames, nt generated frames, n_euler, dims): headline dimensions on one ragged and on three tiles; SM-MNIST dimensions (ny = nz = 20);
+# 27 tiles = more clusters than fit on the chip at once (two co-resident launches, tile0 > 0 in the second); posterior only up to frame 1
+@pytest.mark.parametrize('B,T,nt,ne,dims', [(5, 4, 9, 2, (128, 50, 50, 256, 512, 3, 4, 3)), (70, 3, 7, 2, (128, 50, 50, 256, 512, 3, 4, 2)),
+                                            (40, 5, 8, 1, (32, 20, 20, 64, 512, 2, 4, 3)), (850, 2, 5, 2, (16, 50, 50, 32, 512, 2, 4, 2)),
+                                            (33, 1, 6, 4, (16, 12, 12, 32, 96, 2, 3, 1))])
+def test_generation_chain_persistent_vs_launches_and_oracle(B, T, nt, ne, dims):
+    """The INFERENCE rollout (reference module/srvp.py:377-405: posterior samples while the observed frames last, prior samples p_z(y) afterwards;
+    test.py:237-246) as persistent launches (csrc/rollout_fused.hip rollout_gen_kernel: p_z, the sample and the n_euler residual steps of every
+    frame inside one kernel) against (a) the per-layer launch sequence on the same buffers -- same algorithm, another fp32 summation order -- and
+    (b) the CPU oracle: states y, samples z, prior parameters p_z and residuals at every step."""
+    import ctypes
+    import srvp_amd
+    from oracle import srvp_oracle as O
+    from srvp_amd import _lib as L
+    from srvp_amd import latent as LT
+    nhx, ny, nz, nh_inf, nh_res, nl_inf, nl_res, nt_inf = dims
+    ctor = (64, 1, 4, nhx, ny, nz, False, nt_inf, nh_inf, nl_inf, nh_res, nl_res, 'dcgan')
+    torch.manual_seed(7)
+    model = srvp_amd.StochasticLatentResidualVideoPredictor(*ctor)
+    model.init(0.8)                                            # (contractive residual function: the chain does not amplify rounding differences)
+    cfg = O.make_cfg(*ctor)
+    g = torch.Generator().manual_seed(13)
+    hx = torch.tanh(torch.randn(T, B, nhx, generator=g))
+    eps_y0, eps_z = torch.randn(B, ny, generator=g), torch.randn(nt - 1, B, nz, generator=g)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        y0_r, _ = O.infer_y(sd, cfg, hx[:nt_inf], eps_y0)
+        y_r, z_r, qz_r, pz_r, res_r = O.generate(sd, cfg, y0_r, hx, nt, ne, eps_z, False)
+    model = model.cuda().eval()
+    model.flatten_parameters_()
+    params = model._named_tensors()
+    st = L.stream()
+    dev = torch.device('cuda')
+    lat = LT.LatentNet(model._cfg(), T, B, nt, ne, dev, False)
+    hxg = hx.to(dev)
+    y0_g, _ = lat.infer_y(hxg[:nt_inf], params, eps_y0.to(dev), st)
+    lat.posterior(hxg, params, st)
+    host = torch.zeros(2, dtype=torch.int32).pin_memory()
+    L.call('srvp_cluster_stats_read', host.data_ptr(), st)
+    torch.cuda.synchronize()
+    fails0 = int(host[0])
+    out = {}
+    try:
+        for fused in (True, False):
+            LT.ROLLOUT_GEN_FUSED = fused
+            for t in (lat.y_all, lat.z, lat.p_z, lat.res):
+                t.fill_(7.0)
+            y, z, qz, pz, res = lat.generate(y0_g, T, params, eps_z.to(dev), st)
+            torch.cuda.synchronize()
+            assert bool(lat._rd.fused_ws) == fused, 'generation-chain eligibility changed'
+            out[fused] = [t.clone() for t in (y, z, pz, res)]
+    finally:
+        LT.ROLLOUT_GEN_FUSED = True
+    L.call('srvp_cluster_stats_read', host.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert int(host[0]) == fails0, 'a generation launch found its cluster spread over several XCCs (or a barrier timed out)'
+    for n, a, b in zip(('y', 'z', 'pz', 'res'), out[True], out[False]):
+        assert a.shape == b.shape and rel(a, b) < 2e-5, (n, rel(a, b))
+    for n, a, b in zip(('y', 'z', 'pz', 'res'), out[True], (y_r, z_r, pz_r, res_r)):
+        assert a.shape == b.shape and rel(a, b) < 1e-4, (n, rel(a, b))
+    assert (out[True][1][-1] - out[True][1][0]).abs().max() > 1e-3           # the samples do differ from frame to frame

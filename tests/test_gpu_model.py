@@ -520,6 +520,40 @@ def test_batched_samples_match_per_sample_forward(archi, nc, skipco):
     assert torch.equal(m.sample(x, nt, S, dt=0.5, tape=dict(eps_y0=eps_y0, eps_z=eps_z), chunk=1), xs)
 
 
+def test_sample_more_rows_than_one_persistent_launch():
+    """model.sample with more (video, future) rows than ONE co-resident generation launch holds (16 clusters of 32 rows at 512 hidden units: 600
+    rows = 19 tiles run as two launches, tile0 > 0 in the second) with and without decoder chunking, and against the per-layer launch sequence."""
+    import srvp_amd
+    from srvp_amd import latent as LT
+    dev = torch.device('cuda')
+    torch.manual_seed(3)
+    m = srvp_amd.StochasticLatentResidualVideoPredictor(64, 1, 8, 32, 20, 20, False, 2, 64, 2, 512, 4, 'dcgan')
+    m.init(0.8)
+    m.to(dev).train()
+    T, B, nt, S = 3, 2, 5, 300
+    x = torch.rand(T, B, 1, 64, 64, generator=torch.Generator().manual_seed(4)).to(dev)
+    with torch.no_grad():
+        for _ in range(10):
+            m(x, T, 0.5)
+    m.eval()
+    g = torch.Generator().manual_seed(9)
+    tape = dict(eps_y0=torch.randn(S * B, 20, generator=g).to(dev), eps_z=torch.randn(nt - 1, S * B, 20, generator=g).to(dev))
+    whole = m.sample(x, nt, S, dt=0.5, tape=tape)
+    assert m._last_sample_lat._rd.fused_ws                      # the persistent generation launches were taken
+    chunked = m.sample(x, nt, S, dt=0.5, tape=tape, chunk=60)
+    assert torch.equal(chunked, whole)
+    LT.ROLLOUT_GEN_FUSED = False
+    try:
+        m.drop_sample_plans()
+        launches = m.sample(x, nt, S, dt=0.5, tape=tape, chunk=60)
+        assert not m._last_sample_lat._rd.fused_ws
+    finally:
+        LT.ROLLOUT_GEN_FUSED = True
+        m.drop_sample_plans()
+    assert (launches - chunked).abs().max().item() < 2e-3
+    assert (whole[:, 0] - whole[:, 299]).abs().max() > 1e-5     # the futures do differ (an untrained decoder barely shows it)
+
+
 def test_evaluate_best_of_n_psnr():
     """train.evaluate (reference train.py:132-189): best-of-n_samples_test PSNR per video over the predicted frames, with the
     samples drawn by model.sample and the PSNR by the device metrics kernel -- against the same selection done with the
