@@ -49,6 +49,8 @@ SUB_D = [(2,), (1, 2), (0, 1), (0,)]
 # collects output rows 2 ih - 1 + kh; output row parity a -> [(kernel index kh, padded row offset dy into the s2d tensor)]
 S2D_UP = {0: [(1, 1), (3, 2)], 1: [(0, 0), (2, 1)]}
 S2D_UP_ON = os.environ.get('SRVP_UP_S2D', '1') != '0'
+WGRAD_S2D_SHIFT_SRC = os.environ.get('SRVP_WGRAD_S2D_SHIFT_SRC', '1') != '0'   # 16-tap weight gradients of the 4x4 stride-2 blocks in the sub-pixel blocks' form (halo kernel)
+PHASES_ONE_GRID = os.environ.get('SRVP_PHASES_ONE_GRID', '1') != '0'    # the four phase launches of a 4x4 stride-2 block (forward of 'up', data gradient of 'down') as one grid
 DOWN_S2D = os.environ.get('SRVP_DOWN_S2D', '1') != '0'        # 4x4 stride-2 encoder layers on a space-to-depth source (no skip connections)
 
 
@@ -636,6 +638,7 @@ class Block:
 
     def dgrad_descs(self):
         """ConvDesc list computing dcat = gradient wrt the block input from draw."""
+        self.__dict__.pop('_dg_arr', None)
         out = self._dgrad_descs_raw()
         if self.s2d:
             out[0].wt_fragmajor, out[0].elem_f32 = 1, 0
@@ -772,10 +775,18 @@ class Block:
         self._src_fields(d, None)
         b_in = self.srcs[0].b
         d.ntaps = 16
-        d.dy, d.dx = L.taps([b_in] * 16), L.taps([b_in] * 16)
         ent = [(dy, dx) for a, b in [(0, 0), (0, 1), (1, 0), (1, 1)] for _, dy in S2D_UP[a] for _, dx in S2D_UP[b]]
         d.si, d.so = 1, 1
-        d.ooy, d.oox = L.taps([e[0] for e in ent]), L.taps([e[1] for e in ent])
+        if WGRAD_S2D_SHIFT_SRC and b_in == 1:
+            # the same sum with the index shifted by the tap's offset (p' = p + o_t - 1): the channel-sliced gradient is read at the FIXED interior
+            # position and the tap moves the plain source instead, inside its 3x3 window (both tensors carry zero borders) -- the shape of a
+            # sub-pixel block's 16-tap weight gradient, which the halo kernel takes two phases per workgroup over one staged patch
+            # (wgrad_halo_kernel<.., 8, 2>; grids narrower than 8 columns stay on the per-tap kernel)
+            d.dy, d.dx = L.taps([2 - e[0] for e in ent]), L.taps([2 - e[1] for e in ent])
+            d.ooy, d.oox = L.taps([1] * 16), L.taps([1] * 16)
+        else:
+            d.dy, d.dx = L.taps([b_in] * 16), L.taps([b_in] * 16)
+            d.ooy, d.oox = L.taps([e[0] for e in ent]), L.taps([e[1] for e in ent])
         d.dout, d.Cout, d.dout_cstride, d.dout_coff, d.dout_phase_taps = L.ptr(self.draw), self.cout, 4 * self.cout, 0, 4
         d.DHp, d.DWp = self.Hin + 2, self.Win + 2
         d.N, d.OH, d.OW = self.N, self.Hin, self.Win
@@ -802,10 +813,15 @@ class Block:
         d.src0, d.C0, d.H0p, d.W0p, d.ups0 = L.ptr(self.draw), self.cout, self.OH + 2 * bd, self.OW + 2 * bd, 0
         d.src1, d.C1, d.H1p, d.W1p, d.ups1, d.map1 = None, 0, 1, 1, 0, None
         d.ntaps = 16
-        d.dy, d.dx = L.taps([bd] * 16), L.taps([bd] * 16)
         ent = [(dy, dx) for a, b in [(0, 0), (0, 1), (1, 0), (1, 1)] for _, dy in S2D_UP[a] for _, dx in S2D_UP[b]]
         d.si, d.so = 1, 1
-        d.ooy, d.oox = L.taps([e[0] for e in ent]), L.taps([e[1] for e in ent])
+        if WGRAD_S2D_SHIFT_SRC and bd == 1:
+            # (as in _wgrad_s2d_up: the s2d operand at its fixed interior position, the tap moves the plain one inside its 3x3 window)
+            d.dy, d.dx = L.taps([2 - e[0] for e in ent]), L.taps([2 - e[1] for e in ent])
+            d.ooy, d.oox = L.taps([1] * 16), L.taps([1] * 16)
+        else:
+            d.dy, d.dx = L.taps([bd] * 16), L.taps([bd] * 16)
+            d.ooy, d.oox = L.taps([e[0] for e in ent]), L.taps([e[1] for e in ent])
         d.dout, d.Cout, d.dout_cstride, d.dout_coff, d.dout_phase_taps = L.ptr(f0.t), f0.C, 4 * f0.C, 0, 4
         d.DHp, d.DWp = f0.H // 2 + 2, f0.W // 2 + 2
         d.N, d.OH, d.OW = self.N, self.OH, self.OW
@@ -1063,6 +1079,14 @@ class ConvNetBase:
             if arr is None:
                 arr = blk._fwd_arr = (L.ConvDesc * 4)(*blk._fwd[-4:])
             L.call('srvp_conv_mfma_multi', arr, 4, st)
+        elif blk.geom == 'up' and len(blk._fwd) == 4 and PHASES_ONE_GRID:
+            # transposed 4x4 stride-2 block (conv.py:299-304): its four output phases as ONE grid (same shapes: the library runs them on the
+            # halo kernel back to back per tile, or one after the other where it cannot)
+            arr = blk.__dict__.get('_fwd_arr')
+            if arr is None:
+                arr = blk._fwd_arr = (L.ConvDesc * 4)(*blk._fwd)
+            L.call('srvp_conv_mfma_multi', arr, 4, st)
+            blk.finish_fwd(st)
         else:
             for d in (blk._fwd[1:] if (blk.split and getattr(self, '_skips_done', False)) else blk._fwd):
                 L.call('srvp_conv_mfma', C.byref(d), st)
@@ -1132,8 +1156,15 @@ class ConvNetBase:
         if wgrad:
             self._wgrad(blk, st)
         if need_dgrad:
-            for d in blk._dg:
-                L.call('srvp_conv_mfma', C.byref(d), st)
+            if blk.geom == 'down' and len(blk._dg) == 4 and PHASES_ONE_GRID:
+                # data gradient of a 4x4 stride-2 block: the four input phases as ONE grid
+                arr = blk.__dict__.get('_dg_arr')
+                if arr is None:
+                    arr = blk._dg_arr = (L.ConvDesc * 4)(*blk._dg)
+                L.call('srvp_conv_mfma_multi', arr, 4, st)
+            else:
+                for d in blk._dg:
+                    L.call('srvp_conv_mfma', C.byref(d), st)
             blk.finish_dgrad(st)
 
     # ---- whole-network launches: every layer's pack / unpack in ONE kernel (device-resident job table, rebuilt only when a

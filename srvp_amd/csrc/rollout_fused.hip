@@ -35,6 +35,7 @@ struct RollF {
     // backward
     const float* d_y_all; const float* d_res; float* dhid; float* dinp_all; float* d_y0; int dwd;
     float* part; unsigned* cnt; int xcd_local;
+    unsigned long long* dbg;                              // SRVP_RF_DEBUG=1: per-phase time of cluster 0 / member 0 (10 ns ticks), else null
 };
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -246,6 +247,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int grow = row0 + arow_l < B ? row0 + arow_l : B - 1;
     const size_t hs = (size_t)a.S * B * nh;               // layer stride of hid
 
+    // SRVP_RF_DEBUG: where a step's time goes (member 0 of cluster 0; s_memrealtime = 100 MHz): 0 stage + layer 0, 1 epilogue + barrier 1,
+    // 2 hidden GEMM 1, 3 epilogue + barrier 2, 4 hidden GEMM 2, 5 last layer partials, 6 barrier 3, 7 slab sum + update
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    const bool dbg = a.dbg != nullptr && cl == 0 && g == 0;
+    auto tick = [&](int k) {
+        if (dbg) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); tacc[k] += t - tprev; tprev = t; }
+    };
+    if (dbg) tprev = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < a.S; ++i) {
         // ---- stage [y_i, z] (z part prefilled in inp_all by the caller, constant during the kernel)
 #pragma unroll
@@ -267,6 +276,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[16 * j + e], w0[j * 4 + e], acc, 0, 0, 0);
             }
         }
+        tick(0);
         for (int l = 0; l <= nfull; ++l) {
             // epilogue of full-output layer l: bias, ReLU, store the saved activation (= the exchange buffer)
             float* hdst = a.hid + (size_t)l * hs + (size_t)i * B * nh;
@@ -281,9 +291,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (l == nfull) break;
             bl = a.b[l + 1][colbase + cc];
             cluster_barrier(cnt, target += a.G);
+            tick(l == 0 ? 1 : 3);
             // ---- layer l + 1: A = complete hidden tile from global, B = LDS slice
             acc = f32x4v{0.f, 0.f, 0.f, 0.f};
             gemm_glob_lds(acc, hdst + (size_t)grow * nh, Wl + (size_t)l * nh * CW, nh, q, cc);
+            tick(l == 0 ? 2 : 4);
         }
         __syncthreads();                                  // Hs complete
         // ---- last layer, split-K over the cluster: partial[32 x ny] from this workgroup's 32 hidden units
@@ -300,7 +312,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int e = 0; e < 4; ++e) st_x(pdst + (16 * trh + 4 * q + e) * NYP_MAX + 16 * ct + c16, o[e], xl);
         }
+        tick(5);
         cluster_barrier(cnt, target += a.G);
+        tick(6);
         // ---- every workgroup: sum the G partials in a fixed order, Euler update of its copy of the state
         const float* psrc = part + (size_t)i * a.G * RT * KP0_MAX;
         const int nq = a.nyp / 4;                          // 4-column items per row
@@ -331,7 +345,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
         __syncthreads();
+        tick(7);
     }
+    if (dbg && tid == 0)
+        for (int k = 0; k < 8; ++k) a.dbg[k] = tacc[k];
 }
 
 // ------------------------------------------------------------------------------------------------------------ backward
@@ -1128,11 +1145,26 @@ int srvp_rollout_fused_fwd(const srvp_rollout_desc* d, hipStream_t st) {
     SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd(fused): memset failed");
     int cpx;
     const int per = clusters_per_launch(k.G, tiles, cpx);
+    static int dbg_on = -1;
+    static unsigned long long* dbg_buf = nullptr;
+    if (dbg_on < 0) { const char* e2 = getenv("SRVP_RF_DEBUG"); dbg_on = e2 ? atoi(e2) : 0; }
+    if (dbg_on && !dbg_buf) (void)hipMalloc(&dbg_buf, 8 * sizeof(unsigned long long));
+    k.dbg = dbg_on ? dbg_buf : nullptr;
     for (int t0 = 0; t0 < tiles; t0 += per) {
         k.tile0 = t0; k.ntiles = tiles - t0 < per ? tiles - t0 : per; k.cl_per_xcd = cpx;
         hipLaunchKernelGGL(kern, dim3(8 * cpx * k.G), dim3(256), lds, st, k);
     }
     SRVP_CHECK_LAUNCH("srvp_rollout_fwd(fused)");
+    if (dbg_on && dbg_buf) {
+        // diagnostic only (synchronises): per-phase microseconds per Euler step of cluster 0 / member 0
+        unsigned long long h[8];
+        if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "[SRVP_RF_DEBUG] rollout_fused_fwd B=%d S=%d us/step:", k.B, k.S);
+            static const char* nm[8] = {"stage+L0", "epi+bar1", "gemm1", "epi+bar2", "gemm2", "lastL", "bar3", "sum+upd"};
+            for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.2f", nm[i], h[i] * 0.01 / k.S);
+            fprintf(stderr, "\n");
+        }
+    }
     return SRVP_OK;
 }
 

@@ -615,7 +615,9 @@ static void launch_in_fwd(const float* x, const float* w, bf16_t* raw, double* s
     const long long ntiles = (long long)N * InGeom<KS, S, CIN>::TPI;
     static int tpw_env = -1;
     if (tpw_env < 0) { const char* e = getenv("SRVP_IN_TPW_F"); tpw_env = e ? atoi(e) : 0; }
-    const int tpw = tpw_env > 0 ? tpw_env : (ntiles >= 32768 ? 8 : (ntiles >= 16 ? 2 : 1));
+    // tiles per (persistent) workgroup: ~2048 workgroups per launch, at most 8 tiles each (round 5: the step function 2 / 8 at 32768 tiles left
+    // the 15360-tile layers of config 2 and the 9216-tile layer of a 24-sequence step with 2 tiles and one statistics epilogue per 2 tiles)
+    const int tpw = tpw_env > 0 ? tpw_env : (int)(ntiles / 2048 < 1 ? 1 : (ntiles / 2048 > 8 ? 8 : ntiles / 2048));
     const dim3 grid((unsigned)((ntiles + tpw - 1) / tpw));
     if (bnr_red) {
         if (Cout == 64) hipLaunchKernelGGL((conv_in_fwd_mfma_kernel<KS, S, CIN, 2, true>), grid, dim3(256), 0, st, x, w, raw, stats, N, Cout, Cout_real, tpw, bnr_raw, bnr_coef, bnr_red);
@@ -630,7 +632,9 @@ static void launch_in_wgrad(const float* x, const bf16_t* draw, float* dw, int N
     const long long ntiles = (long long)N * InGeom<KS, S, CIN>::TPI;
     static int tpw_env = -1;
     if (tpw_env < 0) { const char* e = getenv("SRVP_IN_TPW_W"); tpw_env = e ? atoi(e) : 0; }
-    const int tpw = tpw_env > 0 ? tpw_env : (ntiles >= 32768 ? 16 : (ntiles >= 16 ? 2 : 1));
+    // tiles per workgroup: every workgroup ends with an LDS reduction + Cout x K fp32 atomics, so few, long workgroups: ~1024 per launch, at
+    // most 16 tiles each (round 5: was 2 below 32768 tiles -- 7680 epilogues for the 15360 tiles of config 2's image-side layers)
+    const int tpw = tpw_env > 0 ? tpw_env : (int)(ntiles / 1024 < 1 ? 1 : (ntiles / 1024 > 16 ? 16 : ntiles / 1024));
     static int split3 = -1;     // A/B switch: 1 = three-term bf16 split on the bf16 matrix cores, 0 = fp32 MFMA
     if (split3 < 0) { const char* e = getenv("SRVP_IN_WGRAD_SPLIT3"); split3 = e ? atoi(e) : 1; }
     const dim3 grid((unsigned)((ntiles + tpw - 1) / tpw));
@@ -645,7 +649,7 @@ static void launch_in_wgrad(const float* x, const bf16_t* draw, float* dw, int N
 template <int CIN>
 static void launch_in_wgrad_bn(const float* x, float* dw, int N, int Cout, int Cout_real, const InWgradBn& fb, hipStream_t st) {
     const long long ntiles = (long long)N * InGeom<3, 1, CIN>::TPI;
-    const int tpw = ntiles >= 32768 ? 16 : (ntiles >= 16 ? 2 : 1);
+    const int tpw = (int)(ntiles / 1024 < 1 ? 1 : (ntiles / 1024 > 16 ? 16 : ntiles / 1024));      // (as launch_in_wgrad)
     const dim3 grid((unsigned)((ntiles + tpw - 1) / tpw));
     hipLaunchKernelGGL((conv_in_wgrad_mfma3_kernel<3, 1, CIN, 2, true>), grid, dim3(256), 0, st, x, (const bf16_t*)nullptr, dw, N, Cout, Cout_real, tpw, fb);
 }
