@@ -40,9 +40,13 @@ struct RollF {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-// B-operand slice [K][32] in LDS: element (k, c) -- two k rows per 64-float line, 16-float groups XOR-swizzled by the
-// line-pair index so that the four k rows {k0 + 4 q} one MFMA reads (lane group q) fall on four disjoint bank groups
-__device__ __forceinline__ int sw(int k, int c) { return (k >> 1) * 64 + ((((k & 1) << 5) | c) ^ (((k >> 2) & 3) << 4)); }
+// B-operand slice [K][32] in LDS: element (k, c) at [k / 4][c][k % 4] -- the four consecutive k values one lane feeds to four MFMAs
+// are ONE 16-byte read (ds_read_b128; the 16 lanes of a k group read 256 contiguous bytes: conflict-free).  Round 5 (SRVP_RF_DEBUG
+// timestamps): with one 4-byte LDS read in front of every v_mfma_f32_16x16x4_f32 and one wave per SIMD the K = 512 GEMM of a hidden
+// layer took 5.1 us of a 20 us Euler step -- 96 cycles per MFMA, the LDS latency un-overlapped -- against 1.7 us of MFMA issue.
+__device__ __forceinline__ int sw(int k, int c) { return (k >> 2) * 128 + c * 4 + (k & 3); }
+constexpr int IPAD = 4;          // padding of the LDS staging tiles' rows (floats): rows stay 16-byte aligned for ds_read_b128 and sixteen
+                                 // consecutive rows at one column fall on all 64 banks (row strides 116 / 68 floats: 52 i mod 64 and 4 i mod 64 are distinct multiples of 4)
 
 // Everything the workgroups of a cluster exchange inside the kernel is written and read with AGENT-SCOPE accesses (sc1:
 // write-through / miss-always, the code the compiler emits for relaxed agent-scope atomics), so the barrier needs no cache
@@ -126,25 +130,63 @@ __device__ __forceinline__ void ld_chunk(f32x4v (&a4)[8], const float* p, int k0
         asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(a4[j]) : "v"(p + k) : "memory");
     }
 }
-__device__ __forceinline__ void mm_chunk(f32x4v& acc, f32x4v (&a4)[8], const float* Bs, int k0, int K, int q, int cc) {
+__device__ __forceinline__ void ld_chunk_plain(f32x4v (&b4)[8], const float* p, int k0, int K) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + 16 * j < K ? k0 + 16 * j : K - 16;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(b4[j]) : "v"(p + k) : "memory");
+    }
+}
+// B fragments of a 128-wide K chunk: eight 16-byte LDS reads per lane (k = k0 + 16 j + 4 q .. + 3, column cc)
+__device__ __forceinline__ void ld_b_chunk(f32x4v (&b4)[8], const float* Bs, int k0, int K, int q, int cc) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + 16 * j < K ? k0 + 16 * j : K - 16;
+        b4[j] = *reinterpret_cast<const f32x4v*>(Bs + ((k >> 2) + q) * 128 + cc * 4);
+    }
+}
+__device__ __forceinline__ void mm_chunk(f32x4v& acc, f32x4v (&a4)[8], f32x4v (&b4)[8], int k0, int K) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         if (k0 + 16 * j >= K) break;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j][e], Bs[sw(k0 + 16 * j + 4 * q + e, cc)], acc, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j][e], b4[j][e], acc, 0, 0, 0);
     }
 }
 #define WAIT_A4(buf, n) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7]) :: "memory")
+// CACHED (the training kernels in XCD-local mode): the A tile is read with PLAIN loads, i.e. through the CU's vector L1.  Valid there because
+// every exchanged address of those kernels is written ONCE per launch (saved activations / deltas of step i, fresh partial slabs) and first read
+// after the barrier that follows its writes, so the L1 -- invalidated at kernel start, never refreshed by other CUs' stores -- cannot hold an
+// older copy of it.  What it buys (SRVP_RF_DEBUG: a K = 512 hidden-layer GEMM took 4.9 us for 1.7 us of MFMA issue, and neither the LDS operand
+// path nor the clock was the reason): the two waves that share a row half no longer fetch the same 32 KB from L2 twice, and the two 64-byte
+// halves of a line requested by consecutive k groups are one L2 request.  The generation kernel rewrites its buffers every step and keeps sc1.
+template <bool CACHED = false>
 __device__ __forceinline__ void gemm_glob_lds(f32x4v& acc, const float* arow, const float* Bs, int K, int q, int cc) {
     const float* p = arow + 4 * q;
     for (int k0 = 0; k0 < K; k0 += 512) {
-        f32x4v b0[8], b1[8], b2[8], b3[8];
-        ld_chunk(b0, p, k0, K); ld_chunk(b1, p, k0 + 128, K); ld_chunk(b2, p, k0 + 256, K); ld_chunk(b3, p, k0 + 384, K);
-        WAIT_A4(b0, 24); mm_chunk(acc, b0, Bs, k0, K, q, cc);
-        WAIT_A4(b1, 16); mm_chunk(acc, b1, Bs, k0 + 128, K, q, cc);
-        WAIT_A4(b2, 8); mm_chunk(acc, b2, Bs, k0 + 256, K, q, cc);
-        WAIT_A4(b3, 0); mm_chunk(acc, b3, Bs, k0 + 384, K, q, cc);
+        f32x4v b0[8], b1[8], b2[8], b3[8], w0[8], w1[8];
+        if constexpr (CACHED) { ld_chunk_plain(b0, p, k0, K); ld_chunk_plain(b1, p, k0 + 128, K); ld_chunk_plain(b2, p, k0 + 256, K); ld_chunk_plain(b3, p, k0 + 384, K); }
+        else { ld_chunk(b0, p, k0, K); ld_chunk(b1, p, k0 + 128, K); ld_chunk(b2, p, k0 + 256, K); ld_chunk(b3, p, k0 + 384, K); }
+        // the B fragments of chunk i + 1 are requested from LDS before the MFMAs of chunk i (two register sets in turn)
+        ld_b_chunk(w0, Bs, k0, K, q, cc);
+        WAIT_A4(b0, 24); ld_b_chunk(w1, Bs, k0 + 128, K, q, cc); mm_chunk(acc, b0, w0, k0, K);
+        WAIT_A4(b1, 16); ld_b_chunk(w0, Bs, k0 + 256, K, q, cc); mm_chunk(acc, b1, w1, k0 + 128, K);
+        WAIT_A4(b2, 8); ld_b_chunk(w1, Bs, k0 + 384, K, q, cc); mm_chunk(acc, b2, w0, k0 + 256, K);
+        WAIT_A4(b3, 0); mm_chunk(acc, b3, w1, k0 + 384, K);
+    }
+}
+
+// acc(16x16) += A(LDS staging tile, rows 16-byte aligned) x B(register fragments): all A reads (one ds_read_b128 per 16 k) before the MFMAs
+template <int NJ>
+__device__ __forceinline__ void gemm_lds_reg(f32x4v& acc, const float* ar, const float (&w)[NJ * 4], int kw) {
+    f32x4v av[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) av[j] = *reinterpret_cast<const f32x4v*>(ar + (16 * j < kw ? 16 * j : 0));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (16 * j >= kw) break;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][e], w[j * 4 + e], acc, 0, 0, 0);
     }
 }
 
@@ -181,10 +223,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int colbase = g * CW;
     const int nl = a.nl, nh = a.nh, ny = a.ny, nin = a.nin, B = a.B;
     const int nfull = nl - 2;                             // hidden layers with K = nh (LDS-resident slices)
-    // LDS: [nfull][nh][32] slices | Is [32][kp0 + 1] | Ys [32][ny] | Hs [32][33]
+    // LDS: [nfull][nh][32] slices | Is [32][kp0 + IPAD] | Ys [32][ny] | Hs [32][33]
     float* Wl = lds;
     float* Is = Wl + (size_t)nfull * nh * CW;
-    float* Ys = Is + RT * (a.kp0 + 1);
+    float* Ys = Is + RT * (a.kp0 + IPAD);
     float* Hs = Ys + RT * ny;
     float* Bl = Hs + RT * 33;                             // bias of the last layer
     unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;       // one 256-byte line per cluster
@@ -254,28 +296,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto tick = [&](int k) {
         if (dbg) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); tacc[k] += t - tprev; tprev = t; }
     };
-    if (dbg) tprev = __builtin_amdgcn_s_memrealtime();
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (dbg) { tprev = rt0 = __builtin_amdgcn_s_memrealtime(); clk0 = __builtin_readcyclecounter(); }
     for (int i = 0; i < a.S; ++i) {
         // ---- stage [y_i, z] (z part prefilled in inp_all by the caller, constant during the kernel)
 #pragma unroll
         for (int u = 0; u < KP0_MAX * RT / 256; ++u) {
             const int idx = tid + 256 * u, r = idx / a.kp0, k = idx - r * a.kp0;
-            if (idx < RT * a.kp0) Is[r * (a.kp0 + 1) + k] = k < ny ? Ys[r * ny + k] : zr[u];
+            if (idx < RT * a.kp0) Is[r * (a.kp0 + IPAD) + k] = k < ny ? Ys[r * ny + k] : zr[u];
         }
         if (i + 1 < a.S) fetch_z(i + 1);
         __syncthreads();
         // ---- layer 0: A from LDS, B from registers
         f32x4v acc = {0.f, 0.f, 0.f, 0.f};
         float bl = a.b[0][colbase + cc];                  // bias of the layer being finished (loaded ahead of its use)
-        {
-            const float* ar = Is + arow_l * (a.kp0 + 1) + 4 * q;
-#pragma unroll
-            for (int j = 0; j < KP0_MAX / 16; ++j) {
-                if (16 * j >= a.kp0) break;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[16 * j + e], w0[j * 4 + e], acc, 0, 0, 0);
-            }
-        }
+        gemm_lds_reg<KP0_MAX / 16>(acc, Is + arow_l * (a.kp0 + IPAD) + 4 * q, w0, a.kp0);
         tick(0);
         for (int l = 0; l <= nfull; ++l) {
             // epilogue of full-output layer l: bias, ReLU, store the saved activation (= the exchange buffer)
@@ -294,7 +329,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             tick(l == 0 ? 1 : 3);
             // ---- layer l + 1: A = complete hidden tile from global, B = LDS slice
             acc = f32x4v{0.f, 0.f, 0.f, 0.f};
-            gemm_glob_lds(acc, hdst + (size_t)grow * nh, Wl + (size_t)l * nh * CW, nh, q, cc);
+            if (xl) gemm_glob_lds<true>(acc, hdst + (size_t)grow * nh, Wl + (size_t)l * nh * CW, nh, q, cc);
+            else gemm_glob_lds<false>(acc, hdst + (size_t)grow * nh, Wl + (size_t)l * nh * CW, nh, q, cc);
             tick(l == 0 ? 2 : 4);
         }
         __syncthreads();                                  // Hs complete
@@ -347,8 +383,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __syncthreads();
         tick(7);
     }
-    if (dbg && tid == 0)
+    if (dbg && tid == 0) {
         for (int k = 0; k < 8; ++k) a.dbg[k] = tacc[k];
+        a.dbg[8] = __builtin_readcyclecounter() - clk0;          // s_memtime ticks ...
+        a.dbg[9] = __builtin_amdgcn_s_memrealtime() - rt0;       // ... per 100 MHz ticks = the shader clock the chain ran at
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------ backward
@@ -366,10 +405,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int colbase = g * CW;
     const int nl = a.nl, nh = a.nh, ny = a.ny, nin = a.nin, B = a.B, dwd = a.dwd;
     const int nfull = nl - 2;
-    // LDS: [nfull][nh][32] slices (B[k][c] = W_l[k][colbase + c], l = nl-2 .. 1) | Do [32][nyp + 1] | Dy [32][ny] | Hs [32][33]
+    // LDS: [nfull][nh][32] slices (B[k][c] = W_l[k][colbase + c], l = nl-2 .. 1) | Do [32][nyp + IPAD] | Dy [32][ny] | Hs [32][33]
     float* Wl = lds;
     float* Do = Wl + (size_t)nfull * nh * CW;
-    float* Dy = Do + RT * (a.nyp + 1);
+    float* Dy = Do + RT * (a.nyp + IPAD);
     float* Hs = Dy + RT * ny;
     unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;
     float* part = a.part + (size_t)(a.tile0 + cl) * a.S * a.G * RT * KP0_MAX;       // fresh slab per step (see the forward kernel)
@@ -449,21 +488,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 v = a.dt * (dres[u] + Dy[r * ny + c]);
                 if (g == 0 && row0 + r < B) a.dhid[(size_t)(nl - 1) * ds + ((size_t)i * B + row0 + r) * dwd + c] = v;
             }
-            Do[r * (a.nyp + 1) + c] = v;
+            Do[r * (a.nyp + IPAD) + c] = v;
         }
         if (i > 0) fetch_dres(i - 1);
         __syncthreads();
         // ---- delta_{nl-2} slice: A = dout (LDS), B = registers
         f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-        {
-            const float* ar = Do + arow_l * (a.nyp + 1) + 4 * q;
-#pragma unroll
-            for (int j = 0; j < NYP_MAX / 16; ++j) {
-                if (16 * j >= a.nyp) break;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[16 * j + e], wlb[j * 4 + e], acc, 0, 0, 0);
-            }
-        }
+        gemm_lds_reg<NYP_MAX / 16>(acc, Do + arow_l * (a.nyp + IPAD) + 4 * q, wlb, a.nyp);
         for (int l = nl - 2; l >= 0; --l) {
             // epilogue: delta_l = acc * relu'(h_l) (mask from the saved post-ReLU activation), stored for the weight gradients
             float* ddst = a.dhid + (size_t)l * ds + (size_t)i * B * dwd;
@@ -479,7 +510,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             cluster_barrier(cnt, target += a.G);
             // ---- delta_{l-1} slice: A = complete delta_l tile (global), B = LDS slice of W_l
             acc = f32x4v{0.f, 0.f, 0.f, 0.f};
-            gemm_glob_lds(acc, ddst + (size_t)grow * dwd, Wl + (size_t)(l - 1) * nh * CW, nh, q, cc);
+            if (xl) gemm_glob_lds<true>(acc, ddst + (size_t)grow * dwd, Wl + (size_t)(l - 1) * nh * CW, nh, q, cc);
+            else gemm_glob_lds<false>(acc, ddst + (size_t)grow * dwd, Wl + (size_t)(l - 1) * nh * CW, nh, q, cc);
         }
         __syncthreads();
         // ---- dinp partial (split-K over the cluster)
@@ -567,13 +599,6 @@ struct GenF {
 
 __device__ __forceinline__ float softplus_g(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
 
-__device__ __forceinline__ void ld_chunk_plain(f32x4v (&b4)[8], const float* p, int k0, int K) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = k0 + 16 * j < K ? k0 + 16 * j : K - 16;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(b4[j]) : "v"(p + k) : "memory");
-    }
-}
 __device__ __forceinline__ void mm_chunk_rr(f32x4v& acc, f32x4v (&a4)[8], f32x4v (&b4)[8], int k0, int K) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -609,8 +634,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int colbase = g * CW;
     const int nl = a.nl, nh = a.nh, ny = a.ny, nz = a.nz, nin = a.nin, B = a.B, kp0 = a.kp0;
     const int nfull = nl - 2;
-    const int ils = kp0 + 1;                              // row stride of the staging tile
-    // LDS: [nfull][nh][32] dynamics slices | Is [32][kp0 + 1] (also the summed prior parameters) | Ys [32][ny] | Zs [32][nz] | Hs [32][33] | biases
+    const int ils = kp0 + IPAD;                           // row stride of the staging tile
+    // LDS: [nfull][nh][32] dynamics slices | Is [32][kp0 + IPAD] (also the summed prior parameters) | Ys [32][ny] | Zs [32][nz] | Hs [32][33] | biases
     float* Wl = lds;
     float* Is = Wl + (size_t)nfull * nh * CW;
     float* Ys = Is + RT * ils;
@@ -694,15 +719,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __syncthreads();
             f32x4v acc = {0.f, 0.f, 0.f, 0.f};
             float bl = a.Pb[0][colbase + cc];
-            {
-                const float* ar = Is + arow_l * ils + 4 * q;
-#pragma unroll
-                for (int j = 0; j < NYP_MAX / 16; ++j) {
-                    if (16 * j >= a.nyp) break;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[16 * j + e], pw0[j * 4 + e], acc, 0, 0, 0);
-                }
-            }
+            gemm_lds_reg<NYP_MAX / 16>(acc, Is + arow_l * ils + 4 * q, pw0, a.nyp);
             for (int l = 0; l <= nfull; ++l) {
                 float* hdst = hbuf + (size_t)l * hls;
 #pragma unroll
@@ -794,15 +811,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // =============================== one residual step (as rollout_fused_fwd_kernel, nothing saved)
         f32x4v acc = {0.f, 0.f, 0.f, 0.f};
         float bl = a.b[0][colbase + cc];
-        {
-            const float* ar = Is + arow_l * ils + 4 * q;
-#pragma unroll
-            for (int j = 0; j < KP0_MAX / 16; ++j) {
-                if (16 * j >= kp0) break;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[16 * j + e], w0[j * 4 + e], acc, 0, 0, 0);
-            }
-        }
+        gemm_lds_reg<KP0_MAX / 16>(acc, Is + arow_l * ils + 4 * q, w0, kp0);
         for (int l = 0; l <= nfull; ++l) {
             float* hdst = hbuf + (size_t)l * hls;
 #pragma unroll
@@ -1106,8 +1115,8 @@ extern "C" int64_t srvp_rollout_fused_ws_bytes(const srvp_rollout_desc* d) {
     if (!d->pz_external || !d->hid_dyn) return 0;
     if (!clusters_fit(d->nh / CW)) return 0;
     const int kp0 = (nin + 15) / 16 * 16, nyp = (d->ny + 15) / 16 * 16;
-    const size_t lds_f = ((size_t)(d->nl - 2) * d->nh * CW + RT * (kp0 + 1) + RT * d->ny + RT * 33 + NYP_MAX) * 4;
-    const size_t lds_b = ((size_t)(d->nl - 2) * d->nh * CW + RT * (nyp + 1) + RT * d->ny + RT * 33) * 4;
+    const size_t lds_f = ((size_t)(d->nl - 2) * d->nh * CW + RT * (kp0 + IPAD) + RT * d->ny + RT * 33 + NYP_MAX) * 4;
+    const size_t lds_b = ((size_t)(d->nl - 2) * d->nh * CW + RT * (nyp + IPAD) + RT * d->ny + RT * 33) * 4;
     if (lds_f > 160 * 1024 || lds_b > 160 * 1024) return 0;
     const int64_t tiles = (d->B + RT - 1) / RT;
     return tiles * 256 /* counters (padded) */ + tiles * (int64_t)d->nsteps * (d->nh / CW) * RT * KP0_MAX * 4;
@@ -1137,7 +1146,7 @@ int srvp_rollout_fused_fwd(const srvp_rollout_desc* d, hipStream_t st) {
     RollF k{};
     const int tiles = fused_common(*d, k, d->fused_ws);
     k.y0 = d->y0; k.y_all = d->y_all; k.res = d->res; k.inp_all = d->inp_all; k.hid = d->hid_dyn;
-    const size_t lds = ((size_t)(k.nl - 2) * k.nh * CW + RT * (k.kp0 + 1) + RT * k.ny + RT * 33 + NYP_MAX) * 4;
+    const size_t lds = ((size_t)(k.nl - 2) * k.nh * CW + RT * (k.kp0 + IPAD) + RT * k.ny + RT * 33 + NYP_MAX) * 4;
     auto kern = k.G <= 8 ? rollout_fused_fwd_kernel<8> : (k.G <= 16 ? rollout_fused_fwd_kernel<16> : rollout_fused_fwd_kernel<32>);
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd(fused): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
@@ -1148,7 +1157,7 @@ int srvp_rollout_fused_fwd(const srvp_rollout_desc* d, hipStream_t st) {
     static int dbg_on = -1;
     static unsigned long long* dbg_buf = nullptr;
     if (dbg_on < 0) { const char* e2 = getenv("SRVP_RF_DEBUG"); dbg_on = e2 ? atoi(e2) : 0; }
-    if (dbg_on && !dbg_buf) (void)hipMalloc(&dbg_buf, 8 * sizeof(unsigned long long));
+    if (dbg_on && !dbg_buf) (void)hipMalloc(&dbg_buf, 10 * sizeof(unsigned long long));
     k.dbg = dbg_on ? dbg_buf : nullptr;
     for (int t0 = 0; t0 < tiles; t0 += per) {
         k.tile0 = t0; k.ntiles = tiles - t0 < per ? tiles - t0 : per; k.cl_per_xcd = cpx;
@@ -1157,11 +1166,12 @@ int srvp_rollout_fused_fwd(const srvp_rollout_desc* d, hipStream_t st) {
     SRVP_CHECK_LAUNCH("srvp_rollout_fwd(fused)");
     if (dbg_on && dbg_buf) {
         // diagnostic only (synchronises): per-phase microseconds per Euler step of cluster 0 / member 0
-        unsigned long long h[8];
+        unsigned long long h[10];
         if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "[SRVP_RF_DEBUG] rollout_fused_fwd B=%d S=%d us/step:", k.B, k.S);
             static const char* nm[8] = {"stage+L0", "epi+bar1", "gemm1", "epi+bar2", "gemm2", "lastL", "bar3", "sum+upd"};
             for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.2f", nm[i], h[i] * 0.01 / k.S);
+            fprintf(stderr, "  | s_memtime / s_memrealtime = %.2f MHz", h[9] ? 100.0 * (double)h[8] / (double)h[9] : 0.0);
             fprintf(stderr, "\n");
         }
     }
@@ -1174,7 +1184,7 @@ int srvp_rollout_fused_bwd(const srvp_rollout_bwd_desc* d, hipStream_t st) {
     const int tiles = fused_common(f, k, f.fused_ws);
     k.hid = f.hid_dyn; k.d_y_all = d->d_y_all; k.d_res = d->d_res; k.dhid = d->dhid_dyn; k.dinp_all = d->dinp_all; k.d_y0 = d->d_y0;
     k.dwd = f.nh > f.ny ? f.nh : f.ny;
-    const size_t lds = ((size_t)(k.nl - 2) * k.nh * CW + RT * (k.nyp + 1) + RT * k.ny + RT * 33) * 4;
+    const size_t lds = ((size_t)(k.nl - 2) * k.nh * CW + RT * (k.nyp + IPAD) + RT * k.ny + RT * 33) * 4;
     auto kern = k.G <= 8 ? rollout_fused_bwd_kernel<8> : (k.G <= 16 ? rollout_fused_bwd_kernel<16> : rollout_fused_bwd_kernel<32>);
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_bwd(fused): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
@@ -1203,7 +1213,7 @@ extern "C" int64_t srvp_rollout_gen_ws_bytes(const srvp_rollout_desc* d) {
     const int kp0 = (nin + 15) / 16 * 16, nzp2 = (2 * d->nz + 15) / 16 * 16;
     if (nzp2 > kp0) return 0;                             // the summed prior parameters are staged in the input tile
     if (!clusters_fit(d->nh / CW)) return 0;
-    const size_t lds = ((size_t)(d->nl - 2) * d->nh * CW + RT * (kp0 + 1) + RT * d->ny + RT * d->nz + RT * 33 + d->ny + 2 * d->nz) * 4;
+    const size_t lds = ((size_t)(d->nl - 2) * d->nh * CW + RT * (kp0 + IPAD) + RT * d->ny + RT * d->nz + RT * 33 + d->ny + 2 * d->nz) * 4;
     if (lds > 160 * 1024) return 0;
     if (!placement_round_robin()) return 0;
     const int64_t tiles = (d->B + RT - 1) / RT;
@@ -1226,7 +1236,7 @@ int srvp_rollout_gen_fwd(const srvp_rollout_desc* d, hipStream_t st) {
     k.hbuf = (float*)((char*)d->fused_ws + (size_t)tiles * 256);
     k.part = k.hbuf + (size_t)tiles * (d->nl - 2) * RT * d->nh;
     SRVP_REQUIRE(k.n_data <= 1 || k.qz, "srvp_rollout_fwd(gen): posterior frames need q_z_params");
-    const size_t lds = ((size_t)(k.nl - 2) * k.nh * CW + RT * (k.kp0 + 1) + RT * k.ny + RT * k.nz + RT * 33 + k.ny + 2 * k.nz) * 4;
+    const size_t lds = ((size_t)(k.nl - 2) * k.nh * CW + RT * (k.kp0 + IPAD) + RT * k.ny + RT * k.nz + RT * 33 + k.ny + 2 * k.nz) * 4;
     auto kern = k.G <= 8 ? rollout_gen_kernel<8> : (k.G <= 16 ? rollout_gen_kernel<16> : rollout_gen_kernel<32>);
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd(gen): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
