@@ -1227,6 +1227,8 @@ class ConvNetBase:
             return
         lib = L.load()
         for q in self.blocks:
+            # (round 5, measured and not kept: a transposed 4x4 stride-2 consumer in its space-to-depth form -- one stride-1 halo data-gradient launch at
+            # the producer's resolution, the DCGAN decoder's chain -- qualifies as well; 6.36 -> 6.31 ms on config 2, docs/experiments.md)
             if q.role != 'mfma' or getattr(q, 'geom', None) != 'same' or not getattr(q, '_dg', None):
                 continue
             # an upsampling consumer qualifies in its space-to-depth form only: its data gradient is then ONE launch that writes the
@@ -1509,6 +1511,14 @@ class DecoderNet(ConvNetBase):
             L.call('srvp_conv_out_fwd', L.ptr(ob.srcs[0].t), L.ptr(ob.wt_o), L.ptr(self.x_out), self.N, ob.cout_r, 1, st)
             return self.x_out
         # (other geometries: MFMA conv with Cout padded to 32, sigmoid + fp32 frame store in the epilogue)
+        if ob.geom == 'up' and len(ob._fwd) == 4 and PHASES_ONE_GRID:
+            # DCGAN output layer (conv.py:304: ConvTranspose2d(64, nc, 4, 2, 1)): its four output phases as one grid -- the phases of a tile run
+            # back to back, so the 64-channel activation is read from HBM once instead of four times (4 x 94 us for 4 GFLOP at 1920 frames)
+            arr = ob.__dict__.get('_fwd_arr')
+            if arr is None:
+                arr = ob._fwd_arr = (L.ConvDesc * 4)(*ob._fwd)
+            L.call('srvp_conv_mfma_multi', arr, 4, st)
+            return self.x_out
         for d in ob._fwd:
             L.call('srvp_conv_mfma', C.byref(d), st)
         return self.x_out
