@@ -50,6 +50,7 @@ SUB_D = [(2,), (1, 2), (0, 1), (0,)]
 S2D_UP = {0: [(1, 1), (3, 2)], 1: [(0, 0), (2, 1)]}
 S2D_UP_ON = os.environ.get('SRVP_UP_S2D', '1') != '0'
 WGRAD_S2D_SHIFT_SRC = os.environ.get('SRVP_WGRAD_S2D_SHIFT_SRC', '1') != '0'   # 16-tap weight gradients of the 4x4 stride-2 blocks in the sub-pixel blocks' form (halo kernel)
+ENC_WGRAD_AFTER_DGRAD = os.environ.get('SRVP_ENC_WGRAD_AFTER_DGRAD', '0') == '1'     # A/B: encoder weight gradients released after the block's data gradient
 PHASES_ONE_GRID = os.environ.get('SRVP_PHASES_ONE_GRID', '1') != '0'    # the four phase launches of a 4x4 stride-2 block (forward of 'up', data gradient of 'down') as one grid
 DOWN_S2D = os.environ.get('SRVP_DOWN_S2D', '1') != '0'        # 4x4 stride-2 encoder layers on a space-to-depth source (no skip connections)
 
@@ -1426,12 +1427,17 @@ class EncoderNet(ConvNetBase):
             else:
                 self._bn_backward(blk, params, grads, da, st, sync)
                 if side is not None and self.N <= ENC_WGRAD_SIDE_MAXN:
+                    if ENC_WGRAD_AFTER_DGRAD:
+                        # A/B (round 5): the block's weight gradient released only when its data gradient is done, so that it
+                        # runs beside the HBM-bound BatchNorm pass of the block below instead of beside its own MFMA-bound data gradient
+                        self._mfma_backward(blk, grads, st, wgrad=False)
                     ev = torch.cuda.Event()
                     ev.record()
                     with torch.cuda.stream(side):
                         side.wait_event(ev)
                         self._wgrad(blk, L.stream())
-                    self._mfma_backward(blk, grads, st, wgrad=False)
+                    if not ENC_WGRAD_AFTER_DGRAD:
+                        self._mfma_backward(blk, grads, st, wgrad=False)
                 else:
                     self._mfma_backward(blk, grads, st)
                 pooled = blk.spec['pre'] == 'pool'
