@@ -142,7 +142,12 @@ class LatentNet:
         """srvp.py:229-256.  hx: (T, B, nhx) fp32 contiguous; t_w: (nt_inf, B) long (train) or None (last nt_inf frames)."""
         B, ti = self.B, self.nt_inf
         T = hx.shape[0]
-        if t_w is not None:
+        if t_w is not None and not t_w.is_cuda:
+            # frame indices still on the host (the training forward draws them there): the row numbers are formed on the host too and travel
+            # in ONE copy instead of five small device kernels on the latent path's serial chain
+            rows_h = (t_w.reshape(-1).to(torch.long) * B + torch.arange(B).repeat(ti))
+            rows = rows_h.pin_memory().to(hx.device, non_blocking=True)
+        elif t_w is not None:
             rows = (t_w.reshape(-1) * B + torch.arange(B, device=hx.device).repeat(ti)).to(torch.long)
         else:
             rows = torch.arange((T - ti) * B, T * B, device=hx.device)

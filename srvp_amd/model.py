@@ -420,13 +420,23 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             # frame t_skip[b] * B + b of every sample: the index tensors are formed on the host (B integers) and travel in one copy
             ts = t_skip.cpu().to(torch.int32) if training else torch.full((B,), T - 1, dtype=torch.int32)
             sel_h = ts * B + torch.arange(B, dtype=torch.int32)
-            host = torch.zeros(pl['ibuf'].numel(), dtype=torch.int32)
+            # (ONE pinned staging buffer per plan, refilled in place: a fresh .pin_memory() per step is a pinned allocation on the host's
+            # critical path right at the step boundary.  Safe to overwrite: the host has waited for the previous step's ELBO event, which
+            # lies behind the previous copy out of this buffer)
+            host = pl.get('ibuf_host')
+            if host is None:
+                host = pl['ibuf_host'] = torch.zeros(pl['ibuf'].numel(), dtype=torch.int32).pin_memory()
+            elif pl.get('ibuf_copied') is not None:
+                pl['ibuf_copied'].synchronize()                                 # (a caller that runs two forwards without a sync in between)
+            host[:T * B] = 0
             host[sel_h.long()] = 1                                              # keep
             host[T * B:2 * T * B] = -1
             host[T * B + sel_h.long()] = torch.arange(B, dtype=torch.int32)    # skip_idx: frame -> sample (or -1)
             host[2 * T * B:2 * T * B + B] = sel_h                               # skip_sel
             host[2 * T * B + B:] = sel_h.repeat(nt)                             # skip_map
-            pl['ibuf'].copy_(host.pin_memory(), non_blocking=True)
+            pl['ibuf'].copy_(host, non_blocking=True)
+            pl['ibuf_copied'] = torch.cuda.Event()
+            pl['ibuf_copied'].record()
             sel = pl['skip_sel_t']
         hx = enc.forward(x.view(T * B, *x.shape[2:]), params, st, self.sync if training else None, keep=keep, packed=enc_packed)
         hx = hx.contiguous().view(T, B, self.nhx)
@@ -436,6 +446,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         # copy does not block the host behind the work queued so far
         if tape is None:
             tape = self._draw_tape(T, B, nt, training, dev, t_skip=t_skip)
+        t_w_host = tape.get('t_w') if (training and torch.is_tensor(tape.get('t_w')) and not tape['t_w'].is_cuda) else None
         tape = {k: (_to_dev(v, dev) if torch.is_tensor(v) else v) for k, v in tape.items()}
         self.last_tape = tape
         if self.skipco:
@@ -455,7 +466,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         overlap_skips = self.skipco and OVERLAP_SKIP and any(b.split for b in dec.blocks)
         if overlap_skips and not SKIP_LATE:
             s_done = skips_on_side()
-        w = lat.infer_w(hx, params, tape.get('t_w') if training else None, st)
+        w = lat.infer_w(hx, params, (t_w_host if t_w_host is not None else tape.get('t_w')) if training else None, st)
         y0, q_y0 = lat.infer_y(hx[:self.nt_inf], params, tape['eps_y0'], st)
         lat.posterior(hx, params, st)
         if overlap_skips and SKIP_LATE:

@@ -487,6 +487,47 @@ def test_u8_collate_matches_reference_collate(nc):
     assert got.shape == ref.shape and torch.equal(got.cpu(), ref)
 
 
+def test_prefetcher_stages_batches_one_step_ahead():
+    """srvp_amd.data.Prefetcher (reference train.py:84,262: `batch.to(device)` at the top of the step): host batches -- stacked uint8 videos of
+    collate_u8, float32 (T, B, C, H, W), pinned or not -- come out as device float32 batches in order, equal to the in-line conversion, staged
+    on a copy stream while the consumer works on the previous one; device batches pass through; a training loop over it gives the losses of
+    the loop over resident batches."""
+    import numpy as np
+    import srvp_amd
+    from srvp_amd.data import Prefetcher, collate_u8, frames_from_u8
+    from srvp_amd.train import train
+    dev = torch.device('cuda')
+    rng = np.random.RandomState(11)
+    T, B = 4, 3
+    u8s = [collate_u8([rng.randint(0, 256, size=(T, 64, 64, 3)).astype(np.uint8) for _ in range(B)]) for _ in range(5)]
+    f32s = [torch.rand(T, B, 3, 64, 64, generator=torch.Generator().manual_seed(i)) for i in range(3)]          # (not pinned)
+    want = [frames_from_u8(u, dev) for u in u8s] + [f.to(dev) for f in f32s]
+    resident = torch.rand(T, B, 3, 64, 64, device=dev)
+    busy = torch.randn(4096, 4096, device=dev)
+    got = []
+    for i, xb in enumerate(Prefetcher(u8s + f32s + [resident], dev)):
+        busy @ busy                                             # the consumer's stream has work queued while the next batch is staged
+        assert xb.is_cuda and xb.dtype == torch.float32 and xb.shape == (T, B, 3, 64, 64)
+        got.append(xb.clone())
+    assert len(got) == 9 and got[-1].data_ptr() != resident.data_ptr() and torch.equal(got[-1], resident)
+    for a, b in zip(got[:-1], want):
+        assert torch.equal(a, b)
+    assert list(Prefetcher([], dev)) == [] and len(Prefetcher(u8s, dev)) == 5
+
+    def losses(feed):
+        torch.manual_seed(2)
+        m = srvp_amd.StochasticLatentResidualVideoPredictor(64, 3, 8, 16, 4, 4, True, 2, 16, 3, 32, 4, 'vgg')
+        m.init(1.41)
+        m.to(dev).train()
+        o = srvp_amd.FusedAdam(m, lr=1e-3)
+        opt = srvp_amd.DotDict(dict(n_euler_steps=2, obs_scale=1.0, beta_y=1.0, beta_z=1.0, l2_res=1.0))
+        torch.manual_seed(5)
+        return [train(m, o, None, xb, dev, opt)[0] for xb in feed]
+    a = losses(Prefetcher(u8s, dev))
+    b = losses([frames_from_u8(u, dev) for u in u8s])
+    assert all(abs(x - y) <= 1e-4 * abs(y) for x, y in zip(a, b)), (a, b)       # (fp64 statistics atomics: not bitwise)
+
+
 @pytest.mark.parametrize('archi,nc,skipco', [('vgg', 3, True), ('dcgan', 1, False)])
 def test_batched_samples_match_per_sample_forward(archi, nc, skipco):
     """model.sample (one encoding, S futures fanned into the batch dimension of the latent path and the
