@@ -251,17 +251,53 @@ class LatentNet:
         return y, self.z[:self.F], (self.q_z[:nq] if nq > 0 else None), self.p_z[:self.F], self.res[:self.S]
 
     # ------------------------------------------------------------------------------------------------
-    def backward(self, hx, params, grads, eps_y0, eps_z, d_y, d_w, d_qy0, d_qz, d_pz, d_res, d_z, st, defer=None):
+    def backward(self, hx, params, grads, eps_y0, eps_z, d_y, d_w, d_qy0, d_qz, d_pz, d_res, d_z, st, defer=None, aux=None):
         """
         Gradients wrt the latent-path outputs -> parameter gradients (accumulated into `grads`) and d_hx (T*B, nhx).
         Any d_* may be None.  Training forward (n_data = T = nt) must have run.
         d_y == 'in_place': the caller has already written the state gradients into self.d_y_all (zero elsewhere).
         defer (list or None): weight-gradient launches (off the critical path) are collected as closures fn(stream).
+        aux (torch stream or None; round 5): the backward of the two chains that do not pass through the LSTM -- the content variable w (needs
+        d_w only: runs from the start, under the rollout backward) and y_0 (needs the rollout's d_y0: runs beside the q_z / LSTM chain) -- is
+        issued there up to their input gradients; the main stream joins it and adds both into d_hx (the row scatter-adds and the LSTM's input
+        GEMM all accumulate into d_hx, so those stay in stream order).  A dozen dependent micro-kernels less on the step's serial path.
         """
         cfg, B, T, ne, S, F = self.cfg, self.B, self.T, self.ne, self.S, self.F
         ny, nz, nh, nhr, nhx = cfg['ny'], cfg['nz'], cfg['nh_inf'], cfg['nh_res'], cfg['nhx']
         nlr = self.nl_res
+        ti = self.nt_inf
         self.d_hx.zero_()
+
+        def y0_chain(s_):
+            L.call('srvp_rsample_bwd', L.ptr(self.q_y0), L.ptr(eps_y0), L.ptr(self.d_y0), L.ptr(self.d_qy0_tot), B, ny, 0, s_)
+            if d_qy0 is not None:
+                axpby(s_, self.d_qy0_tot, 1.0, self.d_qy0_tot, 1.0, d_qy0)
+            keys = mlp_keys('q_y', self.nl_inf)
+            dcur = self.d_qy0_tot
+            for i in range(len(keys) - 1, -1, -1):
+                x_in = self.qy_in if i == 0 else self.qy_hid[i - 1]
+                dx = self.d_qy_in if i == 0 else self.d_qy_hid[i - 1]
+                linear_bwd(s_, x_in, params[keys[i] + '.weight'], dcur, grads[keys[i] + '.weight'], grads[keys[i] + '.bias'], dx=dx, defer=defer)
+                if i > 0:
+                    L.call('srvp_act_bwd_f32', L.ptr(self.qy_hid[i - 1]), L.ptr(dx), L.ptr(dx), dx.numel(), L.ACT_RELU, 1, s_)
+                dcur = dx
+
+        def w_chain(s_):
+            L.call('srvp_act_bwd_f32', L.ptr(self.w), L.ptr(d_w), L.ptr(self.d_wpre), d_w.numel(), L.ACT_TANH, 1, s_)
+            linear_bwd(s_, self.hsum, params['w_inf.0.weight'], self.d_wpre, grads['w_inf.0.weight'], grads['w_inf.0.bias'],
+                       dx=self.d_hsum, defer=defer)
+            dp = self.d_proj.view(ti, B, nh)
+            for i in range(ti):
+                L.call('srvp_act_bwd_f32', L.ptr(self.proj.view(ti, B, nh)[i]), L.ptr(self.d_hsum), L.ptr(dp[i]), B * nh,
+                       L.ACT_RELU, 1, s_)
+            linear_bwd(s_, self.h_sel, params['w_proj.0.weight'], self.d_proj, grads['w_proj.0.weight'], grads['w_proj.0.bias'],
+                       dx=self.d_hsel, defer=defer)
+        if aux is not None and d_w is not None:
+            ev0 = torch.cuda.Event()
+            ev0.record()                                    # d_w (and everything the caller prepared) exists
+            with torch.cuda.stream(aux):
+                aux.wait_event(ev0)
+                w_chain(L.stream())
         # ---- rollout
         if not (isinstance(d_y, str) and d_y == 'in_place'):
             self.d_y_all.zero_()
@@ -292,6 +328,14 @@ class LatentNet:
             _gemm(st, self.dhid_pz[0].view(F * B, dwp), dwp, 1, params[keys[0] + '.weight'], ny, 1, None, self._pz_dx, ny, F * B, ny, nhr)
             L.call('srvp_add_blocks_f32', L.ptr(self.d_y_all), ne * B * ny, L.ptr(self._pz_dx), F, B * ny, st)
         L.call('srvp_rollout_bwd', C.byref(bd), st)
+        if aux is not None:
+            ev1 = torch.cuda.Event()
+            ev1.record()                                    # d_y0 exists
+            with torch.cuda.stream(aux):
+                aux.wait_event(ev1)
+                y0_chain(L.stream())
+                aux_done = torch.cuda.Event()
+                aux_done.record()
         # weight gradients of dynamics / p_z: one GEMM per layer over all (step, sample) rows
         for name, nrow, width, dh, hid, inp, nin, nout in (
                 ('dynamics', S * B, self.dwd, self.dhid_dyn, self.hid_dyn, self.inp_all.view(S * B, -1), ny + nz, ny),
@@ -345,35 +389,18 @@ class LatentNet:
                        grads['inf_z.bias_ih_l0'], dx=self.d_hx, dx_acc=1, defer=defer)
             if defer is None:
                 bhh(st)
-        # ---- y_0
-        L.call('srvp_rsample_bwd', L.ptr(self.q_y0), L.ptr(eps_y0), L.ptr(self.d_y0), L.ptr(self.d_qy0_tot), B, ny, 0, st)
-        if d_qy0 is not None:
-            axpby(st, self.d_qy0_tot, 1.0, self.d_qy0_tot, 1.0, d_qy0)
-        keys = mlp_keys('q_y', self.nl_inf)
-        dcur = self.d_qy0_tot
-        for i in range(len(keys) - 1, -1, -1):
-            x_in = self.qy_in if i == 0 else self.qy_hid[i - 1]
-            dx = self.d_qy_in if i == 0 else self.d_qy_hid[i - 1]
-            linear_bwd(st, x_in, params[keys[i] + '.weight'], dcur, grads[keys[i] + '.weight'], grads[keys[i] + '.bias'], dx=dx, defer=defer)
-            if i > 0:
-                L.call('srvp_act_bwd_f32', L.ptr(self.qy_hid[i - 1]), L.ptr(dx), L.ptr(dx), dx.numel(), L.ACT_RELU, 1, st)
-            dcur = dx
-        ti = self.nt_inf
-        # d_hx[t][b] += d_qy_in[b][t] for the first nt_inf frames (backward of the (B, nt_inf * nhx) flattening, srvp.py:268)
+        # ---- y_0 and w: see y0_chain / w_chain above; their input gradients are added into d_hx here, in stream order behind the LSTM's
+        if aux is None:
+            y0_chain(st)
+            if d_w is not None:
+                w_chain(st)
+        else:
+            torch.cuda.current_stream().wait_event(aux_done)
         rows = self.__dict__.get('_qy_rows')
         if rows is None:
             rows = self._qy_rows = (torch.arange(ti, dtype=torch.int32).view(1, ti) * B + torch.arange(B, dtype=torch.int32).view(B, 1)).reshape(-1).to(self.dev)
+        # d_hx[t][b] += d_qy_in[b][t] for the first nt_inf frames (backward of the (B, nt_inf * nhx) flattening, srvp.py:268)
         L.call('srvp_rows_scatter_add_f32', L.ptr(self.d_hx), L.ptr(rows), 0, L.ptr(self.d_qy_in), B * ti, nhx, st)
-        # ---- w
         if d_w is not None:
-            L.call('srvp_act_bwd_f32', L.ptr(self.w), L.ptr(d_w), L.ptr(self.d_wpre), d_w.numel(), L.ACT_TANH, 1, st)
-            linear_bwd(st, self.hsum, params['w_inf.0.weight'], self.d_wpre, grads['w_inf.0.weight'], grads['w_inf.0.bias'],
-                       dx=self.d_hsum, defer=defer)
-            dp = self.d_proj.view(ti, B, nh)
-            for i in range(ti):
-                L.call('srvp_act_bwd_f32', L.ptr(self.proj.view(ti, B, nh)[i]), L.ptr(self.d_hsum), L.ptr(dp[i]), B * nh,
-                       L.ACT_RELU, 1, st)
-            linear_bwd(st, self.h_sel, params['w_proj.0.weight'], self.d_proj, grads['w_proj.0.weight'], grads['w_proj.0.bias'],
-                       dx=self.d_hsel, defer=defer)
             L.call('srvp_rows_scatter_add_f32', L.ptr(self.d_hx), L.ptr(self.w_rows), 1, L.ptr(self.d_hsel), self.w_rows.numel(), nhx, st)
         return self.d_hx

@@ -52,6 +52,7 @@ def _to_dev(v, dev):
 OVERLAP_WGRAD = os.environ.get('SRVP_OVERLAP_WGRAD', '1') != '0'
 PZ_AUX = os.environ.get('SRVP_PZ_AUX', '1') != '0'                       # 0: the batched prior MLP of a training forward in line
 SKIP_REDUCE_AUX = os.environ.get('SRVP_SKIP_REDUCE_AUX', '1') != '0'      # 0: the pooled stages' skip-gradient reductions in line on the main stream
+LATENT_AUX = os.environ.get('SRVP_LATENT_AUX', '1') != '0'        # independent chains of the latent path (posterior / w / y_0; their backward) on two streams
 LATENT_WGRAD_STREAM = os.environ.get('SRVP_LATENT_WGRAD_STREAM', '1') != '0'    # the latent networks' weight gradients on a stream of their own
 OVERLAP_SKIP = os.environ.get('SRVP_OVERLAP_SKIP', '1') == '1'
 SKIP_LATE = os.environ.get('SRVP_SKIP_LATE', '1') == '1'        # hoisted skip convs under the rollout kernel (1) / under the inference chain (0)
@@ -466,9 +467,32 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         overlap_skips = self.skipco and OVERLAP_SKIP and any(b.split for b in dec.blocks)
         if overlap_skips and not SKIP_LATE:
             s_done = skips_on_side()
-        w = lat.infer_w(hx, params, (t_w_host if t_w_host is not None else tape.get('t_w')) if training else None, st)
-        y0, q_y0 = lat.infer_y(hx[:self.nt_inf], params, tape['eps_y0'], st)
-        lat.posterior(hx, params, st)
+        t_w_arg = (t_w_host if t_w_host is not None else tape.get('t_w')) if training else None
+        w_done = None
+        if training and LATENT_AUX and OVERLAP_WGRAD:
+            # the three inference chains are independent: the posterior (LSTM + q_z) and the content variable w on the auxiliary stream, y_0 on
+            # the main one; the rollout needs y_0 and q_z, the decoder w (round 5: ~25 dependent micro-kernels became the longest of three chains)
+            if getattr(self, '_lat_stream', None) is None:
+                self._lat_stream = torch.cuda.Stream()
+            aux = self._lat_stream
+            main_stream = torch.cuda.current_stream()
+            ev_hx = torch.cuda.Event()
+            ev_hx.record()
+            with torch.cuda.stream(aux):
+                aux.wait_event(ev_hx)
+                lat.posterior(hx, params, L.stream())
+                post_done = torch.cuda.Event()
+                post_done.record()
+                w = lat.infer_w(hx, params, t_w_arg, L.stream())
+                lat.w_rows.record_stream(main_stream)        # (allocated on the auxiliary stream, read by the backward's scatter on the main one)
+                w_done = torch.cuda.Event()
+                w_done.record()
+            y0, q_y0 = lat.infer_y(hx[:self.nt_inf], params, tape['eps_y0'], st)
+            torch.cuda.current_stream().wait_event(post_done)
+        else:
+            w = lat.infer_w(hx, params, t_w_arg, st)
+            y0, q_y0 = lat.infer_y(hx[:self.nt_inf], params, tape['eps_y0'], st)
+            lat.posterior(hx, params, st)
         if overlap_skips and SKIP_LATE:
             # the hoisted skip halves of the decoder need the encoder only: second stream, under the ROLLOUT kernel (one persistent
             # launch on nh/32 x batch-tiles CUs that leaves the rest of the chip idle for 0.5 ms).  Issued earlier -- under the
@@ -486,6 +510,8 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             torch.cuda.current_stream().wait_event(s_done)
         if pack_done is not None:
             torch.cuda.current_stream().wait_event(pack_done)
+        if w_done is not None:
+            torch.cuda.current_stream().wait_event(w_done)
         # decoder input rows [w[b] | y[t][b]] (srvp.py:216-221) assembled by the library from w and the stored states y_all[t * n_euler]
         x_flat = dec.forward(None, params, st, self.sync if training else None,
                              latent=(w, lat.y_all, lat.ne * B * self.ny, nt, B, self.nh_inf, self.ny))
@@ -578,8 +604,13 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         if self.sync is not None and not overlap:
             self.sync.grads_ready('decoder', self)
         deferred = [] if overlap else None
+        lat_aux = None
+        if overlap and LATENT_AUX:
+            if getattr(self, '_lat_stream', None) is None:
+                self._lat_stream = torch.cuda.Stream()
+            lat_aux = self._lat_stream
         d_hx = lat.backward(pl['hx'], params, grads, tape['eps_y0'], tape['eps_z'], 'in_place', lat.d_w_tot,
-                            cz(d_qy0), cz(d_qz), cz(d_pz), cz(d_res), None, st, defer=deferred)
+                            cz(d_qy0), cz(d_qz), cz(d_pz), cz(d_res), None, st, defer=deferred, aux=lat_aux)
         if overlap:
             # (host order: the main-stream launches of the latent backward -- the critical path -- go out BEFORE the ~25 second-stream
             # launches of the decoder's weight gradients, which only wait for ev_dec on the device: a host that is just ahead of the device
