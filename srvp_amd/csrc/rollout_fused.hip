@@ -574,6 +574,432 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 
+// ------------------------------------------------------------------------------------------------------------ 16-row tiles, K split over the waves
+// Round 5, second form of the two training kernels (SRVP_ROLLOUT_KSPLIT=0: the 32-row kernels above).  What a 32-row hidden-layer GEMM cost
+// per Euler step (SRVP_RF_DEBUG: 4.5 us for 1.7 us of MFMA issue) is moving the 64 KB activation tile into every workgroup -- through the L1
+// twice, because the two column-half waves of a row half both fetch it -- and 128 MFMAs per SIMD behind it.  Both scale with the ROWS a
+// cluster owns, and the chip has CUs to spare (96 of 256 at 192 sequences, 16 at 24): so the batch is cut into 16-row tiles (twice the
+// clusters) and, inside a workgroup, the K loop instead of the output tile is dealt to the four waves: wave w takes the w-th 16-wide k block
+// of every 64 (one 16-byte load per lane and block: 8 loads per hidden layer instead of 32, every byte fetched once per workgroup), feeds
+// it to BOTH 16-column tiles of the slice, and the four partial 16 x 32 tiles are added in a fixed order (((w0 + w1) + w2) + w3) through 8 KB
+// of LDS, where the epilogue (bias / ReLU or ReLU mask, store, hand-off) then runs on all 256 threads, two outputs each, along rows.
+// Taken when every 16-row tile of the batch fits ONE co-resident launch (B <= 256 at nh = 512); otherwise the 32-row kernels.
+constexpr int RT16 = 16;
+#define WAITV1(r, n) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(r) :: "memory")
+
+// acc[ct] (16 x 16, column tiles ct of the 32-column slice) += A(16 rows from global, this wave's k blocks) x B(LDS slice); blocks past K
+// contribute exact zeros (A fragment cleared), no branch between a load and its wait (see gemm_glob_lds)
+template <bool CACHED>
+__device__ __forceinline__ void gemm_ks(f32x4v (&acc)[2], const float* arow, const float* Bs, int K, int w, int q, int c16) {
+    const f32x4v zero = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 512) {
+        f32x4v av[8], b0[8], b1[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int kb = k0 + 64 * jj + 16 * w;
+            const float* p = arow + (kb < K ? kb : 0) + 4 * q;
+            if constexpr (CACHED) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(av[jj]) : "v"(p) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(av[jj]) : "v"(p) : "memory");
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {                  // the B fragments arrive from LDS while the global loads are in flight
+            const int kb = k0 + 64 * jj + 16 * w;
+            const float* bp = Bs + (((kb < K ? kb : 0) >> 2) + q) * 128 + c16 * 4;
+            b0[jj] = *reinterpret_cast<const f32x4v*>(bp);
+            b1[jj] = *reinterpret_cast<const f32x4v*>(bp + 64);
+        }
+#define KS_STEP(jj, n)                                                                                               \
+        {                                                                                                            \
+            WAITV1(av[jj], n);                                                                                       \
+            const f32x4v x = (k0 + 64 * (jj) + 16 * w < K) ? av[jj] : zero;                                          \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                          \
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], b0[jj][e], acc[0], 0, 0, 0);                     \
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], b1[jj][e], acc[1], 0, 0, 0);                     \
+            }                                                                                                        \
+        }
+        KS_STEP(0, 7) KS_STEP(1, 6) KS_STEP(2, 5) KS_STEP(3, 4) KS_STEP(4, 3) KS_STEP(5, 2) KS_STEP(6, 1) KS_STEP(7, 0)
+#undef KS_STEP
+    }
+}
+
+// the four waves' partial tiles -> LDS (MFMA lane layout, 16 bytes per lane and tile); read back per output element by red_sum
+__device__ __forceinline__ void red_store(float* Red, const f32x4v (&acc)[2], int w, int lane) {
+    *reinterpret_cast<f32x4v*>(Red + (w * 2 + 0) * 256 + lane * 4) = acc[0];
+    *reinterpret_cast<f32x4v*>(Red + (w * 2 + 1) * 256 + lane * 4) = acc[1];
+}
+// element (r, c) of the 16 x 32 tile: rows 4 q + e of lane (q, c & 15) of column tile c >> 4
+__device__ __forceinline__ float red_sum(const float* Red, int r, int c) {
+    const int off = (c >> 4) * 256 + ((r >> 2) * 16 + (c & 15)) * 4 + (r & 3);
+    return ((Red[off] + Red[512 + off]) + Red[1024 + off]) + Red[1536 + off];
+}
+
+template <int GP>
+__device__ __forceinline__ void sum_slabs1(f32x4v& sa, const float* pa, int G, size_t slab_stride) {
+    f32x4v va[GP];
+#pragma unroll
+    for (int gg = 0; gg < GP; ++gg) {
+        const size_t o = (size_t)(gg < G ? gg : G - 1) * slab_stride;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(va[gg]) : "v"(pa + o) : "memory");
+    }
+#pragma unroll
+    for (int o = 0; o < GP; o += 8) { WAIT8(va, o); }
+#pragma unroll
+    for (int gg = 0; gg < GP; ++gg)
+        if (gg < G) sa += va[gg];
+}
+
+template <int GP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_ks_fwd_kernel(const RollF a) {
+    extern __shared__ float lds[];
+    int cl, g;
+    if (!locate(a, cl, g)) return;
+    constexpr int RT = RT16;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, c16 = lane & 15;
+    const int ec = tid & 31, er = tid >> 5;               // epilogue: outputs (er, ec) and (er + 8, ec) of the 16 x 32 tile
+    const int row0 = (a.tile0 + cl) * RT;
+    const int colbase = g * CW;
+    const int nl = a.nl, nh = a.nh, ny = a.ny, nin = a.nin, B = a.B, kp0 = a.kp0;
+    const int nfull = nl - 2;
+    // LDS: [nfull][nh][32] slices | Is [16][kp0 + IPAD] | Ys [16][ny] | Hs [16][33] | Bl [64] | Red [4][2][256]
+    float* Wl = lds;
+    float* Is = Wl + (size_t)nfull * nh * CW;
+    float* Ys = Is + RT * (kp0 + IPAD);
+    float* Hs = Ys + RT * ny;
+    float* Bl = Hs + RT * 33;
+    float* Red = Bl + NYP_MAX;
+    unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;
+    float* part = a.part + (size_t)(a.tile0 + cl) * a.S * a.G * RT * KP0_MAX;       // a fresh slab per Euler step (see the 32-row kernel)
+    unsigned target = 0;
+    xcd_announce(cnt);
+
+    for (int l = 1; l <= nfull; ++l) {
+        const float* W = a.W[l];
+        float* dst = Wl + (size_t)(l - 1) * nh * CW;
+        for (int idx = tid; idx < nh * CW; idx += 256) {
+            const int c = idx / nh, k = idx - c * nh;
+            dst[sw(k, c)] = W[(size_t)(colbase + c) * nh + k];
+        }
+    }
+    // first layer: this wave's k blocks j = w + 4 jj of the [kp0] input, both column tiles: B0[k = 16 j + 4 q + e][16 ct + c16]
+    float w0[2][2][4];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 16 * (w + 4 * jj) + 4 * q + e;
+                w0[jj][ct][e] = k < nin ? a.W[0][(size_t)(colbase + 16 * ct + c16) * nin + k] : 0.f;
+            }
+    // last layer (split-K over the cluster): wave w owns output column tile w: BL[k = 4 jj + q][col] = W_last[col][colbase + k]
+    float wl[8];
+    const bool has_lt = 16 * w < a.nyp;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int col = 16 * w + c16;
+        wl[jj] = (has_lt && col < ny) ? a.W[nl - 1][(size_t)col * nh + colbase + 4 * jj + q] : 0.f;
+    }
+    for (int idx = tid; idx < RT * ny; idx += 256) {
+        const int r = idx / ny, c = idx - r * ny;
+        const int row = row0 + r < B ? row0 + r : B - 1;
+        Ys[idx] = a.y0[(size_t)row * ny + c];
+    }
+    if (tid < ny) Bl[tid] = a.b[nl - 1][tid];
+    float zr[KP0_MAX * RT / 256];
+    auto fetch_z = [&](int step) {
+#pragma unroll
+        for (int u = 0; u < KP0_MAX * RT / 256; ++u) {
+            const int idx = tid + 256 * u, r = idx / kp0, k = idx - r * kp0;
+            const int row = row0 + r < B ? row0 + r : B - 1;
+            zr[u] = (idx < RT * kp0 && k >= ny && k < nin) ? a.inp_all[((size_t)step * B + row) * nin + k] : 0.f;
+        }
+    };
+    fetch_z(0);
+    cluster_barrier(cnt, target += a.G);
+    const bool xl = xcd_agreed(cnt, a.xcd_local, g == 0);
+    const int grow = row0 + c16 < B ? row0 + c16 : B - 1;
+    const size_t hs = (size_t)a.S * B * nh;
+
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    const bool dbg = a.dbg != nullptr && cl == 0 && g == 0;
+    auto tick = [&](int k) {
+        if (dbg) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); tacc[k] += t - tprev; tprev = t; }
+    };
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (dbg) { tprev = rt0 = __builtin_amdgcn_s_memrealtime(); clk0 = __builtin_readcyclecounter(); }
+    for (int i = 0; i < a.S; ++i) {
+#pragma unroll
+        for (int u = 0; u < KP0_MAX * RT / 256; ++u) {
+            const int idx = tid + 256 * u, r = idx / kp0, k = idx - r * kp0;
+            if (idx < RT * kp0) Is[r * (kp0 + IPAD) + k] = k < ny ? Ys[r * ny + k] : zr[u];
+        }
+        if (i + 1 < a.S) fetch_z(i + 1);
+        __syncthreads();
+        // ---- layer 0: A from LDS, B from registers, this wave's k blocks
+        f32x4v acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        float bl = a.b[0][colbase + ec];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int kb = 16 * (w + 4 * jj);
+            const bool ok = kb < kp0;
+            f32x4v x = *reinterpret_cast<const f32x4v*>(Is + c16 * (kp0 + IPAD) + (ok ? kb : 0) + 4 * q);
+            if (!ok) x = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], w0[jj][0][e], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], w0[jj][1][e], acc[1], 0, 0, 0);
+            }
+        }
+        tick(0);
+        for (int l = 0; l <= nfull; ++l) {
+            red_store(Red, acc, w, lane);
+            __syncthreads();
+            float* hdst = a.hid + (size_t)l * hs + (size_t)i * B * nh;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = er + 8 * u;
+                float v = red_sum(Red, r, ec) + bl;
+                v = v > 0.f ? v : 0.f;
+                if (row0 + r < B) st_x(hdst + (size_t)(row0 + r) * nh + colbase + ec, v, xl);
+                if (l == nfull) Hs[r * 33 + ec] = v;
+            }
+            if (l == nfull) break;
+            bl = a.b[l + 1][colbase + ec];
+            cluster_barrier(cnt, target += a.G);
+            tick(l == 0 ? 1 : 3);
+            acc[0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[1] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            if (xl) gemm_ks<true>(acc, hdst + (size_t)grow * nh, Wl + (size_t)l * nh * CW, nh, w, q, c16);
+            else gemm_ks<false>(acc, hdst + (size_t)grow * nh, Wl + (size_t)l * nh * CW, nh, w, q, c16);
+            tick(l == 0 ? 2 : 4);
+        }
+        __syncthreads();                                  // Hs complete
+        float* pdst = part + ((size_t)i * a.G + g) * RT * KP0_MAX;
+        if (has_lt) {
+            f32x4v o = {0.f, 0.f, 0.f, 0.f};
+            const float* hr = Hs + c16 * 33 + q;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) o = __builtin_amdgcn_mfma_f32_16x16x4f32(hr[4 * jj], wl[jj], o, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st_x(pdst + (4 * q + e) * NYP_MAX + 16 * w + c16, o[e], xl);
+        }
+        tick(5);
+        cluster_barrier(cnt, target += a.G);
+        tick(6);
+        const float* psrc = part + (size_t)i * a.G * RT * KP0_MAX;
+        const int nq = a.nyp / 4;                          // 16 x nq <= 256 items: one per thread
+        {
+            const int it = tid < RT * nq ? tid : RT * nq - 1;
+            const int r = it / nq, c0 = 4 * (it % nq);
+            f32x4v sv = {0.f, 0.f, 0.f, 0.f};
+            sum_slabs1<GP>(sv, psrc + r * NYP_MAX + c0, a.G, (size_t)RT * KP0_MAX);
+            if (tid < RT * nq) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = c0 + e;
+                    if (c >= ny) break;
+                    const float rs = a.dt * (sv[e] + Bl[c]);
+                    const float yn = Ys[r * ny + c] + rs;
+                    Ys[r * ny + c] = yn;
+                    if (g == 0 && row0 + r < B) {
+                        const size_t o = (size_t)(row0 + r) * ny + c;
+                        a.res[(size_t)i * B * ny + o] = rs;
+                        a.y_all[(size_t)(i + 1) * B * ny + o] = yn;
+                        if (i + 1 < a.S) a.inp_all[((size_t)(i + 1) * B + row0 + r) * nin + c] = yn;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        tick(7);
+    }
+    if (dbg && tid == 0) {
+        for (int k = 0; k < 8; ++k) a.dbg[k] = tacc[k];
+        a.dbg[8] = __builtin_readcyclecounter() - clk0;
+        a.dbg[9] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+}
+
+template <int GP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_ks_bwd_kernel(const RollF a) {
+    extern __shared__ float lds[];
+    int cl, g;
+    if (!locate(a, cl, g)) return;
+    constexpr int RT = RT16;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, c16 = lane & 15;
+    const int ec = tid & 31, er = tid >> 5;
+    const int row0 = (a.tile0 + cl) * RT;
+    const int colbase = g * CW;
+    const int nl = a.nl, nh = a.nh, ny = a.ny, nin = a.nin, B = a.B, dwd = a.dwd, nyp = a.nyp, kp0 = a.kp0;
+    const int nfull = nl - 2;
+    // LDS: [nfull][nh][32] slices (B[k][c] = W_l[k][colbase + c]) | Do [16][nyp + IPAD] | Dy [16][ny] | Hs [16][33] | Red [4][2][256]
+    float* Wl = lds;
+    float* Do = Wl + (size_t)nfull * nh * CW;
+    float* Dy = Do + RT * (nyp + IPAD);
+    float* Hs = Dy + RT * ny;
+    float* Red = Hs + RT * 33;
+    unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;
+    float* part = a.part + (size_t)(a.tile0 + cl) * a.S * a.G * RT * KP0_MAX;
+    unsigned target = 0;
+    xcd_announce(cnt);
+    for (int l = 1; l <= nfull; ++l) {
+        const float* W = a.W[l];
+        float* dst = Wl + (size_t)(l - 1) * nh * CW;
+        for (int idx = tid; idx < nh * CW; idx += 256) {
+            const int k = idx / CW, c = idx - k * CW;
+            dst[sw(k, c)] = W[(size_t)k * nh + colbase + c];
+        }
+    }
+    // last layer backward (K = nyp <= 64: k block w of this wave): B[k = 16 w + 4 q + e][16 ct + c16] = W_{nl-1}[k][colbase + 16 ct + c16]
+    float wlb[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 16 * w + 4 * q + e;
+            wlb[ct][e] = k < ny ? a.W[nl - 1][(size_t)k * nh + colbase + 16 * ct + c16] : 0.f;
+        }
+    // input gradient (split-K over the cluster): this wave's column tiles ct = w + 4 u of the [kp0] outputs: B[k = 4 jj + q][col] = W_0[colbase + k][col]
+    const int nct = kp0 / 16;
+    float w0b[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int ct = w + 4 * u, col = 16 * ct + c16;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+            w0b[u][jj] = (ct < nct && col < nin) ? a.W[0][(size_t)(colbase + 4 * jj + q) * nin + col] : 0.f;
+    }
+    for (int idx = tid; idx < RT * ny; idx += 256) {
+        const int r = idx / ny, c = idx - r * ny;
+        const int row = row0 + r < B ? row0 + r : B - 1;
+        Dy[idx] = a.d_y_all[((size_t)a.S * B + row) * ny + c];
+    }
+    cluster_barrier(cnt, target += a.G);
+    const bool xl = xcd_agreed(cnt, a.xcd_local, g == 0);
+    const int grow = row0 + c16 < B ? row0 + c16 : B - 1;
+    const size_t hs = (size_t)a.S * B * nh;
+    const size_t ds = (size_t)a.S * B * dwd;
+
+    float dres[NYP_MAX * RT / 256];
+    auto fetch_dres = [&](int step) {
+#pragma unroll
+        for (int u = 0; u < NYP_MAX * RT / 256; ++u) {
+            const int idx = tid + 256 * u, r = idx / nyp, c = idx - r * nyp;
+            const int row = row0 + r < B ? row0 + r : B - 1;
+            dres[u] = (a.d_res && idx < RT * nyp && c < ny) ? a.d_res[((size_t)step * B + row) * ny + c] : 0.f;
+        }
+    };
+    float hm[2];                                          // saved activations (ReLU masks) of this thread's two outputs
+    auto fetch_mask = [&](int l, int step) {
+        const float* hsrc = a.hid + (size_t)l * hs + (size_t)step * B * nh;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = er + 8 * u;
+            const int row = row0 + r < B ? row0 + r : B - 1;
+            hm[u] = hsrc[(size_t)row * nh + colbase + ec];
+        }
+    };
+    fetch_dres(a.S - 1);
+    for (int i = a.S - 1; i >= 0; --i) {
+        fetch_mask(nl - 2, i);
+#pragma unroll
+        for (int u = 0; u < NYP_MAX * RT / 256; ++u) {
+            const int idx = tid + 256 * u, r = idx / nyp, c = idx - r * nyp;
+            if (idx >= RT * nyp) break;
+            float v = 0.f;
+            if (c < ny) {
+                v = a.dt * (dres[u] + Dy[r * ny + c]);
+                if (g == 0 && row0 + r < B) a.dhid[(size_t)(nl - 1) * ds + ((size_t)i * B + row0 + r) * dwd + c] = v;
+            }
+            Do[r * (nyp + IPAD) + c] = v;
+        }
+        if (i > 0) fetch_dres(i - 1);
+        __syncthreads();
+        // ---- delta_{nl-2} slice: A = dout (LDS), B = registers, k block w
+        f32x4v acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        {
+            const bool ok = 16 * w < nyp;
+            f32x4v x = *reinterpret_cast<const f32x4v*>(Do + c16 * (nyp + IPAD) + (ok ? 16 * w : 0) + 4 * q);
+            if (!ok) x = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], wlb[0][e], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], wlb[1][e], acc[1], 0, 0, 0);
+            }
+        }
+        for (int l = nl - 2; l >= 0; --l) {
+            red_store(Red, acc, w, lane);
+            __syncthreads();
+            float* ddst = a.dhid + (size_t)l * ds + (size_t)i * B * dwd;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = er + 8 * u;
+                const float s = red_sum(Red, r, ec);
+                const float v = hm[u] > 0.f ? s : 0.f;
+                if (row0 + r < B) st_x(ddst + (size_t)(row0 + r) * dwd + colbase + ec, v, xl);
+                if (l == 0) Hs[r * 33 + ec] = v;
+            }
+            if (l == 0) break;
+            fetch_mask(l - 1, i);
+            cluster_barrier(cnt, target += a.G);
+            acc[0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[1] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            if (xl) gemm_ks<true>(acc, ddst + (size_t)grow * dwd, Wl + (size_t)(l - 1) * nh * CW, nh, w, q, c16);
+            else gemm_ks<false>(acc, ddst + (size_t)grow * dwd, Wl + (size_t)(l - 1) * nh * CW, nh, w, q, c16);
+        }
+        __syncthreads();
+        // ---- dinp partial (split-K over the cluster)
+        float* pdst = part + ((size_t)i * a.G + g) * RT * KP0_MAX;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ct = w + 4 * u;
+            if (ct >= nct) break;
+            f32x4v o = {0.f, 0.f, 0.f, 0.f};
+            const float* hr = Hs + c16 * 33 + q;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) o = __builtin_amdgcn_mfma_f32_16x16x4f32(hr[4 * jj], w0b[u][jj], o, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st_x(pdst + (4 * q + e) * KP0_MAX + 16 * ct + c16, o[e], xl);
+        }
+        const int nq = kp0 / 4;                            // 16 x nq <= 512 items: two per thread
+        const int n_it = RT * nq;
+        const int it = tid < n_it ? tid : n_it - 1, itb = tid + 256 < n_it ? tid + 256 : it;
+        float dyv[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int item = h ? itb : it, r = item / nq, c0 = 4 * (item % nq);
+            const int row = row0 + r < B ? row0 + r : B - 1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dyv[h][e] = c0 + e < ny ? a.d_y_all[((size_t)i * B + row) * ny + c0 + e] : 0.f;
+        }
+        cluster_barrier(cnt, target += a.G);
+        const float* psrc = part + (size_t)i * a.G * RT * KP0_MAX;
+        {
+            f32x4v sv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            sum_slabs2<GP>(sv[0], sv[1], psrc + (it / nq) * KP0_MAX + 4 * (it % nq), psrc + (itb / nq) * KP0_MAX + 4 * (itb % nq), a.G,
+                           (size_t)RT * KP0_MAX);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h ? (tid + 256 >= n_it) : (tid >= n_it)) break;
+                const int item = h ? itb : it;
+                const int r = item / nq, c0 = 4 * (item % nq);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = c0 + e;
+                    if (c >= nin) break;
+                    const float sum = sv[h][e];
+                    if (g == 0 && row0 + r < B) a.dinp_all[((size_t)i * B + row0 + r) * nin + c] = sum;
+                    if (c < ny) Dy[r * ny + c] = dyv[h][e] + Dy[r * ny + c] + sum;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (g == 0)
+        for (int idx = tid; idx < RT * ny; idx += 256) {
+            const int r = idx / ny, c = idx - r * ny;
+            if (row0 + r < B) a.d_y0[(size_t)(row0 + r) * ny + c] = Dy[idx];
+        }
+}
+
 // ------------------------------------------------------------------------------------------------------------ generation chain
 // The INFERENCE rollout (reference module/srvp.py:377-405 with nt > the number of observed frames; test.py:237-246, train.evaluate) as ONE
 // persistent launch per group of row tiles: per frame the prior MLP p_z(y) (srvp.py:383), the sample z ~ posterior while data lasts / prior
@@ -1118,16 +1544,34 @@ extern "C" int64_t srvp_rollout_fused_ws_bytes(const srvp_rollout_desc* d) {
     const size_t lds_f = ((size_t)(d->nl - 2) * d->nh * CW + RT * (kp0 + IPAD) + RT * d->ny + RT * 33 + NYP_MAX) * 4;
     const size_t lds_b = ((size_t)(d->nl - 2) * d->nh * CW + RT * (nyp + IPAD) + RT * d->ny + RT * 33) * 4;
     if (lds_f > 160 * 1024 || lds_b > 160 * 1024) return 0;
-    const int64_t tiles = (d->B + RT - 1) / RT;
-    return tiles * 256 /* counters (padded) */ + tiles * (int64_t)d->nsteps * (d->nh / CW) * RT * KP0_MAX * 4;
+    const int64_t tiles = (d->B + RT - 1) / RT, tiles16 = (d->B + RT16 - 1) / RT16;        // (either form of the kernels: ks_eligible)
+    const int64_t w32 = tiles * 256 /* counters (padded) */ + tiles * (int64_t)d->nsteps * (d->nh / CW) * RT * KP0_MAX * 4;
+    const int64_t w16 = tiles16 * 256 + tiles16 * (int64_t)d->nsteps * (d->nh / CW) * RT16 * KP0_MAX * 4;
+    return w32 > w16 ? w32 : w16;
 }
 
-static int fused_common(const srvp_rollout_desc& f, RollF& k, void* ws) {
+// the 16-row / K-split form: every 16-row tile of the batch in ONE co-resident launch, and its LDS layout fits
+static bool ks_eligible(const srvp_rollout_desc& f) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SRVP_ROLLOUT_KSPLIT"); on = e ? atoi(e) : 1; }
+    if (!on) return false;
+    device_cus();
+    const int G = f.nh / CW;
+    int per_xcd = (g_ncu / 8) / G;
+    if (per_xcd < 1) per_xcd = 1;
+    if ((f.B + RT16 - 1) / RT16 > per_xcd * 8) return false;
+    const int kp0 = (f.ny + f.nz + 15) / 16 * 16, nyp = (f.ny + 15) / 16 * 16;
+    const size_t lds_f = ((size_t)(f.nl - 2) * f.nh * CW + RT16 * (kp0 + IPAD) + RT16 * f.ny + RT16 * 33 + NYP_MAX + 2048) * 4;
+    const size_t lds_b = ((size_t)(f.nl - 2) * f.nh * CW + RT16 * (nyp + IPAD) + RT16 * f.ny + RT16 * 33 + 2048) * 4;
+    return lds_f <= 160 * 1024 && lds_b <= 160 * 1024;
+}
+
+static int fused_common(const srvp_rollout_desc& f, RollF& k, void* ws, int rt) {
     device_cus();
     k.B = f.B; k.ny = f.ny; k.nz = f.nz; k.nh = f.nh; k.nl = f.nl; k.S = f.nsteps; k.ne = f.n_euler; k.G = f.nh / CW;
     k.nin = f.ny + f.nz; k.kp0 = (k.nin + 15) / 16 * 16; k.nyp = (f.ny + 15) / 16 * 16; k.dt = f.dt;
     for (int l = 0; l < MAX_NL; ++l) { k.W[l] = l < f.nl ? f.dyn_w[l] : nullptr; k.b[l] = l < f.nl ? f.dyn_b[l] : nullptr; }
-    const int tiles = (f.B + RT - 1) / RT;
+    const int tiles = (f.B + rt - 1) / rt;
     k.cnt = (unsigned*)ws; k.xcd_local = xcd_local_on();
     k.part = (float*)((char*)ws + (size_t)tiles * 256);
     return tiles;
@@ -1144,10 +1588,13 @@ static int clusters_per_launch(int G, int tiles, int& cl_per_xcd) {
 
 int srvp_rollout_fused_fwd(const srvp_rollout_desc* d, hipStream_t st) {
     RollF k{};
-    const int tiles = fused_common(*d, k, d->fused_ws);
+    const bool ks = ks_eligible(*d);
+    const int tiles = fused_common(*d, k, d->fused_ws, ks ? RT16 : RT);
     k.y0 = d->y0; k.y_all = d->y_all; k.res = d->res; k.inp_all = d->inp_all; k.hid = d->hid_dyn;
-    const size_t lds = ((size_t)(k.nl - 2) * k.nh * CW + RT * (k.kp0 + IPAD) + RT * k.ny + RT * 33 + NYP_MAX) * 4;
-    auto kern = k.G <= 8 ? rollout_fused_fwd_kernel<8> : (k.G <= 16 ? rollout_fused_fwd_kernel<16> : rollout_fused_fwd_kernel<32>);
+    const size_t lds = ks ? ((size_t)(k.nl - 2) * k.nh * CW + RT16 * (k.kp0 + IPAD) + RT16 * k.ny + RT16 * 33 + NYP_MAX + 2048) * 4
+                          : ((size_t)(k.nl - 2) * k.nh * CW + RT * (k.kp0 + IPAD) + RT * k.ny + RT * 33 + NYP_MAX) * 4;
+    auto kern = ks ? (k.G <= 8 ? rollout_ks_fwd_kernel<8> : (k.G <= 16 ? rollout_ks_fwd_kernel<16> : rollout_ks_fwd_kernel<32>))
+                   : (k.G <= 8 ? rollout_fused_fwd_kernel<8> : (k.G <= 16 ? rollout_fused_fwd_kernel<16> : rollout_fused_fwd_kernel<32>));
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd(fused): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
@@ -1181,11 +1628,14 @@ int srvp_rollout_fused_fwd(const srvp_rollout_desc* d, hipStream_t st) {
 int srvp_rollout_fused_bwd(const srvp_rollout_bwd_desc* d, hipStream_t st) {
     RollF k{};
     const srvp_rollout_desc& f = d->f;
-    const int tiles = fused_common(f, k, f.fused_ws);
+    const bool ks = ks_eligible(f);
+    const int tiles = fused_common(f, k, f.fused_ws, ks ? RT16 : RT);
     k.hid = f.hid_dyn; k.d_y_all = d->d_y_all; k.d_res = d->d_res; k.dhid = d->dhid_dyn; k.dinp_all = d->dinp_all; k.d_y0 = d->d_y0;
     k.dwd = f.nh > f.ny ? f.nh : f.ny;
-    const size_t lds = ((size_t)(k.nl - 2) * k.nh * CW + RT * (k.nyp + IPAD) + RT * k.ny + RT * 33) * 4;
-    auto kern = k.G <= 8 ? rollout_fused_bwd_kernel<8> : (k.G <= 16 ? rollout_fused_bwd_kernel<16> : rollout_fused_bwd_kernel<32>);
+    const size_t lds = ks ? ((size_t)(k.nl - 2) * k.nh * CW + RT16 * (k.nyp + IPAD) + RT16 * k.ny + RT16 * 33 + 2048) * 4
+                          : ((size_t)(k.nl - 2) * k.nh * CW + RT * (k.nyp + IPAD) + RT * k.ny + RT * 33) * 4;
+    auto kern = ks ? (k.G <= 8 ? rollout_ks_bwd_kernel<8> : (k.G <= 16 ? rollout_ks_bwd_kernel<16> : rollout_ks_bwd_kernel<32>))
+                   : (k.G <= 8 ? rollout_fused_bwd_kernel<8> : (k.G <= 16 ? rollout_fused_bwd_kernel<16> : rollout_fused_bwd_kernel<32>));
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_bwd(fused): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
