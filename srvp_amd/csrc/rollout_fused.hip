@@ -1485,6 +1485,218 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// ---- second form of the two LSTM kernels (round 5; SRVP_LSTM_KSPLIT=0: the 32-row kernels above), by the same reasoning as rollout_ks_*:
+// the recurrence is a chain of T dependent steps on which 8 CUs worked (32-row tiles, 32 units per workgroup) for 3.4 us of fp32 MFMA issue and
+// 32 KB (forward) / 128 KB (backward) of gathered tile per step.  Here: 16-row tiles and 16 hidden units per workgroup (4 x the workgroups),
+// v_mfma_f32_16x16x4_f32, the A tile read from LDS as 16-byte fragments.
+//   forward : wave q = gate q of the workgroup's 16 units; h_{t-1} tile [16][nh] gathered into LDS; 64 MFMAs per wave and step.
+//   backward: the contraction dh_carry[b][u] = sum_k dgates[b][k] W_hh[k][u] is split over the cluster along k INSTEAD of u: a workgroup
+//     contracts the 64 gate gradients it has just formed itself (they never leave the CU) with its [64][nh] slice of W_hh (64 VGPRs per lane,
+//     wave w = output units [w nh/4, (w+1) nh/4)) into a partial [16][nh] slab, and after ONE barrier gathers the G partial values of its own
+//     16 x 16 units (16 KB written + 16 KB read per step instead of a 128 KB dgates tile), summed in a fixed order.
+struct LstmB2 {
+    int B, nh, T, G, ntiles, tile0, cl_per_xcd;
+    const float* dh_out; const float* whh; const float* c; const float* ga; float* dgates; unsigned* cnt; int xcd_local; float* part;
+};
+
+template <int KST, int NCT>     // nh = 16 KST, 16 NCT hidden units per workgroup
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_ks_fwd_kernel(const LstmF a) {
+    extern __shared__ float lds[];
+    constexpr int NH = 16 * KST, HLD = NH + 4, CWL = 16 * NCT, GLD = CWL + 1, RTL = 16;
+    float* Hs = lds;                          // [16][NH + 4]   h_{t-1} of this batch tile (rows 16-byte aligned)
+    float* Gs = lds + RTL * HLD;              // [4][16][CWL + 1]  activated gates of this workgroup's units
+    const int x = blockIdx.x & 7, kk = blockIdx.x >> 3;
+    const int cl = x * a.cl_per_xcd + kk / a.G, g = kk % a.G;
+    if (cl >= a.ntiles) return;
+    const int tid = threadIdx.x, lane = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int quad = lane >> 4, c16 = lane & 15;
+    const int row0 = (a.tile0 + cl) * RTL;
+    float wreg[NCT][KST][4];                  // B[k = 16 j + 4 quad + e][16 ct + c16] = W_hh[gate row of that unit][k]
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int j = 0; j < KST; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                wreg[ct][j][e] = a.whh[(size_t)(q * NH + g * CWL + 16 * ct + c16) * NH + 16 * j + 4 * quad + e];
+    float cst[NCT];
+#pragma unroll
+    for (int e = 0; e < NCT; ++e) cst[e] = 0.f;
+    unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;
+    const size_t gs = (size_t)a.B * 4 * NH, hs = (size_t)a.B * NH;
+    xcd_announce(cnt);
+    cluster_barrier(cnt, (unsigned)a.G);
+    const bool xl = xcd_agreed(cnt, a.xcd_local, g == 0);
+    for (int t = 0; t < a.T; ++t) {
+        f32x4v acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = row0 + 4 * quad + e;
+                acc[ct][e] = row < a.B ? a.gx[gs * t + (size_t)row * 4 * NH + q * NH + g * CWL + 16 * ct + c16] : 0.f;
+            }
+        if (t > 0) {
+            cluster_barrier(cnt, (unsigned)((t + 1) * a.G));   // every member has stored its slice of h_{t-1}
+            const float* hp = a.h + hs * (t - 1);
+            constexpr int NP = RTL * NH / 4;                    // 16-byte pieces of the tile
+            constexpr int NLD = (NP + 255) / 256;
+            f32x4v hv[NLD];
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int idx0 = tid + 256 * i, idx = idx0 < NP ? idx0 : NP - 1, row = idx / (NH / 4), c4 = idx % (NH / 4);
+                const int gr = row0 + row < a.B ? row0 + row : a.B - 1;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(hv[i]) : "v"(hp + (size_t)gr * NH + c4 * 4) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) asm volatile("" : "+v"(hv[i]));
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int idx = tid + 256 * i, row = idx / (NH / 4), c4 = idx % (NH / 4);
+                if (idx < NP) *reinterpret_cast<f32x4v*>(Hs + row * HLD + c4 * 4) = hv[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < KST; ++j) {
+                const f32x4v av = *reinterpret_cast<const f32x4v*>(Hs + c16 * HLD + 16 * j + 4 * quad);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wreg[ct][j][e], acc[ct], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int rl = 4 * quad + e;
+                const float v = q == 2 ? tanhf(acc[ct][e]) : sigmoid_l(acc[ct][e]);
+                if (row0 + rl < a.B) a.ga[gs * t + (size_t)(row0 + rl) * 4 * NH + q * NH + g * CWL + 16 * ct + c16] = v;
+                Gs[(q * RTL + rl) * GLD + 16 * ct + c16] = v;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NCT; ++e) {
+            const int idx = tid + 256 * e, rl = idx / CWL, u = idx % CWL;
+            const float ig = Gs[(0 * RTL + rl) * GLD + u], fg = Gs[(1 * RTL + rl) * GLD + u], gg = Gs[(2 * RTL + rl) * GLD + u], og = Gs[(3 * RTL + rl) * GLD + u];
+            cst[e] = fg * cst[e] + ig * gg;
+            if (row0 + rl < a.B) {
+                const size_t o = hs * t + (size_t)(row0 + rl) * NH + g * CWL + u;
+                a.c[o] = cst[e];
+                st_x(a.h + o, og * tanhf(cst[e]), xl);
+            }
+        }
+        __syncthreads();                                   // Gs is rewritten by the next step's gates
+    }
+}
+
+template <int KST, int NCT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_ks_bwd_kernel(const LstmB2 a) {
+    extern __shared__ float lds[];
+    constexpr int NH = 16 * KST, CWL = 16 * NCT, KL = 4 * CWL, DLD = KL + 4, RTL = 16, G = NH / CWL, NCW = KST / 4;
+    static_assert(KST % 4 == 0, "nh must be a multiple of 64");
+    float* Dl = lds;                          // [16][4 CWL + 4]  the gate gradients this workgroup forms at step t (k_local = gate CWL + u)
+    const int x = blockIdx.x & 7, kk = blockIdx.x >> 3;
+    const int cl = x * a.cl_per_xcd + kk / G, g = kk % G;
+    if (cl >= a.ntiles) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int quad = lane >> 4, c16 = lane & 15;
+    const int row0 = (a.tile0 + cl) * RTL;
+    float wreg[NCW][KL / 16][4];              // B[k_local = 16 jj + 4 quad + e][col] = W_hh[gate NH + g CWL + u][col], col = w NH / 4 + 16 ct + c16
+#pragma unroll
+    for (int ct = 0; ct < NCW; ++ct)
+#pragma unroll
+        for (int jj = 0; jj < KL / 16; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kl = 16 * jj + 4 * quad + e, gate = kl / CWL, u = kl % CWL;
+                wreg[ct][jj][e] = a.whh[(size_t)(gate * NH + g * CWL + u) * NH + w * (NH / 4) + 16 * ct + c16];
+            }
+    float dcs[NCT], dhc[NCT];
+#pragma unroll
+    for (int e = 0; e < NCT; ++e) { dcs[e] = 0.f; dhc[e] = 0.f; }
+    unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;
+    float* part = a.part + (size_t)(a.tile0 + cl) * a.T * G * RTL * NH;     // a fresh partial slab per step and member
+    const size_t gs = (size_t)a.B * 4 * NH, hs = (size_t)a.B * NH;
+    unsigned target = 0;
+    xcd_announce(cnt);
+    cluster_barrier(cnt, target += (unsigned)G);
+    const bool xl = xcd_agreed(cnt, a.xcd_local, g == 0);
+    // operands of the cell backward, fetched one step ahead (their latency otherwise sits on the chain)
+    float p_ig[NCT], p_fg[NCT], p_gg[NCT], p_og[NCT], p_dh[NCT], p_c[NCT], p_cp[NCT];
+    auto fetch = [&](int t, bool first) {
+#pragma unroll
+        for (int e = 0; e < NCT; ++e) {
+            const int idx = tid + 256 * e, rl = idx / CWL, u = idx % CWL;
+            const int row = row0 + rl < a.B ? row0 + rl : a.B - 1;
+            const size_t ho = hs * t + (size_t)row * NH + g * CWL + u;
+            const size_t go = gs * t + (size_t)row * 4 * NH + g * CWL + u;
+            p_ig[e] = a.ga[go]; p_fg[e] = a.ga[go + NH]; p_gg[e] = a.ga[go + 2 * NH]; p_og[e] = a.ga[go + 3 * NH];
+            p_dh[e] = a.dh_out[ho];
+            p_c[e] = first ? a.c[ho] : p_cp[e];
+            p_cp[e] = t > 0 ? a.c[ho - hs] : 0.f;
+        }
+    };
+    fetch(a.T - 1, true);
+    for (int t = a.T - 1; t >= 0; --t) {
+#pragma unroll
+        for (int e = 0; e < NCT; ++e) {
+            const int idx = tid + 256 * e, rl = idx / CWL, u = idx % CWL;
+            const bool valid = row0 + rl < a.B;
+            const float ig = p_ig[e], fg = p_fg[e], gg = p_gg[e], og = p_og[e];
+            const float dh = p_dh[e] + dhc[e];
+            const float tc = tanhf(p_c[e]);
+            const float dc = dcs[e] + dh * og * (1.f - tc * tc);
+            const float d0 = dc * gg * ig * (1.f - ig), d1 = dc * p_cp[e] * fg * (1.f - fg), d2 = dc * ig * (1.f - gg * gg), d3 = dh * tc * og * (1.f - og);
+            if (valid) {
+                const size_t go = gs * t + (size_t)(row0 + rl) * 4 * NH + g * CWL + u;
+                a.dgates[go] = d0; a.dgates[go + NH] = d1; a.dgates[go + 2 * NH] = d2; a.dgates[go + 3 * NH] = d3;
+            }
+            float* dl = Dl + rl * DLD + u;
+            dl[0] = valid ? d0 : 0.f; dl[CWL] = valid ? d1 : 0.f; dl[2 * CWL] = valid ? d2 : 0.f; dl[3 * CWL] = valid ? d3 : 0.f;
+            dcs[e] = dc * fg;
+        }
+        if (t == 0) break;
+        fetch(t - 1, false);
+        __syncthreads();
+        f32x4v acc[NCW];
+#pragma unroll
+        for (int ct = 0; ct < NCW; ++ct) acc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < KL / 16; ++jj) {
+            const f32x4v av = *reinterpret_cast<const f32x4v*>(Dl + c16 * DLD + 16 * jj + 4 * quad);
+#pragma unroll
+            for (int ct = 0; ct < NCW; ++ct)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wreg[ct][jj][e], acc[ct], 0, 0, 0);
+        }
+        float* slab = part + ((size_t)t * G + g) * RTL * NH;
+#pragma unroll
+        for (int ct = 0; ct < NCW; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st_x(slab + (4 * quad + e) * NH + w * (NH / 4) + 16 * ct + c16, acc[ct][e], xl);
+        cluster_barrier(cnt, target += (unsigned)G);          // every member's partial slab of step t is complete (and Dl has been read)
+        const float* psrc = part + (size_t)t * G * RTL * NH;
+#pragma unroll
+        for (int e = 0; e < NCT; ++e) {
+            const int idx = tid + 256 * e, rl = idx / CWL, u = idx % CWL;
+            const float* pp = psrc + rl * NH + g * CWL + u;
+            float v[G];
+#pragma unroll
+            for (int gg2 = 0; gg2 < G; ++gg2)
+                asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(v[gg2]) : "v"(pp + (size_t)gg2 * RTL * NH) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int gg2 = 0; gg2 < G; ++gg2) asm volatile("" : "+v"(v[gg2]));
+            float s = v[0];
+#pragma unroll
+            for (int gg2 = 1; gg2 < G; ++gg2) s += v[gg2];
+            dhc[e] = s;
+        }
+    }
+}
+
 // Placement probe (once per process): does block b of a plain launch run on XCC b % 8?  The generation chain needs it for correctness of its
 // buffer reuse (and verifies it again inside every launch); the other persistent kernels only run faster when it holds.
 __global__ void xcc_probe_kernel(unsigned* out) { if (threadIdx.x == 0) out[blockIdx.x] = xcc_id(); }
@@ -1713,7 +1925,18 @@ extern "C" int64_t srvp_lstm_fused_ws_bytes(int T, int B, int nh) {
     if (on < 0) { const char* e = getenv("SRVP_LSTM_FUSED"); on = e ? atoi(e) : 1; }
     if (!on || T < 1 || B < 1 || !(nh == 64 || nh == 128 || nh == 256)) return 0;
     if (!clusters_fit(nh / CW)) return 0;
-    return (int64_t)((B + RT - 1) / RT) * 256;
+    const int64_t t16 = (B + 15) / 16;                    // (either form of the kernels: lstm_ks_eligible; the backward's partial slabs)
+    return t16 * 256 + t16 * (int64_t)T * (nh / 16) * 16 * nh * 4;
+}
+// the 16-row / 16-unit form: nh a multiple of 64, every tile of the batch in ONE co-resident launch
+static bool lstm_ks_eligible(int B, int nh) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SRVP_LSTM_KSPLIT"); on = e ? atoi(e) : 1; }
+    if (!on || nh % 64 != 0) return false;
+    device_cus();
+    const int G = nh / 16;
+    const int per_xcd = (g_ncu / 8) / G;
+    return per_xcd >= 1 && (B + 15) / 16 <= per_xcd * 8;
 }
 extern "C" int srvp_lstm_fwd_fused(const float* gates_x, const float* w_hh, float* h_out, float* c_out, float* gates_act, int T, int B,
                                    int nh, void* ws, int64_t ws_bytes, void* stream) {
@@ -1723,10 +1946,12 @@ extern "C" int srvp_lstm_fwd_fused(const float* gates_x, const float* w_hh, floa
     SRVP_REQUIRE(need > 0 && ws_bytes >= need, "srvp_lstm_fwd_fused: shape not eligible or workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)need);
     device_cus();
     LstmF k{};
-    k.B = B; k.nh = nh; k.T = T; k.G = nh / CW; k.gx = gates_x; k.whh = w_hh; k.h = h_out; k.c = c_out; k.ga = gates_act; k.cnt = (unsigned*)ws; k.xcd_local = xcd_local_on();
-    const int tiles = (B + RT - 1) / RT;
-    const size_t lds = ((size_t)RT * (nh + 1) + 4 * RT * 33) * 4;
-    auto kern = nh == 256 ? lstm_fused_fwd_kernel<128> : (nh == 128 ? lstm_fused_fwd_kernel<64> : lstm_fused_fwd_kernel<32>);
+    const bool ks = lstm_ks_eligible(B, nh);
+    k.B = B; k.nh = nh; k.T = T; k.G = ks ? nh / 16 : nh / CW; k.gx = gates_x; k.whh = w_hh; k.h = h_out; k.c = c_out; k.ga = gates_act; k.cnt = (unsigned*)ws; k.xcd_local = xcd_local_on();
+    const int tiles = ks ? (B + 15) / 16 : (B + RT - 1) / RT;
+    const size_t lds = ks ? ((size_t)16 * (nh + 4) + 4 * 16 * 17) * 4 : ((size_t)RT * (nh + 1) + 4 * RT * 33) * 4;
+    auto kern = ks ? (nh == 256 ? lstm_ks_fwd_kernel<16, 1> : (nh == 128 ? lstm_ks_fwd_kernel<8, 1> : lstm_ks_fwd_kernel<4, 1>))
+                   : (nh == 256 ? lstm_fused_fwd_kernel<128> : (nh == 128 ? lstm_fused_fwd_kernel<64> : lstm_fused_fwd_kernel<32>));
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SRVP_REQUIRE(e == hipSuccess, "srvp_lstm_fwd_fused: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
@@ -1750,6 +1975,23 @@ extern "C" int srvp_lstm_bwd_fused(const float* dh_out, const float* w_hh, const
     const int64_t need = srvp_lstm_fused_ws_bytes(T, B, nh);
     SRVP_REQUIRE(need > 0 && ws_bytes >= need, "srvp_lstm_bwd_fused: shape not eligible or workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)need);
     device_cus();
+    if (lstm_ks_eligible(B, nh)) {
+        LstmB2 k{};
+        const int tiles = (B + 15) / 16;
+        k.B = B; k.nh = nh; k.T = T; k.G = nh / 16; k.dh_out = dh_out; k.whh = w_hh; k.c = c_out; k.ga = gates_act; k.dgates = dgates;
+        k.cnt = (unsigned*)ws; k.xcd_local = xcd_local_on(); k.part = (float*)((char*)ws + (size_t)tiles * 256);
+        const size_t lds = (size_t)16 * (4 * 16 + 4) * 4;
+        auto kern = nh == 256 ? lstm_ks_bwd_kernel<16, 1> : (nh == 128 ? lstm_ks_bwd_kernel<8, 1> : lstm_ks_bwd_kernel<4, 1>);
+        hipError_t e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
+        SRVP_REQUIRE(e == hipSuccess, "srvp_lstm_bwd_fused: memset failed");
+        int cpx;
+        const int per = clusters_per_launch(k.G, tiles, cpx);
+        k.tile0 = 0; k.ntiles = tiles; k.cl_per_xcd = cpx;
+        SRVP_REQUIRE(tiles <= per, "srvp_lstm_bwd_fused: %d tiles for %d cluster slots", tiles, per);
+        hipLaunchKernelGGL(kern, dim3(8 * cpx * k.G), dim3(256), lds, st, k);
+        SRVP_CHECK_LAUNCH("srvp_lstm_bwd_fused");
+        return SRVP_OK;
+    }
     LstmB k{};
     k.B = B; k.nh = nh; k.T = T; k.G = nh / CW; k.dh_out = dh_out; k.whh = w_hh; k.c = c_out; k.ga = gates_act; k.dgates = dgates; k.cnt = (unsigned*)ws; k.xcd_local = xcd_local_on();
     const int tiles = (B + RT - 1) / RT;
