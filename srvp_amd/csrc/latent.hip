@@ -8,8 +8,9 @@
 #include "common.h"
 #include "../../include/srvp_hip.h"
 
-int srvp_rollout_fused_fwd(const srvp_rollout_desc* d, hipStream_t st);          // rollout_fused.hip
+int srvp_rollout_fused_fwd(const srvp_rollout_desc* d, hipStream_t st, bool counters_cleared);          // rollout_fused.hip
 int srvp_rollout_fused_bwd(const srvp_rollout_bwd_desc* d, hipStream_t st);
+int64_t srvp_rollout_fused_cnt_words(const srvp_rollout_desc* d);                 // 4-byte words of the two counter blocks at the start of fused_ws
 int srvp_rollout_gen_fwd(const srvp_rollout_desc* d, hipStream_t st);            // rollout_fused.hip: the inference chain, p_z inside
 
 namespace {
@@ -351,6 +352,28 @@ __global__ void fill_inp_kernel(const float* z, const float* y0, float* inp_all,
     if (c >= ny) inp_all[i] = z[((size_t)(st / ne) * B + b) * nz + c - ny];
     else if (st == 0) inp_all[i] = y0[b * ny + c];
 }
+// Everything in front of the persistent chain as ONE launch (round 5; it was a copy, two kernels and a memset on the step's serial path):
+// y_all[0] = y0; z = rsample(q_z, eps) for every frame; the z half of every step's MLP input and the y half of step 0; the cluster counters
+// of the persistent kernels (forward AND backward block) cleared.
+__global__ void rollout_prep_kernel(const float* q_z, const float* eps, const float* y0, float* z, float* y_all, float* inp_all, unsigned* cnt,
+                                    int cnt_words, int F, int S, int ne, int B, int ny, int nz) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = ny + nz;
+    if (i < cnt_words) cnt[i] = 0u;
+    if (i < (long long)B * ny) {
+        const int b = (int)(i / ny), c = (int)(i - (long long)b * ny);
+        const float v = y0[i];
+        y_all[i] = v;
+        inp_all[(size_t)b * w + c] = v;
+    }
+    if (i >= (long long)F * B * nz) return;
+    const long long r = i / nz; const int c = (int)(i - r * nz);
+    const int f = (int)(r / B), b = (int)(r - (long long)f * B);
+    const float* p = q_z + r * 2 * nz;
+    const float v = p[c] + eps[i] * (softplus_f(p[nz + c]) + 1e-8f);
+    z[i] = v;
+    for (int st = f * ne; st < (f + 1) * ne && st < S; ++st) inp_all[((size_t)st * B + b) * w + ny + c] = v;
+}
 // res = dt*out ; y_next = y + res, also written as the y part of the next step's MLP input
 __global__ void euler_update2_kernel(const float* y, const float* out, float dt, float* res, float* y_next, float* inp_next, int B,
                                      int ny, int nin) {
@@ -685,6 +708,16 @@ extern "C" int srvp_rollout_fwd(const srvp_rollout_desc* d, void* stream) {
         const int64_t need = srvp_rollout_gen_ws_bytes(d);
         if (need > 0 && d->fused_ws_bytes >= need) return srvp_rollout_gen_fwd(d, st);
     }
+    if (d->pz_external && d->hid_dyn && use_fused(*d)) {
+        // the whole posterior-only chain: one preparation launch + one persistent kernel
+        const int64_t cw = srvp_rollout_fused_cnt_words(d);
+        long long n = (long long)F * zs;
+        if (n < (long long)ys) n = (long long)ys;
+        if (n < cw) n = cw;
+        hipLaunchKernelGGL(rollout_prep_kernel, g1(n), dim3(256), 0, st, d->q_z_params, d->eps_z, d->y0, d->z, d->y_all, d->inp_all,
+                           (unsigned*)d->fused_ws, (int)cw, F, d->nsteps, d->n_euler, B, ny, nz);
+        return srvp_rollout_fused_fwd(d, st, true);
+    }
     hipError_t e = hipMemcpyAsync(d->y_all, d->y0, sizeof(float) * ys, hipMemcpyDeviceToDevice, st);
     SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd: copy failed");
     if (d->pz_external && d->hid_dyn) {
@@ -692,7 +725,6 @@ extern "C" int srvp_rollout_fwd(const srvp_rollout_desc* d, void* stream) {
         hipLaunchKernelGGL(rsample_fwd_kernel, g1((long long)F * zs), dim3(256), 0, st, d->q_z_params, d->eps_z, d->z, (long long)F * B, nz);
         hipLaunchKernelGGL(fill_inp_kernel, g1((long long)d->nsteps * B * nin), dim3(256), 0, st, d->z, d->y0, d->inp_all, d->nsteps,
                            d->n_euler, B, ny, nz);
-        if (use_fused(*d)) return srvp_rollout_fused_fwd(d, st);          // the whole chain: one persistent kernel
         for (int i = 0; i < d->nsteps; ++i) {
             float* inp = d->inp_all + (size_t)i * B * nin;
             int rc = mlp_fwd(st, d->dyn_w, d->dyn_b, nl, nin, nh, ny, inp, B, d->hid_dyn + (size_t)i * hl, (size_t)d->nsteps * hl, d->scratch_out);
@@ -750,19 +782,19 @@ extern "C" int srvp_rollout_bwd(const srvp_rollout_bwd_desc* d, void* stream) {
     float* dinp = dy + ys;
     float* dz_acc = dinp + (size_t)B * nin;
     float* dypz = dz_acc + zs;
+    if (f.pz_external && d->dinp_all && use_fused(f)) {
+        if (int rc = srvp_rollout_fused_bwd(d, st)) return rc;        // writes every delta, dinp_all and d_y0 (the carry lives in its LDS)
+        hipLaunchKernelGGL(dz_finalize_kernel, g1((long long)F * zs), dim3(256), 0, st, d->dinp_all, d->d_z, f.q_z_params, f.eps_z, d->d_qz,
+                           F, f.nsteps, f.n_euler, B, ny, nz);
+        SRVP_CHECK_LAUNCH("srvp_rollout_bwd(fused)");
+        return SRVP_OK;
+    }
     hipError_t e = hipMemsetAsync(carry, 0, sizeof(float) * ys, st);
     SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_bwd: memset failed");
     if (f.pz_external && d->dinp_all) {
         // posterior-only chain: seed of the last step, then per step nl GEMMs + ONE kernel (close step i, seed step i-1); the
         // gradients wrt z and the posterior samples' backward are finished for all frames at once afterwards
         const int S = f.nsteps;
-        if (use_fused(f)) {
-            if (int rc = srvp_rollout_fused_bwd(d, st)) return rc;        // writes every delta, dinp_all and d_y0
-            hipLaunchKernelGGL(dz_finalize_kernel, g1((long long)F * zs), dim3(256), 0, st, d->dinp_all, d->d_z, f.q_z_params, f.eps_z, d->d_qz,
-                               F, S, f.n_euler, B, ny, nz);
-            SRVP_CHECK_LAUNCH("srvp_rollout_bwd(fused)");
-            return SRVP_OK;
-        }
         hipLaunchKernelGGL(euler_bwd_seed_kernel, g1((long long)ys), dim3(256), 0, st, d->d_y_all + ys * S, carry,
                            d->d_res ? d->d_res + ys * (S - 1) : nullptr, f.dt, dy, d->dhid_dyn + (size_t)(S - 1) * B * dwd + (size_t)(nl - 1) * dls_d,
                            B, ny, dwd);

