@@ -32,8 +32,10 @@ ENC_WGRAD_SIDE_MAXN = int(os.environ.get('SRVP_ENC_WGRAD_SIDE_MAXN', '1000000'))
 BN_FUSED_REDUCE = os.environ.get('SRVP_BN_FUSED_REDUCE', '1') != '0'
 # decoder weight gradients issued on the second stream block by block (each right behind its BatchNorm backward) instead of all after
 # the decoder's data-gradient chain: the MFMA-bound weight gradients then run beside the HBM-bound BatchNorm passes of the blocks below
-# (measured, same box: 41.70 vs 41.21 ms per step at 192 sequences with / without, 8.88 vs 8.86 at 24: off)
-DEC_WGRAD_EARLY = os.environ.get('SRVP_DEC_WGRAD_EARLY', '0') != '0'
+# (measured, same box: 41.70 vs 41.21 ms per step at 192 sequences with / without, 8.88 vs 8.86 at 24 in round 3: off.  Round 5, after the
+# persistent latent kernels had become 0.5 ms shorter -- the weight gradients no longer fit under the latent backward and the step ended on
+# the second queue: 37.54 vs 37.87 ms at 192 sequences, 7.29 vs 7.42 at 24: on)
+DEC_WGRAD_EARLY = os.environ.get('SRVP_DEC_WGRAD_EARLY', '1') != '0'
 IN_WGRAD_BN = os.environ.get('SRVP_IN_WGRAD_BN', '1') != '0'                # 0: the first block's output gradient is written and read back by its weight gradient
 POOL_FUSED_REDUCE = os.environ.get('SRVP_POOL_FUSED_REDUCE', '1') != '0'    # 0: pooled layers keep their own BatchNorm-backward reduction pass
 S_QUAD = os.environ.get('SRVP_S_QUAD', '1') != '0'        # hoisted skip half stored pixel-quad-major (16-byte loads in the consumers)

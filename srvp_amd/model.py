@@ -54,6 +54,7 @@ PZ_AUX = os.environ.get('SRVP_PZ_AUX', '1') != '0'                       # 0: th
 SKIP_REDUCE_AUX = os.environ.get('SRVP_SKIP_REDUCE_AUX', '1') != '0'      # 0: the pooled stages' skip-gradient reductions in line on the main stream
 LATENT_AUX = os.environ.get('SRVP_LATENT_AUX', '1') != '0'        # independent chains of the latent path (posterior / w / y_0; their backward) on two streams
 PZ_BWD_AUX = os.environ.get('SRVP_PZ_BWD_AUX', '1') != '0'          # the prior MLP's backward on the auxiliary stream under the decoder backward
+ENC_WGRAD_STREAM2 = os.environ.get('SRVP_ENC_WGRAD_STREAM2', '0') != '0'   # the encoder's weight gradients on a third stream (not behind the decoder's)
 LATENT_WGRAD_STREAM = os.environ.get('SRVP_LATENT_WGRAD_STREAM', '1') != '0'    # the latent networks' weight gradients on a stream of their own
 OVERLAP_SKIP = os.environ.get('SRVP_OVERLAP_SKIP', '1') == '1'
 SKIP_LATE = os.environ.get('SRVP_SKIP_LATE', '1') == '1'        # hoisted skip convs under the rollout kernel (1) / under the inference chain (0)
@@ -671,8 +672,15 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             if getattr(self, '_lat_stream', None) is None:
                 self._lat_stream = torch.cuda.Stream()
             aux = self._lat_stream
+        enc_side = self._side_stream if overlap else None
+        if overlap and ENC_WGRAD_STREAM2:
+            # the encoder's weight gradients (and their unpacking) on a stream of their own: behind the decoder's on ONE stream the first of
+            # them waited for the last of those, and the step ended on that queue after the main queue had run dry
+            if getattr(self, '_side2_stream', None) is None:
+                self._side2_stream = _make_side_stream()
+            enc_side = self._side2_stream
         enc.backward(pl['x'].view(T * B, *pl['x'].shape[2:]), d_hx_p, skip_grads, params, grads, st, self.sync,
-                     side=self._side_stream if overlap else None, aux=aux)
+                     side=enc_side, aux=aux)
         lat_stream = None
         if deferred:
             # the latent networks' weight gradients feed nothing but the optimizer.  ~25 small launches (a few workgroups each): on the second
@@ -694,6 +702,10 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             side_done = torch.cuda.Event()
             side_done.record(self._side_stream)
             torch.cuda.current_stream().wait_event(side_done)
+            if enc_side is not self._side_stream:
+                side2_done = torch.cuda.Event()
+                side2_done.record(enc_side)
+                torch.cuda.current_stream().wait_event(side2_done)
             if lat_stream is not None and lat_stream is not self._side_stream:
                 lat_done = torch.cuda.Event()
                 lat_done.record(lat_stream)
