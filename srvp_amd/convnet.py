@@ -36,6 +36,12 @@ BN_FUSED_REDUCE = os.environ.get('SRVP_BN_FUSED_REDUCE', '1') != '0'
 # persistent latent kernels had become 0.5 ms shorter -- the weight gradients no longer fit under the latent backward and the step ended on
 # the second queue: 37.54 vs 37.87 ms at 192 sequences, 7.29 vs 7.42 at 24: on)
 DEC_WGRAD_EARLY = os.environ.get('SRVP_DEC_WGRAD_EARLY', '1') != '0'
+# with DEC_WGRAD_EARLY: only the first n blocks of the decoder's backward walk (the 64x64 / 32x32 stages) go out early, the rest behind the
+# data-gradient chain as before (-1: all, -2: half of the blocks).  Same-box sweep n = 0 / 2 / 4 / 6 / 8 / all, ms per step: 24 sequences 7.63 /
+# 7.54 / 7.44 / 7.36 / 7.43 / 7.46, KTH 33.35 / 33.27 / 33.41 / 33.27 / 33.40 / 33.79, Human3.6M 27.97 / 27.84 / 27.75 / 27.62 / 27.75 / 27.89,
+# SM-MNIST (5 blocks) 5.95 / 5.95 / 6.08 / ...: half of the blocks
+DEC_WGRAD_EARLY_N = int(os.environ.get('SRVP_DEC_WGRAD_EARLY_N', '-2'))
+UNPACK_SPLIT = int(os.environ.get('SRVP_UNPACK_SPLIT', '4'))       # encoder: blocks >= this index are unpacked before the weight gradients of the first blocks (0: one unpack at the end)
 IN_WGRAD_BN = os.environ.get('SRVP_IN_WGRAD_BN', '1') != '0'                # 0: the first block's output gradient is written and read back by its weight gradient
 POOL_FUSED_REDUCE = os.environ.get('SRVP_POOL_FUSED_REDUCE', '1') != '0'    # 0: pooled layers keep their own BatchNorm-backward reduction pass
 S_QUAD = os.environ.get('SRVP_S_QUAD', '1') != '0'        # hoisted skip half stored pixel-quad-major (16-byte loads in the consumers)
@@ -1209,13 +1215,16 @@ class ConvNetBase:
         if c['multi']:
             L.call('srvp_pack_weight_multi', L.ptr(c['multi'][0]), c['multi'][1], c['multi'][2], st)
 
-    def unpack_wgrads(self, grads, st):
+    def unpack_wgrads(self, grads, st, part=None):
+        """part = (lo, hi): the blocks lo <= index < hi only (the encoder unpacks its heavy deep blocks while the weight gradients of its
+        first blocks are still to come, UNPACK_SPLIT)."""
         f32_out = getattr(self, '_f32_out', lambda: False)()       # (decoder) the image-side layer accumulates into grads directly
-        jobs = [j for blk in self.blocks if blk.role in ('mfma', 'out') and not (f32_out and blk is self.blocks[-1])
+        jobs = [j for i, blk in enumerate(self.blocks) if blk.role in ('mfma', 'out') and not (f32_out and blk is self.blocks[-1])
+                and (part is None or part[0] <= i < part[1])
                 for j in blk.unpack_jobs(grads[blk.spec['key'] + '.weight'])]
         if not jobs:
             return
-        c = self._job_table(jobs, self.dev, self.__dict__.setdefault('_unpack_cache', {}), True)
+        c = self._job_table(jobs, self.dev, self.__dict__.setdefault('_unpack_cache' if part is None else '_unpack_cache_%d_%d' % part, {}), True)
         if c['tiles']:
             L.call('srvp_unpack_wgrad_tiles', L.ptr(c['tiles'][0]), c['tiles'][1], c['tiles'][2], st)
         if c['multi']:
@@ -1389,6 +1398,8 @@ class EncoderNet(ConvNetBase):
         self.zero_backward_accumulators()
         da = dict(t=d_hx, mode=0, cstride=d_hx.shape[1], coff=0, border=0, f32=True)
         unpacked = False
+        wg_on_side = side is not None and self.N <= ENC_WGRAD_SIDE_MAXN
+        split_at = min(UNPACK_SPLIT, nb - 1) if (wg_on_side and nb > UNPACK_SPLIT > 1 and self.blocks[0].role == 'in') else 0
         skip_red = None
         if aux is not None and skip_grads:
             todo = [(i, b) for i, b in enumerate(self.blocks) if b.pool is not None and getattr(b, '_reduce_fused', False)
@@ -1412,8 +1423,13 @@ class EncoderNet(ConvNetBase):
                 ev.record()
                 with torch.cuda.stream(side):
                     side.wait_event(ev)
-                    self.unpack_wgrads(grads, L.stream())
+                    self.unpack_wgrads(grads, L.stream(), part=(0, split_at) if split_at else None)
                 unpacked = True
+            if split_at and i == split_at - 1 and wg_on_side:
+                # (round 5) every weight gradient of blocks >= split_at has been issued on `side`: their unpacking (97 % of the encoder's
+                # weights: 85 us that ran as the step's tail behind the LAST weight gradient) goes out now, in front of the first blocks'
+                with torch.cuda.stream(side):
+                    self.unpack_wgrads(grads, L.stream(), part=(split_at, nb))
             sk = blk.spec['skip_out']
             if sk is not None and skip_grads and (3 - sk) in skip_grads:
                 da.update(self._skip_term(blk, skip_grads[3 - sk]))
@@ -1541,6 +1557,10 @@ class DecoderNet(ConvNetBase):
                     self._out_wgrad_f32(grads, st)
                 else:
                     self._wgrad(blk, st)
+        else:
+            for fn in self._wg_deferred:                                     # (SRVP_DEC_WGRAD_EARLY_N: the blocks that were not issued early)
+                fn(st)
+        self._wg_deferred = []
         self._wgrads_issued = False
         self.unpack_wgrads(grads, st)
 
@@ -1565,6 +1585,9 @@ class DecoderNet(ConvNetBase):
         ob = self.blocks[-1]
         self.zero_backward_accumulators()
         early = defer_wgrad and side is not None and DEC_WGRAD_EARLY
+        # blocks (in backward order) whose weight gradient goes out early
+        n_early = DEC_WGRAD_EARLY_N if DEC_WGRAD_EARLY_N >= 0 else (len(self.blocks) // 2 if DEC_WGRAD_EARLY_N == -2 else len(self.blocks))
+        self._wg_deferred = []
 
         def on_side(fn):
             ev = torch.cuda.Event()
@@ -1585,8 +1608,10 @@ class DecoderNet(ConvNetBase):
         if f32_out:
             if not defer_wgrad:
                 self._out_wgrad_f32(grads, st)
-            elif early:
+            elif early and n_early > 0:
                 on_side(lambda s_: self._out_wgrad_f32(grads, s_))
+            elif early:
+                self._wg_deferred.append(lambda s_: self._out_wgrad_f32(grads, s_))
             prod = self.blocks[-2] if len(self.blocks) > 1 else None
             fuse = (BN_FUSED_REDUCE and not self.f32 and prod is not None and prod.out is ob.srcs[0] and prod.has_bn and prod.act == L.ACT_LRELU
                     and (ob.k, ob.s, ob.p) == (3, 1, 1) and tuple(prod.raw.shape) == tuple(ob.dcat.shape)
@@ -1601,8 +1626,10 @@ class DecoderNet(ConvNetBase):
             if prod is not None:
                 prod._reduce_fused = bool(fuse)
         else:
-            if early:
+            if early and n_early > 0:
                 on_side(lambda s_: self._wgrad(ob, s_))
+            elif early:
+                self._wg_deferred.append(lambda s_: self._wgrad(ob, s_))
             self._mfma_backward(ob, grads, st, wgrad=not defer_wgrad)
         nxt = ob
         for i in range(len(self.blocks) - 2, -1, -1):
@@ -1610,8 +1637,10 @@ class DecoderNet(ConvNetBase):
             # (a sub-pixel consumer hands back the gradient already summed over each 2x2 upsample cell)
             da = dict(t=nxt.dcat, mode=1 if (blk.spec['post_up'] and not nxt.subpix) else 0, cstride=nxt.dcat_c, coff=0, border=0)
             self._bn_backward(blk, params, grads, da, st, sync)
-            if early:
+            if early and (len(self.blocks) - 1 - i) < n_early:
                 on_side(lambda s_, blk=blk: self._wgrad(blk, s_))
+            elif early:
+                self._wg_deferred.append(lambda s_, blk=blk: self._wgrad(blk, s_))
             self._mfma_backward(blk, grads, st, wgrad=not defer_wgrad)
             nxt = blk
         self._wgrads_issued = bool(early)
