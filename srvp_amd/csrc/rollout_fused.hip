@@ -633,6 +633,29 @@ __device__ __forceinline__ float red_sum(const float* Red, int r, int c) {
     return ((Red[off] + Red[512 + off]) + Red[1024 + off]) + Red[1536 + off];
 }
 
+// the same sum (same order) with half of the loads in flight at a time: for kernels whose registers are spoken for
+template <int GP>
+__device__ __forceinline__ void sum_slabs2h(f32x4v& sa, f32x4v& sb, const float* pa, const float* pb, int G, size_t slab_stride) {
+    constexpr int H = GP / 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f32x4v va[H], vb[H];
+#pragma unroll
+        for (int gg = 0; gg < H; ++gg) {
+            const int gi = h * H + gg;
+            const size_t o = (size_t)(gi < G ? gi : G - 1) * slab_stride;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(va[gg]) : "v"(pa + o) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(vb[gg]) : "v"(pb + o) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int gg = 0; gg < H; ++gg) { asm volatile("" : "+v"(va[gg])); asm volatile("" : "+v"(vb[gg])); }
+#pragma unroll
+        for (int gg = 0; gg < H; ++gg)
+            if (h * H + gg < G) { sa += va[gg]; sb += vb[gg]; }
+    }
+}
+
 template <int GP>
 __device__ __forceinline__ void sum_slabs1(f32x4v& sa, const float* pa, int G, size_t slab_stride) {
     f32x4v va[GP];
@@ -1300,6 +1323,350 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// ---- second form of the generation chain (round 5; SRVP_GEN_KSPLIT=0: the kernel above).  The K loop of every hidden layer is dealt to the
+// four waves as in rollout_ks_* (wave w owns the w-th 16-wide k block of every 64), which has a consequence the output-tiled form cannot have:
+// a wave only ever touches ITS quarter of each weight slice, 64 values per lane and layer -- so the slices of the dynamics' two hidden layers
+// (used n_euler times per frame) live in REGISTERS for the whole launch, 128 VGPRs per lane, and the LDS holds only the staging tiles.  (All four
+// hidden layers in registers -- 256 VGPRs -- was built first: hipcc spilled 300 of them and the chain got slower, 91.1 vs 90.2 ms.)  The prior's
+// two hidden layers (once per frame) still take their B fragments from global memory.  32-row tiles as before (800 rows = 25 tiles must fit two co-resident launches): every A fragment feeds four MFMA
+// tiles (2 row tiles x 2 column tiles), 16 loads per lane and layer instead of 32 + 32.
+template <int GP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_gen_ks_kernel(const GenF a) {
+    extern __shared__ float lds[];
+    const int xq = blockIdx.x & 7, kblk = blockIdx.x >> 3;
+    const int cl = xq * a.cl_per_xcd + kblk / a.G, g = kblk % a.G;
+    if (cl >= a.ntiles) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int q = lane >> 4, c16 = lane & 15;
+    const int ec = tid & 31, er = tid >> 5;               // epilogue: outputs (er + 8 u, ec), u < 4, of the 32 x 32 tile
+    const int row0 = (a.tile0 + cl) * RT;
+    const int colbase = g * CW;
+    const int nl = a.nl, nh = a.nh, ny = a.ny, nz = a.nz, nin = a.nin, B = a.B, kp0 = a.kp0;
+    const int nfull = nl - 2;                             // 1 or 2 (launcher)
+    const int ils = kp0 + IPAD;
+    // LDS: Is [32][kp0 + IPAD] | Ys [32][ny] | Zs [32][nz] | Hs [32][33] | Bl [ny] | Bp [2 nz] (padded to 16 bytes) | Red [4][2][2][256]
+    float* Is = lds;
+    float* Ys = Is + RT * ils;
+    float* Zs = Ys + RT * ny;
+    float* Hs = Zs + RT * nz;
+    float* Bl = Hs + RT * 33;
+    float* Bp = Bl + NYP_MAX;
+    float* Red = Bp + 2 * NYP_MAX;
+    unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;
+    float* hbuf = a.hbuf + (size_t)(a.tile0 + cl) * nfull * RT * nh;
+    float* part = a.part + (size_t)(a.tile0 + cl) * a.G * RT * KP0_MAX;
+    unsigned target = 0;
+    xcd_announce(cnt);
+    // hidden layers: B[k = 64 jj + 16 w + 4 q + e][16 ct + c16] = W_l[colbase + 16 ct + c16][k], this wave's k blocks only
+    float dw[2][8][2][4];
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 64 * jj + 16 * w + 4 * q + e;
+                    const bool ok = l < nfull && k < nh;
+                    dw[l][jj][ct][e] = ok ? a.W[l + 1][(size_t)(colbase + 16 * ct + c16) * nh + k] : 0.f;
+                }
+    // first layers: dynamics K = kp0 (k blocks w and w + 4), prior K = nyp (k block w)
+    float w0[2][2][4], pw0[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int k = 16 * (w + 4 * jj) + 4 * q + e;
+                w0[jj][ct][e] = k < nin ? a.W[0][(size_t)(colbase + 16 * ct + c16) * nin + k] : 0.f;
+            }
+            const int k = 16 * w + 4 * q + e;
+            pw0[ct][e] = k < ny ? a.PW[0][(size_t)(colbase + 16 * ct + c16) * ny + k] : 0.f;
+        }
+    // last layers (split-K over the cluster): dynamics: output column tile w; prior: column tiles w and w + 4; both row tiles each
+    float wl[8], pwl[2][8];
+    const int nctl = a.nyp / 16, nctp = a.nzp2 / 16;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int col = 16 * w + c16;
+        wl[jj] = (w < nctl && col < ny) ? a.W[nl - 1][(size_t)col * nh + colbase + 4 * jj + q] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ct = w + 4 * u, colp = 16 * ct + c16;
+            pwl[u][jj] = (ct < nctp && colp < 2 * nz) ? a.PW[nl - 1][(size_t)colp * nh + colbase + 4 * jj + q] : 0.f;
+        }
+    }
+    for (int idx = tid; idx < RT * ny; idx += 256) {
+        const int r = idx / ny, c = idx - r * ny;
+        const int row = row0 + r < B ? row0 + r : B - 1;
+        Ys[idx] = a.y0[(size_t)row * ny + c];
+    }
+    for (int idx = tid; idx < RT * ils; idx += 256) Is[idx] = 0.f;
+    if (tid < ny) Bl[tid] = a.b[nl - 1][tid];
+    if (tid < 2 * nz) Bp[tid] = a.Pb[nl - 1][tid];
+    cluster_barrier(cnt, target += a.G);
+    if (!xcd_agreed(cnt, a.xcd_local, g == 0)) {
+        if (g == 0 && tid == 0) __hip_atomic_fetch_add(&g_cluster_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const size_t hls = (size_t)RT * nh;
+    const int nq = a.nyp / 4, nq2 = a.nzp2 / 4;
+    const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // acc[mt][ct] += A(32 rows of the exchange buffer, this wave's k blocks: L1-bypassing loads) x B(registers)
+    auto gemm_rr = [&](f32x4v (&acc)[2][2], const float* abuf, const float (&bw)[8][2][4]) {
+        // eight loads (four k blocks x two row tiles) in flight at a time: the fragments of block jj + 4 are requested into the registers block
+        // jj has just been consumed from (the weight slices leave 250 registers for everything else)
+        f32x4v av[8][2];
+        const float* p0 = abuf + (size_t)c16 * nh + 16 * w + 4 * q;         // (nh == 512: every k block exists; block jj = an immediate offset)
+        const float* p1 = p0 + (size_t)16 * nh;
+#define GK_LOAD(jj)                                                                                                                         \
+        {                                                                                                                                   \
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=&v"(av[jj][0]) : "v"(p0), "n"(256 * (jj)) : "memory");         \
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=&v"(av[jj][1]) : "v"(p1), "n"(256 * (jj)) : "memory");         \
+        }
+#define GK_STEP(jj, n)                                                                                                                      \
+        {                                                                                                                                   \
+            asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(av[jj][0]), "+v"(av[jj][1]) :: "memory");                                         \
+            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                                                              \
+                const f32x4v x = av[jj][mt];                                                                                                \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                             \
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], bw[jj][0][e], acc[mt][0], 0, 0, 0);                             \
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], bw[jj][1][e], acc[mt][1], 0, 0, 0);                             \
+                }                                                                                                                           \
+            }                                                                                                                               \
+        }
+        GK_LOAD(0) GK_LOAD(1) GK_LOAD(2) GK_LOAD(3)
+        GK_STEP(0, 6) GK_LOAD(4) GK_STEP(1, 6) GK_LOAD(5) GK_STEP(2, 6) GK_LOAD(6) GK_STEP(3, 6) GK_LOAD(7)
+        GK_STEP(4, 6) GK_STEP(5, 4) GK_STEP(6, 2) GK_STEP(7, 0)
+#undef GK_STEP
+#undef GK_LOAD
+    };
+    // the prior's hidden layers (once per frame): B fragments straight from the weight rows in global memory (L2 / L1 resident), four k blocks
+    // (2 A + 2 B loads each) in flight
+    auto gemm_rg = [&](f32x4v (&acc)[2][2], const float* abuf, const float* W) {
+        f32x4v av[8][2], bv[8][2];
+        const float* p0 = abuf + (size_t)c16 * nh + 16 * w + 4 * q;
+        const float* p1 = p0 + (size_t)16 * nh;
+        const float* b0 = W + (size_t)(colbase + c16) * nh + 16 * w + 4 * q;
+        const float* b1 = b0 + (size_t)16 * nh;
+#define GG_LOAD(jj)                                                                                                                         \
+        {                                                                                                                                   \
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=&v"(av[jj][0]) : "v"(p0), "n"(256 * (jj)) : "memory");         \
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=&v"(av[jj][1]) : "v"(p1), "n"(256 * (jj)) : "memory");         \
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(bv[jj][0]) : "v"(b0), "n"(256 * (jj)) : "memory");             \
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(bv[jj][1]) : "v"(b1), "n"(256 * (jj)) : "memory");             \
+        }
+#define GG_STEP(jj, n)                                                                                                                      \
+        {                                                                                                                                   \
+            asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(av[jj][0]), "+v"(av[jj][1]), "+v"(bv[jj][0]), "+v"(bv[jj][1]) :: "memory");       \
+            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                                                              \
+                const f32x4v x = av[jj][mt];                                                                                                \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                             \
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], bv[jj][0][e], acc[mt][0], 0, 0, 0);                             \
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], bv[jj][1][e], acc[mt][1], 0, 0, 0);                             \
+                }                                                                                                                           \
+            }                                                                                                                               \
+        }
+        GG_LOAD(0) GG_LOAD(1) GG_LOAD(2) GG_LOAD(3)
+        GG_STEP(0, 12) GG_LOAD(4) GG_STEP(1, 12) GG_LOAD(5) GG_STEP(2, 12) GG_LOAD(6) GG_STEP(3, 12) GG_LOAD(7)
+        GG_STEP(4, 12) GG_STEP(5, 8) GG_STEP(6, 4) GG_STEP(7, 0)
+#undef GG_STEP
+#undef GG_LOAD
+    };
+    auto red_store4 = [&](const f32x4v (&acc)[2][2]) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) *reinterpret_cast<f32x4v*>(Red + ((w * 2 + mt) * 2 + ct) * 256 + lane * 4) = acc[mt][ct];
+    };
+    auto red_sum4 = [&](int r, int c) {
+        const int off = (((r >> 4) * 2) + (c >> 4)) * 256 + (((r & 15) >> 2) * 16 + (c & 15)) * 4 + (r & 3);
+        return ((Red[off] + Red[1024 + off]) + Red[2048 + off]) + Red[3072 + off];
+    };
+    // one MLP trunk up to the last hidden activation in Hs: first-layer accumulators in, hidden layers from registers, exchange through hbuf
+    auto trunk = [&](f32x4v (&acc)[2][2], const float* const* bias, const float* const* Wg) {     // Wg: the prior's weights (global) or null: dynamics (registers)
+        float bl = bias[0][colbase + ec];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {                       // (unrolled: the register-resident slices need compile-time indices)
+            red_store4(acc);
+            __syncthreads();
+            float* hdst = hbuf + (size_t)l * hls;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = er + 8 * u;
+                float v = red_sum4(r, ec) + bl;
+                v = v > 0.f ? v : 0.f;
+                if (l < nfull) hdst[(size_t)r * nh + colbase + ec] = v;
+                else Hs[r * 33 + ec] = v;
+            }
+            if (l == nfull) break;
+            bl = bias[l + 1][colbase + ec];
+            cluster_barrier(cnt, target += a.G);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) { acc[mt][0] = zero4; acc[mt][1] = zero4; }
+            if (Wg) gemm_rg(acc, hdst, Wg[l + 1]);
+            else gemm_rr(acc, hdst, dw[l < 2 ? l : 1]);
+        }
+        __syncthreads();                                  // Hs complete
+    };
+
+    for (int i = 0; i < a.S; ++i) {
+        const int f = i / a.ne;
+        if (i % a.ne == 0) {
+            // =============================== frame start: p_z(y), then z
+            for (int idx = tid; idx < RT * ny; idx += 256) {
+                const int r = idx / ny, c = idx - r * ny;
+                Is[r * ils + c] = Ys[idx];
+            }
+            __syncthreads();
+            f32x4v acc[2][2] = {{zero4, zero4}, {zero4, zero4}};
+            {
+                const bool ok = 16 * w < a.nyp;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    f32x4v x = *reinterpret_cast<const f32x4v*>(Is + (16 * mt + c16) * ils + (ok ? 16 * w : 0) + 4 * q);
+                    if (!ok) x = zero4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], pw0[0][e], acc[mt][0], 0, 0, 0);
+                        acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], pw0[1][e], acc[mt][1], 0, 0, 0);
+                    }
+                }
+            }
+            trunk(acc, a.Pb, a.PW);
+            float* pdst = part + (size_t)g * RT * KP0_MAX;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ct = w + 4 * u;
+                if (ct >= nctp) break;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    f32x4v o = zero4;
+                    const float* hr = Hs + (16 * mt + c16) * 33 + q;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) o = __builtin_amdgcn_mfma_f32_16x16x4f32(hr[4 * jj], pwl[u][jj], o, 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pdst[(16 * mt + 4 * q + e) * KP0_MAX + 16 * ct + c16] = o[e];
+                }
+            }
+            const bool posterior = f + 1 < a.n_data;
+            float epsr[NYP_MAX * RT / 256], qlr[NYP_MAX * RT / 256], qsr[NYP_MAX * RT / 256];
+#pragma unroll
+            for (int u = 0; u < NYP_MAX * RT / 256; ++u) {
+                const int idx = tid + 256 * u, r = idx / nz, c = idx - r * nz;
+                const int row = row0 + r < B ? row0 + r : B - 1;
+                const bool ok = idx < RT * nz;
+                epsr[u] = ok ? a.eps[((size_t)f * B + row) * nz + c] : 0.f;
+                qlr[u] = (ok && posterior) ? a.qz[((size_t)f * B + row) * 2 * nz + c] : 0.f;
+                qsr[u] = (ok && posterior) ? a.qz[((size_t)f * B + row) * 2 * nz + nz + c] : 0.f;
+            }
+            cluster_barrier(cnt, target += a.G);
+            for (int it = tid; it < RT * nq2; it += 512) {
+                const int itb = it + 256 < RT * nq2 ? it + 256 : it;
+                f32x4v sv[2] = {zero4, zero4};
+                sum_slabs2h<GP>(sv[0], sv[1], part + (it / nq2) * KP0_MAX + 4 * (it % nq2), part + (itb / nq2) * KP0_MAX + 4 * (itb % nq2), a.G,
+                               (size_t)RT * KP0_MAX);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int item = h ? itb : it;
+                    if (h && itb == it) break;
+                    const int r = item / nq2, c0 = 4 * (item % nq2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c0 + e < 2 * nz) Is[r * ils + c0 + e] = sv[h][e] + Bp[c0 + e];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < NYP_MAX * RT / 256; ++u) {
+                const int idx = tid + 256 * u, r = idx / nz, c = idx - r * nz;
+                if (idx >= RT * nz) break;
+                const float pl = Is[r * ils + c], ps = Is[r * ils + nz + c];
+                const float loc = posterior ? qlr[u] : pl, raw = posterior ? qsr[u] : ps;
+                const float zz = loc + epsr[u] * (softplus_g(raw) + 1e-8f);
+                Zs[idx] = zz;
+                if (g == 0 && row0 + r < B) {
+                    const size_t o = (size_t)f * B + row0 + r;
+                    a.z[o * nz + c] = zz;
+                    a.pz[o * 2 * nz + c] = pl;
+                    a.pz[o * 2 * nz + nz + c] = ps;
+                }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < RT * kp0; idx += 256) {
+                const int r = idx / kp0, k = idx - r * kp0;
+                Is[r * ils + k] = k < ny ? Ys[r * ny + k] : (k < nin ? Zs[r * nz + k - ny] : 0.f);
+            }
+        } else {
+            for (int idx = tid; idx < RT * ny; idx += 256) {
+                const int r = idx / ny, c = idx - r * ny;
+                Is[r * ils + c] = Ys[idx];
+            }
+        }
+        __syncthreads();
+        // =============================== one residual step
+        f32x4v acc[2][2] = {{zero4, zero4}, {zero4, zero4}};
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int kb = 16 * (w + 4 * jj);
+            const bool ok = kb < kp0;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x4v x = *reinterpret_cast<const f32x4v*>(Is + (16 * mt + c16) * ils + (ok ? kb : 0) + 4 * q);
+                if (!ok) x = zero4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], w0[jj][0][e], acc[mt][0], 0, 0, 0);
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], w0[jj][1][e], acc[mt][1], 0, 0, 0);
+                }
+            }
+        }
+        trunk(acc, a.b, nullptr);
+        float* pdst = part + (size_t)g * RT * KP0_MAX;
+        if (w < nctl) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x4v o = zero4;
+                const float* hr = Hs + (16 * mt + c16) * 33 + q;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) o = __builtin_amdgcn_mfma_f32_16x16x4f32(hr[4 * jj], wl[jj], o, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pdst[(16 * mt + 4 * q + e) * KP0_MAX + 16 * w + c16] = o[e];
+            }
+        }
+        cluster_barrier(cnt, target += a.G);
+        for (int it = tid; it < RT * nq; it += 512) {
+            const int itb = it + 256 < RT * nq ? it + 256 : it;
+            f32x4v sv[2] = {zero4, zero4};
+            sum_slabs2h<GP>(sv[0], sv[1], part + (it / nq) * KP0_MAX + 4 * (it % nq), part + (itb / nq) * KP0_MAX + 4 * (itb % nq), a.G,
+                           (size_t)RT * KP0_MAX);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int item = h ? itb : it;
+                if (h && itb == it) break;
+                const int r = item / nq, c0 = 4 * (item % nq);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = c0 + e;
+                    if (c >= ny) break;
+                    const float rs = a.dt * (sv[h][e] + Bl[c]);
+                    const float yn = Ys[r * ny + c] + rs;
+                    Ys[r * ny + c] = yn;
+                    if (g == 0 && row0 + r < B) {
+                        const size_t o = (size_t)(row0 + r) * ny + c;
+                        a.res[(size_t)i * B * ny + o] = rs;
+                        a.y_all[(size_t)(i + 1) * B * ny + o] = yn;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------ LSTM
 // The posterior LSTM (nn.LSTM(nhx, nh, 1), reference module/srvp.py:132,366) as ONE persistent launch over its T steps, same
 // decomposition: 32-row batch tiles, a cluster of nh / 32 workgroups per tile, workgroup g owns hidden units [32 g, 32 g + 32)
@@ -1914,8 +2281,13 @@ int srvp_rollout_gen_fwd(const srvp_rollout_desc* d, hipStream_t st) {
     k.hbuf = (float*)((char*)d->fused_ws + (size_t)tiles * 256);
     k.part = k.hbuf + (size_t)tiles * (d->nl - 2) * RT * d->nh;
     SRVP_REQUIRE(k.n_data <= 1 || k.qz, "srvp_rollout_fwd(gen): posterior frames need q_z_params");
-    const size_t lds = ((size_t)(k.nl - 2) * k.nh * CW + RT * (k.kp0 + IPAD) + RT * k.ny + RT * k.nz + RT * 33 + k.ny + 2 * k.nz) * 4;
-    auto kern = k.G <= 8 ? rollout_gen_kernel<8> : (k.G <= 16 ? rollout_gen_kernel<16> : rollout_gen_kernel<32>);
+    static int gks = -1;
+    if (gks < 0) { const char* e2 = getenv("SRVP_GEN_KSPLIT"); gks = e2 ? atoi(e2) : 1; }
+    const bool ks = gks && k.nl - 2 <= 2 && k.nh == 512;         // (the register-resident form: <= two hidden layers of 512 units per network)
+    const size_t lds = ks ? ((size_t)RT * (k.kp0 + IPAD) + RT * k.ny + RT * k.nz + RT * 33 + 3 * NYP_MAX + 4096) * 4
+                          : ((size_t)(k.nl - 2) * k.nh * CW + RT * (k.kp0 + IPAD) + RT * k.ny + RT * k.nz + RT * 33 + k.ny + 2 * k.nz) * 4;
+    auto kern = ks ? (k.G <= 8 ? rollout_gen_ks_kernel<8> : (k.G <= 16 ? rollout_gen_ks_kernel<16> : rollout_gen_ks_kernel<32>))
+                   : (k.G <= 8 ? rollout_gen_kernel<8> : (k.G <= 16 ? rollout_gen_kernel<16> : rollout_gen_kernel<32>));
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd(gen): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
