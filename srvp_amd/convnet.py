@@ -1349,8 +1349,10 @@ class EncoderNet(ConvNetBase):
         self.skips = {3 - sp['skip_out']: b.out for sp, b in zip(specs, self.blocks) if sp['skip_out'] is not None}
         self.nh_r = specs[-1]['cout']
 
-    def forward(self, x, params, st, sync=None, keep=None, packed=None):
-        """keep: int32 [N] or None.  The full-resolution activation of a POOLED block is read by nothing but the skip connections
+    def forward(self, x, params, st, sync=None, keep=None, packed=None, on_skip=None):
+        """on_skip (callable, optional): called with the decoder's skip index right after the block whose output feeds that skip connection
+        (the caller may start the decoder's hoisted skip convolution of that stage on another stream at once).
+        keep: int32 [N] or None.  The full-resolution activation of a POOLED block is read by nothing but the skip connections
         (the next layer reads the pooled tensor, BN backward recomputes it from the raw output), i.e. for one frame per sample:
         with `keep` given, pooled blocks store it only for the frames with keep[n] != 0 (saves ~2 GB of writes per step at the
         headline config).  packed: event after which the packed MFMA weights are ready (they are packed on another stream while the
@@ -1362,6 +1364,8 @@ class EncoderNet(ConvNetBase):
                 torch.cuda.current_stream().wait_event(packed)
                 packed = None
             self._block_forward(blk, params, st, sync, x=x, keep=keep)
+            if on_skip is not None and blk.spec['skip_out'] is not None:
+                on_skip(3 - blk.spec['skip_out'])
         return self.blocks[-1].out_f32[:, :self.nh_r]
 
     def _skip_term(self, blk, sg):
@@ -1501,14 +1505,15 @@ class DecoderNet(ConvNetBase):
         self.nc = ob.cout_r
         self.x_out = ob.x_out
 
-    def precompute_skips(self, st):
+    def precompute_skips(self, st, cat=None):
         """conv_s(skip) of every hoisted-skip block (the first descriptor of its forward): it depends on the encoder's skip
         tensors only, so the caller may run it on a second stream under the latency-bound latent forward; the next forward()
-        then skips those launches."""
+        then skips those launches.  cat: the blocks reading skip connection `cat` only (the caller goes through all of them)."""
         for blk in self.blocks:
-            if blk.split:
+            if blk.split and (cat is None or blk.spec['cat'] == cat):
                 L.call('srvp_conv_mfma', C.byref(blk._fwd[0]), st)
-        self._skips_done = True
+        if cat is None:
+            self._skips_done = True
 
     def forward(self, z_f32, params, st, sync=None, latent=None, coeffs_current=False):
         """z_f32: fp32 [N][nz_real], or None with latent = (w fp32 [B][nh], y fp32 base pointer tensor, y_tstride, nt, B, nh, ny): the rows

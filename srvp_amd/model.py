@@ -57,6 +57,9 @@ PZ_BWD_AUX = os.environ.get('SRVP_PZ_BWD_AUX', '1') != '0'          # the prior 
 ENC_WGRAD_STREAM2 = os.environ.get('SRVP_ENC_WGRAD_STREAM2', '0') != '0'   # the encoder's weight gradients on a third stream (not behind the decoder's)
 LATENT_WGRAD_STREAM = os.environ.get('SRVP_LATENT_WGRAD_STREAM', '1') != '0'    # the latent networks' weight gradients on a stream of their own
 OVERLAP_SKIP = os.environ.get('SRVP_OVERLAP_SKIP', '1') == '1'
+# training: hoisted skip convs stage by stage under the encoder forward (overrides SKIP_LATE).  Measured (round 5, same box, ms per step on / off):
+# 192 sequences 37.57 / 37.67, 24 sequences 7.34 / 7.25, KTH 32.79 / 32.60, Human3.6M 27.13 / 26.98: off
+SKIP_EARLY = os.environ.get('SRVP_SKIP_EARLY', '0') == '1'
 SKIP_LATE = os.environ.get('SRVP_SKIP_LATE', '1') == '1'        # hoisted skip convs under the rollout kernel (1) / under the inference chain (0)
 OVERLAP_PACK = os.environ.get('SRVP_OVERLAP_PACK', '1') == '1'    # decoder weight packing on the second stream, under the encoder
 
@@ -451,7 +454,25 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             with torch.cuda.stream(self._lat_stream):
                 self._lat_stream.wait_event(ev_p)
                 lat.lstm_bias_prep(params, L.stream())
-        hx = enc.forward(x.view(T * B, *x.shape[2:]), params, st, self.sync if training else None, keep=keep, packed=enc_packed)
+        # (round 5, A/B switch, off) the decoder's hoisted skip convolutions stage by stage on the second stream, each as soon as the encoder
+        # block it reads is done, instead of under the rollout kernel (where a traced step at 192 sequences shows the main stream waiting
+        # 0.46 ms for them now that the rollout takes 0.3 ms; untraced the difference is 0.1 ms, and the other configs lose)
+        skip_early = training and self.skipco and OVERLAP_SKIP and SKIP_EARLY and any(b.split for b in dec.blocks)
+        on_skip = None
+        if skip_early:
+            if getattr(self, '_side_stream', None) is None:
+                self._side_stream = _make_side_stream()
+            cats = {b.spec['cat'] for b in dec.blocks if b.split}
+
+            def on_skip(cat):
+                if cat not in cats:
+                    return
+                ev = torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(self._side_stream):
+                    self._side_stream.wait_event(ev)
+                    dec.precompute_skips(L.stream(), cat=cat)
+        hx = enc.forward(x.view(T * B, *x.shape[2:]), params, st, self.sync if training else None, keep=keep, packed=enc_packed, on_skip=on_skip)
         hx = hx.contiguous().view(T, B, self.nhx)
         ev_hx = None
         if lat_early:
@@ -481,6 +502,11 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             return done
         s_done = None
         overlap_skips = self.skipco and OVERLAP_SKIP and any(b.split for b in dec.blocks)
+        if skip_early:
+            dec._skips_done = True                                  # (every stage's launch is on the second stream by now)
+            s_done = torch.cuda.Event()
+            s_done.record(self._side_stream)
+            overlap_skips = False
         if overlap_skips and not SKIP_LATE:
             s_done = skips_on_side()
         t_w_arg = (t_w_host if t_w_host is not None else tape.get('t_w')) if training else None
