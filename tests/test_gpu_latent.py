@@ -321,3 +321,20 @@ def test_generation_chain_persistent_vs_launches_and_oracle(B, T, nt, ne, dims):
     for n, a, b in zip(('y', 'z', 'pz', 'res'), out[True], (y_r, z_r, pz_r, res_r)):
         assert a.shape == b.shape and rel(a, b) < 1e-4, (n, rel(a, b))
     assert (out[True][1][-1] - out[True][1][0]).abs().max() > 1e-3           # the samples do differ from frame to frame
+
+
+def test_32_row_forms_of_the_persistent_kernels_still_pass():
+    """Round 5 put 16-row / K-split forms of the persistent rollout, LSTM and generation kernels in front of the 32-row kernels of rounds 2-4,
+    which remain the fallback (more 16-row tiles than one co-resident launch holds, widths the new forms do not take) -- reached in the
+    default build by a few shapes only (case 8 above).  The switches that force them are read once per process: a child process runs the
+    oracle comparisons of this file through the 32-row kernels at the headline dimensions."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, SRVP_ROLLOUT_KSPLIT='0', SRVP_LSTM_KSPLIT='0', SRVP_GEN_KSPLIT='0')
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, '-m', 'pytest', here, '-q', '-m', 'gpu', '-x', '-k',
+                        'test_latent_forward_backward or lstm or test_fused_rollout_under_load or generation'],
+                       env=env, cwd=os.path.dirname(os.path.dirname(here)), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout
