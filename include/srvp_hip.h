@@ -367,8 +367,9 @@ int srvp_act_bwd_f32(const float* pre_or_out, const float* dy, float* dx, int64_
  * recurrent part here.  Saves gate activations for backward.  Layout: [T][B][4*nh], gate order i,f,g,o. */
 int srvp_lstm_fwd(const float* gates_x, const float* w_hh, float* h_out, float* c_out, float* gates_act,
                   int T, int B, int nh, void* stream);
-/* the same forward as ONE persistent launch over the T steps (csrc/rollout_fused.hip: clusters of nh / 32 workgroups per 32-row batch
- * tile, W_hh slices resident in registers, h exchanged with agent-scope accesses, one counter barrier per step).
+/* the same forward as ONE persistent launch over the T steps (csrc/rollout_fused.hip: clusters of nh / 16 workgroups per 16-row batch
+ * tile -- nh / 32 per 32-row tile where the batch has more 16-row tiles than one co-resident launch holds or nh is not a multiple of 64 --,
+ * W_hh slices resident in registers, h exchanged through global memory, one counter barrier per step).
  * (both persistent kernels: 0 is also returned when 8 * nh / 32 workgroups cannot be co-resident on the device; a cluster barrier
  *  that waits longer than ~seconds -- workgroups not co-resident after all -- gives up and counts the event in word 1 of the tile's
  *  256-byte counter block at the start of the workspace: results are then invalid, the device is not hung)
@@ -413,7 +414,9 @@ typedef struct {
                                             * feeds the KL term then (srvp.py:383-390), its input is the stored state */
     void* fused_ws; int64_t fused_ws_bytes; /* optional workspace of srvp_rollout_fused_ws_bytes(d) bytes: with it, posterior-only
                                             * training chains (pz_external, hid_dyn) run as ONE persistent kernel forward and ONE
-                                            * backward (csrc/rollout_fused.hip) instead of nl + 1 launches per Euler step */
+                                            * backward (csrc/rollout_fused.hip) instead of nl + 1 launches per Euler step.  The
+                                            * library owns its contents (two cluster-counter blocks, cleared by the forward's
+                                            * preparation launch, then the split-K slabs): no initialisation by the caller */
 } srvp_rollout_desc;
 int srvp_rollout_fwd(const srvp_rollout_desc* d, void* stream);
 /* bytes of fused_ws the persistent kernels need for this chain, 0 if it must run unfused (dimensions / LDS budget / mode) */
