@@ -15,6 +15,7 @@
 //
 // All workgroups of a launch must be co-resident (they spin on each other): the launcher keeps the grid <= the number of CUs
 // (one workgroup per CU: > 80 KB of LDS each) and walks larger batches in several launches.
+#include <atomic>
 #include "common.h"
 #include "../../include/srvp_hip.h"
 
@@ -2163,7 +2164,7 @@ int64_t srvp_rollout_fused_cnt_words(const srvp_rollout_desc* d) {
     return (int64_t)2 * ((d->B + rt - 1) / rt) * 64;
 }
 // the workspace whose backward counter block the last forward launch left cleared (host order; one entry: a training step is forward, backward)
-static const void* g_bwd_cnt_clean = nullptr;
+static std::atomic<const void*> g_bwd_cnt_clean{nullptr};        // (host threads: a lost update only costs the memset)
 
 // clusters per launch: all workgroups co-resident (grid <= CUs), whole clusters per XCD
 static int clusters_per_launch(int G, int tiles, int& cl_per_xcd) {
@@ -2189,7 +2190,7 @@ int srvp_rollout_fused_fwd(const srvp_rollout_desc* d, hipStream_t st, bool coun
         e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
         SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd(fused): memset failed");
     }
-    g_bwd_cnt_clean = counters_cleared ? d->fused_ws : nullptr;
+    g_bwd_cnt_clean.store(counters_cleared ? d->fused_ws : nullptr);
     int cpx;
     const int per = clusters_per_launch(k.G, tiles, cpx);
     static int dbg_on = -1;
@@ -2230,11 +2231,10 @@ int srvp_rollout_fused_bwd(const srvp_rollout_bwd_desc* d, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_bwd(fused): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     k.cnt += (size_t)tiles * 64;                            // the backward's own counter block
-    if (g_bwd_cnt_clean != f.fused_ws) {
+    if (g_bwd_cnt_clean.exchange(nullptr) != f.fused_ws) {
         e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
         SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_bwd(fused): memset failed");
     }
-    g_bwd_cnt_clean = nullptr;
     int cpx;
     const int per = clusters_per_launch(k.G, tiles, cpx);
     for (int t0 = 0; t0 < tiles; t0 += per) {

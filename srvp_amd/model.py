@@ -54,6 +54,7 @@ PZ_AUX = os.environ.get('SRVP_PZ_AUX', '1') != '0'                       # 0: th
 SKIP_REDUCE_AUX = os.environ.get('SRVP_SKIP_REDUCE_AUX', '1') != '0'      # 0: the pooled stages' skip-gradient reductions in line on the main stream
 LATENT_AUX = os.environ.get('SRVP_LATENT_AUX', '1') != '0'        # independent chains of the latent path (posterior / w / y_0; their backward) on two streams
 PZ_BWD_AUX = os.environ.get('SRVP_PZ_BWD_AUX', '1') != '0'          # the prior MLP's backward on the auxiliary stream under the decoder backward
+DEC_ALLREDUCE_STREAM = os.environ.get('SRVP_DEC_ALLREDUCE_STREAM', '1') != '0'   # N > 1: the decoder gradient slice's all-reduce on its own stream
 ENC_WGRAD_STREAM2 = os.environ.get('SRVP_ENC_WGRAD_STREAM2', '0') != '0'   # the encoder's weight gradients on a third stream (not behind the decoder's)
 LATENT_WGRAD_STREAM = os.environ.get('SRVP_LATENT_WGRAD_STREAM', '1') != '0'    # the latent networks' weight gradients on a stream of their own
 OVERLAP_SKIP = os.environ.get('SRVP_OVERLAP_SKIP', '1') == '1'
@@ -672,11 +673,25 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             # (host order: the main-stream launches of the latent backward -- the critical path -- go out BEFORE the ~25 second-stream
             # launches of the decoder's weight gradients, which only wait for ev_dec on the device: a host that is just ahead of the device
             # -- small batches, a profiler attached -- then does not leave the main queue empty for the 0.25 ms the enqueueing takes)
+            comm_done = None
             with torch.cuda.stream(self._side_stream):
                 self._side_stream.wait_event(ev_dec)
                 dec.deferred_wgrads(grads, L.stream())
-                if self.sync is not None:
+                if self.sync is not None and not DEC_ALLREDUCE_STREAM:
                     self.sync.grads_ready('decoder', self)
+                elif self.sync is not None:
+                    ev_dg = torch.cuda.Event()
+                    ev_dg.record()                # the decoder's slice of the flat gradient buffer is complete
+            if self.sync is not None and DEC_ALLREDUCE_STREAM:
+                # the decoder slice's all-reduce (60 % of the gradient bytes) on a stream of its own: enqueued on the second stream it sat
+                # in front of the ENCODER's weight gradients there and held them back for as long as the exchange takes over the links
+                if getattr(self, '_comm_stream', None) is None:
+                    self._comm_stream = torch.cuda.Stream()
+                with torch.cuda.stream(self._comm_stream):
+                    self._comm_stream.wait_event(ev_dg)
+                    self.sync.grads_ready('decoder', self)
+                    comm_done = torch.cuda.Event()
+                    comm_done.record()
         ev_lat = None
         if deferred:
             ev_lat = torch.cuda.Event()
@@ -737,6 +752,8 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
                 lat_done.record(lat_stream)
                 torch.cuda.current_stream().wait_event(lat_done)
         if self.sync is not None:
+            if overlap and comm_done is not None:
+                torch.cuda.current_stream().wait_event(comm_done)     # (same communicator: the rest of the buffer goes after the decoder slice)
             self.sync.grads_ready('all', self)
 
     # ------------------------------------------------------------------------------------------------ reference API
