@@ -343,7 +343,7 @@ def main():
     # HIP events around the launches of the two dominant kernel classes only (~110 per step), on every EVENT_EVERY-th step of
     # the timed region: each event record is a marker packet in the stream (~1 ms per step if every step carries them; timing
     # all 329 launches costs ~3 ms per step), so the full per-kernel table is taken in an extra untimed pass
-    EVENT_EVERY = int(os.environ.get('SRVP_BENCH_EVENT_EVERY', 4))
+    EVENT_EVERY = int(os.environ.get('SRVP_BENCH_EVENT_EVERY', 8))   # (round 5: 8, was 4 -- 3 instrumented steps of a 20-step run)
     timing = not args.no_kernel_timing
     prof, n_prof_steps = ({} if timing else None), 0
     if timing:
