@@ -16,6 +16,7 @@
 // All workgroups of a launch must be co-resident (they spin on each other): the launcher keeps the grid <= the number of CUs
 // (one workgroup per CU: > 80 KB of LDS each) and walks larger batches in several launches.
 #include <atomic>
+#include <type_traits>
 #include "common.h"
 #include "../../include/srvp_hip.h"
 
@@ -1324,6 +1325,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// K-split GEMM of the generation chain's second form: acc[mt][ct] += A(16 MT rows of the exchange buffer, this wave's eight 16-wide k blocks:
+// L1-bypassing loads) x B, B either register-resident (GLOB = false: bw) or fetched with the A fragments from two weight rows in global memory
+// (GLOB = true: b0 / b1).  DEPTH k blocks in flight: the fragments of block jj + DEPTH are requested into the registers block jj has just been
+// consumed from.  nh == 512: every k block exists and block jj is an IMMEDIATE offset on MT (+ 2) base pointers -- as computed addresses hipcc
+// hoisted one 64-bit pointer per unrolled load out of the step loop, 170 registers.
+template <int JJ, int MT, bool GLOB>
+__device__ __forceinline__ void gk_load(f32x4v (&av)[8][MT], f32x4v (&bv)[8][2], const float* const (&pm)[MT], const float* b0, const float* b1) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=&v"(av[JJ][mt]) : "v"(pm[mt]), "n"(256 * JJ) : "memory");
+    if constexpr (GLOB) {
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(bv[JJ][0]) : "v"(b0), "n"(256 * JJ) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(bv[JJ][1]) : "v"(b1), "n"(256 * JJ) : "memory");
+    }
+}
+template <int JJ, int MT, bool GLOB, int DEPTH>
+__device__ __forceinline__ void gk_step(f32x4v (&acc)[MT][2], f32x4v (&av)[8][MT], f32x4v (&bv)[8][2], const float* const (&pm)[MT], const float* b0,
+                                        const float* b1, const float (&bw)[8][2][4]) {
+    constexpr int LPB = MT + (GLOB ? 2 : 0);
+    constexpr int left = (7 - JJ < DEPTH - 1 ? 7 - JJ : DEPTH - 1) * LPB;
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(left) : "memory");
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(av[JJ][mt]));
+    if constexpr (GLOB) { asm volatile("" : "+v"(bv[JJ][0])); asm volatile("" : "+v"(bv[JJ][1])); }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[JJ][mt][e], GLOB ? bv[JJ][0][e] : bw[JJ][0][e], acc[mt][0], 0, 0, 0);
+            acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[JJ][mt][e], GLOB ? bv[JJ][1][e] : bw[JJ][1][e], acc[mt][1], 0, 0, 0);
+        }
+    if constexpr (JJ + DEPTH < 8) gk_load<JJ + DEPTH, MT, GLOB>(av, bv, pm, b0, b1);
+    if constexpr (JJ < 7) gk_step<JJ + 1, MT, GLOB, DEPTH>(acc, av, bv, pm, b0, b1, bw);
+}
+template <int MT, bool GLOB>
+__device__ __forceinline__ void gk_gemm(f32x4v (&acc)[MT][2], const float* const (&pm)[MT], const float* b0, const float* b1, const float (&bw)[8][2][4]) {
+    constexpr int DEPTH = GLOB ? (MT <= 2 ? 4 : 2) : (MT <= 2 ? 4 : 3);
+    f32x4v av[8][MT], bv[8][2];
+    gk_load<0, MT, GLOB>(av, bv, pm, b0, b1);
+    gk_load<1, MT, GLOB>(av, bv, pm, b0, b1);
+    if constexpr (DEPTH > 2) gk_load<2, MT, GLOB>(av, bv, pm, b0, b1);
+    if constexpr (DEPTH > 3) gk_load<3, MT, GLOB>(av, bv, pm, b0, b1);
+    gk_step<0, MT, GLOB, DEPTH>(acc, av, bv, pm, b0, b1, bw);
+}
+
 // ---- second form of the generation chain (round 5; SRVP_GEN_KSPLIT=0: the kernel above).  The K loop of every hidden layer is dealt to the
 // four waves as in rollout_ks_* (wave w owns the w-th 16-wide k block of every 64), which has a consequence the output-tiled form cannot have:
 // a wave only ever touches ITS quarter of each weight slice, 64 values per lane and layer -- so the slices of the dynamics' two hidden layers
@@ -1331,31 +1377,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // hidden layers in registers -- 256 VGPRs -- was built first: hipcc spilled 300 of them and the chain got slower, 91.1 vs 90.2 ms.)  The prior's
 // two hidden layers (once per frame) still take their B fragments from global memory.  32-row tiles as before (800 rows = 25 tiles must fit two co-resident launches): every A fragment feeds four MFMA
 // tiles (2 row tiles x 2 column tiles), 16 loads per lane and layer instead of 32 + 32.
-template <int GP>
+template <int GP, int MT>       // MT: 16-row tiles per cluster tile (2: 32 rows, the one instantiated; 4 was measured: see the launcher)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_gen_ks_kernel(const GenF a) {
     extern __shared__ float lds[];
+    constexpr int RTG = 16 * MT;
     const int xq = blockIdx.x & 7, kblk = blockIdx.x >> 3;
     const int cl = xq * a.cl_per_xcd + kblk / a.G, g = kblk % a.G;
     if (cl >= a.ntiles) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int q = lane >> 4, c16 = lane & 15;
-    const int ec = tid & 31, er = tid >> 5;               // epilogue: outputs (er + 8 u, ec), u < 4, of the 32 x 32 tile
-    const int row0 = (a.tile0 + cl) * RT;
+    const int ec = tid & 31, er = tid >> 5;               // epilogue: outputs (er + 8 u, ec), u < 2 MT, of the (16 MT) x 32 tile
+    const int row0 = (a.tile0 + cl) * RTG;
     const int colbase = g * CW;
     const int nl = a.nl, nh = a.nh, ny = a.ny, nz = a.nz, nin = a.nin, B = a.B, kp0 = a.kp0;
     const int nfull = nl - 2;                             // 1 or 2 (launcher)
     const int ils = kp0 + IPAD;
-    // LDS: Is [32][kp0 + IPAD] | Ys [32][ny] | Zs [32][nz] | Hs [32][33] | Bl [ny] | Bp [2 nz] (padded to 16 bytes) | Red [4][2][2][256]
+    // LDS: Is [32][kp0 + IPAD] | Ys [32][ny] | Zs [32][nz] | Hs [32][33] | Bl [ny] | Bp [2 nz] (padded to 16 bytes) | Red [4][MT][2][256]
     float* Is = lds;
-    float* Ys = Is + RT * ils;
-    float* Zs = Ys + RT * ny;
-    float* Hs = Zs + RT * nz;
-    float* Bl = Hs + RT * 33;
+    float* Ys = Is + RTG * ils;
+    float* Zs = Ys + RTG * ny;
+    float* Hs = Zs + RTG * nz;
+    float* Bl = Hs + RTG * 33;
     float* Bp = Bl + NYP_MAX;
     float* Red = Bp + 2 * NYP_MAX;
     unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;
-    float* hbuf = a.hbuf + (size_t)(a.tile0 + cl) * nfull * RT * nh;
-    float* part = a.part + (size_t)(a.tile0 + cl) * a.G * RT * KP0_MAX;
+    float* hbuf = a.hbuf + (size_t)(a.tile0 + cl) * nfull * RTG * nh;
+    float* part = a.part + (size_t)(a.tile0 + cl) * a.G * RTG * KP0_MAX;
     unsigned target = 0;
     xcd_announce(cnt);
     // hidden layers: B[k = 64 jj + 16 w + 4 q + e][16 ct + c16] = W_l[colbase + 16 ct + c16][k], this wave's k blocks only
@@ -1399,12 +1446,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             pwl[u][jj] = (ct < nctp && colp < 2 * nz) ? a.PW[nl - 1][(size_t)colp * nh + colbase + 4 * jj + q] : 0.f;
         }
     }
-    for (int idx = tid; idx < RT * ny; idx += 256) {
+    for (int idx = tid; idx < RTG * ny; idx += 256) {
         const int r = idx / ny, c = idx - r * ny;
         const int row = row0 + r < B ? row0 + r : B - 1;
         Ys[idx] = a.y0[(size_t)row * ny + c];
     }
-    for (int idx = tid; idx < RT * ils; idx += 256) Is[idx] = 0.f;
+    for (int idx = tid; idx < RTG * ils; idx += 256) Is[idx] = 0.f;
     if (tid < ny) Bl[tid] = a.b[nl - 1][tid];
     if (tid < 2 * nz) Bp[tid] = a.Pb[nl - 1][tid];
     cluster_barrier(cnt, target += a.G);
@@ -1412,83 +1459,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (g == 0 && tid == 0) __hip_atomic_fetch_add(&g_cluster_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    const size_t hls = (size_t)RT * nh;
+    const size_t hls = (size_t)RTG * nh;
     const int nq = a.nyp / 4, nq2 = a.nzp2 / 4;
     const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    // acc[mt][ct] += A(32 rows of the exchange buffer, this wave's k blocks: L1-bypassing loads) x B(registers)
-    auto gemm_rr = [&](f32x4v (&acc)[2][2], const float* abuf, const float (&bw)[8][2][4]) {
-        // eight loads (four k blocks x two row tiles) in flight at a time: the fragments of block jj + 4 are requested into the registers block
-        // jj has just been consumed from (the weight slices leave 250 registers for everything else)
-        f32x4v av[8][2];
-        const float* p0 = abuf + (size_t)c16 * nh + 16 * w + 4 * q;         // (nh == 512: every k block exists; block jj = an immediate offset)
-        const float* p1 = p0 + (size_t)16 * nh;
-#define GK_LOAD(jj)                                                                                                                         \
-        {                                                                                                                                   \
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=&v"(av[jj][0]) : "v"(p0), "n"(256 * (jj)) : "memory");         \
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=&v"(av[jj][1]) : "v"(p1), "n"(256 * (jj)) : "memory");         \
-        }
-#define GK_STEP(jj, n)                                                                                                                      \
-        {                                                                                                                                   \
-            asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(av[jj][0]), "+v"(av[jj][1]) :: "memory");                                         \
-            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                                                              \
-                const f32x4v x = av[jj][mt];                                                                                                \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                             \
-                    acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], bw[jj][0][e], acc[mt][0], 0, 0, 0);                             \
-                    acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], bw[jj][1][e], acc[mt][1], 0, 0, 0);                             \
-                }                                                                                                                           \
-            }                                                                                                                               \
-        }
-        GK_LOAD(0) GK_LOAD(1) GK_LOAD(2) GK_LOAD(3)
-        GK_STEP(0, 6) GK_LOAD(4) GK_STEP(1, 6) GK_LOAD(5) GK_STEP(2, 6) GK_LOAD(6) GK_STEP(3, 6) GK_LOAD(7)
-        GK_STEP(4, 6) GK_STEP(5, 4) GK_STEP(6, 2) GK_STEP(7, 0)
-#undef GK_STEP
-#undef GK_LOAD
+    auto gemm_rr = [&](f32x4v (&acc)[MT][2], const float* abuf, const float (&bw)[8][2][4]) {
+        const float* pm[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) pm[mt] = abuf + (size_t)(16 * mt + c16) * nh + 16 * w + 4 * q;
+        gk_gemm<MT, false>(acc, pm, nullptr, nullptr, bw);
     };
-    // the prior's hidden layers (once per frame): B fragments straight from the weight rows in global memory (L2 / L1 resident), four k blocks
-    // (2 A + 2 B loads each) in flight
-    auto gemm_rg = [&](f32x4v (&acc)[2][2], const float* abuf, const float* W) {
-        f32x4v av[8][2], bv[8][2];
-        const float* p0 = abuf + (size_t)c16 * nh + 16 * w + 4 * q;
-        const float* p1 = p0 + (size_t)16 * nh;
+    auto gemm_rg = [&](f32x4v (&acc)[MT][2], const float* abuf, const float* W) {
+        const float* pm[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) pm[mt] = abuf + (size_t)(16 * mt + c16) * nh + 16 * w + 4 * q;
         const float* b0 = W + (size_t)(colbase + c16) * nh + 16 * w + 4 * q;
-        const float* b1 = b0 + (size_t)16 * nh;
-#define GG_LOAD(jj)                                                                                                                         \
-        {                                                                                                                                   \
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=&v"(av[jj][0]) : "v"(p0), "n"(256 * (jj)) : "memory");         \
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=&v"(av[jj][1]) : "v"(p1), "n"(256 * (jj)) : "memory");         \
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(bv[jj][0]) : "v"(b0), "n"(256 * (jj)) : "memory");             \
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(bv[jj][1]) : "v"(b1), "n"(256 * (jj)) : "memory");             \
-        }
-#define GG_STEP(jj, n)                                                                                                                      \
-        {                                                                                                                                   \
-            asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(av[jj][0]), "+v"(av[jj][1]), "+v"(bv[jj][0]), "+v"(bv[jj][1]) :: "memory");       \
-            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                                                              \
-                const f32x4v x = av[jj][mt];                                                                                                \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                             \
-                    acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], bv[jj][0][e], acc[mt][0], 0, 0, 0);                             \
-                    acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], bv[jj][1][e], acc[mt][1], 0, 0, 0);                             \
-                }                                                                                                                           \
-            }                                                                                                                               \
-        }
-        GG_LOAD(0) GG_LOAD(1) GG_LOAD(2) GG_LOAD(3)
-        GG_STEP(0, 12) GG_LOAD(4) GG_STEP(1, 12) GG_LOAD(5) GG_STEP(2, 12) GG_LOAD(6) GG_STEP(3, 12) GG_LOAD(7)
-        GG_STEP(4, 12) GG_STEP(5, 8) GG_STEP(6, 4) GG_STEP(7, 0)
-#undef GG_STEP
-#undef GG_LOAD
+        gk_gemm<MT, true>(acc, pm, b0, b0 + (size_t)16 * nh, dw[0]);
     };
-    auto red_store4 = [&](const f32x4v (&acc)[2][2]) {
+    auto red_store4 = [&](const f32x4v (&acc)[MT][2]) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) *reinterpret_cast<f32x4v*>(Red + ((w * 2 + mt) * 2 + ct) * 256 + lane * 4) = acc[mt][ct];
+            for (int ct = 0; ct < 2; ++ct) *reinterpret_cast<f32x4v*>(Red + ((w * MT + mt) * 2 + ct) * 256 + lane * 4) = acc[mt][ct];
     };
     auto red_sum4 = [&](int r, int c) {
+        constexpr int WS = MT * 512;                      // floats per wave
         const int off = (((r >> 4) * 2) + (c >> 4)) * 256 + (((r & 15) >> 2) * 16 + (c & 15)) * 4 + (r & 3);
-        return ((Red[off] + Red[1024 + off]) + Red[2048 + off]) + Red[3072 + off];
+        return ((Red[off] + Red[WS + off]) + Red[2 * WS + off]) + Red[3 * WS + off];
     };
     // one MLP trunk up to the last hidden activation in Hs: first-layer accumulators in, hidden layers from registers, exchange through hbuf
-    auto trunk = [&](f32x4v (&acc)[2][2], const float* const* bias, const float* const* Wg) {     // Wg: the prior's weights (global) or null: dynamics (registers)
+    auto trunk = [&](f32x4v (&acc)[MT][2], const float* const* bias, const float* const* Wg) {     // Wg: the prior's weights (global) or null: dynamics (registers)
         float bl = bias[0][colbase + ec];
 #pragma unroll
         for (int l = 0; l < 3; ++l) {                       // (unrolled: the register-resident slices need compile-time indices)
@@ -1496,7 +1496,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __syncthreads();
             float* hdst = hbuf + (size_t)l * hls;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 2 * MT; ++u) {
                 const int r = er + 8 * u;
                 float v = red_sum4(r, ec) + bl;
                 v = v > 0.f ? v : 0.f;
@@ -1507,7 +1507,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             bl = bias[l + 1][colbase + ec];
             cluster_barrier(cnt, target += a.G);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) { acc[mt][0] = zero4; acc[mt][1] = zero4; }
+            for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = zero4; acc[mt][1] = zero4; }
             if (Wg) gemm_rg(acc, hdst, Wg[l + 1]);
             else gemm_rr(acc, hdst, dw[l < 2 ? l : 1]);
         }
@@ -1518,16 +1518,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int f = i / a.ne;
         if (i % a.ne == 0) {
             // =============================== frame start: p_z(y), then z
-            for (int idx = tid; idx < RT * ny; idx += 256) {
+            for (int idx = tid; idx < RTG * ny; idx += 256) {
                 const int r = idx / ny, c = idx - r * ny;
                 Is[r * ils + c] = Ys[idx];
             }
             __syncthreads();
-            f32x4v acc[2][2] = {{zero4, zero4}, {zero4, zero4}};
+            f32x4v acc[MT][2];
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = zero4; acc[mt][1] = zero4; }
             {
                 const bool ok = 16 * w < a.nyp;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     f32x4v x = *reinterpret_cast<const f32x4v*>(Is + (16 * mt + c16) * ils + (ok ? 16 * w : 0) + 4 * q);
                     if (!ok) x = zero4;
 #pragma unroll
@@ -1538,13 +1539,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }
             trunk(acc, a.Pb, a.PW);
-            float* pdst = part + (size_t)g * RT * KP0_MAX;
+            float* pdst = part + (size_t)g * RTG * KP0_MAX;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int ct = w + 4 * u;
                 if (ct >= nctp) break;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     f32x4v o = zero4;
                     const float* hr = Hs + (16 * mt + c16) * 33 + q;
 #pragma unroll
@@ -1554,22 +1555,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }
             const bool posterior = f + 1 < a.n_data;
-            float epsr[NYP_MAX * RT / 256], qlr[NYP_MAX * RT / 256], qsr[NYP_MAX * RT / 256];
+            // (64-row tiles: no registers left for it -- the noise is fetched where it is used, one more latency per frame)
+            constexpr bool PRE = MT <= 2;
+            constexpr int NPRE = PRE ? NYP_MAX * RTG / 256 : 1;
+            float epsr[NPRE], qlr[NPRE], qsr[NPRE];
+            if constexpr (PRE) {
 #pragma unroll
-            for (int u = 0; u < NYP_MAX * RT / 256; ++u) {
-                const int idx = tid + 256 * u, r = idx / nz, c = idx - r * nz;
-                const int row = row0 + r < B ? row0 + r : B - 1;
-                const bool ok = idx < RT * nz;
-                epsr[u] = ok ? a.eps[((size_t)f * B + row) * nz + c] : 0.f;
-                qlr[u] = (ok && posterior) ? a.qz[((size_t)f * B + row) * 2 * nz + c] : 0.f;
-                qsr[u] = (ok && posterior) ? a.qz[((size_t)f * B + row) * 2 * nz + nz + c] : 0.f;
+                for (int u = 0; u < NPRE; ++u) {
+                    const int idx = tid + 256 * u, r = idx / nz, c = idx - r * nz;
+                    const int row = row0 + r < B ? row0 + r : B - 1;
+                    const bool ok = idx < RTG * nz;
+                    epsr[u] = ok ? a.eps[((size_t)f * B + row) * nz + c] : 0.f;
+                    qlr[u] = (ok && posterior) ? a.qz[((size_t)f * B + row) * 2 * nz + c] : 0.f;
+                    qsr[u] = (ok && posterior) ? a.qz[((size_t)f * B + row) * 2 * nz + nz + c] : 0.f;
+                }
             }
             cluster_barrier(cnt, target += a.G);
-            for (int it = tid; it < RT * nq2; it += 512) {
-                const int itb = it + 256 < RT * nq2 ? it + 256 : it;
+            for (int it = tid; it < RTG * nq2; it += 512) {
+                const int itb = it + 256 < RTG * nq2 ? it + 256 : it;
                 f32x4v sv[2] = {zero4, zero4};
                 sum_slabs2h<GP>(sv[0], sv[1], part + (it / nq2) * KP0_MAX + 4 * (it % nq2), part + (itb / nq2) * KP0_MAX + 4 * (itb % nq2), a.G,
-                               (size_t)RT * KP0_MAX);
+                               (size_t)RTG * KP0_MAX);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int item = h ? itb : it;
@@ -1582,12 +1588,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < NYP_MAX * RT / 256; ++u) {
+            for (int u = 0; u < NYP_MAX * RTG / 256; ++u) {
                 const int idx = tid + 256 * u, r = idx / nz, c = idx - r * nz;
-                if (idx >= RT * nz) break;
+                if (idx >= RTG * nz) break;
                 const float pl = Is[r * ils + c], ps = Is[r * ils + nz + c];
-                const float loc = posterior ? qlr[u] : pl, raw = posterior ? qsr[u] : ps;
-                const float zz = loc + epsr[u] * (softplus_g(raw) + 1e-8f);
+                float ev, ql, qs;
+                if constexpr (PRE) { ev = epsr[u]; ql = qlr[u]; qs = qsr[u]; }
+                else {
+                    const int row = row0 + r < B ? row0 + r : B - 1;
+                    ev = a.eps[((size_t)f * B + row) * nz + c];
+                    ql = posterior ? a.qz[((size_t)f * B + row) * 2 * nz + c] : 0.f;
+                    qs = posterior ? a.qz[((size_t)f * B + row) * 2 * nz + nz + c] : 0.f;
+                }
+                const float loc = posterior ? ql : pl, raw = posterior ? qs : ps;
+                const float zz = loc + ev * (softplus_g(raw) + 1e-8f);
                 Zs[idx] = zz;
                 if (g == 0 && row0 + r < B) {
                     const size_t o = (size_t)f * B + row0 + r;
@@ -1597,25 +1611,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }
             __syncthreads();
-            for (int idx = tid; idx < RT * kp0; idx += 256) {
+            for (int idx = tid; idx < RTG * kp0; idx += 256) {
                 const int r = idx / kp0, k = idx - r * kp0;
                 Is[r * ils + k] = k < ny ? Ys[r * ny + k] : (k < nin ? Zs[r * nz + k - ny] : 0.f);
             }
         } else {
-            for (int idx = tid; idx < RT * ny; idx += 256) {
+            for (int idx = tid; idx < RTG * ny; idx += 256) {
                 const int r = idx / ny, c = idx - r * ny;
                 Is[r * ils + c] = Ys[idx];
             }
         }
         __syncthreads();
         // =============================== one residual step
-        f32x4v acc[2][2] = {{zero4, zero4}, {zero4, zero4}};
+        f32x4v acc[MT][2];
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = zero4; acc[mt][1] = zero4; }
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int kb = 16 * (w + 4 * jj);
             const bool ok = kb < kp0;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 f32x4v x = *reinterpret_cast<const f32x4v*>(Is + (16 * mt + c16) * ils + (ok ? kb : 0) + 4 * q);
                 if (!ok) x = zero4;
 #pragma unroll
@@ -1626,10 +1641,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
         trunk(acc, a.b, nullptr);
-        float* pdst = part + (size_t)g * RT * KP0_MAX;
+        float* pdst = part + (size_t)g * RTG * KP0_MAX;
         if (w < nctl) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 f32x4v o = zero4;
                 const float* hr = Hs + (16 * mt + c16) * 33 + q;
 #pragma unroll
@@ -1639,11 +1654,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
         cluster_barrier(cnt, target += a.G);
-        for (int it = tid; it < RT * nq; it += 512) {
-            const int itb = it + 256 < RT * nq ? it + 256 : it;
+        for (int it = tid; it < RTG * nq; it += 512) {
+            const int itb = it + 256 < RTG * nq ? it + 256 : it;
             f32x4v sv[2] = {zero4, zero4};
             sum_slabs2h<GP>(sv[0], sv[1], part + (it / nq) * KP0_MAX + 4 * (it % nq), part + (itb / nq) * KP0_MAX + 4 * (itb % nq), a.G,
-                           (size_t)RT * KP0_MAX);
+                           (size_t)RTG * KP0_MAX);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int item = h ? itb : it;
@@ -2261,8 +2276,9 @@ extern "C" int64_t srvp_rollout_gen_ws_bytes(const srvp_rollout_desc* d) {
     const size_t lds = ((size_t)(d->nl - 2) * d->nh * CW + RT * (kp0 + IPAD) + RT * d->ny + RT * d->nz + RT * 33 + d->ny + 2 * d->nz) * 4;
     if (lds > 160 * 1024) return 0;
     if (!placement_round_robin()) return 0;
-    const int64_t tiles = (d->B + RT - 1) / RT;
-    return tiles * 256 + tiles * (int64_t)(d->nl - 2) * RT * d->nh * 4 + tiles * (int64_t)(d->nh / CW) * RT * KP0_MAX * 4;
+    // (rows rounded up to 64: either tile height of the second form, rollout_gen_ks_kernel<., 2 | 4>)
+    const int64_t rows = (d->B + 63) / 64 * 64, tiles = rows / RT;
+    return tiles * 256 + rows * (int64_t)(d->nl - 2) * d->nh * 4 + rows * (int64_t)(d->nh / CW) * KP0_MAX * 4;
 }
 
 int srvp_rollout_gen_fwd(const srvp_rollout_desc* d, hipStream_t st) {
@@ -2276,18 +2292,25 @@ int srvp_rollout_gen_fwd(const srvp_rollout_desc* d, hipStream_t st) {
         k.PW[l] = l < d->nl ? d->pz_w[l] : nullptr; k.Pb[l] = l < d->nl ? d->pz_b[l] : nullptr;
     }
     k.y0 = d->y0; k.qz = d->q_z_params; k.eps = d->eps_z; k.y_all = d->y_all; k.res = d->res; k.z = d->z; k.pz = d->p_z_params;
-    const int tiles = (d->B + RT - 1) / RT;
-    k.cnt = (unsigned*)d->fused_ws;
-    k.hbuf = (float*)((char*)d->fused_ws + (size_t)tiles * 256);
-    k.part = k.hbuf + (size_t)tiles * (d->nl - 2) * RT * d->nh;
     SRVP_REQUIRE(k.n_data <= 1 || k.qz, "srvp_rollout_fwd(gen): posterior frames need q_z_params");
     static int gks = -1;
     if (gks < 0) { const char* e2 = getenv("SRVP_GEN_KSPLIT"); gks = e2 ? atoi(e2) : 1; }
     const bool ks = gks && k.nl - 2 <= 2 && k.nh == 512;         // (the register-resident form: <= two hidden layers of 512 units per network)
-    const size_t lds = ks ? ((size_t)RT * (k.kp0 + IPAD) + RT * k.ny + RT * k.nz + RT * 33 + 3 * NYP_MAX + 4096) * 4
+    // tile height: 32 rows.  (64-row tiles, rollout_gen_ks_kernel<., 4>, turn the two co-resident launches of the config-5 protocol's 800 rows
+    // into one -- a launch lasts as long as its chain of steps whatever its tile count -- and were built and measured in round 5: hipcc spills
+    // 226 registers in that instantiation and the call gets slower, 89.8 vs 89.2 ms; not instantiated)
+    int cpx;
+    const int rt = RT;
+    const int tiles = (d->B + rt - 1) / rt;
+    const int64_t rows64 = (d->B + 63) / 64 * 64;
+    k.cnt = (unsigned*)d->fused_ws;
+    k.hbuf = (float*)((char*)d->fused_ws + (size_t)(rows64 / RT) * 256);
+    k.part = k.hbuf + (size_t)rows64 * (d->nl - 2) * d->nh;
+    const size_t lds = ks ? ((size_t)rt * (k.kp0 + IPAD) + rt * k.ny + rt * k.nz + rt * 33 + 3 * NYP_MAX + 4 * (rt / 16) * 512) * 4
                           : ((size_t)(k.nl - 2) * k.nh * CW + RT * (k.kp0 + IPAD) + RT * k.ny + RT * k.nz + RT * 33 + k.ny + 2 * k.nz) * 4;
-    auto kern = ks ? (k.G <= 8 ? rollout_gen_ks_kernel<8> : (k.G <= 16 ? rollout_gen_ks_kernel<16> : rollout_gen_ks_kernel<32>))
-                   : (k.G <= 8 ? rollout_gen_kernel<8> : (k.G <= 16 ? rollout_gen_kernel<16> : rollout_gen_kernel<32>));
+    void (*kern)(const GenF) = nullptr;
+    if (ks) kern = k.G <= 8 ? rollout_gen_ks_kernel<8, 2> : (k.G <= 16 ? rollout_gen_ks_kernel<16, 2> : rollout_gen_ks_kernel<32, 2>);
+    else kern = k.G <= 8 ? rollout_gen_kernel<8> : (k.G <= 16 ? rollout_gen_kernel<16> : rollout_gen_kernel<32>);
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd(gen): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
@@ -2297,7 +2320,6 @@ int srvp_rollout_gen_fwd(const srvp_rollout_desc* d, hipStream_t st) {
     // (more tiles than one co-resident launch holds: the groups run one after the other on this stream.  Putting the second group on another
     // stream under the decoding of the first group's rows was measured in round 5 and is slower: its spinning workgroups hold 144 CUs' worth
     // of LDS while they become resident one by one, and the decoder's convolutions lose more than the 3.6 ms the overlap hides)
-    int cpx;
     const int per = clusters_per_launch(k.G, tiles, cpx);
     for (int t0 = 0; t0 < tiles; t0 += per) {
         k.tile0 = t0; k.ntiles = tiles - t0 < per ? tiles - t0 : per; k.cl_per_xcd = cpx;
