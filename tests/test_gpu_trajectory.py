@@ -7,8 +7,8 @@ The same 300-step Adam trajectory -- same initial weights, same mini-batches, sa
 through the product: production precision ('bf16': bf16 MFMA operands / activation storage, fp32 accumulation and masters) and
 parity mode ('fp32': the mode held to 1e-5 against the reference's fixtures).  Asserted: the loss curves agree step by step
 (within 1 % of the range the curve covers), both runs learn, and the validation PSNR of the bf16-trained model (deterministic
-protocol: same draws) agrees with the fp32-mode one to a few tenths of a dB with no systematic sign (+0.25 / -0.15 dB measured with two
-summation orders of the bf16 path; the fp32-mode run repeated -- its atomics are not bitwise reproducible -- stays within 0.05 dB).
+protocol: same draws) agrees with the fp32-mode one to a few tenths of a dB (the fp32-mode run repeated -- its atomics are not bitwise
+reproducible, 300 Adam steps amplify that -- lands up to 0.43 dB from itself; bf16 sits 0.0-0.33 dB from the mean of such a pair).
 Reference: train.py:49-129 (the step), 132-189 (validation PSNR).
 """
 import os
@@ -99,8 +99,11 @@ def test_bf16_trains_like_fp32_over_300_steps():
     # measured 0.3-0.7 % and -0.15 ... +0.25 dB (no systematic sign: a change of summation order inside the bf16 path moves it as much).
     assert max(rel) <= 2e-2, (max(rel), rel.index(max(rel)), max(rel_self))
     assert max(rel_sm) <= 1e-2, max(rel_sm)
-    assert abs(p16 - p32) <= 0.6, (p16, p32, p32b)
-    assert abs(p32b - p32) <= 0.4, (p32, p32b)
+    # PSNR (round 5, eight repeats of this test on two boxes, with the round's kernels and with every round-5 switch off alike): the fp32-mode run
+    # and its repeat land anywhere in 19.00-19.45 dB (up to 0.43 dB apart: the earlier 0.02-0.10 dB came from fewer repeats), bf16 in 18.97-19.24,
+    # 0.0-0.33 dB from the mean of the fp32 pair (0.17 dB lower on average).  bf16 is held against that mean, the pair against its own spread.
+    assert abs(p16 - 0.5 * (p32 + p32b)) <= 0.6, (p16, p32, p32b)
+    assert abs(p32b - p32) <= 0.8, (p32, p32b)
 
 
 def test_fp32_deterministic_mode_is_bit_reproducible():
