@@ -15,6 +15,10 @@
 //
 // All workgroups of a launch must be co-resident (they spin on each other): the launcher keeps the grid <= the number of CUs
 // (one workgroup per CU: > 80 KB of LDS each) and walks larger batches in several launches.
+//
+// Round 5: every chain in this file has a SECOND FORM that the launchers prefer (rollout_ks_*, lstm_ks_*, rollout_gen_ks_kernel: 16-row tiles
+// where the batch fits one co-resident launch that way, the K loop of a layer dealt to the four waves, weight slices in registers where a wave
+// only ever touches its quarter); the kernels described above remain as the fallback.  See "16-row tiles, K split over the waves" below.
 #include <atomic>
 #include <type_traits>
 #include "common.h"
