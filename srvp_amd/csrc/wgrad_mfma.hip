@@ -686,10 +686,11 @@ static int try_launch_halo(const srvp_wgrad_desc* d, const WgradK& k, hipStream_
     const int bj = d->Cout == 32 ? 32 : 64;
     const int pairs = (d->Cout / bj) * (d->C0 / 64) * (two ? 2 : 1);      // (two: x phase pairs)
     // workgroups per launch the split-K aims at: every split pays 9 x 64 x 64 fp32 atomics, amortised over its K steps -- 512 is
-    // the measured best at 2304 frames (43.35 vs 44.1 / 44.4 ms per step for 384 / 256), 320 at 288 frames (10.70 vs 10.98 ms)
+    // the measured best at 2304 frames (43.35 vs 44.1 / 44.4 ms per step for 384 / 256), 320 at 288 frames (10.70 vs 10.98 ms) in round 3;
+    // round 5 at 288 frames, 192 / 256 / 320 / 448 / 640: 7.18 / 7.11 / 7.15 / 7.36 / 7.46 ms per step (two same-box sweeps): 256
     static int target_env = -2;
     if (target_env == -2) { const char* e = getenv("SRVP_WGRAD_HALO_WGS"); target_env = e ? atoi(e) : -1; }
-    const int target = target_env > 0 ? target_env : (d->N < 1024 ? 320 : 512);
+    const int target = target_env > 0 ? target_env : (d->N < 1024 ? 256 : 512);
     int splitk = (target + pairs - 1) / pairs;
     if (splitk > h.ntiles / 8) splitk = h.ntiles / 8 > 0 ? h.ntiles / 8 : 1;
     h.a.splitk = splitk;
