@@ -177,7 +177,7 @@ class PeerStats:
     collectives (csrc/comm.hip: srvp_peer_*).  One slot (two parities) per call site, assigned in order of first use -- the launch
     sequence is the same on every rank; seq counts the uses of the slot.  Ranks of ONE node only (hipIpc), world <= 8."""
 
-    SLOTS, NMAX = 128, 2 * 2048          # call sites (42 BatchNorm layers x 2 directions = 84 for VGG), doubles per collective
+    SLOTS, NMAX = 128, 2 * 2048          # call sites (21 BatchNorm layers x 2 directions = 42 for VGG), doubles per collective
 
     def __init__(self, group=None):
         self.group = group
