@@ -1,4 +1,6 @@
-"""Collectives of one training step at 24 sequences with SRVP_FORCE_COLLECTIVES=1 on one rank, counted by hooks on Sync.allreduce_stats and the\nnative gradient communicator: 42 statistics all-reduces (21 BatchNorm layers x forward / backward) + 3 gradient slices for the VGG recipes.\n    usage: python tools/count_collectives.py"""
+"""Collectives of one training step at 24 sequences with SRVP_FORCE_COLLECTIVES=1 on one rank, counted by hooks on Sync.allreduce_stats and the
+native gradient communicator: 42 statistics all-reduces (21 BatchNorm layers x forward / backward) + 3 gradient slices for the VGG recipes.
+    usage: python tools/count_collectives.py"""
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 os.environ['SRVP_FORCE_COLLECTIVES'] = '1'
