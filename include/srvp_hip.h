@@ -483,6 +483,11 @@ int srvp_rsample_bwd(const float* params, const float* eps, const float* dout, f
 /* fused Adam over one flat fp32 buffer; step_size = lr/(1-b1^t), bc2_sqrt = sqrt(1-b2^t) */
 int srvp_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
               int step, float grad_scale, void* stream);
+/* the same update (train.py:289 / torch.optim.Adam) with the per-step scalars read from DEVICE memory when the launch executes:
+ * hp = float[3] {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), grad_scale}.  The launch carries no per-step value, so a captured hipGraph of
+ * the whole optimisation step can be replayed (srvp_amd/graphstep.py refreshes hp through a pinned-memory copy in front of it). */
+int srvp_adam_hp(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps, const float* hp,
+                 void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Data parallelism over the GPUs of a node: RCCL (xGMI) collectives enqueued on the caller's stream -- the gradient
@@ -499,6 +504,9 @@ int srvp_comm_info(void* comm, int* info3);
 /* in-place sum over ranks */
 int srvp_allreduce_f64(void* comm, double* buf, int64_t n, void* stream);
 int srvp_allreduce_f32(void* comm, float* buf, int64_t n, void* stream);
+/* generic in-place all-reduce: dtype 0 = fp32, 1 = fp64, 2 = bf16; op 0 = sum, 1 = average over ranks (ncclAvg -- DistributedDataParallel's
+ * gradient averaging, train.py:309-314, without a separate 1/world pass over the buffer) */
+int srvp_allreduce(void* comm, void* buf, int64_t n, int dtype, int op, void* stream);
 int srvp_bcast_bytes(void* comm, void* buf, int64_t nbytes, int root, void* stream);
 /* PROTOTYPE, SRVP_COMM=peer: the SyncBatchNorm statistics exchange as a one-sided peer read (csrc/comm.hip).  Every rank creates a slab
  * (device memory, exported through hipIpc: ipc_handle64 receives the 64-byte handle), opens the other ranks' slabs, and a collective is one
@@ -530,6 +538,8 @@ int srvp_mmnist_render(const void* digits_u8, int n_digits, int dh, int dw, cons
 int srvp_mmnist_trajectories(uint64_t seed, uint64_t batch_counter, int B, int num_digits, int T, int nx, int dh, int dw,
                              int max_speed, int deterministic, int n_digits, int* idx, int* pos, int* contacts, void* stream);
 int srvp_cast_f32_bf16(const float* src, void* dst, int64_t rows, int cols, int dst_cols, void* stream);
+/* dst fp32 [n] = scale * src bf16 [n] (the way back of the opt-in bf16 gradient payload of the data-parallel exchange) */
+int srvp_cast_bf16_f32(const void* src, float* dst, int64_t n, float scale, void* stream);
 /* dst bf16 [M][C] = sum_z parts[z * slab_elems + m * C + c] (z ascending), the slabs of an srvp_conv_mfma launch with splitk > 1;
  * stats (may be NULL): += per-column sum and sum of squares of the fp32 sums (column c -> stats[c % stat_mod], stats[stat_mod + c %
  * stat_mod]), i.e. what the convolution's own BatchNorm-statistics epilogue computes (conv.py:104) */

@@ -159,12 +159,14 @@ _SIGS = {
     'srvp_rsample_fwd': ([c_vp, c_vp, c_vp, c_i64, c_i32, c_vp], c_i32),
     'srvp_rsample_bwd': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp], c_i32),
     'srvp_adam': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_vp], c_i32),
+    'srvp_adam_hp': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp, c_vp], c_i32),
     'srvp_comm_unique_id': ([c_vp], c_i32),
     'srvp_comm_init': ([c_vp, c_i32, c_i32, C.POINTER(c_vp)], c_i32),
     'srvp_comm_destroy': ([c_vp], c_i32),
     'srvp_comm_info': ([c_vp, C.POINTER(c_i32)], c_i32),
     'srvp_allreduce_f64': ([c_vp, c_vp, c_i64, c_vp], c_i32),
     'srvp_allreduce_f32': ([c_vp, c_vp, c_i64, c_vp], c_i32),
+    'srvp_allreduce': ([c_vp, c_vp, c_i64, c_i32, c_i32, c_vp], c_i32),
     'srvp_bcast_bytes': ([c_vp, c_vp, c_i64, c_i32, c_vp], c_i32),
     'srvp_peer_slab_create': ([c_i64, C.POINTER(c_vp), c_vp], c_i32),
     'srvp_peer_slab_open': ([c_vp, C.POINTER(c_vp)], c_i32),
@@ -175,6 +177,7 @@ _SIGS = {
     'srvp_mmnist_render': ([c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp], c_i32),
     'srvp_mmnist_trajectories': ([C.c_uint64, C.c_uint64] + [c_i32] * 9 + [c_vp, c_vp, c_vp, c_vp], c_i32),
     'srvp_cast_f32_bf16': ([c_vp, c_vp, c_i64, c_i32, c_i32, c_vp], c_i32),
+    'srvp_cast_bf16_f32': ([c_vp, c_vp, c_i64, c_f32, c_vp], c_i32),
     'srvp_splitk_finish': ([c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp], c_i32),
     'srvp_pad_f32': ([c_vp, c_vp, c_i64, c_i32, c_i32, c_vp], c_i32),
     'srvp_skip_grad_reduce_f32': ([c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp], c_i32),

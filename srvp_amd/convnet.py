@@ -1389,8 +1389,11 @@ class EncoderNet(ConvNetBase):
         d3.da_mode, d3.N, d3.da2_idx = 3, da['da2'].shape[0], L.ptr(da['da2_sel'])     # rows of da2 and the frame each belongs to
         L.call('srvp_bn_bwd_reduce', C.byref(d3), L.ptr(blk.red), st)
 
-    def backward(self, x, d_hx, skip_grads, params, grads, st, sync=None, side=None, aux=None):
+    def backward(self, x, d_hx, skip_grads, params, grads, st, sync=None, side=None, aux=None, on_part=None):
         """
+        on_part (callable, optional): on_part(lo, hi) is called, with `side` current, right after the weight gradients of blocks
+        lo <= index < hi have been unpacked there (every parameter gradient of those blocks is then final behind that point of `side`: the
+        data-parallel exchange of that slice may start while the first stages are still going backward).
         d_hx: fp32 [N][nh_padded] gradient of the encoder output; skip_grads: {stage: (dsel bf16 [B][H][W][C], idx int32 [N])}
         side (a torch stream, optional): the unpacking of the MFMA layers' weight gradients runs there, under the image-side layer's
         backward (its BatchNorm passes and weight gradient, ~1 ms that needs none of it); the caller joins the stream afterwards.
@@ -1434,6 +1437,8 @@ class EncoderNet(ConvNetBase):
                 # weights: 85 us that ran as the step's tail behind the LAST weight gradient) goes out now, in front of the first blocks'
                 with torch.cuda.stream(side):
                     self.unpack_wgrads(grads, L.stream(), part=(split_at, nb))
+                    if on_part is not None:
+                        on_part(split_at, nb)
             sk = blk.spec['skip_out']
             if sk is not None and skip_grads and (3 - sk) in skip_grads:
                 da.update(self._skip_term(blk, skip_grads[3 - sk]))
@@ -1567,7 +1572,10 @@ class DecoderNet(ConvNetBase):
                 fn(st)
         self._wg_deferred = []
         self._wgrads_issued = False
-        self.unpack_wgrads(grads, st)
+        lo = getattr(self, '_unpacked_from', None)                          # blocks >= lo were unpacked early (backward(on_part=...))
+        self._unpacked_from = None
+        self.unpack_wgrads(grads, st, part=None if lo is None else (0, lo))
+        return 0, (len(self.blocks) if lo is None else lo)
 
     def _f32_out(self):
         """The image-side layer's gradients run on the exact-fp32 MFMA first-layer kernels (see backward)."""
@@ -1584,11 +1592,15 @@ class DecoderNet(ConvNetBase):
         L.call('srvp_conv_in_wgrad_f32' if self.f32 else 'srvp_conv_in_wgrad', L.ptr(self.dpre_f32), L.ptr(f0.t), L.ptr(grads[ob.spec['key'] + '.weight']),
                self.N, ob.cout_r, 64, 64, f0.C, ob.cin_r[0], ob.k, ob.s, ob.p, st)
 
-    def backward(self, d_x, params, grads, st, sync=None, defer_wgrad=False, side=None):
+    def backward(self, d_x, params, grads, st, sync=None, defer_wgrad=False, side=None, on_part=None):
         """d_x: fp32 (N, C, 64, 64).  Returns dz bf16 [N][nz_padded]; skip gradients are left in the blocks' dcat.
-        side (torch stream, with defer_wgrad): every block's weight gradient is issued there as soon as its output gradient exists."""
+        side (torch stream, with defer_wgrad): every block's weight gradient is issued there as soon as its output gradient exists.
+        on_part (callable, optional; with the early weight gradients): the blocks whose weight gradients went out early are unpacked on `side`
+        as soon as the last of them is issued and on_part(lo, hi) is called there (their parameter gradients are final behind that point:
+        the data-parallel exchange of that slice starts under the rest of the decoder backward); deferred_wgrads() unpacks the rest."""
         ob = self.blocks[-1]
         self.zero_backward_accumulators()
+        self._unpacked_from = None
         early = defer_wgrad and side is not None and DEC_WGRAD_EARLY
         # blocks (in backward order) whose weight gradient goes out early
         n_early = DEC_WGRAD_EARLY_N if DEC_WGRAD_EARLY_N >= 0 else (len(self.blocks) // 2 if DEC_WGRAD_EARLY_N == -2 else len(self.blocks))
@@ -1644,6 +1656,12 @@ class DecoderNet(ConvNetBase):
             self._bn_backward(blk, params, grads, da, st, sync)
             if early and (len(self.blocks) - 1 - i) < n_early:
                 on_side(lambda s_, blk=blk: self._wgrad(blk, s_))
+                if on_part is not None and (len(self.blocks) - 1 - i) == n_early - 1 and i > 0:
+                    def part(s_, lo=i):
+                        self.unpack_wgrads(grads, s_, part=(lo, len(self.blocks)))
+                        on_part(lo, len(self.blocks))
+                    on_side(part)
+                    self._unpacked_from = i
             elif early:
                 self._wg_deferred.append(lambda s_, blk=blk: self._wgrad(blk, s_))
             self._mfma_backward(blk, grads, st, wgrad=not defer_wgrad)

@@ -102,6 +102,17 @@ extern "C" int srvp_allreduce_f32(void* comm, float* buf, int64_t n, void* strea
     return SRVP_OK;
 }
 
+// Generic form (round 6): dtype 0 = fp32, 1 = fp64, 2 = bf16 (the opt-in compressed gradient payload); op 0 = sum, 1 = average over ranks
+// (ncclAvg: RCCL pre-scales by 1 / ranks inside the collective -- the 1/world pass of DistributedDataParallel's averaging costs no
+// extra sweep over the 95 MB gradient buffer).
+extern "C" int srvp_allreduce(void* comm, void* buf, int64_t n, int dtype, int op, void* stream) {
+    SRVP_REQUIRE(comm && buf && n > 0 && g_api.lib && dtype >= 0 && dtype <= 2 && (op == 0 || op == 1),
+                 "srvp_allreduce: bad args / communicator not initialised");
+    const ncclDataType_t dt = dtype == 0 ? ncclFloat32 : (dtype == 1 ? ncclFloat64 : ncclBfloat16);
+    RCCL_CHECK(g_api.AllReduce(buf, buf, (size_t)n, dt, op == 1 ? ncclAvg : ncclSum, (ncclComm_t)comm, (hipStream_t)stream), "ncclAllReduce");
+    return SRVP_OK;
+}
+
 extern "C" int srvp_bcast_bytes(void* comm, void* buf, int64_t nbytes, int root, void* stream) {
     SRVP_REQUIRE(comm && buf && nbytes > 0 && g_api.lib, "srvp_bcast_bytes: bad args / communicator not initialised");
     RCCL_CHECK(g_api.Broadcast(buf, buf, (size_t)nbytes, ncclUint8, root, (ncclComm_t)comm, (hipStream_t)stream), "ncclBroadcast");
@@ -111,7 +122,7 @@ extern "C" int srvp_bcast_bytes(void* comm, void* buf, int64_t nbytes, int root,
 
 // ---------------------------------------------------------------------------------------------------------------------
 // PROTOTYPE (SRVP_COMM=peer): the SyncBatchNorm statistics exchange (reference train.py:278-283) as a one-sided peer read instead of
-// an all-reduce.  84 of these per VGG step feed the very next kernel, each a few KB: through RCCL every one is a collective kernel
+// an all-reduce.  42 of these per VGG step (21 BatchNorm layers x 2 directions) feed the very next kernel, each a few KB: through RCCL every one is a collective kernel
 // with its own rendezvous (~10-20 us on xGMI), which at 24 sequences per GPU is 1-1.7 ms of a ~9 ms step.  Here every rank owns a
 // slab (device memory shared with the other ranks of the node through hipIpc); a collective is ONE single-workgroup launch per rank:
 // publish the local sums into the own slab (system-scope stores), raise the own flag to the sequence number, wait for the peers'

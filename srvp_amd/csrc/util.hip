@@ -221,6 +221,23 @@ extern "C" int srvp_cast_f32_bf16(const float* src, void* dst, int64_t rows, int
     SRVP_CHECK_LAUNCH("srvp_cast_f32_bf16");
     return SRVP_OK;
 }
+// bf16 -> fp32 with a scale: the way back of the opt-in bf16 gradient payload (SRVP_GRAD_BF16=1: a gradient slice is cast to bf16,
+// all-reduced at half the bytes over xGMI, and widened back into the flat fp32 gradient buffer)
+namespace {
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long long n, float scale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = (float)src[i] * scale;
+}
+}  // namespace
+extern "C" int srvp_cast_bf16_f32(const void* src, float* dst, int64_t n, float scale, void* stream) {
+    SRVP_REQUIRE(src && dst, "srvp_cast_bf16_f32: null pointer");
+    if (n <= 0) return SRVP_OK;
+    long long b = (n + 255) / 256;
+    if (b > 16384) b = 16384;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, (long long)n, scale);
+    SRVP_CHECK_LAUNCH("srvp_cast_bf16_f32");
+    return SRVP_OK;
+}
 // fp32 parity mode: the same zero-padding copy into an fp32 tensor
 extern "C" int srvp_pad_f32(const float* src, float* dst, int64_t rows, int cols, int dst_cols, void* stream) {
     long long n = (long long)rows * dst_cols;

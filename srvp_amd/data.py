@@ -59,7 +59,12 @@ class Prefetcher:
     -- and yields DEVICE batches.  Batch i + 1 is staged (pinned -> HBM copy, and for uint8 the device-side collate) on a copy stream of
     its own right before batch i is handed out, i.e. under step i; the consumer's stream waits on the staging event, so by the time the
     step's first kernel needs the frames they are resident and the step pays neither the PCIe transfer nor the collate.
-    Iterables that already yield device tensors (the device Moving-MNIST generator) pass through untouched."""
+    Iterables that already yield device tensors (the device Moving-MNIST generator) pass through untouched.
+    Lifetime of a yielded batch: it is record_stream'ed for the consumer's CURRENT stream only, while the step also reads it from the
+    model's side / auxiliary streams (weight gradient of the image-side layer).  That is safe because srvp_amd.train.train holds the
+    batch until it returns and every stream of a step is joined into the current one before the step's last launch (model._backward_impl):
+    the allocator's free marker on the current stream lies behind every reader.  A caller that drops the batch earlier must keep it alive
+    itself.  Create ONE Prefetcher per run (one copy stream) and iterate it once per epoch."""
 
     def __init__(self, loader, device):
         self.loader, self.device = loader, torch.device(device)

@@ -120,8 +120,16 @@ class StepWatchdog:
         self.step += 1
         self.t_begin = None
 
+    def cancel(self):
+        """The step was abandoned (an exception left srvp_amd.train.train): the clock stops, the step is not counted."""
+        self.t_begin = None
+
     def stop(self):
+        """Ends the watchdog thread (before the final checkpoint writes: nothing may os._exit() in the middle of them)."""
+        self.t_begin = None
         self._stop.set()
+        if self._thread is not None and self._thread.is_alive():
+            self._thread.join(timeout=2.0)
 
     def _limit(self):
         return self.first_s if self.step < 0 else self.timeout_s
@@ -411,38 +419,75 @@ class Sync:
         self._peer_err_event = torch.cuda.Event()
         self._peer_err_event.record()
 
-    def grads_ready(self, what, model):
+    # ---- gradient exchange (reference train.py:309-314: DistributedDataParallel's bucketed all-reduce overlapped with backward, averaged over
+    # ranks).  The flat fp32 gradient buffer is exchanged in SLICES, each as soon as the backward has completed it (model._backward_impl:
+    # decoder tail, decoder head, encoder deep stages, latent networks; only the first encoder stages -- < 1 MB -- are left for the step's end),
+    # all on ONE stream and ONE communicator in the same order on every rank.  The average rides the collective (ncclAvg) on the native
+    # transport; torch.distributed transports sum and grads_finish() scales.  SRVP_GRAD_BF16=1: bf16 payload (half the bytes over xGMI; the
+    # sum is then formed in bf16 by RCCL: relative error <= 2^-8 per addend, tests/test_two_rank_equality.py states the tolerance).
+    def reduce_slice(self, model, lo, hi):
+        """All-reduce (average over ranks) of flat gradient elements [lo, hi), enqueued on the CURRENT stream."""
+        if (self.world == 1 and not self.force) or hi <= lo:
+            return
+        flat_g = model._flat[1]
+        sl = flat_g[lo:hi]
+        bf16 = os.environ.get('SRVP_GRAD_BF16', '0') == '1'
+        if bf16:
+            buf = self.__dict__.get('_bf16_buf')
+            if buf is None or buf.numel() != flat_g.numel() or buf.device != flat_g.device:
+                buf = self._bf16_buf = torch.empty(flat_g.numel(), dtype=torch.bfloat16, device=flat_g.device)
+            pay = buf[lo:hi]
+        if self.native_grads is not None:
+            st = L.stream()
+            if bf16:
+                L.call('srvp_cast_f32_bf16', L.ptr(sl), L.ptr(pay), 1, hi - lo, hi - lo, st)
+                L.call('srvp_allreduce', self.native_grads.handle, L.ptr(pay), hi - lo, 2, 1, st)
+                L.call('srvp_cast_bf16_f32', L.ptr(pay), L.ptr(sl), hi - lo, 1.0, st)
+            else:
+                L.call('srvp_allreduce', self.native_grads.handle, L.ptr(sl), hi - lo, 0, 1, st)
+            return
+        if bf16:
+            pay.copy_(sl)
+            self.handles.append((dist.all_reduce(pay, group=self.group, async_op=True), pay, sl))
+        else:
+            self.handles.append((dist.all_reduce(sl, group=self.group, async_op=True), None, None))
+        self._pending_scale = True
+
+    def grads_finish(self, model):
+        """After the last reduce_slice of a step (same stream): torch.distributed transports wait for their handles and apply the 1/world
+        average; the native transport has nothing left to do (ncclAvg).  Also the once-per-step poll of the peer exchange's error word."""
         if self.world == 1 and not self.force:
             return
-        if what == 'all':
-            self._poll_peer_error()
-        flat_g = model._flat[1]
-        enc_end, dec_end, total = self._slices(model)
-        if self.native_grads is not None:
-            # in-stream: the decoder slice on the stream it is called from (the weight-gradient side stream, which the caller
-            # joins before the final call), the rest + the DDP average on the compute stream
-            if what == 'decoder':
-                self.native_grads.allreduce(flat_g[enc_end:dec_end])
-            else:
-                self.native_grads.allreduce(flat_g[:enc_end])
-                self.native_grads.allreduce(flat_g[dec_end:])
-                flat_g.mul_(1.0 / self.world)
-            return
-        if what == 'decoder':
-            self.handles.append(dist.all_reduce(flat_g[enc_end:dec_end], group=self.group, async_op=True))
-        else:
-            self.handles.append(dist.all_reduce(flat_g[:enc_end], group=self.group, async_op=True))
-            self.handles.append(dist.all_reduce(flat_g[dec_end:], group=self.group, async_op=True))
-            for h in self.handles:
+        self._poll_peer_error()
+        if self.handles:
+            for h, pay, sl in self.handles:
                 h.wait()
+                if pay is not None:
+                    sl.copy_(pay)
             self.handles = []
-            flat_g.mul_(1.0 / self.world)     # DDP averages gradients over ranks
+        if self.__dict__.get('_pending_scale'):
+            model._flat[1].mul_(1.0 / self.world)     # DDP averages gradients over ranks
+            self._pending_scale = False
+
+    def grads_ready(self, what, model):
+        """Two-phase form kept for callers of the older interface (tests): 'decoder' = the decoder slice, 'all' = the rest + finish."""
+        if self.world == 1 and not self.force:
+            return
+        enc_end, dec_end, total = self._slices(model)
+        if what == 'decoder':
+            self.reduce_slice(model, enc_end, dec_end)
+        else:
+            self.reduce_slice(model, 0, enc_end)
+            self.reduce_slice(model, dec_end, total)
+            self.grads_finish(model)
 
     def after_rank0_phase(self):
         """Called by EVERY rank at an iteration where rank 0 alone did something long (validation, checkpoint writes; reference
-        train.py:355-366 has no barrier there, an RCCL all-reduce simply blocks until rank 0 arrives).  The peer exchange waits on the
-        device with a deadline instead, so the ranks meet on the host first."""
-        if self.peer is not None and self.world > 1:
+        train.py:355-366 has no barrier there, an RCCL all-reduce simply blocks until rank 0 arrives).  The ranks meet on the HOST here,
+        on every transport: without it ranks >= 1 enter the next step, start their StepWatchdog clock and sit in the step's
+        first statistics all-reduce for as long as rank 0 validates / writes -- a healthy job killed after SRVP_WATCHDOG_S; and the peer
+        exchange waits on the device with a deadline.  A monitored barrier is not needed: a rank-0 phase has no step clock running."""
+        if self.world > 1:
             dist.barrier(group=self.group)
 
     def broadcast(self, t):

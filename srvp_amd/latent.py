@@ -144,9 +144,18 @@ class LatentNet:
         T = hx.shape[0]
         if t_w is not None and not t_w.is_cuda:
             # frame indices still on the host (the training forward draws them there): the row numbers are formed on the host too and travel
-            # in ONE copy instead of five small device kernels on the latent path's serial chain
-            rows_h = (t_w.reshape(-1).to(torch.long) * B + torch.arange(B).repeat(ti))
-            rows = rows_h.pin_memory().to(hx.device, non_blocking=True)
+            # in ONE copy instead of five small device kernels on the latent path's serial chain -- through ONE pinned staging buffer and ONE
+            # device buffer per plan (round 6: no pinned allocation per step; fixed addresses, so a captured step can be replayed after the
+            # host has refilled the staging buffer, fill_w_rows_host)
+            if self.__dict__.get('_w_rows_copied') is not None and not torch.cuda.is_current_stream_capturing():
+                self._w_rows_copied.synchronize()          # (a caller that runs two forwards without a sync in between)
+            host = self.fill_w_rows_host(t_w)
+            rows = self.__dict__.get('_w_rows_dev')
+            if rows is None:
+                rows = self._w_rows_dev = torch.zeros(ti * B, dtype=torch.long, device=hx.device)
+            rows.copy_(host, non_blocking=True)
+            self._w_rows_copied = torch.cuda.Event()
+            self._w_rows_copied.record()
         elif t_w is not None:
             rows = (t_w.reshape(-1) * B + torch.arange(B, device=hx.device).repeat(ti)).to(torch.long)
         else:
@@ -160,6 +169,15 @@ class LatentNet:
             axpby(st, self.hsum, 1.0, self.hsum, 1.0, pv[i])
         linear_fwd(st, self.hsum, params['w_inf.0.weight'], params['w_inf.0.bias'], self.w, L.ACT_TANH)
         return self.w
+
+    def fill_w_rows_host(self, t_w):
+        """t_w (nt_inf, B) CPU frame indices -> the rows t_w[i][b] * B + b of hx they select, in the plan's pinned staging buffer."""
+        B, ti = self.B, self.nt_inf
+        host = self.__dict__.get('_w_rows_host')
+        if host is None:
+            host = self._w_rows_host = torch.zeros(ti * B, dtype=torch.long).pin_memory()
+        torch.add(t_w.reshape(-1).to(torch.long) * B, torch.arange(B).repeat(ti), out=host)
+        return host
 
     def infer_y(self, hx_first, params, eps_y0, st):
         """srvp.py:258-278.  hx_first: (nt_inf, B, nhx)."""

@@ -54,7 +54,8 @@ PZ_AUX = os.environ.get('SRVP_PZ_AUX', '1') != '0'                       # 0: th
 SKIP_REDUCE_AUX = os.environ.get('SRVP_SKIP_REDUCE_AUX', '1') != '0'      # 0: the pooled stages' skip-gradient reductions in line on the main stream
 LATENT_AUX = os.environ.get('SRVP_LATENT_AUX', '1') != '0'        # independent chains of the latent path (posterior / w / y_0; their backward) on two streams
 PZ_BWD_AUX = os.environ.get('SRVP_PZ_BWD_AUX', '1') != '0'          # the prior MLP's backward on the auxiliary stream under the decoder backward
-DEC_ALLREDUCE_STREAM = os.environ.get('SRVP_DEC_ALLREDUCE_STREAM', '1') != '0'   # N > 1: the decoder gradient slice's all-reduce on its own stream
+DEC_ALLREDUCE_STREAM = os.environ.get('SRVP_DEC_ALLREDUCE_STREAM', '1') != '0'   # N > 1: the gradient slices' all-reduces on a stream of their own
+GRAD_SLICES = os.environ.get('SRVP_GRAD_SLICES', '1') != '0'      # N > 1: gradient exchange slice by slice under the backward (0: decoder slice + the rest at the end)
 ENC_WGRAD_STREAM2 = os.environ.get('SRVP_ENC_WGRAD_STREAM2', '0') != '0'   # the encoder's weight gradients on a third stream (not behind the decoder's)
 LATENT_WGRAD_STREAM = os.environ.get('SRVP_LATENT_WGRAD_STREAM', '1') != '0'    # the latent networks' weight gradients on a stream of their own
 OVERLAP_SKIP = os.environ.get('SRVP_OVERLAP_SKIP', '1') == '1'
@@ -368,17 +369,39 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             dec_done.record()
         return enc_done, dec_done
 
-    def _draw_tape(self, T, B, nt, training, dev, t_skip=None):
+    def _draw_tape(self, T, B, nt, training, dev, t_skip=None, have=None):
         """Random draws in the reference's order: CPU generator for the frame indices, device
-        generator for the normals."""
-        tape = {}
+        generator for the normals.  have (optional): a partial tape -- only what it lacks is drawn (a captured step is handed the
+        host-drawn frame indices and draws the normals inside the graph, srvp_amd/graphstep.py)."""
+        tape = dict(have) if have else {}
         if training:
-            if self.skipco:
+            if self.skipco and 't_skip' not in tape:
                 tape['t_skip'] = t_skip if t_skip is not None else torch.randint(T, size=(B,))
-            tape['t_w'] = torch.stack([torch.randperm(T)[:self.nt_inf] for _ in range(B)], 1)
-        tape['eps_y0'] = torch.randn(B, self.ny, device=dev)
-        tape['eps_z'] = torch.randn(max(nt - 1, 1), B, self.nz, device=dev)
+            if 't_w' not in tape:
+                tape['t_w'] = torch.stack([torch.randperm(T)[:self.nt_inf] for _ in range(B)], 1)
+        if 'eps_y0' not in tape:
+            tape['eps_y0'] = torch.randn(B, self.ny, device=dev)
+        if 'eps_z' not in tape:
+            tape['eps_z'] = torch.randn(max(nt - 1, 1), B, self.nz, device=dev)
         return tape
+
+    @staticmethod
+    def _fill_index_host(pl, T, B, nt, t_skip, training):
+        """The step's small index tensors [keep | skip_idx | skip_sel | skip_map] formed on the host (B integers) in the plan's ONE pinned
+        staging buffer, refilled in place (a fresh .pin_memory() per step is a pinned allocation on the host's critical path right at the
+        step boundary); the caller (or a captured graph's copy node) moves it to pl['ibuf'] in one copy.  t_skip: CPU tensor (B,)."""
+        ts = t_skip.cpu().to(torch.int32) if training else torch.full((B,), T - 1, dtype=torch.int32)
+        sel_h = ts * B + torch.arange(B, dtype=torch.int32)
+        host = pl.get('ibuf_host')
+        if host is None:
+            host = pl['ibuf_host'] = torch.zeros(pl['ibuf'].numel(), dtype=torch.int32).pin_memory()
+        host[:T * B] = 0
+        host[sel_h.long()] = 1                                              # keep
+        host[T * B:2 * T * B] = -1
+        host[T * B + sel_h.long()] = torch.arange(B, dtype=torch.int32)    # skip_idx: frame -> sample (or -1)
+        host[2 * T * B:2 * T * B + B] = sel_h                               # skip_sel
+        host[2 * T * B + B:] = sel_h.repeat(nt)                             # skip_map
+        return host
 
     def _poll_cluster(self, every=32):
         """Every `every` calls (and on the first): the library's count of cluster failures of the persistent latent kernels -- barrier timeouts
@@ -402,6 +425,24 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         ev = self.__dict__['_ct_event'] = torch.cuda.Event()
         ev.record()
 
+    def _check_cluster_now(self):
+        """INFERENCE entry points fail closed: a generation launch whose cluster was not on one XCD (or a chain whose barrier
+        timed out) writes nothing and only counts a failure, so frames decoded after it would come from stale latent buffers.  The deferred
+        poll of training (one poll late, every n-th call) is not good enough for a caller that returns results: the failure word is read back
+        in stream order behind EVERYTHING the call queued and waited for before the call returns.  Cost: the pipeline bubble between two
+        inference calls (the callers -- evaluate, test.py's protocol -- read results on the host between calls anyway)."""
+        host = self.__dict__.get('_ct_host_now')
+        if host is None:
+            host = self.__dict__['_ct_host_now'] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        L.call('srvp_cluster_timeouts_read', host.data_ptr(), L.stream())
+        ev = torch.cuda.Event()
+        ev.record()
+        ev.synchronize()
+        if int(host[0]) != 0:
+            raise L.SrvpHipError(f'{int(host[0])} cluster failure(s) in the persistent latent kernels (workgroups of a cluster were not co-resident, or not '
+                                 'on one XCD for the generation chain): the results of this call are invalid and were not returned; set '
+                                 'SRVP_ROLLOUT_GEN_FUSED=0 (launch-per-layer generation chain)')
+
     # ------------------------------------------------------------------------------------------------ core
     def _forward_impl(self, x, nt, n_euler, tape, training):
         dev = self._require_gpu()
@@ -424,23 +465,12 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         keep = pl['keep']
         sel = None
         if self.skipco:
-            # frame t_skip[b] * B + b of every sample: the index tensors are formed on the host (B integers) and travel in one copy
-            ts = t_skip.cpu().to(torch.int32) if training else torch.full((B,), T - 1, dtype=torch.int32)
-            sel_h = ts * B + torch.arange(B, dtype=torch.int32)
-            # (ONE pinned staging buffer per plan, refilled in place: a fresh .pin_memory() per step is a pinned allocation on the host's
-            # critical path right at the step boundary.  Safe to overwrite: the host has waited for the previous step's ELBO event, which
-            # lies behind the previous copy out of this buffer)
-            host = pl.get('ibuf_host')
-            if host is None:
-                host = pl['ibuf_host'] = torch.zeros(pl['ibuf'].numel(), dtype=torch.int32).pin_memory()
-            elif pl.get('ibuf_copied') is not None:
-                pl['ibuf_copied'].synchronize()                                 # (a caller that runs two forwards without a sync in between)
-            host[:T * B] = 0
-            host[sel_h.long()] = 1                                              # keep
-            host[T * B:2 * T * B] = -1
-            host[T * B + sel_h.long()] = torch.arange(B, dtype=torch.int32)    # skip_idx: frame -> sample (or -1)
-            host[2 * T * B:2 * T * B + B] = sel_h                               # skip_sel
-            host[2 * T * B + B:] = sel_h.repeat(nt)                             # skip_map
+            # frame t_skip[b] * B + b of every sample: the index tensors are formed on the host (B integers) and travel in one copy.
+            # (Safe to overwrite the staging buffer: the host has waited for the previous step's ELBO event, which lies behind the previous
+            # copy out of it; a caller that runs two forwards without a sync in between is held on the copy's event)
+            if pl.get('ibuf_copied') is not None and not torch.cuda.is_current_stream_capturing():
+                pl['ibuf_copied'].synchronize()
+            host = self._fill_index_host(pl, T, B, nt, t_skip, training)
             pl['ibuf'].copy_(host, non_blocking=True)
             pl['ibuf_copied'] = torch.cuda.Event()
             pl['ibuf_copied'].record()
@@ -483,10 +513,11 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         # draws them inside encode / infer_w / infer_y / generate): the per-sample randperm calls cost ~0.3 ms of host time that
         # the GPU now spends in the encoder instead of idling; the small index tensors travel through pinned memory so that the
         # copy does not block the host behind the work queued so far
-        if tape is None:
-            tape = self._draw_tape(T, B, nt, training, dev, t_skip=t_skip)
+        if tape is None or any(k not in tape for k in ('eps_y0', 'eps_z') + (('t_w',) if training else ())):
+            tape = self._draw_tape(T, B, nt, training, dev, t_skip=t_skip, have=tape)
         t_w_host = tape.get('t_w') if (training and torch.is_tensor(tape.get('t_w')) and not tape['t_w'].is_cuda) else None
-        tape = {k: (_to_dev(v, dev) if torch.is_tensor(v) else v) for k, v in tape.items()}
+        # (the host-drawn frame indices t_skip / t_w are consumed on the host -- they stay there; the normals go to the device)
+        tape = {k: (_to_dev(v, dev) if (torch.is_tensor(v) and not (k in ('t_skip', 't_w') and not v.is_cuda)) else v) for k, v in tape.items()}
         self.last_tape = tape
         if self.skipco:
             pl['skip_sel'] = sel
@@ -528,7 +559,8 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
                 post_done.record()
                 aux.wait_event(ev_tape)
                 w = lat.infer_w(hx, params, t_w_arg, L.stream())
-                lat.w_rows.record_stream(main_stream)        # (allocated on the auxiliary stream, read by the backward's scatter on the main one)
+                if lat.w_rows is not lat.__dict__.get('_w_rows_dev'):
+                    lat.w_rows.record_stream(main_stream)    # (allocated on the auxiliary stream, read by the backward's scatter on the main one)
                 w_done = torch.cuda.Event()
                 w_done.record()
             y0, q_y0 = lat.infer_y(hx[:self.nt_inf], params, tape['eps_y0'], st)
@@ -565,7 +597,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         pl['hx'], pl['x'] = hx, x
         self._last_plan = pl
         if not training:
-            self._poll_cluster(8)                 # (training: srvp_amd.train.train polls once per step)
+            self._check_cluster_now()             # (training: srvp_amd.train.train polls once per step)
         return x_, y, z, w, q_y0, qz, pz, res
 
     @torch.no_grad()
@@ -602,10 +634,11 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         y0, _ = lat.infer_y(hx_s[:self.nt_inf], params, tape['eps_y0'], st)
         lat.posterior(hx_s, params, st)
         lat.generate(y0, T, params, tape['eps_z'], st)
-        self._poll_cluster(8)
         if Sd == S:
             x_flat = dec.forward(None, params, st, None, latent=(w, lat.y_all, lat.ne * B * S * self.ny, nt, B * S, self.nh_inf, self.ny))
-            return x_flat.view(nt, S, B, *x_flat.shape[1:]).clone()
+            out = x_flat.view(nt, S, B, *x_flat.shape[1:]).clone()
+            self._check_cluster_now()            # fail closed: behind everything queued, before anything is returned
+            return out
         out = torch.empty(nt, S, B, *dec.x_out.shape[1:], dtype=torch.float32, device=dev)
         for s0 in range(0, S, Sd):
             # the last chunk is decoded at the common size (one decoder plan per evaluation shape), re-using the final samples
@@ -613,7 +646,51 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             x_flat = dec.forward(None, params, st, None, latent=(w[s0 * B:], lat.y_all[:, s0 * B:], lat.ne * B * S * self.ny, nt, B * Sd,
                                                                   self.nh_inf, self.ny), coeffs_current=s0 > 0)
             out[:, s0:s0 + Sd] = x_flat.view(nt, Sd, B, *x_flat.shape[1:])
+        self._check_cluster_now()                # fail closed: behind everything queued, before anything is returned
         return out
+
+    def _grad_offsets(self):
+        """name -> (offset, numel) of every parameter's gradient inside the flat gradient buffer (registration order: encoder, decoder,
+        latent networks); cached per flat buffer."""
+        c = self.__dict__.get('_goff')
+        if c is None or c[0] is not self._flat[1]:
+            off, d = 0, {}
+            for name, p in self.named_parameters():
+                d[name] = (off, p.numel())
+                off += p.numel()
+            enc_end = min(o for k, (o, _) in d.items() if k.startswith('decoder.'))
+            dec_end = min(o for k, (o, _) in d.items() if not k.startswith(('encoder.', 'decoder.')))
+            c = self.__dict__['_goff'] = (self._flat[1], d, (enc_end, dec_end, off))
+        return c[1], c[2]
+
+    def _block_range(self, net, lo, hi):
+        """[start, end) flat gradient elements of the parameters (conv weight, BatchNorm weight / bias) of net.blocks[lo:hi]."""
+        offs, _ = self._grad_offsets()
+        keys = []
+        for blk in net.blocks[lo:hi]:
+            keys.append(blk.spec['key'] + '.weight')
+            if blk.spec['bnkey'] is not None:
+                keys += [blk.spec['bnkey'] + '.weight', blk.spec['bnkey'] + '.bias']
+        a = min(offs[k][0] for k in keys)
+        b = max(offs[k][0] + offs[k][1] for k in keys)
+        assert b - a == sum(offs[k][1] for k in keys), 'the parameters of consecutive blocks are contiguous in the flat buffer'
+        return a, b
+
+    def _exchange(self, lo, hi, after=None):
+        """Data-parallel exchange of flat gradient elements [lo, hi) (complete behind event `after`, or behind the current stream's work so
+        far) on the communication stream: every gradient collective of a step goes through this ONE stream and ONE communicator in program
+        order -- the same order on every rank."""
+        if hi <= lo:
+            return
+        if after is None:
+            after = torch.cuda.Event()
+            after.record()
+        if getattr(self, '_comm_stream', None) is None:
+            self._comm_stream = torch.cuda.Stream()
+        with torch.cuda.stream(self._comm_stream):
+            self._comm_stream.wait_event(after)
+            self.sync.reduce_slice(self, lo, hi)
+        self._exchanged.append((lo, hi))
 
     def _backward_impl(self, d_x, d_y, d_w, d_qy0, d_qz, d_pz, d_res):
         pl = self._last_plan
@@ -646,8 +723,18 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
                 lat.pz_backward_chain(params, d_pz_c, L.stream())
                 pz_pre = torch.cuda.Event()
                 pz_pre.record()
+        # multi-GPU: the flat gradient buffer is exchanged slice by slice, each as soon as it is final (SURVEY §5 / train.py:309-314: DDP's
+        # bucketed all-reduce under backward): decoder tail, decoder head, encoder deep stages, latent networks; the encoder's first stages
+        # (< 1 MB) at the step's end.  SRVP_GRAD_SLICES=0: decoder slice + everything else at the end (the round-5 form).
+        exch = self.sync is not None and (self.sync.world > 1 or self.sync.force)
+        sliced = exch and overlap and GRAD_SLICES and DEC_ALLREDUCE_STREAM
+        self._exchanged = []
+        (_, (enc_end, dec_end, g_total)) = self._grad_offsets() if exch else (None, (0, 0, 0))
+
+        def dec_part(lo, hi):
+            self._exchange(*self._block_range(dec, lo, hi))            # (called with the weight-gradient stream current, behind the unpack)
         dz = dec.backward(cz(d_x).view(nt * B, *dec.x_out.shape[1:]), params, grads, st, self.sync, defer_wgrad=overlap,
-                          side=self._side_stream if overlap else None)
+                          side=self._side_stream if overlap else None, on_part=dec_part if sliced else None)
         ev_dec = None
         if overlap:
             ev_dec = torch.cuda.Event()
@@ -659,8 +746,8 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         lat.d_y_all.zero_()
         L.call('srvp_dz_split', L.ptr(dz), dz.shape[1], 1 if dz.dtype == torch.float32 else 0, nt, B, self.nh_inf, self.ny,
                L.ptr(cz(d_w)), L.ptr(cz(d_y)), L.ptr(lat.d_w_tot), L.ptr(lat.d_y_all), lat.ne * B * self.ny, st)
-        if self.sync is not None and not overlap:
-            self.sync.grads_ready('decoder', self)
+        if exch and not overlap:
+            self._exchange(enc_end, dec_end)
         deferred = [] if overlap else None
         lat_aux = None
         if overlap and LATENT_AUX:
@@ -673,25 +760,17 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             # (host order: the main-stream launches of the latent backward -- the critical path -- go out BEFORE the ~25 second-stream
             # launches of the decoder's weight gradients, which only wait for ev_dec on the device: a host that is just ahead of the device
             # -- small batches, a profiler attached -- then does not leave the main queue empty for the 0.25 ms the enqueueing takes)
-            comm_done = None
             with torch.cuda.stream(self._side_stream):
                 self._side_stream.wait_event(ev_dec)
-                dec.deferred_wgrads(grads, L.stream())
-                if self.sync is not None and not DEC_ALLREDUCE_STREAM:
-                    self.sync.grads_ready('decoder', self)
-                elif self.sync is not None:
-                    ev_dg = torch.cuda.Event()
-                    ev_dg.record()                # the decoder's slice of the flat gradient buffer is complete
-            if self.sync is not None and DEC_ALLREDUCE_STREAM:
-                # the decoder slice's all-reduce (60 % of the gradient bytes) on a stream of its own: enqueued on the second stream it sat
-                # in front of the ENCODER's weight gradients there and held them back for as long as the exchange takes over the links
-                if getattr(self, '_comm_stream', None) is None:
-                    self._comm_stream = torch.cuda.Stream()
-                with torch.cuda.stream(self._comm_stream):
-                    self._comm_stream.wait_event(ev_dg)
-                    self.sync.grads_ready('decoder', self)
-                    comm_done = torch.cuda.Event()
-                    comm_done.record()
+                b_lo, b_hi = dec.deferred_wgrads(grads, L.stream())
+                if exch and not DEC_ALLREDUCE_STREAM:
+                    self.sync.reduce_slice(self, enc_end, dec_end)          # (A/B: in line on the weight-gradient stream, the round-4 form)
+                    self._exchanged.append((enc_end, dec_end))
+                elif exch:
+                    # the decoder's (remaining) slice on the communication stream: enqueued on the second stream it sat in front of the
+                    # ENCODER's weight gradients there and held them back for as long as the exchange takes over the links
+                    # (blocks [b_lo, b_hi) were unpacked just now; the blocks behind them went out early: dec_part)
+                    self._exchange(enc_end, dec_end if b_hi == len(dec.blocks) else self._block_range(dec, b_hi, len(dec.blocks))[0])
         ev_lat = None
         if deferred:
             ev_lat = torch.cuda.Event()
@@ -720,8 +799,10 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             if getattr(self, '_side2_stream', None) is None:
                 self._side2_stream = _make_side_stream()
             enc_side = self._side2_stream
+        def enc_part(lo, hi):
+            self._exchange(*self._block_range(enc, lo, hi))               # (weight-gradient stream current, behind the deep blocks' unpack)
         enc.backward(pl['x'].view(T * B, *pl['x'].shape[2:]), d_hx_p, skip_grads, params, grads, st, self.sync,
-                     side=enc_side, aux=aux)
+                     side=enc_side, aux=aux, on_part=enc_part if sliced else None)
         lat_stream = None
         if deferred:
             # the latent networks' weight gradients feed nothing but the optimizer.  ~25 small launches (a few workgroups each): on the second
@@ -738,6 +819,8 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
                 s2 = L.stream()
                 for fn in deferred:
                     fn(s2)
+                if sliced:
+                    self._exchange(dec_end, g_total)                      # every gradient of the latent networks is final behind this point
         if overlap:
             # (the side stream holds the decoder's weight gradients + unpack and, behind them, the encoder's unpack)
             side_done = torch.cuda.Event()
@@ -751,10 +834,19 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
                 lat_done = torch.cuda.Event()
                 lat_done.record(lat_stream)
                 torch.cuda.current_stream().wait_event(lat_done)
-        if self.sync is not None:
-            if overlap and comm_done is not None:
-                torch.cuda.current_stream().wait_event(comm_done)     # (same communicator: the rest of the buffer goes after the decoder slice)
-            self.sync.grads_ready('all', self)
+        if exch:
+            # what has not been exchanged yet (sliced: the encoder's first stages; otherwise encoder + latent slice, or everything)
+            done = sorted(self._exchanged)
+            cur = 0
+            for lo, hi in done + [(g_total, g_total)]:
+                if lo > cur:
+                    self._exchange(cur, lo)
+                cur = max(cur, hi)
+            if getattr(self, '_comm_stream', None) is not None:
+                comm_done = torch.cuda.Event()
+                comm_done.record(self._comm_stream)
+                torch.cuda.current_stream().wait_event(comm_done)     # the optimizer reads the averaged gradients
+            self.sync.grads_finish(self)
 
     # ------------------------------------------------------------------------------------------------ reference API
     def forward(self, x, nt, dt, remove_intermediate=True, tape=None):
@@ -925,4 +1017,6 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         if not remove_intermediate:
             y = lat.y_all[:lat.S + 1]                     # the rollout stores every sub-step anyway (BPTT / weight gradients)
         cl = lambda t: None if t is None else t.clone()
-        return cl(y), (cl(z) if nt > 1 else None), cl(qz), (cl(pz) if nt > 1 else None), cl(res)
+        outs = cl(y), (cl(z) if nt > 1 else None), cl(qz), (cl(pz) if nt > 1 else None), cl(res)
+        self._check_cluster_now()                         # fail closed (granular inference entry point: test.py:244)
+        return outs

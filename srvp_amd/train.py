@@ -100,17 +100,25 @@ def train(forward_fn, optimizer, scaler, batch, device, opt):
     wd = model.__dict__.get('_watchdog')
     if wd is not None:
         wd.begin()
-    optimizer.zero_grad()
-    if batch.dtype == torch.uint8:                     # stacked uint8 videos (data.collate_u8): finish the collate on the GPU
-        from .data import frames_from_u8
-        x = frames_from_u8(batch, device)
-    else:
-        x = batch.to(device, non_blocking=True)
-    n = x.shape[1]
-    acc = fused_step(model, x, opt)
-    optimizer.step()
-    _poll_cluster_timeouts(model)
-    model._elbo_event.synchronize()                     # the step's single host sync: waits for the forward + ELBO only
+    try:
+        optimizer.zero_grad()
+        if batch.dtype == torch.uint8:                     # stacked uint8 videos (data.collate_u8): finish the collate on the GPU
+            from .data import frames_from_u8
+            x = frames_from_u8(batch, device)
+        else:
+            x = batch.to(device, non_blocking=True)
+        n = x.shape[1]
+        fused_step(model, x, opt)
+        optimizer.step()
+        _poll_cluster_timeouts(model)
+        model._elbo_event.synchronize()                     # the step's single host sync: waits for the forward + ELBO only
+    except BaseException:
+        #  a step that raised -- SrvpHipError of the cluster poll, an OOM, KeyboardInterrupt inside the sync -- is not a step in
+        # flight any more: an armed clock would os._exit() the process up to SRVP_WATCHDOG_S later, e.g. in the middle of main()'s final
+        # checkpoint writes, or kill a pytest session after a test that expected the error
+        if wd is not None:
+            wd.cancel()
+        raise
     if wd is not None:
         wd.beat()                                       # (distributed.StepWatchdog: a step that never gets here ends the job with a report)
     nll, kl_y_0, kl_z, l2 = model._elbo_host.tolist()
@@ -304,12 +312,14 @@ def main(opt):
     gc.freeze()
     import time as _time
     t_loop, t_val, itr0 = _time.perf_counter(), 0.0, itr
+    # ONE prefetcher (and one copy stream) for the run, re-iterated per epoch (a fresh one -- a new stream -- per epoch)
+    prefetch = sdata.Prefetcher(train_loader, device)
     try:
         while not finished:
             if sampler is not None:
                 sampler.set_epoch(opt.seed + itr)
             # batch i + 1 is copied to the device (and, for uint8 videos, collated there) on a copy stream under step i (data.Prefetcher)
-            for batch in sdata.Prefetcher(train_loader, device):
+            for batch in prefetch:
                 if itr >= opt.n_iter:
                     finished = True
                     break
@@ -342,6 +352,9 @@ def main(opt):
                               f'val {val_metric} best {best_val_metric}', flush=True)
     except KeyboardInterrupt:
         status_code = 130
+    wd = model.__dict__.get('_watchdog')
+    if wd is not None:
+        wd.stop()                                  # nothing may os._exit() during the final checkpoint writes below
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     if itr > itr0 + 1:

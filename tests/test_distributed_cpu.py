@@ -72,3 +72,70 @@ def test_two_rank_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, 'ok'), (1, 'ok')], res
+
+
+def _watchdog_worker(rank, world, port, q, meet):
+    """Rank 0 spends 1.5 s between steps (validation / checkpoint writes) with a 0.5 s step limit armed on every rank."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import time
+    from srvp_amd import distributed as sdist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        sync = sdist.Sync(native=False)
+        fired = []
+        wd = sdist.StepWatchdog(timeout_s=0.5, first_s=0.5, rank=rank, on_timeout=lambda w: fired.append(w.step))
+        for it in range(2):
+            wd.begin()                                    # srvp_amd.train.train on entry
+            t = torch.ones(4, dtype=torch.float64)
+            sync.allreduce_stats(t, 1.0)                  # the step's first collective: blocks until every rank is in the step
+            wd.beat()
+            if rank == 0:
+                time.sleep(1.5)                           # rank 0 alone: evaluate() + checkpoint writes
+            if meet:
+                sync.after_rank0_phase()                  # what srvp_amd.train.main calls on every rank at such an iteration
+        wd.begin()
+        sync.allreduce_stats(torch.ones(4, dtype=torch.float64), 1.0)
+        wd.beat()
+        wd.stop()
+        q.put((rank, bool(fired)))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_watchdog(meet):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_watchdog_worker, args=(r, 2, port, q, meet)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    return res
+
+
+def test_watchdog_does_not_count_rank0_phase():
+    """ranks >= 1 used to start the next step's clock while rank 0 was still validating and were killed in the step's first
+    all-reduce.  With the host meeting point of after_rank0_phase no clock fires; without it (control) rank 1's does."""
+    assert _run_watchdog(meet=True) == {0: False, 1: False}
+    res = _run_watchdog(meet=False)
+    assert res[1] is True and res[0] is False, res
+
+
+def test_watchdog_cancel_and_stop():
+    """a step that raised leaves no armed clock behind; stop() ends the thread."""
+    import time
+    from srvp_amd import distributed as sdist
+    fired = []
+    wd = sdist.StepWatchdog(timeout_s=0.3, first_s=0.3, on_timeout=lambda w: fired.append(1))
+    wd.begin()
+    wd.cancel()                                           # (train()'s except path)
+    time.sleep(0.8)
+    assert not fired and wd.step == -1
+    wd.begin()
+    wd.stop()
+    time.sleep(0.6)
+    assert not fired and not wd._thread.is_alive()

@@ -22,7 +22,7 @@ from srvp_amd.train import train, elbo_terms_and_grads
 RECIPES = {'kth': dict(nc=1, T=20, B=20), 'human': dict(nc=3, T=16, B=26)}
 
 
-def run(name, steps=300, every=100, oracle_at=None, log=print, seed=0):
+def run(name, steps=300, every=100, oracle_at=None, log=print, seed=0, grads_at=()):
     from oracle import srvp_oracle as O
     r = RECIPES[name]
     nc, T, B, ne = r['nc'], r['T'], r['B'], 2
@@ -64,6 +64,32 @@ def run(name, steps=300, every=100, oracle_at=None, log=print, seed=0):
             res = O.elbo(x_eval, outs, hp['obs_scale'], hp['beta_y'], hp['beta_z'], hp['l2_res'])
         return float(res['loss'])
 
+    def grad_gate():
+        """(round 6) every parameter gradient of the PRODUCTION (bf16) path on the held-out batch against the fp32 CPU
+        oracle's autograd at the same weights: per tensor cosine and norm ratio.  The model's flat gradient buffer / Adam state are left
+        as they were (the training run goes on unchanged)."""
+        from srvp_amd.train import fused_step
+        model.set_precision('bf16')
+        model.flatten_parameters_()
+        saved = model._flat[1].clone()
+        model._flat[1].zero_()
+        for p_, g_ in zip(model.parameters(), model._flat[3]):
+            p_.grad = g_
+        fused_step(model, xg, opt, tape=tape)
+        torch.cuda.synchronize()
+        got = {k: p_.grad.detach().cpu().double().clone() for k, p_ in model.named_parameters()}
+        model._flat[1].copy_(saved)
+        model.set_precision('fp32')
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        _, _, ref = O.train_step(sd, O.make_cfg(*ctor), x_eval, ne, tape, hp)
+        out = {}
+        for k, g_ in got.items():
+            r_ = ref[k].double()
+            nr = r_.norm().item()
+            out[k] = dict(cos=(torch.dot(g_.flatten(), r_.flatten()) / (g_.norm() * r_.norm() + 1e-300)).item(), ratio=g_.norm().item() / max(nr, 1e-300),
+                          norm=nr, numel=r_.numel())
+        return out
+
     rows = []
     rel = lambda a, b: abs(a - b) / abs(b)
     for it in range(steps + 1):
@@ -77,6 +103,14 @@ def run(name, steps=300, every=100, oracle_at=None, log=print, seed=0):
                 t0 = time.time()
                 lo = oracle()
                 row.update(loss_oracle=lo, fp32_mode_vs_oracle=rel(l32, lo), bf16_vs_oracle=rel(l16, lo), oracle_s=round(time.time() - t0, 1))
+            if it in grads_at:
+                gg = grad_gate()
+                worst_c = min(gg, key=lambda k: gg[k]['cos'])
+                worst_r = max(gg, key=lambda k: abs(gg[k]['ratio'] - 1))
+                row.update(grad_gate=dict(tensors=len(gg), worst_cos=gg[worst_c]['cos'], worst_cos_tensor=worst_c, worst_ratio=gg[worst_r]['ratio'],
+                                          worst_ratio_tensor=worst_r, below_0p99=sorted(k for k in gg if gg[k]['cos'] < 0.99),
+                                          outside_5pct=sorted(k for k in gg if abs(gg[k]['ratio'] - 1) > 0.05)),
+                           grad_gate_all={k: (round(v['cos'], 5), round(v['ratio'], 4), float('%.3g' % v['norm'])) for k, v in gg.items()})
             rows.append(row)
             log(json.dumps(row))
             model.set_precision('fp32')
@@ -91,4 +125,4 @@ if __name__ == '__main__':
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     every = int(sys.argv[3]) if len(sys.argv) > 3 else 100
     seed = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-    run(name, steps, every, oracle_at=range(0, steps + 1, every), seed=seed)
+    run(name, steps, every, oracle_at=range(0, steps + 1, every), seed=seed, grads_at=(100,) if os.environ.get('GRAD_GATE', '1') == '1' else ())

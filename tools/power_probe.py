@@ -47,4 +47,23 @@ phase('hipBLASLt bf16 8192^3', lambda: torch.matmul(w1, w2))
 z1 = torch.zeros(8192, 8192, device=dev, dtype=torch.bfloat16)
 phase('hipBLASLt bf16 8192^3 on zeros', lambda: torch.matmul(z1, z1))
 phase('whole training step (B=192)', lambda: train(model, optim, None, x, dev, opt), 6.0)
+# round 6: do the weight gradients lose their rate in-step because the chip is at its power cap (clocks drop under sharing)
+# or because of LDS / L2 contention?  (i) a data-gradient conv and a weight-gradient launch of the same 8x8x512 layer back to back on ONE
+# stream, (ii) the same two on TWO streams (co-running), (iii) the step with the second stream off
+dg, wg = blk._dg[0], (blk._wg if not isinstance(blk._wg, list) else blk._wg[0])
+s2 = torch.cuda.Stream()
+def serial():
+    L.call('srvp_conv_mfma', C.byref(dg), st); L.call('srvp_wgrad_mfma', C.byref(wg), st)
+def corun():
+    L.call('srvp_conv_mfma', C.byref(dg), st)
+    with torch.cuda.stream(s2):
+        L.call('srvp_wgrad_mfma', C.byref(wg), L.stream())
+phase('enc08 dgrad alone', lambda: L.call('srvp_conv_mfma', C.byref(dg), st))
+phase('enc08 wgrad alone', lambda: L.call('srvp_wgrad_mfma', C.byref(wg), st))
+phase('enc08 dgrad + wgrad, one stream (per pair)', serial)
+phase('enc08 dgrad + wgrad, two streams co-running (per pair)', corun)
+import srvp_amd.model as _m, srvp_amd.convnet as _cn
+_m.OVERLAP_WGRAD, _m.OVERLAP_SKIP, _m.OVERLAP_PACK, _cn.ENC_WGRAD_SIDE_MAXN = False, False, False, 0
+for _ in range(2): train(model, optim, None, x, dev, opt)
+phase('whole training step (B=192), second stream OFF', lambda: train(model, optim, None, x, dev, opt), 6.0)
 stop = True; th.join()
