@@ -483,11 +483,6 @@ int srvp_rsample_bwd(const float* params, const float* eps, const float* dout, f
 /* fused Adam over one flat fp32 buffer; step_size = lr/(1-b1^t), bc2_sqrt = sqrt(1-b2^t) */
 int srvp_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
               int step, float grad_scale, void* stream);
-/* the same update (train.py:289 / torch.optim.Adam) with the per-step scalars read from DEVICE memory when the launch executes:
- * hp = float[3] {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), grad_scale}.  The launch carries no per-step value, so a captured hipGraph of
- * the whole optimisation step can be replayed (srvp_amd/graphstep.py refreshes hp through a pinned-memory copy in front of it). */
-int srvp_adam_hp(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps, const float* hp,
-                 void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Data parallelism over the GPUs of a node: RCCL (xGMI) collectives enqueued on the caller's stream -- the gradient

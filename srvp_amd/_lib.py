@@ -159,7 +159,6 @@ _SIGS = {
     'srvp_rsample_fwd': ([c_vp, c_vp, c_vp, c_i64, c_i32, c_vp], c_i32),
     'srvp_rsample_bwd': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp], c_i32),
     'srvp_adam': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_vp], c_i32),
-    'srvp_adam_hp': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp, c_vp], c_i32),
     'srvp_comm_unique_id': ([c_vp], c_i32),
     'srvp_comm_init': ([c_vp, c_i32, c_i32, C.POINTER(c_vp)], c_i32),
     'srvp_comm_destroy': ([c_vp], c_i32),

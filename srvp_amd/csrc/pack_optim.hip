@@ -746,10 +746,7 @@ __global__ __launch_bounds__(256) void l2rows_kernel(const float* __restrict__ r
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float step_size, float beta1, float beta2,
-                                                   float eps, float inv_bc2_sqrt, float grad_scale, const float* __restrict__ hp) {
-    // hp (device, optional): {step_size, 1 / sqrt(1 - beta2^t), grad_scale} of THIS step, written by the host into a buffer the launch
-    // reads when it runs -- the launch itself carries no per-step scalar, so a captured hipGraph of the step can be replayed (srvp_adam_hp)
-    if (hp) { step_size = hp[0]; inv_bc2_sqrt = hp[1]; grad_scale = hp[2]; }
+                                                   float eps, float inv_bc2_sqrt, float grad_scale) {
     for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
         if (i + 4 <= n) {
             f32x4_t gv = *reinterpret_cast<const f32x4_t*>(g + i) * grad_scale;
@@ -906,19 +903,7 @@ extern "C" int srvp_adam(float* p, const float* g, float* m, float* v, int64_t n
     if (n <= 0) return SRVP_OK;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(capped_grid(n, 1024, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n,
-                       (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale, (const float*)nullptr);
+                       (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale);
     SRVP_CHECK_LAUNCH("srvp_adam");
-    return SRVP_OK;
-}
-
-// The same update with the per-step scalars read from DEVICE memory at execution time: hp = {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t),
-// grad_scale} (3 floats; the host refreshes them -- e.g. by a pinned-memory copy node -- before every replay of a captured step).
-extern "C" int srvp_adam_hp(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps, const float* hp,
-                            void* stream) {
-    SRVP_REQUIRE(p && g && m && v && hp, "srvp_adam_hp: bad args");
-    if (n <= 0) return SRVP_OK;
-    hipLaunchKernelGGL(adam_kernel, dim3(capped_grid(n, 1024, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n,
-                       0.f, beta1, beta2, eps, 1.f, 1.f, hp);
-    SRVP_CHECK_LAUNCH("srvp_adam_hp");
     return SRVP_OK;
 }
