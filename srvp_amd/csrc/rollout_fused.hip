@@ -3,22 +3,19 @@
 // forward, and ONE launch runs the whole backward-through-time chain, instead of (nl GEMMs + 1 update) launches per step
 // (236 dependent micro-launches per training step at the headline config, ~6 ms that did not shrink with the batch).
 //
-// Decomposition: samples are independent, hidden units are not.  The batch is cut into 32-row tiles; a CLUSTER of
-// G = nh / 32 workgroups owns one row tile, workgroup g of the cluster owns hidden columns [32 g, 32 g + 32) of every
-// layer for the whole kernel, so its weight slices (nh x 32 fp32 per hidden layer: 64 KB at nh = 512) are loaded ONCE into
-// LDS / registers and stay there for all steps -- no weight traffic inside the chain.  Per layer the cluster exchanges the
-// 32 x nh activation tile through global memory (the hid_dyn / dhid_dyn tensors the weight-gradient GEMMs need anyway) and
-// synchronises with a monotonic counter (agent-scope release / acquire); the first-in-cluster layer of a step needs no
-// exchange (every workgroup carries the y / dy state itself) and the last layer is split-K over the cluster with
-// deterministic partial sums.  nl - 1 cluster barriers per Euler step.  Arithmetic: exact fp32 on the matrix cores
-// (v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain), wave tile 16 x 16 with the full K per wave (no cross-wave reduction).
+// Decomposition: samples are independent, hidden units are not.  The batch is cut into 16-row tiles (32 rows for the generation chain); a
+// CLUSTER of G = nh / 32 workgroups (LSTM: nh / 16) owns one row tile, workgroup g of the cluster owns a slice of the hidden columns of every
+// layer for the whole kernel, so its weight slices are loaded ONCE into LDS / registers and stay there for all steps -- no weight traffic
+// inside the chain.  Per layer the cluster exchanges the activation tile through global memory (the hid_dyn / dhid_dyn tensors the
+// weight-gradient GEMMs need anyway) and synchronises with a monotonic counter; the first-in-cluster layer of a step needs no exchange
+// (every workgroup carries the y / dy state itself) and the last layer is split-K over the cluster with fixed-order partial sums.
+// Inside a workgroup the K loop of a layer (not the output tile) is dealt to the four waves; partial tiles are added in a fixed order through
+// LDS.  Arithmetic: exact fp32 on the matrix cores (v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain).
 //
-// All workgroups of a launch must be co-resident (they spin on each other): the launcher keeps the grid <= the number of CUs
-// (one workgroup per CU: > 80 KB of LDS each) and walks larger batches in several launches.
-//
-// Round 5: every chain in this file has a SECOND FORM that the launchers prefer (rollout_ks_*, lstm_ks_*, rollout_gen_ks_kernel: 16-row tiles
-// where the batch fits one co-resident launch that way, the K loop of a layer dealt to the four waves, weight slices in registers where a wave
-// only ever touches its quarter); the kernels described above remain as the fallback.  See "16-row tiles, K split over the waves" below.
+// All workgroups of a launch must be co-resident (they spin on each other): the launcher keeps the grid <= the number of CUs and walks
+// larger batches in several launches on the same stream (tile0).  Round 6: the 32-row / output-tiled kernels of rounds 2-4 that these forms
+// replaced in round 5 (and that stayed as a fallback for B > 256, nh != 512) are gone -- every shape takes the kernels below, the generation
+// chain of widths other than 512 takes the per-layer launch sequence of csrc/latent.hip.
 #include <atomic>
 #include <type_traits>
 #include "common.h"
@@ -59,7 +56,6 @@ constexpr int IPAD = 4;          // padding of the LDS staging tiles' rows (floa
 // maintenance: a whole-L2 write-back + invalidate per barrier (what an agent-scope release / acquire FENCE costs on this
 // multi-XCD part while other kernels keep the L2 full of dirty lines) measured 27 us per layer.
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // XCD-LOCAL EXCHANGE (round 5).  The launchers deal the workgroups of a cluster to ONE XCD (locate()); HIP promises nothing about placement, so
 // each launch VERIFIES it: every member ORs the bit of the XCC it really runs on (HW_REG_XCC_ID) into word 2 of the cluster's counter block before
@@ -125,80 +121,9 @@ __device__ __forceinline__ bool locate(const RollF& a, int& cl, int& g) {
     return cl < a.ntiles;
 }
 
-// acc(16x16, this wave) += A(rows from global -- written by the other workgroups of the cluster: agent-scope loads, 16 bytes
-// each, counted by hand) x B(LDS slice).  K is walked in 512-wide blocks of four 128-wide chunks, all 32 loads of a block
-// issued before its first MFMA.  The loads are UNCONDITIONAL (addresses clamped into the row) and no in-flight register lives
-// across a loop back-edge or a branch: hipcc places phi copies of such registers BEFORE the hand-written wait.
-__device__ __forceinline__ void ld_chunk(f32x4v (&a4)[8], const float* p, int k0, int K) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = k0 + 16 * j < K ? k0 + 16 * j : K - 16;
-        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(a4[j]) : "v"(p + k) : "memory");
-    }
-}
-__device__ __forceinline__ void ld_chunk_plain(f32x4v (&b4)[8], const float* p, int k0, int K) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = k0 + 16 * j < K ? k0 + 16 * j : K - 16;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(b4[j]) : "v"(p + k) : "memory");
-    }
-}
-// B fragments of a 128-wide K chunk: eight 16-byte LDS reads per lane (k = k0 + 16 j + 4 q .. + 3, column cc)
-__device__ __forceinline__ void ld_b_chunk(f32x4v (&b4)[8], const float* Bs, int k0, int K, int q, int cc) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = k0 + 16 * j < K ? k0 + 16 * j : K - 16;
-        b4[j] = *reinterpret_cast<const f32x4v*>(Bs + ((k >> 2) + q) * 128 + cc * 4);
-    }
-}
-__device__ __forceinline__ void mm_chunk(f32x4v& acc, f32x4v (&a4)[8], f32x4v (&b4)[8], int k0, int K) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (k0 + 16 * j >= K) break;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j][e], b4[j][e], acc, 0, 0, 0);
-    }
-}
-#define WAIT_A4(buf, n) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7]) :: "memory")
-// CACHED (the training kernels in XCD-local mode): the A tile is read with PLAIN loads, i.e. through the CU's vector L1.  Valid there because
-// every exchanged address of those kernels is written ONCE per launch (saved activations / deltas of step i, fresh partial slabs) and first read
-// after the barrier that follows its writes, so the L1 -- invalidated at kernel start, never refreshed by other CUs' stores -- cannot hold an
-// older copy of it.  What it buys (SRVP_RF_DEBUG: a K = 512 hidden-layer GEMM took 4.9 us for 1.7 us of MFMA issue, and neither the LDS operand
-// path nor the clock was the reason): the two waves that share a row half no longer fetch the same 32 KB from L2 twice, and the two 64-byte
-// halves of a line requested by consecutive k groups are one L2 request.  The generation kernel rewrites its buffers every step and keeps sc1.
-template <bool CACHED = false>
-__device__ __forceinline__ void gemm_glob_lds(f32x4v& acc, const float* arow, const float* Bs, int K, int q, int cc) {
-    const float* p = arow + 4 * q;
-    for (int k0 = 0; k0 < K; k0 += 512) {
-        f32x4v b0[8], b1[8], b2[8], b3[8], w0[8], w1[8];
-        if constexpr (CACHED) { ld_chunk_plain(b0, p, k0, K); ld_chunk_plain(b1, p, k0 + 128, K); ld_chunk_plain(b2, p, k0 + 256, K); ld_chunk_plain(b3, p, k0 + 384, K); }
-        else { ld_chunk(b0, p, k0, K); ld_chunk(b1, p, k0 + 128, K); ld_chunk(b2, p, k0 + 256, K); ld_chunk(b3, p, k0 + 384, K); }
-        // the B fragments of chunk i + 1 are requested from LDS before the MFMAs of chunk i (two register sets in turn)
-        ld_b_chunk(w0, Bs, k0, K, q, cc);
-        WAIT_A4(b0, 24); ld_b_chunk(w1, Bs, k0 + 128, K, q, cc); mm_chunk(acc, b0, w0, k0, K);
-        WAIT_A4(b1, 16); ld_b_chunk(w0, Bs, k0 + 256, K, q, cc); mm_chunk(acc, b1, w1, k0 + 128, K);
-        WAIT_A4(b2, 8); ld_b_chunk(w1, Bs, k0 + 384, K, q, cc); mm_chunk(acc, b2, w0, k0 + 256, K);
-        WAIT_A4(b3, 0); mm_chunk(acc, b3, w1, k0 + 384, K);
-    }
-}
-
-// acc(16x16) += A(LDS staging tile, rows 16-byte aligned) x B(register fragments): all A reads (one ds_read_b128 per 16 k) before the MFMAs
-template <int NJ>
-__device__ __forceinline__ void gemm_lds_reg(f32x4v& acc, const float* ar, const float (&w)[NJ * 4], int kw) {
-    f32x4v av[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) av[j] = *reinterpret_cast<const f32x4v*>(ar + (16 * j < kw ? 16 * j : 0));
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        if (16 * j >= kw) break;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][e], w[j * 4 + e], acc, 0, 0, 0);
-    }
-}
-
 // Sum of the G split-K slabs for two (row, 4-column) items per thread: all 2 GP 16-byte agent-scope loads in flight at once
 // (a serial per-slab loop of 4-byte loads cost 24-48 us per Euler step: half of the whole kernel), fixed summation order.
-// Unconditional loads (slab index clamped), see gemm_glob_lds.
+// Unconditional loads (slab index clamped): no in-flight register lives across a branch (hipcc places phi copies BEFORE a hand-written wait).
 #define WAIT8(v, o) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[o]), "+v"(v[o + 1]), "+v"(v[o + 2]), "+v"(v[o + 3]), "+v"(v[o + 4]), "+v"(v[o + 5]), "+v"(v[o + 6]), "+v"(v[o + 7]) :: "memory")
 template <int GP>
 __device__ __forceinline__ void sum_slabs2(f32x4v& sa, f32x4v& sb, const float* pa, const float* pb, int G, size_t slab_stride) {
@@ -216,385 +141,18 @@ __device__ __forceinline__ void sum_slabs2(f32x4v& sa, f32x4v& sb, const float* 
         if (gg < G) { sa += va[gg]; sb += vb[gg]; }
 }
 
-// ------------------------------------------------------------------------------------------------------------ forward
-template <int GP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_fused_fwd_kernel(const RollF a) {
-    extern __shared__ float lds[];
-    int cl, g;
-    if (!locate(a, cl, g)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int rh = wid >> 1, ch = wid & 1, q = lane >> 4, c16 = lane & 15;
-    const int cc = 16 * ch + c16;                         // column inside the workgroup's 32-column slice
-    const int row0 = (a.tile0 + cl) * RT;
-    const int colbase = g * CW;
-    const int nl = a.nl, nh = a.nh, ny = a.ny, nin = a.nin, B = a.B;
-    const int nfull = nl - 2;                             // hidden layers with K = nh (LDS-resident slices)
-    // LDS: [nfull][nh][32] slices | Is [32][kp0 + IPAD] | Ys [32][ny] | Hs [32][33]
-    float* Wl = lds;
-    float* Is = Wl + (size_t)nfull * nh * CW;
-    float* Ys = Is + RT * (a.kp0 + IPAD);
-    float* Hs = Ys + RT * ny;
-    float* Bl = Hs + RT * 33;                             // bias of the last layer
-    unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;       // one 256-byte line per cluster
-    // split-K partials: a FRESH slab per Euler step (agent-scope loads are served by the reader's L2: a slab address that was
-    // read before would be answered with the old line when the producing workgroup sits on another XCD)
-    float* part = a.part + (size_t)(a.tile0 + cl) * a.S * a.G * RT * KP0_MAX;
-    unsigned target = 0;
-    xcd_announce(cnt);
-
-    // ---- one-time: weight slices.  hidden layers l = 1 .. nl-2 into LDS (B[k][c] = W_l[colbase + c][k])
-    for (int l = 1; l <= nfull; ++l) {
-        const float* W = a.W[l];
-        float* dst = Wl + (size_t)(l - 1) * nh * CW;
-        for (int idx = tid; idx < nh * CW; idx += 256) {
-            const int c = idx / nh, k = idx - c * nh;     // consecutive threads walk k: coalesced rows of W
-            dst[sw(k, c)] = W[(size_t)(colbase + c) * nh + k];
-        }
-    }
-    // first layer (K = nin) and last layer (split-K: this workgroup's 32 hidden units x ny outputs): B fragments in registers
-    float w0[KP0_MAX / 4];                                // B0[k = 16 j + 4 q + e][cc] = W_0[colbase + cc][k]
-#pragma unroll
-    for (int j = 0; j < KP0_MAX / 16; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = 16 * j + 4 * q + e;
-            w0[j * 4 + e] = k < nin ? a.W[0][(size_t)(colbase + cc) * nin + k] : 0.f;
-        }
-    // last-layer tiles of this wave: tile t = wid + 4 u -> (row half t & 1, output column tile t >> 1)
-    float wl[2][8];                                       // BL[k = 4 jj + q][col] = W_last[col][colbase + k]
-    const int ntl = 2 * (a.nyp / 16);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int t = wid + 4 * u, col = 16 * (t >> 1) + c16;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj)
-            wl[u][jj] = (t < ntl && col < ny) ? a.W[nl - 1][(size_t)col * nh + colbase + 4 * jj + q] : 0.f;
-    }
-    // state
-    for (int idx = tid; idx < RT * ny; idx += 256) {
-        const int r = idx / ny, c = idx - r * ny;
-        const int row = row0 + r < B ? row0 + r : B - 1;
-        Ys[idx] = a.y0[(size_t)row * ny + c];
-    }
-    if (tid < ny) Bl[tid] = a.b[nl - 1][tid];
-    // z part of the first-layer input: this thread's elements of the [32][kp0] staging tile, fetched ONE STEP AHEAD (the
-    // dependent global-load latencies of a step, not its arithmetic, are most of what a step costs)
-    float zr[KP0_MAX * RT / 256];
-    auto fetch_z = [&](int step) {
-#pragma unroll
-        for (int u = 0; u < KP0_MAX * RT / 256; ++u) {
-            const int idx = tid + 256 * u, r = idx / a.kp0, k = idx - r * a.kp0;
-            const int row = row0 + r < B ? row0 + r : B - 1;
-            zr[u] = (idx < RT * a.kp0 && k >= ny && k < nin) ? a.inp_all[((size_t)step * B + row) * nin + k] : 0.f;
-        }
-    };
-    fetch_z(0);
-    cluster_barrier(cnt, target += a.G);                  // (also the workgroup barrier behind the one-time loads) every member has announced its XCC
-    const bool xl = xcd_agreed(cnt, a.xcd_local, g == 0);
-    const int arow_l = 16 * rh + c16;                     // A row of this lane inside the tile
-    const int grow = row0 + arow_l < B ? row0 + arow_l : B - 1;
-    const size_t hs = (size_t)a.S * B * nh;               // layer stride of hid
-
-    // SRVP_RF_DEBUG: where a step's time goes (member 0 of cluster 0; s_memrealtime = 100 MHz): 0 stage + layer 0, 1 epilogue + barrier 1,
-    // 2 hidden GEMM 1, 3 epilogue + barrier 2, 4 hidden GEMM 2, 5 last layer partials, 6 barrier 3, 7 slab sum + update
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-    const bool dbg = a.dbg != nullptr && cl == 0 && g == 0;
-    auto tick = [&](int k) {
-        if (dbg) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); tacc[k] += t - tprev; tprev = t; }
-    };
-    unsigned long long clk0 = 0, rt0 = 0;
-    if (dbg) { tprev = rt0 = __builtin_amdgcn_s_memrealtime(); clk0 = __builtin_readcyclecounter(); }
-    for (int i = 0; i < a.S; ++i) {
-        // ---- stage [y_i, z] (z part prefilled in inp_all by the caller, constant during the kernel)
-#pragma unroll
-        for (int u = 0; u < KP0_MAX * RT / 256; ++u) {
-            const int idx = tid + 256 * u, r = idx / a.kp0, k = idx - r * a.kp0;
-            if (idx < RT * a.kp0) Is[r * (a.kp0 + IPAD) + k] = k < ny ? Ys[r * ny + k] : zr[u];
-        }
-        if (i + 1 < a.S) fetch_z(i + 1);
-        __syncthreads();
-        // ---- layer 0: A from LDS, B from registers
-        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-        float bl = a.b[0][colbase + cc];                  // bias of the layer being finished (loaded ahead of its use)
-        gemm_lds_reg<KP0_MAX / 16>(acc, Is + arow_l * (a.kp0 + IPAD) + 4 * q, w0, a.kp0);
-        tick(0);
-        for (int l = 0; l <= nfull; ++l) {
-            // epilogue of full-output layer l: bias, ReLU, store the saved activation (= the exchange buffer)
-            float* hdst = a.hid + (size_t)l * hs + (size_t)i * B * nh;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 16 * rh + 4 * q + e;
-                float v = acc[e] + bl;
-                v = v > 0.f ? v : 0.f;
-                if (row0 + r < B) st_x(hdst + (size_t)(row0 + r) * nh + colbase + cc, v, xl);
-                if (l == nfull) Hs[r * 33 + cc] = v;
-            }
-            if (l == nfull) break;
-            bl = a.b[l + 1][colbase + cc];
-            cluster_barrier(cnt, target += a.G);
-            tick(l == 0 ? 1 : 3);
-            // ---- layer l + 1: A = complete hidden tile from global, B = LDS slice
-            acc = f32x4v{0.f, 0.f, 0.f, 0.f};
-            if (xl) gemm_glob_lds<true>(acc, hdst + (size_t)grow * nh, Wl + (size_t)l * nh * CW, nh, q, cc);
-            else gemm_glob_lds<false>(acc, hdst + (size_t)grow * nh, Wl + (size_t)l * nh * CW, nh, q, cc);
-            tick(l == 0 ? 2 : 4);
-        }
-        __syncthreads();                                  // Hs complete
-        // ---- last layer, split-K over the cluster: partial[32 x ny] from this workgroup's 32 hidden units
-        float* pdst = part + ((size_t)i * a.G + g) * RT * KP0_MAX;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int t = wid + 4 * u;
-            if (t >= ntl) break;
-            const int trh = t & 1, ct = t >> 1;
-            f32x4v o = {0.f, 0.f, 0.f, 0.f};
-            const float* hr = Hs + (16 * trh + c16) * 33 + q;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) o = __builtin_amdgcn_mfma_f32_16x16x4f32(hr[4 * jj], wl[u][jj], o, 0, 0, 0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) st_x(pdst + (16 * trh + 4 * q + e) * NYP_MAX + 16 * ct + c16, o[e], xl);
-        }
-        tick(5);
-        cluster_barrier(cnt, target += a.G);
-        tick(6);
-        // ---- every workgroup: sum the G partials in a fixed order, Euler update of its copy of the state
-        const float* psrc = part + (size_t)i * a.G * RT * KP0_MAX;
-        const int nq = a.nyp / 4;                          // 4-column items per row
-        for (int it = tid; it < RT * nq; it += 512) {
-            const int itb = it + 256 < RT * nq ? it + 256 : it;
-            f32x4v sv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            sum_slabs2<GP>(sv[0], sv[1], psrc + (it / nq) * NYP_MAX + 4 * (it % nq), psrc + (itb / nq) * NYP_MAX + 4 * (itb % nq), a.G,
-                               (size_t)RT * KP0_MAX);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int item = h ? itb : it;
-                if (h && itb == it) break;
-                const int r = item / nq, c0 = 4 * (item % nq);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = c0 + e;
-                    if (c >= ny) break;
-                    const float rs = a.dt * (sv[h][e] + Bl[c]);
-                    const float yn = Ys[r * ny + c] + rs;
-                    Ys[r * ny + c] = yn;
-                    if (g == 0 && row0 + r < B) {
-                        const size_t o = (size_t)(row0 + r) * ny + c;
-                        a.res[(size_t)i * B * ny + o] = rs;
-                        a.y_all[(size_t)(i + 1) * B * ny + o] = yn;
-                        if (i + 1 < a.S) a.inp_all[((size_t)(i + 1) * B + row0 + r) * nin + c] = yn;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        tick(7);
-    }
-    if (dbg && tid == 0) {
-        for (int k = 0; k < 8; ++k) a.dbg[k] = tacc[k];
-        a.dbg[8] = __builtin_readcyclecounter() - clk0;          // s_memtime ticks ...
-        a.dbg[9] = __builtin_amdgcn_s_memrealtime() - rt0;       // ... per 100 MHz ticks = the shader clock the chain ran at
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------ backward
-// per step (descending): dout = dt (d_res_i + dy);  delta_{nl-2} = (dout W_{nl-1}) relu'(h_{nl-2});  delta_{l-1} =
-// (delta_l W_l) relu'(h_{l-1});  dinp = delta_0 W_0;  dy <- d_y_all[i] + dy + dinp[:, :ny]
-template <int GP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_fused_bwd_kernel(const RollF a) {
-    extern __shared__ float lds[];
-    int cl, g;
-    if (!locate(a, cl, g)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int rh = wid >> 1, ch = wid & 1, q = lane >> 4, c16 = lane & 15;
-    const int cc = 16 * ch + c16;
-    const int row0 = (a.tile0 + cl) * RT;
-    const int colbase = g * CW;
-    const int nl = a.nl, nh = a.nh, ny = a.ny, nin = a.nin, B = a.B, dwd = a.dwd;
-    const int nfull = nl - 2;
-    // LDS: [nfull][nh][32] slices (B[k][c] = W_l[k][colbase + c], l = nl-2 .. 1) | Do [32][nyp + IPAD] | Dy [32][ny] | Hs [32][33]
-    float* Wl = lds;
-    float* Do = Wl + (size_t)nfull * nh * CW;
-    float* Dy = Do + RT * (a.nyp + IPAD);
-    float* Hs = Dy + RT * ny;
-    unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;
-    float* part = a.part + (size_t)(a.tile0 + cl) * a.S * a.G * RT * KP0_MAX;       // fresh slab per step (see the forward kernel)
-    unsigned target = 0;
-    xcd_announce(cnt);
-    for (int l = 1; l <= nfull; ++l) {
-        const float* W = a.W[l];
-        float* dst = Wl + (size_t)(l - 1) * nh * CW;
-        for (int idx = tid; idx < nh * CW; idx += 256) {
-            const int k = idx / CW, c = idx - k * CW;     // consecutive threads walk the 32 columns of row k
-            dst[sw(k, c)] = W[(size_t)k * nh + colbase + c];
-        }
-    }
-    // last layer backward (K = ny): B[k = 16 j + 4 q + e][cc] = W_{nl-1}[k][colbase + cc] in registers
-    float wlb[NYP_MAX / 4];
-#pragma unroll
-    for (int j = 0; j < NYP_MAX / 16; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = 16 * j + 4 * q + e;
-            wlb[j * 4 + e] = k < ny ? a.W[nl - 1][(size_t)k * nh + colbase + cc] : 0.f;
-        }
-    // input gradient (split-K: this workgroup's 32 units of delta_0): tiles t = wid + 4 u -> (row half t & 1, column tile t >> 1)
-    // B[k = 4 jj + q][col] = W_0[colbase + k][col]
-    const int ntl = 2 * (a.kp0 / 16);
-    float w0b[KP0_MAX / 16 * 2 / 4][8];
-#pragma unroll
-    for (int u = 0; u < KP0_MAX / 16 * 2 / 4; ++u) {
-        const int t = wid + 4 * u, col = 16 * (t >> 1) + c16;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj)
-            w0b[u][jj] = (t < ntl && col < nin) ? a.W[0][(size_t)(colbase + 4 * jj + q) * nin + col] : 0.f;
-    }
-    for (int idx = tid; idx < RT * ny; idx += 256) {
-        const int r = idx / ny, c = idx - r * ny;
-        const int row = row0 + r < B ? row0 + r : B - 1;
-        Dy[idx] = a.d_y_all[((size_t)a.S * B + row) * ny + c];
-    }
-    cluster_barrier(cnt, target += a.G);                  // (workgroup barrier behind the one-time loads + ) every member has announced its XCC
-    const bool xl = xcd_agreed(cnt, a.xcd_local, g == 0);
-    const int arow_l = 16 * rh + c16;
-    const int grow = row0 + arow_l < B ? row0 + arow_l : B - 1;
-    const size_t hs = (size_t)a.S * B * nh;               // layer stride of hid
-    const size_t ds = (size_t)a.S * B * dwd;              // layer stride of dhid
-
-    // global operands that do not depend on the chain are fetched ahead of their use (one step / one layer), so that their
-    // latencies do not add up on the serial path: d_res of the next step to visit, the ReLU masks of the next layer
-    float dres[NYP_MAX * RT / 256];
-    auto fetch_dres = [&](int step) {
-#pragma unroll
-        for (int u = 0; u < NYP_MAX * RT / 256; ++u) {
-            const int idx = tid + 256 * u, r = idx / a.nyp, c = idx - r * a.nyp;
-            const int row = row0 + r < B ? row0 + r : B - 1;
-            dres[u] = (a.d_res && idx < RT * a.nyp && c < ny) ? a.d_res[((size_t)step * B + row) * ny + c] : 0.f;
-        }
-    };
-    float hm[4];                                          // saved activations (ReLU masks) of this lane's 4 output elements
-    auto fetch_mask = [&](int l, int step) {
-        const float* hsrc = a.hid + (size_t)l * hs + (size_t)step * B * nh;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int r = 16 * rh + 4 * q + e;
-            const int row = row0 + r < B ? row0 + r : B - 1;
-            hm[e] = hsrc[(size_t)row * nh + colbase + cc];
-        }
-    };
-    fetch_dres(a.S - 1);
-    for (int i = a.S - 1; i >= 0; --i) {
-        // ---- dout = dt (d_res_i + dy): every workgroup from its own state; member 0 stores it (delta of the last layer)
-        fetch_mask(nl - 2, i);
-#pragma unroll
-        for (int u = 0; u < NYP_MAX * RT / 256; ++u) {
-            const int idx = tid + 256 * u, r = idx / a.nyp, c = idx - r * a.nyp;
-            if (idx >= RT * a.nyp) break;
-            float v = 0.f;
-            if (c < ny) {
-                v = a.dt * (dres[u] + Dy[r * ny + c]);
-                if (g == 0 && row0 + r < B) a.dhid[(size_t)(nl - 1) * ds + ((size_t)i * B + row0 + r) * dwd + c] = v;
-            }
-            Do[r * (a.nyp + IPAD) + c] = v;
-        }
-        if (i > 0) fetch_dres(i - 1);
-        __syncthreads();
-        // ---- delta_{nl-2} slice: A = dout (LDS), B = registers
-        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-        gemm_lds_reg<NYP_MAX / 16>(acc, Do + arow_l * (a.nyp + IPAD) + 4 * q, wlb, a.nyp);
-        for (int l = nl - 2; l >= 0; --l) {
-            // epilogue: delta_l = acc * relu'(h_l) (mask from the saved post-ReLU activation), stored for the weight gradients
-            float* ddst = a.dhid + (size_t)l * ds + (size_t)i * B * dwd;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 16 * rh + 4 * q + e;
-                const float v = hm[e] > 0.f ? acc[e] : 0.f;
-                if (row0 + r < B) st_x(ddst + (size_t)(row0 + r) * dwd + colbase + cc, v, xl);
-                if (l == 0) Hs[r * 33 + cc] = v;
-            }
-            if (l == 0) break;
-            fetch_mask(l - 1, i);
-            cluster_barrier(cnt, target += a.G);
-            // ---- delta_{l-1} slice: A = complete delta_l tile (global), B = LDS slice of W_l
-            acc = f32x4v{0.f, 0.f, 0.f, 0.f};
-            if (xl) gemm_glob_lds<true>(acc, ddst + (size_t)grow * dwd, Wl + (size_t)(l - 1) * nh * CW, nh, q, cc);
-            else gemm_glob_lds<false>(acc, ddst + (size_t)grow * dwd, Wl + (size_t)(l - 1) * nh * CW, nh, q, cc);
-        }
-        __syncthreads();
-        // ---- dinp partial (split-K over the cluster)
-        float* pdst = part + ((size_t)i * a.G + g) * RT * KP0_MAX;
-#pragma unroll
-        for (int u = 0; u < KP0_MAX / 16 * 2 / 4; ++u) {
-            const int t = wid + 4 * u;
-            if (t >= ntl) break;
-            const int trh = t & 1, ct = t >> 1;
-            f32x4v o = {0.f, 0.f, 0.f, 0.f};
-            const float* hr = Hs + (16 * trh + c16) * 33 + q;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) o = __builtin_amdgcn_mfma_f32_16x16x4f32(hr[4 * jj], w0b[u][jj], o, 0, 0, 0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) st_x(pdst + (16 * trh + 4 * q + e) * KP0_MAX + 16 * ct + c16, o[e], xl);
-        }
-        // d_y_all[i] of this thread's items (c < ny only), fetched before the barrier wait
-        const int nq = a.kp0 / 4;
-        float dyv[KP0_MAX / 4 * RT / 256][4];
-#pragma unroll
-        for (int u = 0; u < KP0_MAX / 4 * RT / 256; ++u) {
-            const int item = tid + 256 * u, r = item / nq, c0 = 4 * (item % nq);
-            const int row = row0 + r < B ? row0 + r : B - 1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                dyv[u][e] = (item < RT * nq && c0 + e < ny) ? a.d_y_all[((size_t)i * B + row) * ny + c0 + e] : 0.f;
-        }
-        cluster_barrier(cnt, target += a.G);
-        const float* psrc = part + (size_t)i * a.G * RT * KP0_MAX;
-#pragma unroll
-        for (int u2 = 0; u2 < KP0_MAX / 4 * RT / 512; ++u2) {
-            const int it = tid + 512 * u2;
-            if (it >= RT * nq) break;
-            const int itb = it + 256 < RT * nq ? it + 256 : it;
-            f32x4v sv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            sum_slabs2<GP>(sv[0], sv[1], psrc + (it / nq) * KP0_MAX + 4 * (it % nq), psrc + (itb / nq) * KP0_MAX + 4 * (itb % nq), a.G,
-                               (size_t)RT * KP0_MAX);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int item = h ? itb : it;
-                if (h && itb == it) break;
-                const int r = item / nq, c0 = 4 * (item % nq);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = c0 + e;
-                    if (c >= nin) break;
-                    const float sum = sv[h][e];
-                    if (g == 0 && row0 + r < B) a.dinp_all[((size_t)i * B + row0 + r) * nin + c] = sum;
-                    if (c < ny) Dy[r * ny + c] = dyv[2 * u2 + h][e] + Dy[r * ny + c] + sum;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (g == 0)
-        for (int idx = tid; idx < RT * ny; idx += 256) {
-            const int r = idx / ny, c = idx - r * ny;
-            if (row0 + r < B) a.d_y0[(size_t)(row0 + r) * ny + c] = Dy[idx];
-        }
-}
-
-
 // ------------------------------------------------------------------------------------------------------------ 16-row tiles, K split over the waves
-// Round 5, second form of the two training kernels (SRVP_ROLLOUT_KSPLIT=0: the 32-row kernels above).  What a 32-row hidden-layer GEMM cost
-// per Euler step (SRVP_RF_DEBUG: 4.5 us for 1.7 us of MFMA issue) is moving the 64 KB activation tile into every workgroup -- through the L1
-// twice, because the two column-half waves of a row half both fetch it -- and 128 MFMAs per SIMD behind it.  Both scale with the ROWS a
-// cluster owns, and the chip has CUs to spare (96 of 256 at 192 sequences, 16 at 24): so the batch is cut into 16-row tiles (twice the
-// clusters) and, inside a workgroup, the K loop instead of the output tile is dealt to the four waves: wave w takes the w-th 16-wide k block
-// of every 64 (one 16-byte load per lane and block: 8 loads per hidden layer instead of 32, every byte fetched once per workgroup), feeds
-// it to BOTH 16-column tiles of the slice, and the four partial 16 x 32 tiles are added in a fixed order (((w0 + w1) + w2) + w3) through 8 KB
-// of LDS, where the epilogue (bias / ReLU or ReLU mask, store, hand-off) then runs on all 256 threads, two outputs each, along rows.
-// Taken when every 16-row tile of the batch fits ONE co-resident launch (B <= 256 at nh = 512); otherwise the 32-row kernels.
+// The two training kernels.  What a hidden-layer GEMM costs per Euler step (SRVP_RF_DEBUG timestamps) is moving the activation tile into
+// every workgroup plus the MFMA issue behind it; both scale with the ROWS a cluster owns, and the chip has CUs to spare (96 of 256 at 192
+// sequences, 16 at 24): 16-row tiles, and the K loop dealt to the four waves: wave w takes the w-th 16-wide k block of every 64 (one
+// 16-byte load per lane and block, every byte fetched once per workgroup), feeds it to BOTH 16-column tiles of the slice, and the four
+// partial 16 x 32 tiles are added in a fixed order (((w0 + w1) + w2) + w3) through 8 KB of LDS, where the epilogue (bias / ReLU or ReLU
+// mask, store, hand-off) then runs on all 256 threads, two outputs each, along rows.
 constexpr int RT16 = 16;
 #define WAITV1(r, n) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(r) :: "memory")
 
 // acc[ct] (16 x 16, column tiles ct of the 32-column slice) += A(16 rows from global, this wave's k blocks) x B(LDS slice); blocks past K
-// contribute exact zeros (A fragment cleared), no branch between a load and its wait (see gemm_glob_lds)
+// contribute exact zeros (A fragment cleared), no branch between a load and its wait
 template <bool CACHED>
 __device__ __forceinline__ void gemm_ks(f32x4v (&acc)[2], const float* arow, const float* Bs, int K, int w, int q, int c16) {
     const f32x4v zero = {0.f, 0.f, 0.f, 0.f};
@@ -697,7 +255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* Bl = Hs + RT * 33;
     float* Red = Bl + NYP_MAX;
     unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;
-    float* part = a.part + (size_t)(a.tile0 + cl) * a.S * a.G * RT * KP0_MAX;       // a fresh slab per Euler step (see the 32-row kernel)
+    float* part = a.part + (size_t)(a.tile0 + cl) * a.S * a.G * RT * KP0_MAX;       // a fresh slab per Euler step
     unsigned target = 0;
     xcd_announce(cnt);
 
@@ -1033,11 +591,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // The INFERENCE rollout (reference module/srvp.py:377-405 with nt > the number of observed frames; test.py:237-246, train.evaluate) as ONE
 // persistent launch per group of row tiles: per frame the prior MLP p_z(y) (srvp.py:383), the sample z ~ posterior while data lasts / prior
 // afterwards (srvp.py:385-391), then the n_euler residual steps with that z (srvp.py:394-400) -- as launches: (nl + 2) + n_euler (nl + 2)
-// dependent micro-kernels per frame (579 GEMM launches for the 53-frame horizon of config 5).  Same decomposition as the training kernels:
-// 32-row tiles, a cluster of nh / 32 workgroups per tile, workgroup g owns hidden columns [32 g, 32 g + 32) of every layer.  The DYNAMICS
-// slices stay in LDS for the whole launch (they are used n_euler times per frame); the LDS has no room for the prior's two 64 KB slices as
-// well, so the prior's hidden layers take their B operand straight from global memory (16 contiguous bytes per lane and MFMA k group: the
-// same 64 KB per workgroup re-read once per frame, L2-resident).  Nothing is saved for a backward pass: the exchanged activation tiles live
+// dependent micro-kernels per frame (579 GEMM launches for the 53-frame horizon of config 5).  Same decomposition as the training kernels
+// (32-row tiles, a cluster of nh / 32 workgroups per tile, workgroup g owns hidden columns [32 g, 32 g + 32) of every layer); the weight
+// placement is described at rollout_gen_ks_kernel.  Nothing is saved for a backward pass: the exchanged activation tiles live
 // in one small per-tile buffer per layer that is rewritten every step (a cluster barrier separates any write from the previous reads), which
 // is only safe when every member of the cluster shares one L2 -- the XCD-local exchange, VERIFIED per launch; a launch that finds its
 // cluster spread over several XCCs writes nothing and counts a cluster failure (srvp_cluster_stats_read word 0; the host refuses to go on).
@@ -1053,281 +609,6 @@ struct GenF {
 };
 
 __device__ __forceinline__ float softplus_g(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
-
-__device__ __forceinline__ void mm_chunk_rr(f32x4v& acc, f32x4v (&a4)[8], f32x4v (&b4)[8], int k0, int K) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (k0 + 16 * j >= K) break;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j][e], b4[j][e], acc, 0, 0, 0);
-    }
-}
-#define WAIT_AB(ba, bb, n) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(ba[0]), "+v"(ba[1]), "+v"(ba[2]), "+v"(ba[3]), "+v"(ba[4]), "+v"(ba[5]), "+v"(ba[6]), "+v"(ba[7]), \
-                                        "+v"(bb[0]), "+v"(bb[1]), "+v"(bb[2]), "+v"(bb[3]), "+v"(bb[4]), "+v"(bb[5]), "+v"(bb[6]), "+v"(bb[7]) :: "memory")
-// acc(16x16) += A(rows from the cluster's exchange buffer: L1-bypassing loads) x B(k-contiguous weight rows from global: plain loads)
-__device__ __forceinline__ void gemm_glob_glob(f32x4v& acc, const float* arow, const float* brow, int K, int q) {
-    const float* pa = arow + 4 * q;
-    const float* pb = brow + 4 * q;
-    for (int k0 = 0; k0 < K; k0 += 256) {
-        f32x4v a0[8], b0[8], a1[8], b1[8];
-        ld_chunk(a0, pa, k0, K); ld_chunk_plain(b0, pb, k0, K); ld_chunk(a1, pa, k0 + 128, K); ld_chunk_plain(b1, pb, k0 + 128, K);
-        WAIT_AB(a0, b0, 16); mm_chunk_rr(acc, a0, b0, k0, K);
-        WAIT_AB(a1, b1, 0); mm_chunk_rr(acc, a1, b1, k0 + 128, K);
-    }
-}
-
-template <int GP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_gen_kernel(const GenF a) {
-    extern __shared__ float lds[];
-    const int xq = blockIdx.x & 7, kblk = blockIdx.x >> 3;
-    const int cl = xq * a.cl_per_xcd + kblk / a.G, g = kblk % a.G;
-    if (cl >= a.ntiles) return;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int rh = wid >> 1, ch = wid & 1, q = lane >> 4, c16 = lane & 15;
-    const int cc = 16 * ch + c16;
-    const int row0 = (a.tile0 + cl) * RT;
-    const int colbase = g * CW;
-    const int nl = a.nl, nh = a.nh, ny = a.ny, nz = a.nz, nin = a.nin, B = a.B, kp0 = a.kp0;
-    const int nfull = nl - 2;
-    const int ils = kp0 + IPAD;                           // row stride of the staging tile
-    // LDS: [nfull][nh][32] dynamics slices | Is [32][kp0 + IPAD] (also the summed prior parameters) | Ys [32][ny] | Zs [32][nz] | Hs [32][33] | biases
-    float* Wl = lds;
-    float* Is = Wl + (size_t)nfull * nh * CW;
-    float* Ys = Is + RT * ils;
-    float* Zs = Ys + RT * ny;
-    float* Hs = Zs + RT * nz;
-    float* Bl = Hs + RT * 33;                             // dynamics: bias of the last layer [ny]
-    float* Bp = Bl + ny;                                  // prior: bias of the last layer [2 nz]
-    unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;
-    float* hbuf = a.hbuf + (size_t)(a.tile0 + cl) * (nfull > 0 ? nfull : 1) * RT * nh;
-    float* part = a.part + (size_t)(a.tile0 + cl) * a.G * RT * KP0_MAX;
-    unsigned target = 0;
-    xcd_announce(cnt);
-    for (int l = 1; l <= nfull; ++l) {
-        const float* W = a.W[l];
-        float* dst = Wl + (size_t)(l - 1) * nh * CW;
-        for (int idx = tid; idx < nh * CW; idx += 256) {
-            const int c = idx / nh, k = idx - c * nh;
-            dst[sw(k, c)] = W[(size_t)(colbase + c) * nh + k];
-        }
-    }
-    // first layers (B fragments in registers): dynamics K = nin, prior K = ny
-    float w0[KP0_MAX / 4], pw0[NYP_MAX / 4];
-#pragma unroll
-    for (int j = 0; j < KP0_MAX / 16; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = 16 * j + 4 * q + e;
-            w0[j * 4 + e] = k < nin ? a.W[0][(size_t)(colbase + cc) * nin + k] : 0.f;
-        }
-#pragma unroll
-    for (int j = 0; j < NYP_MAX / 16; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = 16 * j + 4 * q + e;
-            pw0[j * 4 + e] = k < ny ? a.PW[0][(size_t)(colbase + cc) * ny + k] : 0.f;
-        }
-    // last layers, split-K over the cluster: tiles t = wid + 4 u -> (row half t & 1, output column tile t >> 1)
-    float wl[2][8], pwl[4][8];
-    const int ntl = 2 * (a.nyp / 16), ntp = 2 * (a.nzp2 / 16);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int t = wid + 4 * u, col = 16 * (t >> 1) + c16;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj)
-            wl[u][jj] = (t < ntl && col < ny) ? a.W[nl - 1][(size_t)col * nh + colbase + 4 * jj + q] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int t = wid + 4 * u, col = 16 * (t >> 1) + c16;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj)
-            pwl[u][jj] = (t < ntp && col < 2 * nz) ? a.PW[nl - 1][(size_t)col * nh + colbase + 4 * jj + q] : 0.f;
-    }
-    for (int idx = tid; idx < RT * ny; idx += 256) {
-        const int r = idx / ny, c = idx - r * ny;
-        const int row = row0 + r < B ? row0 + r : B - 1;
-        Ys[idx] = a.y0[(size_t)row * ny + c];
-    }
-    for (int idx = tid; idx < RT * ils; idx += 256) Is[idx] = 0.f;
-    if (tid < ny) Bl[tid] = a.b[nl - 1][tid];
-    if (tid < 2 * nz) Bp[tid] = a.Pb[nl - 1][tid];
-    cluster_barrier(cnt, target += a.G);                  // (workgroup barrier behind the one-time loads + ) every member has announced its XCC
-    if (!xcd_agreed(cnt, a.xcd_local, g == 0)) {
-        // the members do not share one L2: the single-buffer exchange below would read stale lines.  Nothing is written; counted as a cluster
-        // failure (every member takes this branch: the mask is the same for all)
-        if (g == 0 && tid == 0) __hip_atomic_fetch_add(&g_cluster_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    const int arow_l = 16 * rh + c16;                     // A row of this lane inside the tile
-    const size_t hls = (size_t)RT * nh;                   // layer stride of hbuf
-    const int nq = a.nyp / 4, nq2 = a.nzp2 / 4;
-
-    for (int i = 0; i < a.S; ++i) {
-        const int f = i / a.ne;
-        if (i % a.ne == 0) {
-            // =============================== frame start: p_z(y), then z
-            for (int idx = tid; idx < RT * ny; idx += 256) {
-                const int r = idx / ny, c = idx - r * ny;
-                Is[r * ils + c] = Ys[idx];                // (columns >= ny: the previous z or zeros; their weights are zero)
-            }
-            __syncthreads();
-            f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-            float bl = a.Pb[0][colbase + cc];
-            gemm_lds_reg<NYP_MAX / 16>(acc, Is + arow_l * ils + 4 * q, pw0, a.nyp);
-            for (int l = 0; l <= nfull; ++l) {
-                float* hdst = hbuf + (size_t)l * hls;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 16 * rh + 4 * q + e;
-                    float v = acc[e] + bl;
-                    v = v > 0.f ? v : 0.f;
-                    if (l < nfull) hdst[(size_t)r * nh + colbase + cc] = v;
-                    else Hs[r * 33 + cc] = v;
-                }
-                if (l == nfull) break;
-                bl = a.Pb[l + 1][colbase + cc];
-                cluster_barrier(cnt, target += a.G);
-                acc = f32x4v{0.f, 0.f, 0.f, 0.f};
-                gemm_glob_glob(acc, hdst + (size_t)arow_l * nh, a.PW[l + 1] + (size_t)(colbase + cc) * nh, nh, q);
-            }
-            __syncthreads();                              // Hs complete
-            float* pdst = part + (size_t)g * RT * KP0_MAX;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = wid + 4 * u;
-                if (t >= ntp) break;
-                const int trh = t & 1, ct = t >> 1;
-                f32x4v o = {0.f, 0.f, 0.f, 0.f};
-                const float* hr = Hs + (16 * trh + c16) * 33 + q;
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) o = __builtin_amdgcn_mfma_f32_16x16x4f32(hr[4 * jj], pwl[u][jj], o, 0, 0, 0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pdst[(16 * trh + 4 * q + e) * KP0_MAX + 16 * ct + c16] = o[e];
-            }
-            // this frame's noise and (while data lasts) posterior parameters, fetched before the barrier wait
-            const bool posterior = f + 1 < a.n_data;
-            float epsr[NYP_MAX * RT / 256], qlr[NYP_MAX * RT / 256], qsr[NYP_MAX * RT / 256];
-#pragma unroll
-            for (int u = 0; u < NYP_MAX * RT / 256; ++u) {
-                const int idx = tid + 256 * u, r = idx / nz, c = idx - r * nz;
-                const int row = row0 + r < B ? row0 + r : B - 1;
-                const bool ok = idx < RT * nz;
-                epsr[u] = ok ? a.eps[((size_t)f * B + row) * nz + c] : 0.f;
-                qlr[u] = (ok && posterior) ? a.qz[((size_t)f * B + row) * 2 * nz + c] : 0.f;
-                qsr[u] = (ok && posterior) ? a.qz[((size_t)f * B + row) * 2 * nz + nz + c] : 0.f;
-            }
-            cluster_barrier(cnt, target += a.G);
-            // every workgroup: the prior's parameters of its 32 rows = sum of the G partials (fixed order) + bias -> the staging tile
-            for (int it = tid; it < RT * nq2; it += 512) {
-                const int itb = it + 256 < RT * nq2 ? it + 256 : it;
-                f32x4v sv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-                sum_slabs2<GP>(sv[0], sv[1], part + (it / nq2) * KP0_MAX + 4 * (it % nq2), part + (itb / nq2) * KP0_MAX + 4 * (itb % nq2), a.G,
-                               (size_t)RT * KP0_MAX);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int item = h ? itb : it;
-                    if (h && itb == it) break;
-                    const int r = item / nq2, c0 = 4 * (item % nq2);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (c0 + e < 2 * nz) Is[r * ils + c0 + e] = sv[h][e] + Bp[c0 + e];
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < NYP_MAX * RT / 256; ++u) {
-                const int idx = tid + 256 * u, r = idx / nz, c = idx - r * nz;
-                if (idx >= RT * nz) break;
-                const float pl = Is[r * ils + c], ps = Is[r * ils + nz + c];
-                const float loc = posterior ? qlr[u] : pl, raw = posterior ? qsr[u] : ps;
-                const float zz = loc + epsr[u] * (softplus_g(raw) + 1e-8f);
-                Zs[idx] = zz;
-                if (g == 0 && row0 + r < B) {
-                    const size_t o = (size_t)f * B + row0 + r;
-                    a.z[o * nz + c] = zz;
-                    a.pz[o * 2 * nz + c] = pl;
-                    a.pz[o * 2 * nz + nz + c] = ps;
-                }
-            }
-            __syncthreads();
-            // the dynamics' input tile [y | z | 0]
-            for (int idx = tid; idx < RT * kp0; idx += 256) {
-                const int r = idx / kp0, k = idx - r * kp0;
-                Is[r * ils + k] = k < ny ? Ys[r * ny + k] : (k < nin ? Zs[r * nz + k - ny] : 0.f);
-            }
-        } else {
-            for (int idx = tid; idx < RT * ny; idx += 256) {
-                const int r = idx / ny, c = idx - r * ny;
-                Is[r * ils + c] = Ys[idx];                // (the z part of the tile stays for the whole frame)
-            }
-        }
-        __syncthreads();
-        // =============================== one residual step (as rollout_fused_fwd_kernel, nothing saved)
-        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-        float bl = a.b[0][colbase + cc];
-        gemm_lds_reg<KP0_MAX / 16>(acc, Is + arow_l * ils + 4 * q, w0, kp0);
-        for (int l = 0; l <= nfull; ++l) {
-            float* hdst = hbuf + (size_t)l * hls;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 16 * rh + 4 * q + e;
-                float v = acc[e] + bl;
-                v = v > 0.f ? v : 0.f;
-                if (l < nfull) hdst[(size_t)r * nh + colbase + cc] = v;
-                else Hs[r * 33 + cc] = v;
-            }
-            if (l == nfull) break;
-            bl = a.b[l + 1][colbase + cc];
-            cluster_barrier(cnt, target += a.G);
-            acc = f32x4v{0.f, 0.f, 0.f, 0.f};
-            gemm_glob_lds(acc, hdst + (size_t)arow_l * nh, Wl + (size_t)l * nh * CW, nh, q, cc);
-        }
-        __syncthreads();
-        float* pdst = part + (size_t)g * RT * KP0_MAX;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int t = wid + 4 * u;
-            if (t >= ntl) break;
-            const int trh = t & 1, ct = t >> 1;
-            f32x4v o = {0.f, 0.f, 0.f, 0.f};
-            const float* hr = Hs + (16 * trh + c16) * 33 + q;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) o = __builtin_amdgcn_mfma_f32_16x16x4f32(hr[4 * jj], wl[u][jj], o, 0, 0, 0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pdst[(16 * trh + 4 * q + e) * KP0_MAX + 16 * ct + c16] = o[e];
-        }
-        cluster_barrier(cnt, target += a.G);
-        for (int it = tid; it < RT * nq; it += 512) {
-            const int itb = it + 256 < RT * nq ? it + 256 : it;
-            f32x4v sv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            sum_slabs2<GP>(sv[0], sv[1], part + (it / nq) * KP0_MAX + 4 * (it % nq), part + (itb / nq) * KP0_MAX + 4 * (itb % nq), a.G,
-                           (size_t)RT * KP0_MAX);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int item = h ? itb : it;
-                if (h && itb == it) break;
-                const int r = item / nq, c0 = 4 * (item % nq);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = c0 + e;
-                    if (c >= ny) break;
-                    const float rs = a.dt * (sv[h][e] + Bl[c]);
-                    const float yn = Ys[r * ny + c] + rs;
-                    Ys[r * ny + c] = yn;
-                    if (g == 0 && row0 + r < B) {
-                        const size_t o = (size_t)(row0 + r) * ny + c;
-                        a.res[(size_t)i * B * ny + o] = rs;
-                        a.y_all[(size_t)(i + 1) * B * ny + o] = yn;
-                    }
-                }
-            }
-        }
-        // (the next phase's first cluster barrier -- every phase has at least the split-K one -- separates these slab reads from the next
-        // writes of the slabs and of the exchange buffers)
-        __syncthreads();
-    }
-}
 
 // K-split GEMM of the generation chain's second form: acc[mt][ct] += A(16 MT rows of the exchange buffer, this wave's eight 16-wide k blocks:
 // L1-bypassing loads) x B, B either register-resident (GLOB = false: bw) or fetched with the A fragments from two weight rows in global memory
@@ -1374,12 +655,12 @@ __device__ __forceinline__ void gk_gemm(f32x4v (&acc)[MT][2], const float* const
     gk_step<0, MT, GLOB, DEPTH>(acc, av, bv, pm, b0, b1, bw);
 }
 
-// ---- second form of the generation chain (round 5; SRVP_GEN_KSPLIT=0: the kernel above).  The K loop of every hidden layer is dealt to the
+// ---- the generation kernel.  The K loop of every hidden layer is dealt to the
 // four waves as in rollout_ks_* (wave w owns the w-th 16-wide k block of every 64), which has a consequence the output-tiled form cannot have:
 // a wave only ever touches ITS quarter of each weight slice, 64 values per lane and layer -- so the slices of the dynamics' two hidden layers
 // (used n_euler times per frame) live in REGISTERS for the whole launch, 128 VGPRs per lane, and the LDS holds only the staging tiles.  (All four
 // hidden layers in registers -- 256 VGPRs -- was built first: hipcc spilled 300 of them and the chain got slower, 91.1 vs 90.2 ms.)  The prior's
-// two hidden layers (once per frame) still take their B fragments from global memory.  32-row tiles as before (800 rows = 25 tiles must fit two co-resident launches): every A fragment feeds four MFMA
+// two hidden layers (once per frame) take their B fragments from global memory (L2-resident).  32-row tiles (800 rows = 25 tiles must fit two co-resident launches): every A fragment feeds four MFMA
 // tiles (2 row tiles x 2 column tiles), 16 loads per lane and layer instead of 32 + 32.
 template <int GP, int MT>       // MT: 16-row tiles per cluster tile (2: 32 rows, the one instantiated; 4 was measured: see the launcher)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_gen_ks_kernel(const GenF a) {
@@ -1688,13 +969,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 // ------------------------------------------------------------------------------------------------------------ LSTM
-// The posterior LSTM (nn.LSTM(nhx, nh, 1), reference module/srvp.py:132,366) as ONE persistent launch over its T steps, same
-// decomposition: 32-row batch tiles, a cluster of nh / 32 workgroups per tile, workgroup g owns hidden units [32 g, 32 g + 32)
-// -- the four gate rows of those units, one gate per wave, its nh x 32 slice of W_hh held in 128 VGPRs per lane (B operand of
-// v_mfma_f32_32x32x2_f32) for the whole kernel.  Per step: the h_{t-1} tile of the batch tile (written by the cluster with
-// agent-scope stores) is staged in LDS, each wave forms its gate, the cell update runs on the workgroup's 32 x 32 units with
-// the cell state in registers, one counter barrier.  (As launches: a GEMM + a cell kernel per step, 20 us of dependent
-// latency each.)
+// The posterior LSTM (nn.LSTM(nhx, nh, 1), reference module/srvp.py:132,366) as ONE persistent launch over its T steps (as launches: a GEMM
+// + a cell kernel per step, 20 us of dependent latency each), forward and backward recurrence.
 struct LstmF {
     int B, nh, T, G, ntiles, tile0, cl_per_xcd;
     const float* gx; const float* whh; float* h; float* c; float* ga; unsigned* cnt; int xcd_local;
@@ -1702,180 +978,8 @@ struct LstmF {
 
 __device__ __forceinline__ float sigmoid_l(float x) { return 1.f / (1.f + __expf(-x)); }
 
-template <int KST>      // nh / 2 MFMA k steps
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fused_fwd_kernel(const LstmF a) {
-    extern __shared__ float lds[];
-    constexpr int NH = 2 * KST, HLD = NH + 1;
-    float* Hs = lds;                          // [32][NH + 1]  h_{t-1} of this batch tile
-    float* Gs = lds + RT * HLD;               // [4][32][33]   activated gates of this workgroup's units
-    const int x = blockIdx.x & 7, kk = blockIdx.x >> 3;
-    const int cl = x * a.cl_per_xcd + kk / a.G, g = kk % a.G;
-    if (cl >= a.ntiles) return;
-    const int tid = threadIdx.x, lane = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lcol = lane & 31, lhalf = lane >> 5;
-    const int row0 = (a.tile0 + cl) * RT;
-    const int col = q * NH + g * CW + lcol;               // this lane's gate column (row of W_hh)
-    float wreg[KST];
-#pragma unroll
-    for (int j = 0; j < KST; ++j) wreg[j] = a.whh[(size_t)col * NH + 2 * j + lhalf];
-    float cst[4] = {0.f, 0.f, 0.f, 0.f};
-    unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;
-    const size_t gs = (size_t)a.B * 4 * NH, hs = (size_t)a.B * NH;
-    xcd_announce(cnt);
-    cluster_barrier(cnt, (unsigned)a.G);                   // every member has announced its XCC (XCD-LOCAL EXCHANGE)
-    const bool xl = xcd_agreed(cnt, a.xcd_local, g == 0);
-    for (int t = 0; t < a.T; ++t) {
-        f32x16_t acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-            acc[r] = row < a.B ? a.gx[gs * t + (size_t)row * 4 * NH + col] : 0.f;
-        }
-        if (t > 0) {
-            cluster_barrier(cnt, (unsigned)((t + 1) * a.G));   // every member has stored its slice of h_{t-1}
-            const float* hp = a.h + hs * (t - 1);
-            constexpr int NLD = RT * NH / 4 / 256;          // 16-byte pieces per thread (8 at nh = 256): all in flight, one wait
-            f32x4v hv[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int idx = tid + 256 * (i < NLD ? i : 0), row = idx / (NH / 4), c4 = idx % (NH / 4);
-                const int gr = row0 + row < a.B ? row0 + row : a.B - 1;
-                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(hv[i]) : "v"(hp + (size_t)gr * NH + c4 * 4) : "memory");
-            }
-            WAIT8(hv, 0);
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const int idx = tid + 256 * i, row = idx / (NH / 4), c4 = idx % (NH / 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) Hs[row * HLD + c4 * 4 + e] = hv[i][e];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < KST; ++j)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hs[lcol * HLD + 2 * j + lhalf], wreg[j], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rl = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-            const float v = q == 2 ? tanhf(acc[r]) : sigmoid_l(acc[r]);
-            if (row0 + rl < a.B) a.ga[gs * t + (size_t)(row0 + rl) * 4 * NH + col] = v;
-            Gs[(q * RT + rl) * 33 + lcol] = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int idx = tid + 256 * e, rl = idx >> 5, u = idx & 31;
-            const float ig = Gs[(0 * RT + rl) * 33 + u], fg = Gs[(1 * RT + rl) * 33 + u], gg = Gs[(2 * RT + rl) * 33 + u], og = Gs[(3 * RT + rl) * 33 + u];
-            cst[e] = fg * cst[e] + ig * gg;
-            if (row0 + rl < a.B) {
-                const size_t o = hs * t + (size_t)(row0 + rl) * NH + g * CW + u;
-                a.c[o] = cst[e];
-                st_x(a.h + o, og * tanhf(cst[e]), xl);
-            }
-        }
-        __syncthreads();                                   // Gs is rewritten by the next step's gates
-    }
-}
-
-// The BACKWARD recurrence of the posterior LSTM as ONE persistent launch (srvp_lstm_bwd_fused), the mirror image of the forward kernel:
-// workgroup g of a cluster owns hidden units [32 g, 32 g + 32) of a 32-row batch tile.  Per step t (T-1 ... 0): the cell backward of its
-// 32 x 32 units (dh = dh_out[t] + the carry, dc carried in registers) writes the four gate gradients of those units into dgates[t]
-// (agent-scope stores: the other members read them); one counter barrier; the whole dgates[t] tile of the batch tile [32][4 nh] is
-// staged in LDS and every wave contracts ITS gate's nh columns with its W_hh[gate rows][own 32 units] slice held in 128 VGPRs per lane
-// (B operand of v_mfma_f32_32x32x2_f32: dh_carry[b][u] = sum_k dgates[b][k] W_hh[k][u]); the four partial tiles are summed through LDS
-// into the carry registers.  (As launches: a cell kernel + a GEMM per step, ~18 us of dependent latency each.)
-struct LstmB {
-    int B, nh, T, G, ntiles, tile0, cl_per_xcd;
-    const float* dh_out; const float* whh; const float* c; const float* ga; float* dgates; unsigned* cnt; int xcd_local;
-};
-
-template <int KST>      // nh / 2 MFMA k steps per wave (one gate's nh columns)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fused_bwd_kernel(const LstmB a) {
-    extern __shared__ float lds[];
-    constexpr int NH = 2 * KST, DLD = 4 * NH + 1;
-    float* Ds = lds;                          // [32][4 NH + 1]  gate gradients of this batch tile at step t
-    float* Ps = lds + RT * DLD;               // [4][32][33]     the four waves' partial carries
-    const int x = blockIdx.x & 7, kk = blockIdx.x >> 3;
-    const int cl = x * a.cl_per_xcd + kk / a.G, g = kk % a.G;
-    if (cl >= a.ntiles) return;
-    const int tid = threadIdx.x, lane = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lcol = lane & 31, lhalf = lane >> 5;
-    const int row0 = (a.tile0 + cl) * RT;
-    float wreg[KST];
-#pragma unroll
-    for (int j = 0; j < KST; ++j) wreg[j] = a.whh[(size_t)(q * NH + 2 * j + lhalf) * NH + g * CW + lcol];
-    float dcs[4] = {0.f, 0.f, 0.f, 0.f}, dhc[4] = {0.f, 0.f, 0.f, 0.f};
-    unsigned* cnt = a.cnt + (size_t)(a.tile0 + cl) * 64;
-    const size_t gs = (size_t)a.B * 4 * NH, hs = (size_t)a.B * NH;
-    unsigned target = 0;
-    xcd_announce(cnt);
-    cluster_barrier(cnt, target += (unsigned)a.G);         // every member has announced its XCC (XCD-LOCAL EXCHANGE)
-    const bool xl = xcd_agreed(cnt, a.xcd_local, g == 0);
-    for (int t = a.T - 1; t >= 0; --t) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int idx = tid + 256 * e, rl = idx >> 5, u = idx & 31;
-            if (row0 + rl >= a.B) continue;
-            const size_t ho = hs * t + (size_t)(row0 + rl) * NH + g * CW + u;
-            const size_t go = gs * t + (size_t)(row0 + rl) * 4 * NH + g * CW + u;
-            const float ig = a.ga[go], fg = a.ga[go + NH], gg = a.ga[go + 2 * NH], og = a.ga[go + 3 * NH];
-            const float dh = a.dh_out[ho] + dhc[e];
-            const float tc = tanhf(a.c[ho]);
-            const float dc = dcs[e] + dh * og * (1.f - tc * tc);
-            const float cp = t > 0 ? a.c[ho - hs] : 0.f;
-            st_x(a.dgates + go, dc * gg * ig * (1.f - ig), xl);
-            st_x(a.dgates + go + NH, dc * cp * fg * (1.f - fg), xl);
-            st_x(a.dgates + go + 2 * NH, dc * ig * (1.f - gg * gg), xl);
-            st_x(a.dgates + go + 3 * NH, dh * tc * og * (1.f - og), xl);
-            dcs[e] = dc * fg;
-        }
-        if (t == 0) break;
-        cluster_barrier(cnt, target += (unsigned)a.G);          // every member has stored its gate gradients of step t
-        {
-            const float* dp = a.dgates + gs * t;
-            constexpr int NLD = RT * 4 * NH / 4 / 256;            // 16-byte pieces per thread (32 at nh = 256), eight in flight at a time
-#pragma unroll
-            for (int i0 = 0; i0 < NLD; i0 += 8) {
-                f32x4v hv[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int idx = tid + 256 * (i0 + i < NLD ? i0 + i : 0), row = idx / NH, c4 = idx % NH;      // (4 NH / 4 = NH pieces per row)
-                    const int gr = row0 + row < a.B ? row0 + row : a.B - 1;
-                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(hv[i]) : "v"(dp + (size_t)gr * 4 * NH + c4 * 4) : "memory");
-                }
-                WAIT8(hv, 0);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    if (i0 + i >= NLD) break;
-                    const int idx = tid + 256 * (i0 + i), row = idx / NH, c4 = idx % NH;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) Ds[row * DLD + c4 * 4 + e] = hv[i][e];
-                }
-            }
-        }
-        __syncthreads();
-        f32x16_t acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int j = 0; j < KST; ++j)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ds[lcol * DLD + q * NH + 2 * j + lhalf], wreg[j], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Ps[(q * RT + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * 33 + lcol] = acc[r];
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int idx = tid + 256 * e, rl = idx >> 5, u = idx & 31;
-            dhc[e] = (Ps[(0 * RT + rl) * 33 + u] + Ps[(1 * RT + rl) * 33 + u]) + (Ps[(2 * RT + rl) * 33 + u] + Ps[(3 * RT + rl) * 33 + u]);
-        }
-        __syncthreads();                                   // Ds / Ps are rewritten by the next step
-    }
-}
-
-// ---- second form of the two LSTM kernels (round 5; SRVP_LSTM_KSPLIT=0: the 32-row kernels above), by the same reasoning as rollout_ks_*:
-// the recurrence is a chain of T dependent steps on which 8 CUs worked (32-row tiles, 32 units per workgroup) for 3.4 us of fp32 MFMA issue and
-// 32 KB (forward) / 128 KB (backward) of gathered tile per step.  Here: 16-row tiles and 16 hidden units per workgroup (4 x the workgroups),
-// v_mfma_f32_16x16x4_f32, the A tile read from LDS as 16-byte fragments.
+// 16-row tiles and 16 hidden units per workgroup (a cluster of nh / 16 workgroups per tile), v_mfma_f32_16x16x4_f32, the A tile read from LDS
+// as 16-byte fragments:
 //   forward : wave q = gate q of the workgroup's 16 units; h_{t-1} tile [16][nh] gathered into LDS; 64 MFMAs per wave and step.
 //   backward: the contraction dh_carry[b][u] = sum_k dgates[b][k] W_hh[k][u] is split over the cluster along k INSTEAD of u: a workgroup
 //     contracts the 64 gate gradients it has just formed itself (they never leave the CU) with its [64][nh] slice of W_hh (64 VGPRs per lane,
@@ -2140,30 +1244,12 @@ extern "C" int64_t srvp_rollout_fused_ws_bytes(const srvp_rollout_desc* d) {
     if (!d->pz_external || !d->hid_dyn) return 0;
     if (!clusters_fit(d->nh / CW)) return 0;
     const int kp0 = (nin + 15) / 16 * 16, nyp = (d->ny + 15) / 16 * 16;
-    const size_t lds_f = ((size_t)(d->nl - 2) * d->nh * CW + RT * (kp0 + IPAD) + RT * d->ny + RT * 33 + NYP_MAX) * 4;
-    const size_t lds_b = ((size_t)(d->nl - 2) * d->nh * CW + RT * (nyp + IPAD) + RT * d->ny + RT * 33) * 4;
+    const size_t lds_f = ((size_t)(d->nl - 2) * d->nh * CW + RT16 * (kp0 + IPAD) + RT16 * d->ny + RT16 * 33 + NYP_MAX + 2048) * 4;
+    const size_t lds_b = ((size_t)(d->nl - 2) * d->nh * CW + RT16 * (nyp + IPAD) + RT16 * d->ny + RT16 * 33 + 2048) * 4;
     if (lds_f > 160 * 1024 || lds_b > 160 * 1024) return 0;
-    const int64_t tiles = (d->B + RT - 1) / RT, tiles16 = (d->B + RT16 - 1) / RT16;        // (either form of the kernels: ks_eligible)
+    const int64_t tiles16 = (d->B + RT16 - 1) / RT16;
     // two counter blocks (forward / backward launch: the forward's preparation kernel clears both), then the split-K slabs
-    const int64_t w32 = 2 * tiles * 256 /* counters (padded) */ + tiles * (int64_t)d->nsteps * (d->nh / CW) * RT * KP0_MAX * 4;
-    const int64_t w16 = 2 * tiles16 * 256 + tiles16 * (int64_t)d->nsteps * (d->nh / CW) * RT16 * KP0_MAX * 4;
-    return w32 > w16 ? w32 : w16;
-}
-
-// the 16-row / K-split form: every 16-row tile of the batch in ONE co-resident launch, and its LDS layout fits
-static bool ks_eligible(const srvp_rollout_desc& f) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("SRVP_ROLLOUT_KSPLIT"); on = e ? atoi(e) : 1; }
-    if (!on) return false;
-    device_cus();
-    const int G = f.nh / CW;
-    int per_xcd = (g_ncu / 8) / G;
-    if (per_xcd < 1) per_xcd = 1;
-    if ((f.B + RT16 - 1) / RT16 > per_xcd * 8) return false;
-    const int kp0 = (f.ny + f.nz + 15) / 16 * 16, nyp = (f.ny + 15) / 16 * 16;
-    const size_t lds_f = ((size_t)(f.nl - 2) * f.nh * CW + RT16 * (kp0 + IPAD) + RT16 * f.ny + RT16 * 33 + NYP_MAX + 2048) * 4;
-    const size_t lds_b = ((size_t)(f.nl - 2) * f.nh * CW + RT16 * (nyp + IPAD) + RT16 * f.ny + RT16 * 33 + 2048) * 4;
-    return lds_f <= 160 * 1024 && lds_b <= 160 * 1024;
+    return 2 * tiles16 * 256 + tiles16 * (int64_t)d->nsteps * (d->nh / CW) * RT16 * KP0_MAX * 4;
 }
 
 static int fused_common(const srvp_rollout_desc& f, RollF& k, void* ws, int rt) {
@@ -2179,8 +1265,7 @@ static int fused_common(const srvp_rollout_desc& f, RollF& k, void* ws, int rt) 
 
 // the counter blocks of this chain's persistent launches (forward + backward) in 4-byte words, from the start of fused_ws
 int64_t srvp_rollout_fused_cnt_words(const srvp_rollout_desc* d) {
-    const int rt = ks_eligible(*d) ? RT16 : RT;
-    return (int64_t)2 * ((d->B + rt - 1) / rt) * 64;
+    return (int64_t)2 * ((d->B + RT16 - 1) / RT16) * 64;
 }
 // the workspace whose backward counter block the last forward launch left cleared (host order; one entry: a training step is forward, backward)
 static std::atomic<const void*> g_bwd_cnt_clean{nullptr};        // (host threads: a lost update only costs the memset)
@@ -2196,13 +1281,10 @@ static int clusters_per_launch(int G, int tiles, int& cl_per_xcd) {
 
 int srvp_rollout_fused_fwd(const srvp_rollout_desc* d, hipStream_t st, bool counters_cleared) {
     RollF k{};
-    const bool ks = ks_eligible(*d);
-    const int tiles = fused_common(*d, k, d->fused_ws, ks ? RT16 : RT);
+    const int tiles = fused_common(*d, k, d->fused_ws, RT16);
     k.y0 = d->y0; k.y_all = d->y_all; k.res = d->res; k.inp_all = d->inp_all; k.hid = d->hid_dyn;
-    const size_t lds = ks ? ((size_t)(k.nl - 2) * k.nh * CW + RT16 * (k.kp0 + IPAD) + RT16 * k.ny + RT16 * 33 + NYP_MAX + 2048) * 4
-                          : ((size_t)(k.nl - 2) * k.nh * CW + RT * (k.kp0 + IPAD) + RT * k.ny + RT * 33 + NYP_MAX) * 4;
-    auto kern = ks ? (k.G <= 8 ? rollout_ks_fwd_kernel<8> : (k.G <= 16 ? rollout_ks_fwd_kernel<16> : rollout_ks_fwd_kernel<32>))
-                   : (k.G <= 8 ? rollout_fused_fwd_kernel<8> : (k.G <= 16 ? rollout_fused_fwd_kernel<16> : rollout_fused_fwd_kernel<32>));
+    const size_t lds = ((size_t)(k.nl - 2) * k.nh * CW + RT16 * (k.kp0 + IPAD) + RT16 * k.ny + RT16 * 33 + NYP_MAX + 2048) * 4;
+    auto kern = k.G <= 8 ? rollout_ks_fwd_kernel<8> : (k.G <= 16 ? rollout_ks_fwd_kernel<16> : rollout_ks_fwd_kernel<32>);
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd(fused): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     if (!counters_cleared) {
@@ -2239,14 +1321,11 @@ int srvp_rollout_fused_fwd(const srvp_rollout_desc* d, hipStream_t st, bool coun
 int srvp_rollout_fused_bwd(const srvp_rollout_bwd_desc* d, hipStream_t st) {
     RollF k{};
     const srvp_rollout_desc& f = d->f;
-    const bool ks = ks_eligible(f);
-    const int tiles = fused_common(f, k, f.fused_ws, ks ? RT16 : RT);
+    const int tiles = fused_common(f, k, f.fused_ws, RT16);
     k.hid = f.hid_dyn; k.d_y_all = d->d_y_all; k.d_res = d->d_res; k.dhid = d->dhid_dyn; k.dinp_all = d->dinp_all; k.d_y0 = d->d_y0;
     k.dwd = f.nh > f.ny ? f.nh : f.ny;
-    const size_t lds = ks ? ((size_t)(k.nl - 2) * k.nh * CW + RT16 * (k.nyp + IPAD) + RT16 * k.ny + RT16 * 33 + 2048) * 4
-                          : ((size_t)(k.nl - 2) * k.nh * CW + RT * (k.nyp + IPAD) + RT * k.ny + RT * 33) * 4;
-    auto kern = ks ? (k.G <= 8 ? rollout_ks_bwd_kernel<8> : (k.G <= 16 ? rollout_ks_bwd_kernel<16> : rollout_ks_bwd_kernel<32>))
-                   : (k.G <= 8 ? rollout_fused_bwd_kernel<8> : (k.G <= 16 ? rollout_fused_bwd_kernel<16> : rollout_fused_bwd_kernel<32>));
+    const size_t lds = ((size_t)(k.nl - 2) * k.nh * CW + RT16 * (k.nyp + IPAD) + RT16 * k.ny + RT16 * 33 + 2048) * 4;
+    auto kern = k.G <= 8 ? rollout_ks_bwd_kernel<8> : (k.G <= 16 ? rollout_ks_bwd_kernel<16> : rollout_ks_bwd_kernel<32>);
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_bwd(fused): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     k.cnt += (size_t)tiles * 64;                            // the backward's own counter block
@@ -2274,11 +1353,13 @@ extern "C" int64_t srvp_rollout_gen_ws_bytes(const srvp_rollout_desc* d) {
     const int nin = d->ny + d->nz;
     if (d->nl < 3 || d->nl > MAX_NL || d->nh % CW != 0 || d->nh / CW > 32 || d->nh < 32 || nin > KP0_MAX || d->ny > NYP_MAX || d->nz > NYP_MAX || d->ny > d->nh ||
         2 * d->nz > KP0_MAX || d->nsteps < 1 || d->n_euler < 1 || d->pz_external) return 0;
+    // the persistent form keeps the dynamics' hidden slices in registers: <= two hidden layers of 512 units per network (every recipe of the
+    // reference: nh_res 512, nlayers_res 4).  Other widths take the per-layer launch sequence (round 6: the 32-row LDS-resident kernel of
+    // rounds 3-4 that used to catch them is gone).
+    if (d->nl - 2 > 2 || d->nh != 512) return 0;
     const int kp0 = (nin + 15) / 16 * 16, nzp2 = (2 * d->nz + 15) / 16 * 16;
     if (nzp2 > kp0) return 0;                             // the summed prior parameters are staged in the input tile
     if (!clusters_fit(d->nh / CW)) return 0;
-    const size_t lds = ((size_t)(d->nl - 2) * d->nh * CW + RT * (kp0 + IPAD) + RT * d->ny + RT * d->nz + RT * 33 + d->ny + 2 * d->nz) * 4;
-    if (lds > 160 * 1024) return 0;
     if (!placement_round_robin()) return 0;
     // (rows rounded up to 64: either tile height of the second form, rollout_gen_ks_kernel<., 2 | 4>)
     const int64_t rows = (d->B + 63) / 64 * 64, tiles = rows / RT;
@@ -2297,9 +1378,6 @@ int srvp_rollout_gen_fwd(const srvp_rollout_desc* d, hipStream_t st) {
     }
     k.y0 = d->y0; k.qz = d->q_z_params; k.eps = d->eps_z; k.y_all = d->y_all; k.res = d->res; k.z = d->z; k.pz = d->p_z_params;
     SRVP_REQUIRE(k.n_data <= 1 || k.qz, "srvp_rollout_fwd(gen): posterior frames need q_z_params");
-    static int gks = -1;
-    if (gks < 0) { const char* e2 = getenv("SRVP_GEN_KSPLIT"); gks = e2 ? atoi(e2) : 1; }
-    const bool ks = gks && k.nl - 2 <= 2 && k.nh == 512;         // (the register-resident form: <= two hidden layers of 512 units per network)
     // tile height: 32 rows.  (64-row tiles, rollout_gen_ks_kernel<., 4>, turn the two co-resident launches of the config-5 protocol's 800 rows
     // into one -- a launch lasts as long as its chain of steps whatever its tile count -- and were built and measured in round 5: hipcc spills
     // 226 registers in that instantiation and the call gets slower, 89.8 vs 89.2 ms; not instantiated)
@@ -2310,11 +1388,9 @@ int srvp_rollout_gen_fwd(const srvp_rollout_desc* d, hipStream_t st) {
     k.cnt = (unsigned*)d->fused_ws;
     k.hbuf = (float*)((char*)d->fused_ws + (size_t)(rows64 / RT) * 256);
     k.part = k.hbuf + (size_t)rows64 * (d->nl - 2) * d->nh;
-    const size_t lds = ks ? ((size_t)rt * (k.kp0 + IPAD) + rt * k.ny + rt * k.nz + rt * 33 + 3 * NYP_MAX + 4 * (rt / 16) * 512) * 4
-                          : ((size_t)(k.nl - 2) * k.nh * CW + RT * (k.kp0 + IPAD) + RT * k.ny + RT * k.nz + RT * 33 + k.ny + 2 * k.nz) * 4;
-    void (*kern)(const GenF) = nullptr;
-    if (ks) kern = k.G <= 8 ? rollout_gen_ks_kernel<8, 2> : (k.G <= 16 ? rollout_gen_ks_kernel<16, 2> : rollout_gen_ks_kernel<32, 2>);
-    else kern = k.G <= 8 ? rollout_gen_kernel<8> : (k.G <= 16 ? rollout_gen_kernel<16> : rollout_gen_kernel<32>);
+    SRVP_REQUIRE(k.nl - 2 <= 2 && k.nh == 512, "srvp_rollout_fwd(gen): shape not eligible (srvp_rollout_gen_ws_bytes returned 0)");
+    const size_t lds = ((size_t)rt * (k.kp0 + IPAD) + rt * k.ny + rt * k.nz + rt * 33 + 3 * NYP_MAX + 4 * (rt / 16) * 512) * 4;
+    void (*kern)(const GenF) = rollout_gen_ks_kernel<16, 2>;        // (nh == 512: G = 16)
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SRVP_REQUIRE(e == hipSuccess, "srvp_rollout_fwd(gen): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
@@ -2339,18 +1415,8 @@ extern "C" int64_t srvp_lstm_fused_ws_bytes(int T, int B, int nh) {
     if (on < 0) { const char* e = getenv("SRVP_LSTM_FUSED"); on = e ? atoi(e) : 1; }
     if (!on || T < 1 || B < 1 || !(nh == 64 || nh == 128 || nh == 256)) return 0;
     if (!clusters_fit(nh / CW)) return 0;
-    const int64_t t16 = (B + 15) / 16;                    // (either form of the kernels: lstm_ks_eligible; the backward's partial slabs)
+    const int64_t t16 = (B + 15) / 16;                    // (counter blocks + the backward's partial slabs)
     return t16 * 256 + t16 * (int64_t)T * (nh / 16) * 16 * nh * 4;
-}
-// the 16-row / 16-unit form: nh a multiple of 64, every tile of the batch in ONE co-resident launch
-static bool lstm_ks_eligible(int B, int nh) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("SRVP_LSTM_KSPLIT"); on = e ? atoi(e) : 1; }
-    if (!on || nh % 64 != 0) return false;
-    device_cus();
-    const int G = nh / 16;
-    const int per_xcd = (g_ncu / 8) / G;
-    return per_xcd >= 1 && (B + 15) / 16 <= per_xcd * 8;
 }
 extern "C" int srvp_lstm_fwd_fused(const float* gates_x, const float* w_hh, float* h_out, float* c_out, float* gates_act, int T, int B,
                                    int nh, void* ws, int64_t ws_bytes, void* stream) {
@@ -2360,12 +1426,10 @@ extern "C" int srvp_lstm_fwd_fused(const float* gates_x, const float* w_hh, floa
     SRVP_REQUIRE(need > 0 && ws_bytes >= need, "srvp_lstm_fwd_fused: shape not eligible or workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)need);
     device_cus();
     LstmF k{};
-    const bool ks = lstm_ks_eligible(B, nh);
-    k.B = B; k.nh = nh; k.T = T; k.G = ks ? nh / 16 : nh / CW; k.gx = gates_x; k.whh = w_hh; k.h = h_out; k.c = c_out; k.ga = gates_act; k.cnt = (unsigned*)ws; k.xcd_local = xcd_local_on();
-    const int tiles = ks ? (B + 15) / 16 : (B + RT - 1) / RT;
-    const size_t lds = ks ? ((size_t)16 * (nh + 4) + 4 * 16 * 17) * 4 : ((size_t)RT * (nh + 1) + 4 * RT * 33) * 4;
-    auto kern = ks ? (nh == 256 ? lstm_ks_fwd_kernel<16, 1> : (nh == 128 ? lstm_ks_fwd_kernel<8, 1> : lstm_ks_fwd_kernel<4, 1>))
-                   : (nh == 256 ? lstm_fused_fwd_kernel<128> : (nh == 128 ? lstm_fused_fwd_kernel<64> : lstm_fused_fwd_kernel<32>));
+    k.B = B; k.nh = nh; k.T = T; k.G = nh / 16; k.gx = gates_x; k.whh = w_hh; k.h = h_out; k.c = c_out; k.ga = gates_act; k.cnt = (unsigned*)ws; k.xcd_local = xcd_local_on();
+    const int tiles = (B + 15) / 16;
+    const size_t lds = ((size_t)16 * (nh + 4) + 4 * 16 * 17) * 4;
+    auto kern = nh == 256 ? lstm_ks_fwd_kernel<16, 1> : (nh == 128 ? lstm_ks_fwd_kernel<8, 1> : lstm_ks_fwd_kernel<4, 1>);
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SRVP_REQUIRE(e == hipSuccess, "srvp_lstm_fwd_fused: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
@@ -2389,35 +1453,17 @@ extern "C" int srvp_lstm_bwd_fused(const float* dh_out, const float* w_hh, const
     const int64_t need = srvp_lstm_fused_ws_bytes(T, B, nh);
     SRVP_REQUIRE(need > 0 && ws_bytes >= need, "srvp_lstm_bwd_fused: shape not eligible or workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)need);
     device_cus();
-    if (lstm_ks_eligible(B, nh)) {
-        LstmB2 k{};
-        const int tiles = (B + 15) / 16;
-        k.B = B; k.nh = nh; k.T = T; k.G = nh / 16; k.dh_out = dh_out; k.whh = w_hh; k.c = c_out; k.ga = gates_act; k.dgates = dgates;
-        k.cnt = (unsigned*)ws; k.xcd_local = xcd_local_on(); k.part = (float*)((char*)ws + (size_t)tiles * 256);
-        const size_t lds = (size_t)16 * (4 * 16 + 4) * 4;
-        auto kern = nh == 256 ? lstm_ks_bwd_kernel<16, 1> : (nh == 128 ? lstm_ks_bwd_kernel<8, 1> : lstm_ks_bwd_kernel<4, 1>);
-        hipError_t e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
-        SRVP_REQUIRE(e == hipSuccess, "srvp_lstm_bwd_fused: memset failed");
-        int cpx;
-        const int per = clusters_per_launch(k.G, tiles, cpx);
-        k.tile0 = 0; k.ntiles = tiles; k.cl_per_xcd = cpx;
-        SRVP_REQUIRE(tiles <= per, "srvp_lstm_bwd_fused: %d tiles for %d cluster slots", tiles, per);
-        hipLaunchKernelGGL(kern, dim3(8 * cpx * k.G), dim3(256), lds, st, k);
-        SRVP_CHECK_LAUNCH("srvp_lstm_bwd_fused");
-        return SRVP_OK;
-    }
-    LstmB k{};
-    k.B = B; k.nh = nh; k.T = T; k.G = nh / CW; k.dh_out = dh_out; k.whh = w_hh; k.c = c_out; k.ga = gates_act; k.dgates = dgates; k.cnt = (unsigned*)ws; k.xcd_local = xcd_local_on();
-    const int tiles = (B + RT - 1) / RT;
-    const size_t lds = ((size_t)RT * (4 * nh + 1) + 4 * RT * 33) * 4;
-    SRVP_REQUIRE(lds <= 160 * 1024, "srvp_lstm_bwd_fused: %zu bytes of LDS", lds);
-    auto kern = nh == 256 ? lstm_fused_bwd_kernel<128> : (nh == 128 ? lstm_fused_bwd_kernel<64> : lstm_fused_bwd_kernel<32>);
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    SRVP_REQUIRE(e == hipSuccess, "srvp_lstm_bwd_fused: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-    e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
+    LstmB2 k{};
+    const int tiles = (B + 15) / 16;
+    k.B = B; k.nh = nh; k.T = T; k.G = nh / 16; k.dh_out = dh_out; k.whh = w_hh; k.c = c_out; k.ga = gates_act; k.dgates = dgates;
+    k.cnt = (unsigned*)ws; k.xcd_local = xcd_local_on(); k.part = (float*)((char*)ws + (size_t)tiles * 256);
+    const size_t lds = (size_t)16 * (4 * 16 + 4) * 4;
+    auto kern = nh == 256 ? lstm_ks_bwd_kernel<16, 1> : (nh == 128 ? lstm_ks_bwd_kernel<8, 1> : lstm_ks_bwd_kernel<4, 1>);
+    hipError_t e = hipMemsetAsync(k.cnt, 0, (size_t)tiles * 256, st);
     SRVP_REQUIRE(e == hipSuccess, "srvp_lstm_bwd_fused: memset failed");
     int cpx;
     const int per = clusters_per_launch(k.G, tiles, cpx);
+    // (more 16-row tiles than one co-resident launch holds -- B > 256 at nh = 256: the groups run one after the other on this stream)
     for (int t0 = 0; t0 < tiles; t0 += per) {
         k.tile0 = t0; k.ntiles = tiles - t0 < per ? tiles - t0 : per; k.cl_per_xcd = cpx;
         hipLaunchKernelGGL(kern, dim3(8 * cpx * k.G), dim3(256), lds, st, k);

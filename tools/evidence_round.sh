@@ -35,7 +35,6 @@ stats _rollout_human --config human --mode rollout --no-cpu-baseline
 python bench.py --h2d u8 --no-cpu-baseline --no-kernel-timing > $OUT/${R}_bench_h2d_u8.json 2>/dev/null
 # persistent latent kernels in isolation, both forms
 python tools/rollout_time.py 24 100 192 > $OUT/${R}_rollout_time.jsonl 2>/dev/null
-SRVP_ROLLOUT_KSPLIT=0 SRVP_LSTM_KSPLIT=0 python tools/rollout_time.py 24 100 192 > $OUT/${R}_rollout_time_32row.jsonl 2>/dev/null
-(SRVP_RF_DEBUG=1 python tools/rollout_time.py 24 2>&1 | grep RF_DEBUG | tail -1; SRVP_ROLLOUT_KSPLIT=0 SRVP_RF_DEBUG=1 python tools/rollout_time.py 24 2>&1 | grep RF_DEBUG | tail -1) > $OUT/${R}_rollout_phase_times.txt
+(SRVP_RF_DEBUG=1 python tools/rollout_time.py 24 2>&1 | grep RF_DEBUG | tail -1) > $OUT/${R}_rollout_phase_times.txt
 ls -la $OUT | grep ${R}_ | wc -l
 for f in $OUT/${R}_bench*.json; do echo $f; python -c "import json,sys; d=json.loads(open('$f').read().strip().splitlines()[-1]); print(d['ms_per_step'], d.get('roofline',{}).get('frac'))"; done
