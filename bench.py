@@ -267,6 +267,8 @@ def main():
     ap.add_argument('--samples', type=int, default=None, help='rollout mode: futures per video (default: the recipe, 100)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-unshared', action='store_true', help='skip the extra untimed steps with the second stream off (a rocprofv3 --stats run of this '
+                    'command then tabulates default-schedule steps only)')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # `python bench.py --gpus N` on its own: start the N ranks ourselves (one process per GPU under torch.distributed.run,
@@ -397,7 +399,7 @@ def main():
     # on the second stream, concurrently with the data-gradient / BatchNorm kernels of the main stream (a faster step, and launch
     # durations that include the sharing); two more untimed steps with the second stream switched off give the kernels' own rate.
     unshared = None
-    if prof is not None:
+    if prof is not None and not args.no_unshared:
         import srvp_amd.model as _m
         import srvp_amd.convnet as _cn
         saved = (_m.OVERLAP_WGRAD, _m.OVERLAP_SKIP, _m.OVERLAP_PACK, _cn.ENC_WGRAD_SIDE_MAXN)

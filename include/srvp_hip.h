@@ -110,6 +110,13 @@ int srvp_conv_mfma(const srvp_conv_desc* d, void* stream);
  * the geometry is the one this kernel covers (SRVP_CONV_OUT_STREAM=0 switches it off: the layer then runs through srvp_conv_mfma). */
 int srvp_conv_out_eligible(int C0, int H, int W, int Cout_real, int k, int s, int p);
 int srvp_conv_out_fwd(const void* act, const void* wt_tapmajor, float* out, int N, int Cout_real, int sigmoid, void* stream);
+/* Image-side OUTPUT layer of the DCGAN decoder (conv.py:304-305: ConvTranspose2d(64 -> nc <= 3, 4x4, stride 2, pad 1) + sigmoid, 32x32 -> 64x64)
+ * as a streaming kernel of the same kind (csrc/conv_out.hip): act = bf16 [N][34][34][64] (1-pixel zero border), w_f32 = the layer's fp32 master
+ * weight (Cin = 64, nc, 4, 4) -- rounded to bf16 by the kernel itself (round to nearest even, as srvp_pack_weight does), out = fp32
+ * (N, Cout_real, 64, 64).  Sub-pixel form: the 4 nc (phase, channel) pairs are the N dimension of the 16x16x32 MFMA, K = 64 channels x the
+ * 3x3 window of low-resolution pixels.  srvp_conv_up_out_eligible: 1 for the geometry covered (SRVP_CONV_OUT_STREAM=0: off). */
+int srvp_conv_up_out_eligible(int C0, int Hin, int Win, int Cout_real, int k, int s, int p);
+int srvp_conv_up_out_fwd(const void* act, const float* w_f32, float* out, int N, int Cout_real, int sigmoid, void* stream);
 /* 1 (default): 3x3 stride-1 single-source convolutions run on the halo-tiled kernel (input patch staged in LDS once
  * per channel chunk, taps = LDS offsets); 0: every convolution on the generic tap-gather kernel.  Same results, bit for bit. */
 int srvp_conv_set_halo(int on);

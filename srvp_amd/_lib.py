@@ -132,6 +132,8 @@ _SIGS = {
     'srvp_conv_set_in_stream': ([c_i32], c_i32),
     'srvp_conv_out_eligible': ([c_i32] * 7, c_i32),
     'srvp_conv_out_fwd': ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
+    'srvp_conv_up_out_eligible': ([c_i32] * 7, c_i32),
+    'srvp_conv_up_out_fwd': ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
     'srvp_pack_weight_tiles': ([c_vp, c_i32, c_i64, c_vp], c_i32),
     'srvp_unpack_wgrad_tiles': ([c_vp, c_i32, c_i64, c_vp], c_i32),
     'srvp_unpack_wgrad': ([c_vp, c_vp, C.POINTER(PackDesc), c_vp], c_i32),

@@ -391,6 +391,11 @@ class Block:
         self.stream_out = bool(self.role == 'out' and self.geom == 'sameT' and not self.f32 and len(self.srcs) == 1 and co_p == 32 and
                                self.srcs[0].b == 1 and self.srcs[0].C == 64 and not self.ups and not getattr(self.srcs[0], 's2d', False) and
                                L.load().srvp_conv_out_eligible(self.ctot, self.OH, self.OW, co_r, self.k, self.s, self.p))
+        # image-side output layer of the DCGAN decoder (transposed 4x4 stride 2, 32x32 -> 64x64) on its streaming kernel (csrc/conv_out.hip,
+        # round 6): reads the bordered [N][34][34][64] activation and the fp32 master weight directly
+        self.stream_up_out = bool(self.role == 'out' and self.geom == 'up' and not self.f32 and len(self.srcs) == 1 and self.srcs[0].b == 1
+                                  and self.srcs[0].C == 64 and not self.ups and not getattr(self.srcs[0], 's2d', False)
+                                  and L.load().srvp_conv_up_out_eligible(self.ctot, self.Hin, self.Win, co_r, self.k, self.s, self.p))
         if self.stream_out:
             self.pf_o = _pack_desc(order_f, co_p, self.ctot, osegs, isegs, sj_f, sk_f)
             self.pf_o.layout = 0
@@ -1543,6 +1548,11 @@ class DecoderNet(ConvNetBase):
         if getattr(ob, 'stream_out', False):
             # image-side output layer on the streaming kernel: rolling LDS row window, packed-bf16 dot products, sigmoid + fp32 frames
             L.call('srvp_conv_out_fwd', L.ptr(ob.srcs[0].t), L.ptr(ob.wt_o), L.ptr(self.x_out), self.N, ob.cout_r, 1, st)
+            return self.x_out
+        if getattr(ob, 'stream_up_out', False):
+            # DCGAN output layer (conv.py:304-305: ConvTranspose2d(64, nc, 4, 2, 1) + sigmoid) on its streaming kernel: 4 nc (phase, channel)
+            # columns of a 16-wide MFMA tile instead of four phase convolutions with nc padded to 32 (0.31 -> 0.07 ms at 1920 frames)
+            L.call('srvp_conv_up_out_fwd', L.ptr(ob.srcs[0].t), L.ptr(params[ob.spec['key'] + '.weight']), L.ptr(self.x_out), self.N, ob.cout_r, 1, st)
             return self.x_out
         # (other geometries: MFMA conv with Cout padded to 32, sigmoid + fp32 frame store in the epilogue)
         if ob.geom == 'up' and len(ob._fwd) == 4 and PHASES_ONE_GRID:

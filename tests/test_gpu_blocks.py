@@ -555,6 +555,36 @@ def test_conv_out_stream_matches_tile_kernel(N, nc):
     assert (blk.x_out[:3].cpu() - t).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize('N,nc', [(5, 1), (300, 1), (700, 3), (1100, 1), (1920, 1)])
+def test_conv_up_out_stream_matches_tile_kernel_and_torch(N, nc):
+    """csrc/conv_out.hip, second kernel (round 6): the DCGAN decoder's image-side output layer -- ConvTranspose2d(64 -> nc, 4x4, stride 2,
+    pad 1) + sigmoid, 32x32 -> 64x64 (reference module/conv.py:304-305) -- as a streaming kernel in sub-pixel form, against the padded
+    32-column tile kernel (four phase convolutions as one grid) and, on three frames, against torch's conv_transpose2d on the CPU with
+    bf16-rounded operands."""
+    from srvp_amd import _lib as L
+    from srvp_amd.convnet import Block
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(29)
+    f0 = make_feat(N, 32, 32, 64, dev, g)
+    spec = dict(kind='convT', key='w', bnkey=None, cin=64, cout=nc, k=4, s=2, p=1, act='sigmoid')
+    blk = Block(spec, 'out', [f0], False, N, dev, False)
+    assert blk.stream_up_out and blk.geom == 'up'
+    blk._fwd = blk.fwd_descs()
+    w = (torch.randn(64, nc, 4, 4, generator=g) * 0.1).to(dev)
+    st = L.stream()
+    blk.pack(w, st)
+    arr = (L.ConvDesc * 4)(*blk._fwd)
+    L.call('srvp_conv_mfma_multi', arr, 4, st)
+    torch.cuda.synchronize()
+    ref = blk.x_out.clone()
+    blk.x_out.fill_(7.0)
+    L.call('srvp_conv_up_out_fwd', L.ptr(f0.t), L.ptr(w), L.ptr(blk.x_out), N, nc, 1, st)
+    torch.cuda.synchronize()
+    assert (blk.x_out - ref).abs().max().item() < 2e-6, (blk.x_out - ref).abs().max().item()
+    t = torch.sigmoid(F.conv_transpose2d(feat_nchw(f0)[:3], bf(w.cpu()), None, 2, 1))
+    assert (blk.x_out[:3].cpu() - t).abs().max().item() < 1e-5
+
+
 SPLIT_CASES = [
     # c0r (low-res main input, upsampled x2), c1r (skip), Hs, cout, T, B
     (512, 512, 4, 512, 3, 2),       # decoder.conv.0.0: 1024 -> 512 @ 8x8 (split skip half + sub-pixel main half)

@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 python $ROOT/bench.py --config $CFG > $OUT/${R}_bench$SUF.json 2> $OUT/${R}_bench$SUF.err
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/prof && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o p -- python $ROOT/bench.py --config $CFG --no-cpu-baseline > $OUT/prof_run.log 2>&1
+rm -rf /tmp/prof && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o p -- python $ROOT/bench.py --config $CFG --no-cpu-baseline --no-unshared > $OUT/prof_run.log 2>&1
 cp /tmp/prof/p_kernel_stats.csv $OUT/${R}_kernel_stats$SUF.csv 2>/dev/null || find /tmp/prof -name "*kernel_stats.csv" -exec cp {} $OUT/${R}_kernel_stats$SUF.csv \;
 if [ "$CFG" == "bair" ]; then
 rm -rf /tmp/pmc && rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum \
