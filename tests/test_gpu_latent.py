@@ -44,19 +44,23 @@ def test_latent_forward_backward(case, ne, T, B, dims):
     hx = torch.tanh(torch.randn(T, B, nhx, generator=g))
     tape = dict(t_w=torch.stack([torch.randperm(T, generator=g)[:nt_inf] for _ in range(B)], 1),
                 eps_y0=torch.randn(B, ny, generator=g), eps_z=torch.randn(T - 1, B, nz, generator=g))
-    # ---- oracle
-    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    # ---- oracle (the large-batch cases in float64: the CPU's own fp32 autograd moves by 1.5e-4 on d_hx / 2.5e-3 on a bias gradient between
+    # 8 and 128 host threads at B = 300 -- more than the tolerances below -- while the HIP result is the same to 1e-9 either way; measured
+    # round 6, when the case passed alone and failed behind any test file that had called torch.set_num_threads(8))
+    odt = torch.float64 if B >= 300 else torch.float32
+    cast = lambda v: v.to(odt) if v.is_floating_point() else v
+    sd = {k: cast(v.detach().clone()) for k, v in model.state_dict().items()}
     lat_keys = [k for k in sd if not k.startswith(('encoder.', 'decoder.'))]
     leaves = {k: sd[k].clone().requires_grad_(True) for k in lat_keys}
     work = dict(sd)
     work.update(leaves)
-    hxr = hx.clone().requires_grad_(True)
+    hxr = cast(hx).clone().requires_grad_(True)
     w = O.infer_w(work, cfg, hxr, True, tape['t_w'])
-    y0, qy0 = O.infer_y(work, cfg, hxr[:nt_inf], tape['eps_y0'])
-    y, z, qz, pz, res = O.generate(work, cfg, y0, hxr, T, ne, tape['eps_z'], True)
+    y0, qy0 = O.infer_y(work, cfg, hxr[:nt_inf], cast(tape['eps_y0']))
+    y, z, qz, pz, res = O.generate(work, cfg, y0, hxr, T, ne, cast(tape['eps_z']), True)
     cot = {n: torch.randn(t.shape, generator=g) for n, t in dict(y=y, w=w, qy0=qy0, qz=qz, pz=pz, res=res).items()}
-    total = (y * cot['y']).sum() + (w * cot['w']).sum() + (qy0 * cot['qy0']).sum() + (qz * cot['qz']).sum() + \
-        (pz * cot['pz']).sum() + (res * cot['res']).sum()
+    total = (y * cast(cot['y'])).sum() + (w * cast(cot['w'])).sum() + (qy0 * cast(cot['qy0'])).sum() + (qz * cast(cot['qz'])).sum() + \
+        (pz * cast(cot['pz'])).sum() + (res * cast(cot['res'])).sum()
     gl = torch.autograd.grad(total, [hxr] + [leaves[k] for k in lat_keys])
     g_hx, g_par = gl[0], dict(zip(lat_keys, gl[1:]))
     # ---- HIP

@@ -107,8 +107,8 @@ def test_hip_two_ranks_bf16_gradient_payload(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('cfg,batch', [('bair', 8), ('smmnist', 8)])
-def test_gradient_slices_tile_the_buffer_and_overlap_backward(cfg, batch):
+@pytest.mark.parametrize('cfg,batch,bf16', [('bair', 8, '0'), ('smmnist', 8, '0'), ('bair', 8, '1')])
+def test_gradient_slices_tile_the_buffer_and_overlap_backward(cfg, batch, bf16):
     """The sliced gradient exchange (model._backward_impl / Sync.reduce_slice; reference train.py:309-314: DDP's bucketed all-reduce under
     backward) on one rank with the collectives forced on, through the native RCCL path: the slices tile the flat gradient buffer exactly
     once (nothing exchanged twice, nothing left out), at least 5 of them are issued (VGG), and what is issued after the step's last
@@ -116,7 +116,8 @@ def test_gradient_slices_tile_the_buffer_and_overlap_backward(cfg, batch):
     gradients are enqueued last on the host but run on a stream of their own right behind the latent backward, so on the device the slice
     is final before the encoder backward is) and the encoder's first stages (1 MB, final with the step's last kernel)."""
     import json
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    # (bf16 = '1': the same with SRVP_GRAD_BF16=1 -- cast, ncclAllReduce(bf16, avg), widen on the native path of a 1-rank communicator)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), SRVP_GRAD_BF16=bf16)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'count_collectives.py'), cfg, str(batch)], capture_output=True, text=True,

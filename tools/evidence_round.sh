@@ -23,7 +23,7 @@ python bench.py --batch 24 --no-cpu-baseline > $OUT/${R}_bench_b24.json 2>/dev/n
 python bench.py --batch 24 --no-cpu-baseline --no-kernel-timing --steps 40 --warmup 10 > $OUT/${R}_bench_b24_untimed.json 2>/dev/null
 SRVP_FORCE_COLLECTIVES=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --batch 24 --no-cpu-baseline --no-kernel-timing --steps 40 --warmup 10 > $OUT/${R}_bench_b24_forced.json 2> $OUT/forced.err
 stats _b24 --batch 24 --no-cpu-baseline --no-unshared
-python tools/count_collectives.py bair 24 2>/dev/null | tail -1 > $OUT/${R}_collectives_b24.json
+python tools/count_collectives.py bair 24 2>/dev/null | grep "^{" | tail -1 > $OUT/${R}_collectives_b24.json
 B=24 python tools/layer_times.py > $OUT/${R}_layer_times_b24.txt 2>/dev/null
 python tools/layer_times.py > $OUT/${R}_layer_times_b192.txt 2>/dev/null
 B=24 python tools/host_time.py > $OUT/${R}_host_time_b24.txt 2>/dev/null

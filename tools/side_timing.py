@@ -29,8 +29,9 @@ def ev(name, stream=None):
 orig_dw = convnet.DecoderNet.deferred_wgrads
 def dw(self, grads, st):
     ev('side: decoder wgrads start', torch.cuda.current_stream())
-    orig_dw(self, grads, st)
+    r = orig_dw(self, grads, st)
     ev('side: decoder wgrads end', torch.cuda.current_stream())
+    return r
 convnet.DecoderNet.deferred_wgrads = dw
 orig_db = convnet.DecoderNet.backward
 def db(self, *a, **k):
