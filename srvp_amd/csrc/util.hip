@@ -226,7 +226,7 @@ extern "C" int srvp_cast_f32_bf16(const float* src, void* dst, int64_t rows, int
 namespace {
 __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long long n, float scale) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        dst[i] = (float)src[i] * scale;
+        dst[i] = bf2f(src[i]) * scale;
 }
 }  // namespace
 extern "C" int srvp_cast_bf16_f32(const void* src, float* dst, int64_t n, float scale, void* stream) {

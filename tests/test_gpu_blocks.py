@@ -585,6 +585,26 @@ def test_conv_up_out_stream_matches_tile_kernel_and_torch(N, nc):
     assert (blk.x_out[:3].cpu() - t).abs().max().item() < 1e-5
 
 
+def test_bf16_payload_casts_round_trip():
+    """srvp_cast_f32_bf16 / srvp_cast_bf16_f32 (the two ends of the opt-in bf16 gradient payload, SRVP_GRAD_BF16=1): fp32 -> bf16 is torch's
+    round-to-nearest-even, bf16 -> fp32 * scale is exact, at odd offsets and lengths."""
+    from srvp_amd import _lib as L
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(1_000_003, generator=g) * torch.logspace(-6, 3, 1_000_003)).to(dev)
+    st = L.stream()
+    for lo, hi in ((0, 1_000_003), (1, 4098), (77777, 900001)):
+        sl = x[lo:hi].contiguous()
+        pay = torch.zeros(hi - lo + 8, dtype=torch.bfloat16, device=dev)[3:3 + hi - lo]
+        L.call('srvp_cast_f32_bf16', L.ptr(sl), L.ptr(pay), 1, hi - lo, hi - lo, st)
+        torch.cuda.synchronize()
+        assert torch.equal(pay, sl.bfloat16())
+        out = torch.empty(hi - lo, dtype=torch.float32, device=dev)
+        L.call('srvp_cast_bf16_f32', L.ptr(pay), L.ptr(out), hi - lo, 0.5, st)
+        torch.cuda.synchronize()
+        assert torch.equal(out, pay.float() * 0.5)
+
+
 SPLIT_CASES = [
     # c0r (low-res main input, upsampled x2), c1r (skip), Hs, cout, T, B
     (512, 512, 4, 512, 3, 2),       # decoder.conv.0.0: 1024 -> 512 @ 8x8 (split skip half + sub-pixel main half)

@@ -124,6 +124,14 @@ def test_gradient_slices_tile_the_buffer_and_overlap_backward(cfg, batch, bf16):
                        timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    if bf16 == '1':
+        # the gradient that comes out of the bf16 exchange is the fp32 one rounded to bf16 (one rank: the average is the identity): same
+        # length to 2^-8 -- a payload path that mangled the values (round 6: a widening kernel that read the bf16 BITS as integers) fails here
+        r0 = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'count_collectives.py'), cfg, str(batch)], capture_output=True, text=True,
+                            timeout=600, cwd=ROOT, env=dict(env, SRVP_GRAD_BF16='0', MASTER_PORT=str(_free_port())))
+        assert r0.returncode == 0, r0.stdout[-2000:] + r0.stderr[-3000:]
+        d0 = json.loads([l for l in r0.stdout.splitlines() if l.startswith('{')][-1])
+        assert abs(d['grad_norm_after_exchange'] - d0['grad_norm_after_exchange']) <= 4e-3 * d0['grad_norm_after_exchange'], (d, d0)
     assert d['tiles_buffer_exactly_once'], d
     assert 'rccl' in d['transport'], d
     if cfg == 'bair':

@@ -55,7 +55,8 @@ after = [(e[1], e[2]) for e in events[last_wg + 1:] if e[0] == 'slice']
 total = m._flat[1].numel() if sum(p.numel() for p in m.parameters()) == m._flat[1].numel() else sum(p.numel() for p in m.parameters())
 srt = sorted(slices)
 tiles = bool(srt) and srt[0][0] == 0 and all(a[1] == b[0] for a, b in zip(srt, srt[1:])) and srt[-1][1] == sum(p.numel() for p in m.parameters())
-print(json.dumps(dict(config=sys.argv[1] if len(sys.argv) > 1 else 'bair', batch=B, statistics_allreduces=cnt['stats'], gradient_allreduces=cnt['grads'],
+gnorm = float(m._flat[1][:sum(p.numel() for p in m.parameters())].double().norm().item())
+print(json.dumps(dict(grad_norm_after_exchange=gnorm, config=sys.argv[1] if len(sys.argv) > 1 else 'bair', batch=B, statistics_allreduces=cnt['stats'], gradient_allreduces=cnt['grads'],
                       slices_in_issue_order=slices, slice_mbytes=[round((b - a) * 4 / 1e6, 2) for a, b in slices],
                       after_last_weight_gradient=after, after_last_weight_gradient_mbytes=[round((b - a) * 4 / 1e6, 2) for a, b in after],
                       tiles_buffer_exactly_once=tiles, transport=sync.describe())))
