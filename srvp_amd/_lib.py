@@ -230,7 +230,16 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_get_dev = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def stream():
+    """Raw handle of torch's CURRENT stream on the current device (what `with torch.cuda.stream(s)` sets).  Through torch's raw getter:
+    torch.cuda.current_stream().cuda_stream builds a Stream object behind four Python-level device lookups, 9 us a call, ~120 calls per
+    step (round 6, tools/host_profile.py)."""
+    if _raw_stream is not None and _get_dev is not None:
+        return _raw_stream(_get_dev())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -238,10 +247,90 @@ PROFILE = None      # set to a dict by bench.py: name -> list of (start_event, e
 PROFILE_ONLY = None  # optional set of entry-point names to time (None = all); keeps the event overhead out of a timed run
 
 
+# ---- torch's CURRENT stream, tracked on the step path.  torch.cuda.current_stream() costs ~10 us of Python per call (four device-index
+# helpers and a Stream object), and `with torch.cuda.stream(s)`, `event.record()`, `event.wait()` each call it: ~120 calls = 1 ms of the
+# host work of a step (round 6, tools/host_profile.py).  The step therefore sets / restores torch's current stream through the helpers
+# below, which remember the Stream OBJECT they made current: step_scope() looks the caller's stream up once, on_stream(s) replaces
+# `with torch.cuda.stream(s)`, record() / wait(e) replace the argument-less Event.record() / current_stream().wait_event(e).  torch's own
+# current stream is always the one these helpers believe it is (they call torch.cuda.set_stream), so torch ops inside keep working.
+import threading
+
+_tls = threading.local()
+
+
+def _stack():
+    st = getattr(_tls, 'stack', None)
+    if st is None:
+        st = _tls.stack = []
+    return st
+
+
+def cur_stream():
+    """torch's current Stream object (tracked inside a step_scope / on_stream; looked up otherwise)."""
+    st = _stack()
+    return st[-1] if st else torch.cuda.current_stream()
+
+
+class step_scope:
+    """Looks the caller's current stream up ONCE for everything below (model._forward_impl / _backward_impl, optimizer step)."""
+    __slots__ = ('pushed',)
+
+    def __enter__(self):
+        st = _stack()
+        self.pushed = not st
+        if self.pushed:
+            st.append(torch.cuda.current_stream())
+        return st[-1]
+
+    def __exit__(self, *exc):
+        if self.pushed:
+            _stack().pop()
+        return False
+
+
+class on_stream:
+    """`with torch.cuda.stream(s)` on the same device, without the look-ups."""
+    __slots__ = ('s', 'prev')
+
+    def __init__(self, s):
+        self.s = s
+
+    def __enter__(self):
+        st = _stack()
+        self.prev = st[-1] if st else torch.cuda.current_stream()
+        torch.cuda.set_stream(self.s)
+        st.append(self.s)
+        return self.s
+
+    def __exit__(self, *exc):
+        _stack().pop()
+        torch.cuda.set_stream(self.prev)
+        return False
+
+
+def record(event=None):
+    """A (new) event recorded on the current stream."""
+    e = torch.cuda.Event() if event is None else event
+    e.record(cur_stream())
+    return e
+
+
+def wait(event):
+    """The current stream waits for `event`."""
+    event.wait(cur_stream())
+
+
+_FN = {}
+
+
 def call(name, *args):
-    fn = getattr(load(), name)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(load(), name)
     if PROFILE is None or (PROFILE_ONLY is not None and name not in PROFILE_ONLY):
-        check(fn(*args), name)
+        rc = fn(*args)
+        if rc != 0:
+            check(rc, name)
         return
     # torch.cuda.Event records on torch's current stream, which is the stream every launch is issued on (stream())
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1366,7 +1366,7 @@ class EncoderNet(ConvNetBase):
             self.zero_forward_accumulators()
         for blk in self.blocks:
             if packed is not None and blk.role != 'in':
-                torch.cuda.current_stream().wait_event(packed)
+                L.wait(packed)
                 packed = None
             self._block_forward(blk, params, st, sync, x=x, keep=keep)
             if on_skip is not None and blk.spec['skip_out'] is not None:
@@ -1417,30 +1417,27 @@ class EncoderNet(ConvNetBase):
             todo = [(i, b) for i, b in enumerate(self.blocks) if b.pool is not None and getattr(b, '_reduce_fused', False)
                     and b.has_bn and b.spec['skip_out'] is not None and (3 - b.spec['skip_out']) in skip_grads and i + 1 < nb]
             if todo:
-                ev = torch.cuda.Event()
-                ev.record()                                               # accumulators cleared, skip gradients written
-                with torch.cuda.stream(aux):
+                ev = L.record()                                               # accumulators cleared, skip gradients written
+                with L.on_stream(aux):
                     aux.wait_event(ev)
                     for i, b in todo:
                         q = self.blocks[i + 1]
                         self._skip_reduce(b, dict(t=q.dcat, mode=2, cstride=q.dcat_c, coff=0, border=0,
                                                   **self._skip_term(b, skip_grads[3 - b.spec['skip_out']])), L.stream())
-                    skip_red = torch.cuda.Event()
-                    skip_red.record()
+                    skip_red = L.record()
                 self._skip_red_blocks = {id(b) for _, b in todo}
         for i in range(nb - 1, -1, -1):
             blk = self.blocks[i]
             if blk.role == 'in' and side is not None and nb > 1:
-                ev = torch.cuda.Event()
-                ev.record()
-                with torch.cuda.stream(side):
+                ev = L.record()
+                with L.on_stream(side):
                     side.wait_event(ev)
                     self.unpack_wgrads(grads, L.stream(), part=(0, split_at) if split_at else None)
                 unpacked = True
             if split_at and i == split_at - 1 and wg_on_side:
                 # (round 5) every weight gradient of blocks >= split_at has been issued on `side`: their unpacking (97 % of the encoder's
                 # weights: 85 us that ran as the step's tail behind the LAST weight gradient) goes out now, in front of the first blocks'
-                with torch.cuda.stream(side):
+                with L.on_stream(side):
                     self.unpack_wgrads(grads, L.stream(), part=(split_at, nb))
                     if on_part is not None:
                         on_part(split_at, nb)
@@ -1448,7 +1445,7 @@ class EncoderNet(ConvNetBase):
             if sk is not None and skip_grads and (3 - sk) in skip_grads:
                 da.update(self._skip_term(blk, skip_grads[3 - sk]))
                 if skip_red is not None and id(blk) in self._skip_red_blocks:
-                    torch.cuda.current_stream().wait_event(skip_red)      # (its da_mode 3 term was accumulated on `aux`)
+                    L.wait(skip_red)      # (its da_mode 3 term was accumulated on `aux`)
                     da['da2_reduced'] = True
             if blk.role == 'in':
                 w = blk.spec['key'] + '.weight'
@@ -1463,9 +1460,8 @@ class EncoderNet(ConvNetBase):
                         # A/B (round 5): the block's weight gradient released only when its data gradient is done, so that it
                         # runs beside the HBM-bound BatchNorm pass of the block below instead of beside its own MFMA-bound data gradient
                         self._mfma_backward(blk, grads, st, wgrad=False)
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    with torch.cuda.stream(side):
+                    ev = L.record()
+                    with L.on_stream(side):
                         side.wait_event(ev)
                         self._wgrad(blk, L.stream())
                     if not ENC_WGRAD_AFTER_DGRAD:
@@ -1617,9 +1613,8 @@ class DecoderNet(ConvNetBase):
         self._wg_deferred = []
 
         def on_side(fn):
-            ev = torch.cuda.Event()
-            ev.record()
-            with torch.cuda.stream(side):
+            ev = L.record()
+            with L.on_stream(side):
                 side.wait_event(ev)
                 fn(L.stream())
         # The data-gradient of the image-side layer contracts over nc*k*k <= 48 values per pixel: as an MFMA conv on the

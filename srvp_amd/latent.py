@@ -154,8 +154,7 @@ class LatentNet:
             if rows is None:
                 rows = self._w_rows_dev = torch.zeros(ti * B, dtype=torch.long, device=hx.device)
             rows.copy_(host, non_blocking=True)
-            self._w_rows_copied = torch.cuda.Event()
-            self._w_rows_copied.record()
+            self._w_rows_copied = L.record()
         elif t_w is not None:
             rows = (t_w.reshape(-1) * B + torch.arange(B, device=hx.device).repeat(ti)).to(torch.long)
         else:
@@ -260,13 +259,11 @@ class LatentNet:
                 if pz_stream is None:
                     prior(st)
                 else:
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    with torch.cuda.stream(pz_stream):
+                    ev = L.record()
+                    with L.on_stream(pz_stream):
                         pz_stream.wait_event(ev)
                         prior(L.stream())
-                        self.pz_done = torch.cuda.Event()
-                        self.pz_done.record()
+                        self.pz_done = L.record()
         else:
             self.y_all[0].copy_(y0)
         y = self.y_all[::self.ne]
@@ -338,9 +335,8 @@ class LatentNet:
             linear_bwd(s_, self.h_sel, params['w_proj.0.weight'], self.d_proj, grads['w_proj.0.weight'], grads['w_proj.0.bias'],
                        dx=self.d_hsel, defer=defer)
         if aux is not None and d_w is not None:
-            ev0 = torch.cuda.Event()
-            ev0.record()                                    # d_w (and everything the caller prepared) exists
-            with torch.cuda.stream(aux):
+            ev0 = L.record()                                    # d_w (and everything the caller prepared) exists
+            with L.on_stream(aux):
                 aux.wait_event(ev0)
                 w_chain(L.stream())
         # ---- rollout
@@ -361,17 +357,15 @@ class LatentNet:
             if pz_pre is None:
                 self.pz_backward_chain(params, d_pz, st)
             else:
-                torch.cuda.current_stream().wait_event(pz_pre)
+                L.wait(pz_pre)
             L.call('srvp_add_blocks_f32', L.ptr(self.d_y_all), ne * B * ny, L.ptr(self._pz_dx), F, B * ny, st)
         L.call('srvp_rollout_bwd', C.byref(bd), st)
         if aux is not None:
-            ev1 = torch.cuda.Event()
-            ev1.record()                                    # d_y0 exists
-            with torch.cuda.stream(aux):
+            ev1 = L.record()                                    # d_y0 exists
+            with L.on_stream(aux):
                 aux.wait_event(ev1)
                 y0_chain(L.stream())
-                aux_done = torch.cuda.Event()
-                aux_done.record()
+                aux_done = L.record()
         # weight gradients of dynamics / p_z: one GEMM per layer over all (step, sample) rows
         for name, nrow, width, dh, hid, inp, nin, nout in (
                 ('dynamics', S * B, self.dwd, self.dhid_dyn, self.hid_dyn, self.inp_all.view(S * B, -1), ny + nz, ny),
@@ -431,7 +425,7 @@ class LatentNet:
             if d_w is not None:
                 w_chain(st)
         else:
-            torch.cuda.current_stream().wait_event(aux_done)
+            L.wait(aux_done)
         rows = self.__dict__.get('_qy_rows')
         if rows is None:
             rows = self._qy_rows = (torch.arange(ti, dtype=torch.int32).view(1, ti) * B + torch.arange(B, dtype=torch.int32).view(B, 1)).reshape(-1).to(self.dev)

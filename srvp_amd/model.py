@@ -250,7 +250,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
                     nlayers_res=self.nlayers_res, archi=self.archi)
 
     def _device(self):
-        return next(self.parameters()).device
+        return self._enumerate()['plist'][0].device
 
     def _require_gpu(self):
         dev = self._device()
@@ -260,10 +260,30 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         L.load()
         return dev
 
+    # ---- cached enumeration of the module tree.  nn.Module.parameters() / named_parameters() / named_buffers() walk the whole hierarchy
+    # (~100 modules) on every call; the step asked for them ~10 times (1.5 ms of the 4 ms of host work per step at 24 sequences,
+    # tools/host_profile.py).  The Parameter OBJECTS survive everything the training loop does to the model (.to() / .cuda() re-home
+    # .data in place, load_state_dict copies in place, SyncBatchNorm conversion re-uses them); buffers are replaced by _apply(), so
+    # the cache is dropped there.  Adding / removing submodules after the first step is not supported.
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self.__dict__.pop('_enum', None)
+        self._pack_version = None
+        return r
+
+    def _enumerate(self):
+        e = self.__dict__.get('_enum')
+        if e is None:
+            named_p = list(self.named_parameters())
+            d = dict(named_p)
+            d.update(dict(self.named_buffers()))
+            e = self.__dict__['_enum'] = dict(plist=[p for _, p in named_p], pnames=[k for k, _ in named_p], named=d)
+        return e
+
     def flatten_parameters_(self):
         """Re-homes every parameter (and its gradient) into one flat fp32 buffer: one fused Adam launch and one
         contiguous all-reduce payload.  Parameter objects (and hence optimizers / state dicts) are unchanged."""
-        ps = list(self.parameters())
+        ps = self._enumerate()['plist']
         dev = ps[0].device
         if self._flat is not None and self._flat[0].device == dev and all(
                 p.data_ptr() == v.data_ptr() for p, v in zip(ps, self._flat[2])):
@@ -288,24 +308,27 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         self._pack_version = None
 
     def _named_tensors(self):
-        d = dict(self.named_parameters())
-        d.update(dict(self.named_buffers()))
-        return d
+        """name -> Parameter / buffer of the whole model (cached: _enumerate)."""
+        return self._enumerate()['named']
 
     def _grads(self):
         """name -> gradient view inside the flat gradient buffer (re-attached if an optimizer set .grad to None)."""
         self.flatten_parameters_()
         _, flat_g, _, gviews = self._flat
+        e = self._enumerate()
         fresh = False
-        for p, g in zip(self.parameters(), gviews):
-            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+        for p, g in zip(e['plist'], gviews):
+            if p.grad is not g and (p.grad is None or p.grad.data_ptr() != g.data_ptr()):
                 fresh = True
                 break
         if fresh:
             flat_g.zero_()
-            for p, g in zip(self.parameters(), gviews):
+            for p, g in zip(e['plist'], gviews):
                 p.grad = g
-        return {k: p.grad for k, p in self.named_parameters()}
+        gd = e.get('gdict')
+        if gd is None or gd[0] is not gviews:
+            gd = e['gdict'] = (gviews, dict(zip(e['pnames'], gviews)))
+        return gd[1]
 
     def _plan(self, T, B, nt, n_euler, training, S=1, S_lat=None):
         """S > 1 (inference only): the conditioning frames are encoded once for B videos, the latent path and the decoder run
@@ -346,7 +369,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         """bf16 MFMA-layout copies of the conv weights, redone when a parameter changed.  overlap: on the second stream -- the
         encoder's share under the image-side layer (which reads the fp32 weights), the decoder's (60 % of the bytes; nothing reads
         it before the decoder forward) under the rest of the encoder; returns the two events to wait for (None: nothing pending)."""
-        ver = (id(pl), tuple(p._version for p in self.parameters()))
+        ver = (id(pl), tuple(p._version for p in self._enumerate()['plist']))
         if ver == self._pack_version:
             return None, None
         self._pack_version = ver
@@ -357,16 +380,13 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             return None, None
         if getattr(self, '_side_stream', None) is None:
             self._side_stream = _make_side_stream()
-        ev = torch.cuda.Event()
-        ev.record()
-        with torch.cuda.stream(self._side_stream):
+        ev = L.record()
+        with L.on_stream(self._side_stream):
             self._side_stream.wait_event(ev)
             pl['enc'].pack_weights(params, L.stream())
-            enc_done = torch.cuda.Event()
-            enc_done.record()
+            enc_done = L.record()
             pl['dec'].pack_weights(params, L.stream())
-            dec_done = torch.cuda.Event()
-            dec_done.record()
+            dec_done = L.record()
         return enc_done, dec_done
 
     def _draw_tape(self, T, B, nt, training, dev, t_skip=None, have=None):
@@ -422,8 +442,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
                                  'on one XCD for the generation chain): results since then are invalid; set SRVP_ROLLOUT_FUSED=0 SRVP_LSTM_FUSED=0 '
                                  'SRVP_LSTM_BWD_FUSED=0')
         L.call('srvp_cluster_timeouts_read', host.data_ptr(), L.stream())
-        ev = self.__dict__['_ct_event'] = torch.cuda.Event()
-        ev.record()
+        self.__dict__['_ct_event'] = L.record()
 
     def _check_cluster_now(self):
         """INFERENCE entry points fail closed: a generation launch whose cluster was not on one XCD (or a chain whose barrier
@@ -435,8 +454,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         if host is None:
             host = self.__dict__['_ct_host_now'] = torch.zeros(1, dtype=torch.int32).pin_memory()
         L.call('srvp_cluster_timeouts_read', host.data_ptr(), L.stream())
-        ev = torch.cuda.Event()
-        ev.record()
+        ev = L.record()
         ev.synchronize()
         if int(host[0]) != 0:
             raise L.SrvpHipError(f'{int(host[0])} cluster failure(s) in the persistent latent kernels (workgroups of a cluster were not co-resident, or not '
@@ -445,6 +463,11 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
 
     # ------------------------------------------------------------------------------------------------ core
     def _forward_impl(self, x, nt, n_euler, tape, training):
+        self._require_gpu()                       # (fails loudly on a CPU model before anything touches the device runtime)
+        with L.step_scope():
+            return self._forward_body(x, nt, n_euler, tape, training)
+
+    def _forward_body(self, x, nt, n_euler, tape, training):
         dev = self._require_gpu()
         T, B = x.shape[0], x.shape[1]
         if training:
@@ -472,17 +495,15 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
                 pl['ibuf_copied'].synchronize()
             host = self._fill_index_host(pl, T, B, nt, t_skip, training)
             pl['ibuf'].copy_(host, non_blocking=True)
-            pl['ibuf_copied'] = torch.cuda.Event()
-            pl['ibuf_copied'].record()
+            pl['ibuf_copied'] = L.record()
             sel = pl['skip_sel_t']
         lat_early = training and LATENT_AUX and OVERLAP_WGRAD
         if lat_early:
             # (what the posterior chain needs besides hx -- the summed LSTM bias -- is formed on the auxiliary stream under the encoder)
             if getattr(self, '_lat_stream', None) is None:
                 self._lat_stream = torch.cuda.Stream()
-            ev_p = torch.cuda.Event()
-            ev_p.record()                         # behind the previous step's optimizer
-            with torch.cuda.stream(self._lat_stream):
+            ev_p = L.record()                         # behind the previous step's optimizer
+            with L.on_stream(self._lat_stream):
                 self._lat_stream.wait_event(ev_p)
                 lat.lstm_bias_prep(params, L.stream())
         # (round 5, A/B switch, off) the decoder's hoisted skip convolutions stage by stage on the second stream, each as soon as the encoder
@@ -498,17 +519,15 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             def on_skip(cat):
                 if cat not in cats:
                     return
-                ev = torch.cuda.Event()
-                ev.record()
-                with torch.cuda.stream(self._side_stream):
+                ev = L.record()
+                with L.on_stream(self._side_stream):
                     self._side_stream.wait_event(ev)
                     dec.precompute_skips(L.stream(), cat=cat)
         hx = enc.forward(x.view(T * B, *x.shape[2:]), params, st, self.sync if training else None, keep=keep, packed=enc_packed, on_skip=on_skip)
         hx = hx.contiguous().view(T, B, self.nhx)
         ev_hx = None
         if lat_early:
-            ev_hx = torch.cuda.Event()
-            ev_hx.record()                        # hx exists (recorded BEFORE the draws below: the posterior chain does not wait for them)
+            ev_hx = L.record()                        # hx exists (recorded BEFORE the draws below: the posterior chain does not wait for them)
         # the draws come AFTER the encoder launches (same order within the CPU and the device generator as the reference, which
         # draws them inside encode / infer_w / infer_y / generate): the per-sample randperm calls cost ~0.3 ms of host time that
         # the GPU now spends in the encoder instead of idling; the small index tensors travel through pinned memory so that the
@@ -524,13 +543,11 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         def skips_on_side():
             if getattr(self, '_side_stream', None) is None:
                 self._side_stream = _make_side_stream()
-            ev = torch.cuda.Event()
-            ev.record()
-            with torch.cuda.stream(self._side_stream):
+            ev = L.record()
+            with L.on_stream(self._side_stream):
                 self._side_stream.wait_event(ev)
                 dec.precompute_skips(L.stream())
-                done = torch.cuda.Event()
-                done.record()
+                done = L.record()
             return done
         s_done = None
         overlap_skips = self.skipco and OVERLAP_SKIP and any(b.split for b in dec.blocks)
@@ -549,22 +566,19 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             if getattr(self, '_lat_stream', None) is None:
                 self._lat_stream = torch.cuda.Stream()
             aux = self._lat_stream
-            main_stream = torch.cuda.current_stream()
-            ev_tape = torch.cuda.Event()
-            ev_tape.record()                      # the index / noise tensors of the tape are on the device
-            with torch.cuda.stream(aux):
+            main_stream = L.cur_stream()
+            ev_tape = L.record()                      # the index / noise tensors of the tape are on the device
+            with L.on_stream(aux):
                 aux.wait_event(ev_hx)
                 lat.posterior(hx, params, L.stream(), bias_ready=True)
-                post_done = torch.cuda.Event()
-                post_done.record()
+                post_done = L.record()
                 aux.wait_event(ev_tape)
                 w = lat.infer_w(hx, params, t_w_arg, L.stream())
                 if lat.w_rows is not lat.__dict__.get('_w_rows_dev'):
                     lat.w_rows.record_stream(main_stream)    # (allocated on the auxiliary stream, read by the backward's scatter on the main one)
-                w_done = torch.cuda.Event()
-                w_done.record()
+                w_done = L.record()
             y0, q_y0 = lat.infer_y(hx[:self.nt_inf], params, tape['eps_y0'], st)
-            torch.cuda.current_stream().wait_event(post_done)
+            L.wait(post_done)
         else:
             w = lat.infer_w(hx, params, t_w_arg, st)
             y0, q_y0 = lat.infer_y(hx[:self.nt_inf], params, tape['eps_y0'], st)
@@ -583,16 +597,16 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             pz_stream = self._lat_stream
         y, z, qz, pz, res = lat.generate(y0, T, params, tape['eps_z'], st, pz_stream=pz_stream)
         if s_done is not None:
-            torch.cuda.current_stream().wait_event(s_done)
+            L.wait(s_done)
         if pack_done is not None:
-            torch.cuda.current_stream().wait_event(pack_done)
+            L.wait(pack_done)
         if w_done is not None:
-            torch.cuda.current_stream().wait_event(w_done)
+            L.wait(w_done)
         # decoder input rows [w[b] | y[t][b]] (srvp.py:216-221) assembled by the library from w and the stored states y_all[t * n_euler]
         x_flat = dec.forward(None, params, st, self.sync if training else None,
                              latent=(w, lat.y_all, lat.ne * B * self.ny, nt, B, self.nh_inf, self.ny))
         if getattr(lat, 'pz_done', None) is not None:
-            torch.cuda.current_stream().wait_event(lat.pz_done)          # p_z is read (KL term, callers) from here on
+            L.wait(lat.pz_done)          # p_z is read (KL term, callers) from here on
         x_ = x_flat.view(nt, B, *x_flat.shape[1:])
         pl['hx'], pl['x'] = hx, x
         self._last_plan = pl
@@ -655,7 +669,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         c = self.__dict__.get('_goff')
         if c is None or c[0] is not self._flat[1]:
             off, d = 0, {}
-            for name, p in self.named_parameters():
+            for name, p in zip(self._enumerate()['pnames'], self._enumerate()['plist']):
                 d[name] = (off, p.numel())
                 off += p.numel()
             enc_end = min(o for k, (o, _) in d.items() if k.startswith('decoder.'))
@@ -683,16 +697,19 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         if hi <= lo:
             return
         if after is None:
-            after = torch.cuda.Event()
-            after.record()
+            after = L.record()
         if getattr(self, '_comm_stream', None) is None:
             self._comm_stream = torch.cuda.Stream()
-        with torch.cuda.stream(self._comm_stream):
+        with L.on_stream(self._comm_stream):
             self._comm_stream.wait_event(after)
             self.sync.reduce_slice(self, lo, hi)
         self._exchanged.append((lo, hi))
 
     def _backward_impl(self, d_x, d_y, d_w, d_qy0, d_qz, d_pz, d_res):
+        with L.step_scope():
+            return self._backward_body(d_x, d_y, d_w, d_qy0, d_qz, d_pz, d_res)
+
+    def _backward_body(self, d_x, d_y, d_w, d_qy0, d_qz, d_pz, d_res):
         pl = self._last_plan
         enc, dec, lat = pl['enc'], pl['dec'], pl['lat']
         st = L.stream()
@@ -716,13 +733,11 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
         if overlap and LATENT_AUX and PZ_BWD_AUX and getattr(lat, 'pz_ext', False) and lat.S > 0:
             if getattr(self, '_lat_stream', None) is None:
                 self._lat_stream = torch.cuda.Stream()
-            ev_in = torch.cuda.Event()
-            ev_in.record()                        # d_pz exists
-            with torch.cuda.stream(self._lat_stream):
+            ev_in = L.record()                        # d_pz exists
+            with L.on_stream(self._lat_stream):
                 self._lat_stream.wait_event(ev_in)
                 lat.pz_backward_chain(params, d_pz_c, L.stream())
-                pz_pre = torch.cuda.Event()
-                pz_pre.record()
+                pz_pre = L.record()
         # multi-GPU: the flat gradient buffer is exchanged slice by slice, each as soon as it is final (SURVEY §5 / train.py:309-314: DDP's
         # bucketed all-reduce under backward): decoder tail, decoder head, encoder deep stages, latent networks; the encoder's first stages
         # (< 1 MB) at the step's end.  SRVP_GRAD_SLICES=0: decoder slice + everything else at the end (the round-5 form).
@@ -737,8 +752,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
                           side=self._side_stream if overlap else None, on_part=dec_part if sliced else None)
         ev_dec = None
         if overlap:
-            ev_dec = torch.cuda.Event()
-            ev_dec.record()                       # the decoder's output gradients exist: its weight gradients may start (second stream, below)
+            ev_dec = L.record()                       # the decoder's output gradients exist: its weight gradients may start (second stream, below)
         # backward of the time-expansion of w and of the concatenation [w | y_t] (srvp.py:216-221): d_w = sum over time, d_y_t straight
         # into the rollout's state-gradient buffer (frame t = Euler step t * n_euler)
         if not hasattr(lat, 'd_w_tot'):
@@ -760,7 +774,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             # (host order: the main-stream launches of the latent backward -- the critical path -- go out BEFORE the ~25 second-stream
             # launches of the decoder's weight gradients, which only wait for ev_dec on the device: a host that is just ahead of the device
             # -- small batches, a profiler attached -- then does not leave the main queue empty for the 0.25 ms the enqueueing takes)
-            with torch.cuda.stream(self._side_stream):
+            with L.on_stream(self._side_stream):
                 self._side_stream.wait_event(ev_dec)
                 b_lo, b_hi = dec.deferred_wgrads(grads, L.stream())
                 if exch and not DEC_ALLREDUCE_STREAM:
@@ -773,8 +787,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
                     self._exchange(enc_end, dec_end if b_hi == len(dec.blocks) else self._block_range(dec, b_hi, len(dec.blocks))[0])
         ev_lat = None
         if deferred:
-            ev_lat = torch.cuda.Event()
-            ev_lat.record()                       # every delta the latent weight gradients read exists
+            ev_lat = L.record()                       # every delta the latent weight gradients read exists
         skip_grads = None
         if self.skipco:
             skip_grads = {}
@@ -814,7 +827,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
                 if getattr(self, '_lat_stream', None) is None:
                     self._lat_stream = torch.cuda.Stream()
                 lat_stream = self._lat_stream
-            with torch.cuda.stream(lat_stream):
+            with L.on_stream(lat_stream):
                 lat_stream.wait_event(ev_lat)
                 s2 = L.stream()
                 for fn in deferred:
@@ -825,15 +838,15 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             # (the side stream holds the decoder's weight gradients + unpack and, behind them, the encoder's unpack)
             side_done = torch.cuda.Event()
             side_done.record(self._side_stream)
-            torch.cuda.current_stream().wait_event(side_done)
+            L.wait(side_done)
             if enc_side is not self._side_stream:
                 side2_done = torch.cuda.Event()
                 side2_done.record(enc_side)
-                torch.cuda.current_stream().wait_event(side2_done)
+                L.wait(side2_done)
             if lat_stream is not None and lat_stream is not self._side_stream:
                 lat_done = torch.cuda.Event()
                 lat_done.record(lat_stream)
-                torch.cuda.current_stream().wait_event(lat_done)
+                L.wait(lat_done)
         if exch:
             # what has not been exchanged yet (sliced: the encoder's first stages; otherwise encoder + latent slice, or everything)
             done = sorted(self._exchanged)
@@ -845,7 +858,7 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
             if getattr(self, '_comm_stream', None) is not None:
                 comm_done = torch.cuda.Event()
                 comm_done.record(self._comm_stream)
-                torch.cuda.current_stream().wait_event(comm_done)     # the optimizer reads the averaged gradients
+                L.wait(comm_done)     # the optimizer reads the averaged gradients
             self.sync.grads_finish(self)
 
     # ------------------------------------------------------------------------------------------------ reference API

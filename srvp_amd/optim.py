@@ -22,8 +22,9 @@ class FusedAdam(torch.optim.Optimizer):
         # gradients live in the flat buffer; the backward pass accumulates into it, so it is cleared here
         self.model.flatten_parameters_()
         self.model._flat[1].zero_()
-        for p, g in zip(self.model.parameters(), self.model._flat[3]):
-            p.grad = g
+        for p, g in zip(self.model._enumerate()['plist'], self.model._flat[3]):
+            if p.grad is not g:
+                p.grad = g
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):

@@ -76,8 +76,7 @@ def fused_step(model, x, opt, tape=None):
     if host is None:
         host = model.__dict__['_elbo_host'] = torch.empty(4, dtype=torch.float64).pin_memory()
     host.copy_(acc, non_blocking=True)
-    ev = model.__dict__['_elbo_event'] = torch.cuda.Event()
-    ev.record()
+    model.__dict__['_elbo_event'] = L.record()
     model._backward_impl(d_x, None, None, d_qy0, d_qz, d_pz, d_res)
     return acc
 
@@ -101,16 +100,17 @@ def train(forward_fn, optimizer, scaler, batch, device, opt):
     if wd is not None:
         wd.begin()
     try:
-        optimizer.zero_grad()
-        if batch.dtype == torch.uint8:                     # stacked uint8 videos (data.collate_u8): finish the collate on the GPU
-            from .data import frames_from_u8
-            x = frames_from_u8(batch, device)
-        else:
-            x = batch.to(device, non_blocking=True)
-        n = x.shape[1]
-        fused_step(model, x, opt)
-        optimizer.step()
-        _poll_cluster_timeouts(model)
+        with L.step_scope():                                # (torch's current stream looked up once for the whole step)
+            optimizer.zero_grad()
+            if batch.dtype == torch.uint8:                 # stacked uint8 videos (data.collate_u8): finish the collate on the GPU
+                from .data import frames_from_u8
+                x = frames_from_u8(batch, device)
+            else:
+                x = batch.to(device, non_blocking=True)
+            n = x.shape[1]
+            fused_step(model, x, opt)
+            optimizer.step()
+            _poll_cluster_timeouts(model)
         model._elbo_event.synchronize()                     # the step's single host sync: waits for the forward + ELBO only
     except BaseException:
         #  a step that raised -- SrvpHipError of the cluster poll, an OOM, KeyboardInterrupt inside the sync -- is not a step in

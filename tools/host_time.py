@@ -14,7 +14,7 @@ model.init(res_gain=cfg['res_gain'])
 model.to(dev).train()
 optim = srvp_amd.FusedAdam(model, lr=3e-4)
 opt = srvp_amd.DotDict(dict(n_euler_steps=cfg['n_euler'], obs_scale=cfg['obs_scale'], beta_y=1.0, beta_z=cfg['beta_z'], l2_res=1.0))
-x = torch.rand(T, B, cfg['ctor'][0] if False else 3, 64, 64).to(dev) if cfg is bench.CONFIGS['bair'] else None
+x = torch.rand(T, B, cfg['ctor'][1], 64, 64).to(dev)
 for _ in range(8):
     train(model, optim, None, x, dev, opt)
 torch.cuda.synchronize()
