@@ -1109,6 +1109,20 @@ class ConvNetBase:
 
     @staticmethod
     def _bnbwd_desc(blk, da):
+        """BnBwdDesc of (block, gradient source).  Built once per distinct source (the step hands the same plan-owned tensors over every
+        time: 24 descriptors of ~25 fields per step otherwise, ~0.25 ms of host work) -- the key holds every field that comes from `da`."""
+        key = (da['t'].data_ptr(), da['mode'], da['cstride'], da['coff'], da['border'], bool(da.get('f32')),
+               L.ptr(da.get('da2')), L.ptr(da.get('da2_idx')), blk.raw.data_ptr(), blk.out.t.data_ptr() if blk.out is not None else 0)
+        cache = blk.__dict__.setdefault('_bnbwd_cache', {})
+        d = cache.get(key)
+        if d is None:
+            if len(cache) > 8:
+                cache.clear()
+            d = cache[key] = ConvNetBase._bnbwd_desc_build(blk, da)
+        return d
+
+    @staticmethod
+    def _bnbwd_desc_build(blk, da):
         d = L.BnBwdDesc()
         d.elem_f32 = 1 if blk.f32 else 0
         d.draw_s2d = 1 if getattr(blk, 's2d', False) else 0
@@ -1390,7 +1404,7 @@ class EncoderNet(ConvNetBase):
 
     def _skip_reduce(self, blk, da, st):
         """srvp_bn_bwd_reduce da_mode 3: the skip-connection term of a pooled stage whose arg-max terms ride its consumer's data gradient"""
-        d3 = self._bnbwd_desc(blk, da)
+        d3 = L.BnBwdDesc.from_buffer_copy(self._bnbwd_desc(blk, da))       # (a copy: the cached descriptor serves _bn_backward unchanged)
         d3.da_mode, d3.N, d3.da2_idx = 3, da['da2'].shape[0], L.ptr(da['da2_sel'])     # rows of da2 and the frame each belongs to
         L.call('srvp_bn_bwd_reduce', C.byref(d3), L.ptr(blk.red), st)
 
