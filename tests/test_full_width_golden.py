@@ -267,3 +267,58 @@ def test_hip_vs_full_width_reference_fixture(name, precision):
         xr = torch.from_numpy(synth_video(nt_cond, fx.meta['B'], fx.ctor[1], seed=322)).cuda()
         o = m2(xr, nt, dt=1 / ne, tape=fx.tape('roll.tape.'))
         check_rollout(fx, o[1], o[0], 2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['full_w3_kth_vgg_b5', 'full_w5_human_vgg_b6'])
+def test_streaming_kernels_tight_per_layer_on_reference_fixtures(name):
+    """the bf16 ELBO bounds of the KTH / Human3.6M fixtures above are tripwires (4 x measured: the step-0 ELBO of these
+    recipes amplifies single roundings), so a regression of a few 1e-4 inside conv_stream64 / conv_stream_sub64 / the image-side streaming
+    kernels would pass there.  Here the SAME reference-made inputs and weights (>= 96 frames) go through the training forward twice -- the
+    streaming kernels on (default) and off (the halo / tile kernels) -- and every layer the streaming kernels produce is held tightly,
+    layer by layer: raw conv outputs equal up to single bf16 ulps (on < 0.5 % of the elements where the inputs are identical -- the first block --,
+    < 15 % behind it, never more than 2^-6 of the layer's range), BatchNorm statistics to 1e-5 (first block: measured 2.3e-6) / 1e-4 (second) relative, decoded frames to 2e-2; both forms then sit inside the fixture's bounds (test above)."""
+    from srvp_amd import _lib as L
+    fx = Full(name)
+    ne = fx.meta['n_euler']
+    res = {}
+    for on in (1, 0):
+        m, x = fx.model_and_input()
+        m = m.cuda().train().set_precision('bf16')
+        m.flatten_parameters_()
+        for sw in ('srvp_conv_set_stream64', 'srvp_conv_set_in_stream'):
+            L.call(sw, on)
+        try:
+            cnt = [L.load().srvp_conv_stream_count(i) for i in range(3)]
+            outs = m._forward_impl(x.cuda(), x.shape[0], ne, fx.tape(), training=True)
+            torch.cuda.synchronize()
+            took = [L.load().srvp_conv_stream_count(i) - cnt[i] for i in range(3)]
+        finally:
+            for sw in ('srvp_conv_set_stream64', 'srvp_conv_set_in_stream'):
+                L.call(sw, 1)
+        pl = m._last_plan
+        layers = {f'enc{i}': b for i, b in enumerate(pl['enc'].blocks[:2])}
+        layers.update({f'dec{len(pl["dec"].blocks) - 2}': pl['dec'].blocks[-2]})
+        res[on] = dict(took=took, x_=outs[0].float().clone(),
+                       raw={k: b.raw.float().clone() for k, b in layers.items()},
+                       stats={k: b.stats.clone() for k, b in layers.items() if getattr(b, 'stats', None) is not None})
+    assert res[1]['took'][0] >= 1 and res[0]['took'] == [0, 0, 0], (res[1]['took'], res[0]['took'])
+    for k in res[1]['raw']:
+        a, b = res[1]['raw'][k], res[0]['raw'][k]
+        diff = (a - b).abs()
+        scale = max(1.0, b.abs().max().item())
+        assert diff.max().item() <= 2 ** -6 * scale, (k, diff.max().item())                    # isolated roundings, never a wrong value
+        frac = (diff > 0).float().mean().item()
+        # the first layer sees identical inputs: isolated one-ulp flips only (measured 7e-5 of the elements in round 5); the layers behind it see
+        # inputs that already differ by those flips and the one-ulp BatchNorm coefficients they cause (measured 4.4 % at the second block)
+        # (the decoder's stage entry sits behind the whole latent path of an ill-conditioned recipe: bounded in size above, not in count)
+        assert frac < (5e-3 if k == 'enc0' else (0.15 if k == 'enc1' else 1.01)), (k, frac)
+        try:
+            from test_gpu_parity_gate import report
+            report(test='streaming_vs_tile_on_fixture', name=name, layer=k, frac_differing=frac, max_diff=diff.max().item())
+        except Exception:
+            pass
+    for k, tol in (('enc0', 1e-5), ('enc1', 1e-4)):            # (statistics: fp64 sums of fp32 accumulators; the second block's inputs differ by the flips above)
+        a, b = res[1]['stats'][k], res[0]['stats'][k]
+        assert ((a - b).abs().max() / b.abs().max()).item() < tol, (k, ((a - b).abs().max() / b.abs().max()).item())
+    assert (res[1]['x_'] - res[0]['x_']).abs().max().item() <= 2e-2          # (both within 3e-2 of the reference's frames: test above; measured 1.1e-2)
