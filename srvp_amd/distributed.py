@@ -268,6 +268,12 @@ class Sync:
         self.world = dist.get_world_size(group)
         self.handles = []
         self.sync_bn = True
+        # host meeting point of after_rank0_phase: a gloo group with a day-long timeout.  Not the training backend's barrier: rank 0's
+        # validation may take longer than ProcessGroupNCCL's collective timeout (10 minutes by default), which would abort a healthy job
+        self.host_group = group
+        if self.world > 1 and dist.get_backend(group) != 'gloo':
+            import datetime
+            self.host_group = dist.new_group(backend='gloo', timeout=datetime.timedelta(hours=24))
         # SRVP_FORCE_COLLECTIVES=1: issue every collective even on a single rank (exercises the RCCL call path on a
         # 1-GPU box: tests/test_gpu_model.py::test_single_rank_collectives)
         self.force = os.environ.get('SRVP_FORCE_COLLECTIVES', '0') == '1'
@@ -488,7 +494,7 @@ class Sync:
         first statistics all-reduce for as long as rank 0 validates / writes -- a healthy job killed after SRVP_WATCHDOG_S; and the peer
         exchange waits on the device with a deadline.  A monitored barrier is not needed: a rank-0 phase has no step clock running."""
         if self.world > 1:
-            dist.barrier(group=self.group)
+            dist.barrier(group=self.host_group)
 
     def broadcast(self, t):
         if self.native_grads is not None:

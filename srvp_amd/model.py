@@ -391,8 +391,8 @@ class StochasticLatentResidualVideoPredictor(nn.Module):
 
     def _draw_tape(self, T, B, nt, training, dev, t_skip=None, have=None):
         """Random draws in the reference's order: CPU generator for the frame indices, device
-        generator for the normals.  have (optional): a partial tape -- only what it lacks is drawn (a captured step is handed the
-        host-drawn frame indices and draws the normals inside the graph, srvp_amd/graphstep.py)."""
+        generator for the normals.  have (optional): a partial tape -- only what it lacks is drawn (e.g. host-drawn frame indices given, normals
+        drawn here: what a stream capture of the step needs, tools/graph_probe.py)."""
         tape = dict(have) if have else {}
         if training:
             if self.skipco and 't_skip' not in tape:
