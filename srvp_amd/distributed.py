@@ -273,7 +273,10 @@ class Sync:
         self.host_group = group
         if self.world > 1 and dist.get_backend(group) != 'gloo':
             import datetime
-            self.host_group = dist.new_group(backend='gloo', timeout=datetime.timedelta(hours=24))
+            try:
+                self.host_group = dist.new_group(backend='gloo', timeout=datetime.timedelta(hours=24))
+            except Exception as e:                       # noqa: BLE001 -- (every rank of the node fails alike: same host, same interfaces)
+                print(f'srvp_amd.distributed: no gloo host group ({e}); rank-0 phases meet on the training backend\'s barrier')
         # SRVP_FORCE_COLLECTIVES=1: issue every collective even on a single rank (exercises the RCCL call path on a
         # 1-GPU box: tests/test_gpu_model.py::test_single_rank_collectives)
         self.force = os.environ.get('SRVP_FORCE_COLLECTIVES', '0') == '1'
