@@ -105,6 +105,109 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
     }
 }
 
+// The same GEMM for the shapes with thousands of rows (the batched inference MLPs and their data gradients: M = frames x batch, N and K a few
+// hundred; round 6).  The 32x32 kernel above reads both operands straight from L2 with no reuse -- 4 MAC per byte: [2112 x 512] x [512 x 512]
+// took 35 us (31 TFLOP/s of the 157 the fp32 matrix pipe has) and doubling these launches cost 0.30 ms of a 38 ms step, 0.20 of SM-MNIST's
+// 5.6.  Here: a 64 x 64 tile per workgroup (four waves, 32 x 32 each), 32-wide K stages of both operands staged in LDS through registers
+// (double-buffered), fragments read back as 16-byte pieces -- 16 MAC per byte from L2.  Same exact-fp32 arithmetic (v_mfma_f32_32x32x2_f32); the K
+// order inside a stage is 8 j + 4 h + {0..3} for half-wave h on BOTH operands.  A: row-major, K contiguous.  BT: B given as [N][K] (K contiguous:
+// y = x W^T); !BT: B row-major [K][N] (N contiguous: dx = dy W).
+template <bool BT>
+__global__ __launch_bounds__(256) void gemm_f32_tiled_kernel(const GemmArgs g) {
+    // 32-wide K stages: the loads of stage s + 1 are issued before the arithmetic of stage s and stored behind it.  (Measured, round 6: two
+    // register sets / two stages ahead -- behind the loop's branches hipcc waits with vmcnt(0) for the prefetch it has just issued, so the
+    // distance collapses to one stage anyway -- and 64-wide stages: the same 27 us for [2112 x 512] x [512 x 512], slower at K = 128.)
+    constexpr int BM = 64, BN = 64, BK = 32, LDA = BK + 4, LDBT = BK + 4, LDBN = BN + 4;
+    constexpr int KQ = BK / 4, NP = BM * KQ / 256;           // float4 pieces per row, pieces per thread and operand
+    __shared__ __attribute__((aligned(16))) float As[2][BM][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BT ? BN * LDBT : BK * LDBN];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int r = lane & 31, h = lane >> 5;
+    // staging: loads are UNCONDITIONAL at clamped addresses, the validity is applied when the piece is stored (a guarded load is a branch)
+    f32x4_t ra[NP], rb[NP];
+    bool va[NP], vb[NP];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int q = tid + i * 256;
+            const int row = q / KQ, kq = (q % KQ) * 4;
+            const int m = m0 + row, k = k0 + kq;
+            va[i] = m < g.M && k < g.K;
+            const int mc = m < g.M ? m : g.M - 1, kc = k < g.K ? k : g.K - 4;
+            ra[i] = *reinterpret_cast<const f32x4_t*>(g.A + (long long)mc * g.a_rs + kc);
+            if constexpr (BT) {
+                const int n = n0 + row;
+                vb[i] = n < g.N && k < g.K;
+                rb[i] = *reinterpret_cast<const f32x4_t*>(g.B + (long long)(n < g.N ? n : g.N - 1) * g.b_cs + kc);
+            } else {
+                const int kr = q >> 4, nq = (q & 15) * 4;
+                const int kk = k0 + kr, n = n0 + nq;
+                vb[i] = kk < g.K && n < g.N;
+                rb[i] = *reinterpret_cast<const f32x4_t*>(g.B + (long long)(kk < g.K ? kk : g.K - 1) * g.b_rs + (n < g.N ? n : g.N - 4));
+            }
+        }
+    };
+    auto store = [&](int buf) {
+        const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int q = tid + i * 256;
+            *reinterpret_cast<f32x4_t*>(&As[buf][q / KQ][(q % KQ) * 4]) = va[i] ? ra[i] : zero;
+            if constexpr (BT) *reinterpret_cast<f32x4_t*>(&Bs[buf][(q / KQ) * LDBT + (q % KQ) * 4]) = vb[i] ? rb[i] : zero;
+            else *reinterpret_cast<f32x4_t*>(&Bs[buf][(q >> 4) * LDBN + (q & 15) * 4]) = vb[i] ? rb[i] : zero;
+        }
+    };
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    auto compute = [&](int buf) {
+        const float* ar = &As[buf][wm * 32 + r][4 * h];
+#pragma unroll
+        for (int jj = 0; jj < BK / 32; ++jj) {               // fragments of 32 k requested, then their 16 MFMAs
+            f32x4_t a4[4], b4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kb = 32 * jj + 8 * j;
+                a4[j] = *reinterpret_cast<const f32x4_t*>(ar + kb);
+                if constexpr (BT) b4[j] = *reinterpret_cast<const f32x4_t*>(&Bs[buf][(wn * 32 + r) * LDBT + kb + 4 * h]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b4[j][e] = Bs[buf][(kb + 4 * h + e) * LDBN + wn * 32 + r];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j][e], b4[j][e], acc, 0, 0, 0);
+        }
+    };
+    const int nst = (g.K + BK - 1) / BK;
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+        if (s + 1 < nst) load((s + 1) * BK);                 // the next stage's global loads fly under this stage's MFMAs
+        compute(s & 1);
+        if (s + 1 < nst) store((s & 1) ^ 1);
+        __syncthreads();
+    }
+    // C/D layout: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+    const int n = n0 + wn * 32 + r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int m = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (m >= g.M || n >= g.N) continue;
+        float v = acc[i] * g.alpha;
+        if (g.bias) v += g.bias[n];
+        v = act_fwd(v, g.act);
+        if (g.mask) v = g.mask[(long long)m * g.mask_rs + n] > 0.f ? v : 0.f;
+        float* c = g.C + (long long)m * g.c_rs + n;
+        *c = g.accumulate ? *c + v : v;
+    }
+}
+
 __global__ void colsum_kernel(const float* A, long long a_rs, float* out, int M, int N, int rows_per_block);
 
 // Weight-gradient shape: C[M][N] += A^T B with BOTH operands row-major over the reduction index (A = delta [K][M], B =
@@ -223,6 +326,17 @@ int gemm(hipStream_t st, const float* A, long long a_rs, long long a_cs, const f
     dim3 grid((N + 31) / 32, (M + 31) / 32);
     const bool av = a_cs == 1 && K % 4 == 0 && a_rs % 4 == 0 && ((uintptr_t)A % 16) == 0;
     const bool bv = b_rs == 1 && K % 4 == 0 && b_cs % 4 == 0 && ((uintptr_t)B % 16) == 0;
+    // many rows, a wide enough output: the LDS-tiled kernel (SRVP_GEMM_TILED=0: the 32x32 kernel for every shape, A/B switch)
+    static int tiled_on = -1;
+    if (tiled_on < 0) { const char* e = getenv("SRVP_GEMM_TILED"); tiled_on = e ? atoi(e) : 1; }
+    const bool bn = b_cs == 1 && N % 4 == 0 && b_rs % 4 == 0 && ((uintptr_t)B % 16) == 0;
+    if (tiled_on && av && (bv || bn) && M >= 512 && N >= 96 && K >= 32) {
+        dim3 tg((N + 63) / 64, (M + 63) / 64);
+        if (bv) hipLaunchKernelGGL(gemm_f32_tiled_kernel<true>, tg, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(gemm_f32_tiled_kernel<false>, tg, dim3(256), 0, st, g);
+        SRVP_CHECK_LAUNCH("srvp_gemm_f32(tiled)");
+        return SRVP_OK;
+    }
     if (av && bv) hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, true>), grid, dim3(256), 0, st, g);
     else if (av) hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, false>), grid, dim3(256), 0, st, g);
     else if (bv) hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, true>), grid, dim3(256), 0, st, g);

@@ -177,6 +177,35 @@ def test_gemm_tn_weight_gradient_shape(M, N, K):
     assert rel(Cm, ref) < 2e-6, rel(Cm, ref)
 
 
+@pytest.mark.parametrize('M,N,K,bt,act,acc,bias', [(2112, 512, 512, True, 3, 0, True), (2304, 1024, 128, True, 0, 0, True), (2112, 100, 512, True, 0, 0, True),
+                                                  (2112, 512, 100, False, 0, 0, False), (2304, 128, 1024, False, 0, 1, False), (1792, 512, 40, True, 3, 0, True),
+                                                  (515, 100, 36, True, 2, 1, True), (1000, 260, 68, False, 0, 0, False)])
+def test_gemm_tiled_rows_in_the_thousands(M, N, K, bt, act, acc, bias):
+    """srvp_gemm_f32 on the shapes of the batched inference MLPs and their data gradients (round 6: 64x64 LDS-tiled exact-fp32 MFMA kernel,
+    csrc/latent.hip gemm_f32_tiled_kernel): y = act(x W^T + b) with W given as [N][K] (bt) and dx (+)= dy W with W row-major [K][N], ragged
+    M / N / K, against float64 -- and against the 32x32 kernel the small shapes keep (same exact-fp32 products, another summation order)."""
+    from srvp_amd import _lib as L
+    g = torch.Generator().manual_seed(M + N + K)
+    dev = torch.device('cuda')
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) if bt else torch.randn(K, N, generator=g)).to(dev)
+    b = torch.randn(N, generator=g).to(dev) if bias else None
+    C0 = torch.randn(M, N, generator=g).to(dev)
+    Cm = C0.clone()
+    if bt:      # B[k][n] = W[n][k]: b_rs = 1, b_cs = K
+        L.call('srvp_gemm_f32', L.ptr(A), K, 1, L.ptr(W), 1, K, L.ptr(b), L.ptr(Cm), N, M, N, K, act, acc, L.stream())
+        pre = A.double() @ W.double().t()
+    else:       # B[k][n] = W[k][n]: b_rs = N, b_cs = 1
+        L.call('srvp_gemm_f32', L.ptr(A), K, 1, L.ptr(W), N, 1, L.ptr(b), L.ptr(Cm), N, M, N, K, act, acc, L.stream())
+        pre = A.double() @ W.double()
+    if bias:
+        pre = pre + b.double()
+    ref = {0: lambda v: v, 2: torch.tanh, 3: torch.relu}[act](pre)
+    if acc:
+        ref = ref + C0.double()
+    assert rel(Cm, ref) < 2e-6, rel(Cm, ref)
+
+
 def test_elbo_and_adam_kernels():
     """srvp_nll / srvp_kl / srvp_l2rows values + gradients and srvp_adam against the oracle formulas (train.py:90-106,289)."""
     import srvp_amd
