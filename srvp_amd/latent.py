@@ -11,13 +11,8 @@ import torch
 from . import _lib as L
 
 
-_GEMM_TWICE = __import__('os').environ.get('SRVP_GEMM_TWICE') == '1'      # sensitivity probe only (wrong results for accumulating calls)
-
-
 def _gemm(st, A, a_rs, a_cs, B, b_rs, b_cs, bias, Cm, c_rs, M, N, K, act=L.ACT_NONE, acc=0):
     L.call('srvp_gemm_f32', L.ptr(A), a_rs, a_cs, L.ptr(B), b_rs, b_cs, L.ptr(bias), L.ptr(Cm), c_rs, M, N, K, act, acc, st)
-    if _GEMM_TWICE:
-        L.call('srvp_gemm_f32', L.ptr(A), a_rs, a_cs, L.ptr(B), b_rs, b_cs, L.ptr(bias), L.ptr(Cm), c_rs, M, N, K, act, acc, st)
 
 
 def linear_fwd(st, x, w, b, out, act=L.ACT_NONE):
