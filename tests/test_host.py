@@ -281,3 +281,25 @@ def test_step_watchdog_reports_a_step_that_does_not_complete(capsys):
     off = StepWatchdog(timeout_s=0)                          # SRVP_WATCHDOG_S=0: no thread
     assert off._thread is None
     assert StepWatchdog.EXIT_CODE != 0
+
+
+def test_cached_enumeration_follows_the_module():
+    """model._enumerate (round 6: the step no longer walks the module tree ten times) must never serve stale objects: _apply (to / double /
+    cuda) replaces BUFFER tensors -- the cache is dropped there --, load_state_dict copies in place, SyncBatchNorm conversion re-uses the
+    Parameter and buffer objects."""
+    import srvp_amd
+    m = srvp_amd.StochasticLatentResidualVideoPredictor(64, 1, 4, 8, 3, 3, True, 2, 8, 3, 16, 4, 'vgg')
+    m.init()
+    live = lambda: dict(list(m.named_parameters()) + list(m.named_buffers()))
+    same = lambda a, b: a.keys() == b.keys() and all(a[k] is b[k] for k in a)
+    assert same(m._named_tensors(), live())
+    m.double()                                            # _apply: every buffer tensor is a new object now
+    assert same(m._named_tensors(), live())
+    m.float()
+    sd = {k: v.clone() + 1 for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)                                 # in place: same objects, new values
+    nt = m._named_tensors()
+    assert same(nt, live()) and all(torch.equal(nt[k], sd[k]) for k in sd)
+    torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)      # (reference train.py:278-283) module objects change, tensors do not
+    assert same(m._named_tensors(), live())
+    assert [p for p in m.parameters()] == m._enumerate()['plist'] or all(a is b for a, b in zip(m.parameters(), m._enumerate()['plist']))
