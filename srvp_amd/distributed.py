@@ -273,6 +273,8 @@ class Sync:
         self.host_group = group
         if self.world > 1 and dist.get_backend(group) != 'gloo':
             import datetime
+            if os.environ.get('MASTER_ADDR') in ('127.0.0.1', 'localhost'):
+                os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')     # one node: the loopback interface (the container's hostname may not resolve)
             try:
                 self.host_group = dist.new_group(backend='gloo', timeout=datetime.timedelta(hours=24))
             except Exception as e:                       # noqa: BLE001 -- (every rank of the node fails alike: same host, same interfaces)
