@@ -276,7 +276,8 @@ class Sync:
             if os.environ.get('MASTER_ADDR') in ('127.0.0.1', 'localhost'):
                 os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')     # one node: the loopback interface (the container's hostname may not resolve)
             try:
-                self.host_group = dist.new_group(backend='gloo', timeout=datetime.timedelta(hours=24))
+                self.host_group = dist.new_group(ranks=None if group is None else dist.get_process_group_ranks(group), backend='gloo',
+                                                 timeout=datetime.timedelta(hours=24))
             except Exception as e:                       # noqa: BLE001 -- (every rank of the node fails alike: same host, same interfaces)
                 print(f'srvp_amd.distributed: no gloo host group ({e}); rank-0 phases meet on the training backend\'s barrier')
         # SRVP_FORCE_COLLECTIVES=1: issue every collective even on a single rank (exercises the RCCL call path on a
